@@ -1,0 +1,206 @@
+/*
+ * p3m_hip.h -- C ABI of the MI355X-native P3M gravity step that drops in behind
+ * cubep3m's `subroutine particle_mesh`
+ * (reference: source_threads/particle_mesh_threaded.f90:2, callers cubepm.f90:143,
+ * report_force.f90:41,100).
+ *
+ * The reference has no plugin API: `particle_mesh` takes no arguments and exchanges
+ * all state through COMMON blocks (source_threads/cubep3m.fh:147-171).  Its only FFI
+ * precedent is the F77-style `pp_force_c_` (source_threads/nbody-ueli.cu:368, called at
+ * particle_mesh_cuda.f90:578): lower-case name + trailing underscore, every argument by
+ * reference, caller-owned arrays.  This header therefore offers
+ *   (1) a context API with plain pointers and sizes (what an ISO_C_BINDING adapter or
+ *       ctypes binds), and
+ *   (2) `particle_mesh_hip_` -- an F77-ABI one-call wrapper in the style of
+ *       `pp_force_c_` for hosts that want the smallest possible change.
+ * Every entry point cites the reference routine it replaces.
+ *
+ * Conventions shared with the reference:
+ *   - all reals are fp32 (`real(4)`), indices int32, particle ids int64 (cubep3m.fh:75-79)
+ *   - xv is AoS (6,np): x,y,z,vx,vy,vz; positions are in fine-cell units local to the
+ *     rank, physical range [0, nf_physical_node_dim)                (cubep3m.fh:75)
+ *   - kern_f(3, nf_tile/2+1, nf_tile, nf_tile), kern_c(3, nc_dim/2+1, nc_dim, nc_slab)
+ *     with the component index fastest                             (cubep3m.fh:35,56)
+ * Errors: the reference calls mpi_abort/stop (particle_pass.f90:96-99,136-139;
+ * particle_mesh_threaded.f90:280-283).  This library never aborts the host: every
+ * function returns 0 on success or a negative P3M_E* code; p3m_hip_last_error() returns
+ * the message.
+ */
+#ifndef P3M_HIP_H
+#define P3M_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- compile-time switches of the reference, as run-time flags -------------------- */
+#define P3M_FLAG_NGP        (1u << 0) /* -DNGP : fine NGP deposit+gather; else CIC
+                                         (particle_mesh_threaded.f90:119-161,260-317)   */
+#define P3M_FLAG_PPINT      (1u << 1) /* -DPPINT: intra-fine-cell PP (requires NGP)
+                                         (particle_mesh_threaded.f90:274-285,324-361)   */
+#define P3M_FLAG_PP_EXT     (1u << 2) /* -DPP_EXT: extended PP over pp_range cells
+                                         (particle_mesh_threaded.f90:378-624) and the
+                                         zeroed kernel corner (kernel_initialization.f90:38-54) */
+#define P3M_FLAG_LRCKCORR   (1u << 3) /* -DLRCKCORR: long-range coarse kernel correction
+                                         (kernel_initialization.f90:465-687)             */
+#define P3M_FLAG_MOVE_GRID_BACK (1u << 4) /* -DMOVE_GRID_BACK (move_grid_back.f90)       */
+
+/* ---- error codes -------------------------------------------------------------------- */
+#define P3M_OK            0
+#define P3M_EINVAL       -1  /* bad parameter / unsupported size                         */
+#define P3M_ENOMEM       -2  /* device allocation failed                                 */
+#define P3M_ECAPACITY    -3  /* particle/ghost capacity exceeded ("exceeded max_np in pass",
+                                particle_pass.f90:136-139)                               */
+#define P3M_EDEVICE      -4  /* HIP runtime error                                        */
+#define P3M_ESTATE       -5  /* call sequence error (e.g. step before kernels are set)   */
+#define P3M_ECOMM        -6  /* transport error                                          */
+
+/* Compile-time parameters of the reference (parameters.example, cubepm.par) as a struct. */
+typedef struct p3m_params {
+  int32_t nodes_dim;       /* ranks per dimension, nodes = nodes_dim^3  (parameters.example:14) */
+  int32_t tiles_node_dim;  /* fine tiles per rank per dimension          (parameters.example:17) */
+  int32_t nf_tile;         /* fine tile size incl. buffers               (parameters.example:32) */
+  int32_t nf_cutoff;       /* fine force cut-off, 16                     (parameters.example:50) */
+  int32_t nf_buf;          /* tile buffer, nf_cutoff+8 = 24              (parameters.example:53) */
+  int32_t mesh_scale;      /* coarse/fine ratio, 4                       (cubepm.par:157)        */
+  int32_t pp_range;        /* extended-PP reach in fine cells, 2         (cubepm.par:92)         */
+  int32_t cores;           /* OpenMP threads of the reference; only reproduces the per-thread
+                              `pp_ext_force_max` overwrite (particle_mesh_threaded.f90:617)      */
+  uint32_t flags;          /* P3M_FLAG_*                                                         */
+  float rsoft;             /* PP hard cut, 0.1                           (cubepm.par:76)         */
+  float pp_bias;           /* 1.0                                        (cubepm.par:80)         */
+  float dt_pp_scale;       /* 0.05                                       (cubepm.par:78)         */
+  float density_buffer;    /* capacity factor for max_np                 (parameters.example:24) */
+  int32_t rank;            /* this process' rank, 0..nodes-1; x <-> rank%nodes_dim
+                              (mpi_initialization.f90:42-76, kernel_initialization.f90:293-298)  */
+  int32_t device;          /* HIP device ordinal to use (-1: current device)                     */
+} p3m_params;
+
+/* What `particle_mesh` leaves in COMMON for the next `timestep` (cubep3m.fh:20-21) + DIAG sums. */
+typedef struct p3m_step_out {
+  float dt_f_acc;          /* particle_mesh_threaded.f90:643-656 */
+  float dt_pp_acc;         /* :662-673 (1000 if PPINT off, variable_initialization.f90:22-29)   */
+  float dt_pp_ext_acc;     /* :685-696                                                          */
+  float dt_c_acc;          /* coarse_max_dt.f90:36                                              */
+  double sum_rho_f;        /* DIAG "sum of rho_f", particle_mesh_threaded.f90:166-174,702-706   */
+  double sum_rho_c;        /* DIAG "sum of rho_c", coarse_mesh.f90:31-43                        */
+  int64_t np_total;        /* DIAG "total number of particles", delete_particles.f90:62-64      */
+  int32_t np_local;        /* particles left on this rank after delete_particles                 */
+  int32_t np_ghost;        /* ghosts this rank held after particle_pass                          */
+  int32_t np_deleted;      /* out-of-range particles dropped by link_list (link_list.f90:26-53)  */
+  float f_force_max;       /* sqrt(max |F_fine|^2), :643                                         */
+  float pp_force_max;      /* :662                                                               */
+  float pp_ext_force_max;  /* :685                                                               */
+  float c_force_max;       /* coarse_max_dt.f90:24-31                                            */
+} p3m_step_out;
+
+/*
+ * Transport for multi-rank runs (replaces the MPI calls of particle_pass.f90,
+ * fftw3ds.f90:24-39,84-99, coarse_force_buffer.f90:25-63 and the mpi_reduce/bcast pairs).
+ * All buffers handed to the callbacks are HOST pointers (pinned staging owned by the
+ * library) so that any transport can serve: MPI in a Fortran host, torch.distributed
+ * (gloo or nccl) in the Python host.  With nodes_dim == 1 no transport is needed.
+ * When the library is built with RCCL and p3m_hip_comm_init_rccl() has been called the
+ * callbacks are bypassed and device buffers go straight over xGMI.
+ */
+typedef struct p3m_transport {
+  void *user;
+  /* exchange with two peers at once: send sbytes to dst, receive up to rcap bytes from src;
+     *rbytes returns what arrived.  (mpi_sendrecv_replace + isend/irecv pairs) */
+  int (*sendrecv)(void *user, const void *sbuf, int64_t sbytes, int32_t dst,
+                  void *rbuf, int64_t rcap, int64_t *rbytes, int32_t src, int32_t tag);
+  /* personalised all-to-all with equal block size (FFT transpose, pack_slab/unpack_slab) */
+  int (*alltoall)(void *user, const void *sbuf, void *rbuf, int64_t block_bytes);
+  /* in-place max / sum over all ranks (mpi_reduce + mpi_bcast pairs) */
+  int (*allreduce_max_f32)(void *user, float *v, int32_t n);
+  int (*allreduce_sum_f64)(void *user, double *v, int32_t n);
+} p3m_transport;
+
+typedef struct p3m_ctx p3m_ctx;
+
+/* -- lifecycle ------------------------------------------------------------------------- */
+/* Replaces the static COMMON storage of cubep3m.fh: allocates all device buffers once.   */
+int p3m_hip_create(const p3m_params *params, p3m_ctx **out);
+void p3m_hip_destroy(p3m_ctx *ctx);
+const char *p3m_hip_last_error(void);
+/* Derived sizes exactly as cubepm.par:170-208 computes them. what: 0 max_np, 1 nc_dim,
+   2 nc_node_dim, 3 nf_physical_node_dim, 4 nc_slab, 5 nf_physical_tile_dim */
+int64_t p3m_hip_derived(const p3m_ctx *ctx, int32_t what);
+
+int p3m_hip_set_transport(p3m_ctx *ctx, const p3m_transport *t);
+/* RCCL over xGMI: unique_id is the 128-byte ncclUniqueId the host broadcast from rank 0
+   (p3m_hip_rccl_unique_id fills it on rank 0). */
+int p3m_hip_rccl_unique_id(void *unique_id_128);
+int p3m_hip_comm_init_rccl(p3m_ctx *ctx, const void *unique_id_128);
+
+/* -- Green's functions (kernel_initialization.f90) -------------------------------------- */
+/* fine_table: the 16^3 rows of kernels/wfxyzf.3.ascii as float[16][16][16][3] with the file's
+   row order (i fastest, then j, then k; 3 components per row) -- fine_kernel :25-36.
+   coarse_table: kernels/wfxyzc.2.ascii as float[4][4][4][3] -- coarse_kernel :349-358.
+   Builds kern_f / kern_c on the device with the library's own FFT. */
+int p3m_hip_set_kernel_tables(p3m_ctx *ctx, const float *fine_table, const float *coarse_table);
+/* Alternatively hand over the arrays the reference already computed (COMMON /rvar/ kern_f,
+   kern_c) in the reference's own layout. Single-rank contexts only for kern_c. */
+int p3m_hip_set_kernels_raw(p3m_ctx *ctx, const float *kern_f, const float *kern_c);
+/* Read the device kernels back in the reference layout (tests, kernel_checkpoint.f90). */
+int p3m_hip_get_kernels(p3m_ctx *ctx, float *kern_f, float *kern_c);
+
+/* -- particle store (xv, PID, np_local of cubep3m.fh:75-79) ----------------------------- */
+int p3m_hip_upload_particles(p3m_ctx *ctx, const float *xv6, const int64_t *pid, int32_t np_local);
+/* Order differs from the reference's swap-with-last compaction (delete_particles.f90:17-47):
+   match by PID. xv6/pid may be NULL to query np_local only. */
+int p3m_hip_download_particles(p3m_ctx *ctx, float *xv6, int64_t *pid, int32_t *np_local);
+
+/* -- the step: subroutine particle_mesh (particle_mesh_threaded.f90:2-726) --------------- */
+/* offset: the DISP_MESH shift added in update_position (update_position.f90:56-58,71), or NULL.
+   The host keeps the RNG (random_number on rank 0). move_back: with P3M_FLAG_MOVE_GRID_BACK,
+   the accumulated shake_offset subtracted after the kick (move_grid_back.f90:17-24), or NULL. */
+int p3m_hip_particle_mesh(p3m_ctx *ctx, float a_mid, float dt, float dt_old, float mass_p,
+                          const float *offset, const float *move_back, p3m_step_out *out);
+
+/* -- individual phases (same order as particle_mesh calls them); used by tests, the
+      benchmark's per-kernel timing and hosts that interleave their own work ------------- */
+int p3m_hip_update_position(p3m_ctx *ctx, float dt, float dt_old, const float *offset); /* update_position.f90 */
+int p3m_hip_link_list_and_pass(p3m_ctx *ctx);   /* link_list.f90 + particle_pass.f90 (sort replaces hoc/ll) */
+int p3m_hip_fine_mesh(p3m_ctx *ctx, float a_mid, float dt, float mass_p);   /* :72-628 */
+int p3m_hip_coarse_mesh(p3m_ctx *ctx, float a_mid, float dt, float mass_p); /* coarse_mesh.f90 */
+int p3m_hip_delete_particles(p3m_ctx *ctx, const float *move_back);        /* delete_particles.f90 */
+int p3m_hip_get_step_out(p3m_ctx *ctx, float a_mid, p3m_step_out *out);
+
+/* -- mesh-level probes for parity tests and the roofline benchmark ----------------------- */
+/* One tile's density after deposit, reference layout rho_f(nf_tile+2, nf_tile, nf_tile)
+   (particle_mesh_threaded.f90:100-164). Requires p3m_hip_link_list_and_pass first. */
+int p3m_hip_probe_tile_density(p3m_ctx *ctx, int32_t tile_x, int32_t tile_y, int32_t tile_z,
+                               float mass_p, float *rho_f);
+/* One tile's force_f(3, nf_buf-1:nf_tile-nf_buf+1, ...) from a given density (:176-204). */
+int p3m_hip_probe_tile_force(p3m_ctx *ctx, const float *rho_f, float *force_f, float *force_max2);
+/* Local coarse density rho_c(nc_node_dim^3) (coarse_mass.f90) and force_c(3,0:ncn+1,...) */
+int p3m_hip_probe_coarse(p3m_ctx *ctx, float mass_p, float *rho_c, float *force_c);
+/* In-place 3-D r2c / c2r of a host array in the reference layout (nf+2, nf, nf) through the
+   library's FFT: dir=+1 forward (fftw2.f90:19), dir=-1 inverse incl. 1/n^3 (fftw2.f90:21-22). */
+int p3m_hip_fft3d(p3m_ctx *ctx, float *data, int32_t n, int32_t dir);
+/* Fine-mesh sweep over all tiles `reps` times with device-resident inputs, timed with HIP
+   events on the library's stream; returns average milliseconds per sweep (benchmark leg). */
+int p3m_hip_time_fine_sweep(p3m_ctx *ctx, float mass_p, int32_t reps, float *ms_per_sweep);
+/* HIP stream the kernels are launched on (for hipEvent timing by the host). */
+void *p3m_hip_stream(p3m_ctx *ctx);
+
+/* -- F77-ABI one-call wrapper in the style of pp_force_c_ (nbody-ueli.cu:368) ------------ */
+/* Single-rank hosts: uploads xv/PID, runs the step, downloads, returns the four dt limits.
+   handle: integer(8) holding the context (0 on first call: created from params and the
+   kernel tables; pass it back on later calls). */
+void particle_mesh_hip_(int64_t *handle, const p3m_params *params,
+                        const float *fine_table, const float *coarse_table,
+                        float *xv, int64_t *pid, int32_t *np_local,
+                        const float *a_mid, const float *dt, const float *dt_old,
+                        const float *mass_p, const float *offset, const float *move_back,
+                        float *dt_f_acc, float *dt_pp_acc, float *dt_pp_ext_acc,
+                        float *dt_c_acc, int32_t *ierr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3M_HIP_H */

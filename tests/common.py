@@ -1,0 +1,70 @@
+"""Shared synthetic inputs and comparison helpers for the parity tests."""
+from __future__ import annotations
+
+import numpy as np
+
+from cubep3m_amd.kernels import default_tables
+from cubep3m_amd.params import Params
+
+FINE_TABLE, COARSE_TABLE = default_tables()
+
+
+def cfg1(**kw):
+    """BASELINE config 1: 64^3 fine / 32^3 particles, nf_tile=80, 2^3 tiles, one rank."""
+    d = dict(nodes_dim=1, tiles_node_dim=2, nf_tile=80, cores=2, ngp=True)
+    d.update(kw)
+    return Params(**d)
+
+
+def uniform_particles(n, box, seed=12345):
+    """(A) uniform: SURVEY Appendix C input -- default_rng(seed).random((N,3),float32)*box, clipped."""
+    x = np.random.default_rng(seed).random((n, 3), dtype=np.float32) * np.float32(box)
+    x = np.minimum(x, np.float32(box - 1e-4 * box / 64.0)).astype(np.float32)
+    xv = np.zeros((n, 6), np.float32)
+    xv[:, :3] = x
+    return xv
+
+
+def grid_jitter_particles(nside, box, seed=777, sigma=0.3):
+    """(B) grid+jitter: grid_ic (particle_initialization.f90:38-51) + N(0,sigma) displacement."""
+    g = (np.arange(nside, dtype=np.float32) * np.float32(box / nside) + np.float32(0.5))
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    pos = np.stack([x.ravel(), y.ravel(), z.ravel()], 1)
+    pos = pos + np.random.default_rng(seed).normal(0, sigma, pos.shape).astype(np.float32)
+    pos = np.mod(pos, np.float32(box)).astype(np.float32)
+    pos = np.minimum(pos, np.float32(box * (1 - 2e-6))).astype(np.float32)
+    xv = np.zeros((len(pos), 6), np.float32)
+    xv[:, :3] = pos
+    return xv
+
+
+def clustered_particles(n, box, seed=2024, frac=0.3, nblobs=48, sigma=0.6, vel_sigma=0.0):
+    """(C) clustered: `frac` of the particles in Gaussian blobs (stress for PP / atomics)."""
+    rng = np.random.default_rng(seed)
+    nb = int(frac * n)
+    pos = rng.random((n, 3)) * box
+    centers = rng.random((nblobs, 3)) * box
+    which = rng.integers(0, nblobs, nb)
+    pos[:nb] = centers[which] + rng.normal(0, sigma, (nb, 3))
+    pos = np.mod(pos, box).astype(np.float32)
+    pos = np.minimum(pos, np.float32(box * (1 - 2e-6))).astype(np.float32)
+    xv = np.zeros((n, 6), np.float32)
+    xv[:, :3] = pos
+    if vel_sigma:
+        xv[:, 3:] = rng.normal(0, vel_sigma, (n, 3)).astype(np.float32)
+    return xv
+
+
+def by_pid(xv, pid):
+    o = np.argsort(pid, kind="stable")
+    return xv[o], pid[o]
+
+
+def rms(a):
+    a = np.asarray(a, np.float64)
+    return float(np.sqrt((a ** 2).mean()))
+
+
+def rel_rms(test, ref):
+    """rms(|test-ref|)/rms(|ref|) -- the parity metric of SURVEY section 8d."""
+    return rms(np.asarray(test, np.float64) - np.asarray(ref, np.float64)) / max(rms(ref), 1e-300)

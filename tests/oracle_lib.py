@@ -1,0 +1,191 @@
+"""TEST INFRASTRUCTURE: ctypes binding of oracle/_build/libp3m_oracle.so (the CPU restatement).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from cubep3m_amd.params import P3MParams, P3MStepOut, Params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "_build", "libp3m_oracle.so")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+
+def build():
+    src = os.path.join(ROOT, "oracle", "p3m_oracle.c")
+    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(P3MParams)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_derived.restype = C.c_int64
+        L.orc_derived.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fine_kernel.argtypes = [C.c_void_p, f32p]
+        L.orc_coarse_kernel.argtypes = [C.c_void_p, f32p]
+        L.orc_kern_f.restype = C.POINTER(C.c_float)
+        L.orc_kern_f.argtypes = [C.c_void_p]
+        L.orc_kern_c.restype = C.POINTER(C.c_float)
+        L.orc_kern_c.argtypes = [C.c_void_p]
+        L.orc_set_particles.argtypes = [C.c_void_p, C.c_int, f32p, C.c_void_p, C.c_int]
+        L.orc_get_np.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_particles.argtypes = [C.c_void_p, C.c_int, f32p, i64p]
+        L.orc_update_position.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.orc_link_list.argtypes = [C.c_void_p]
+        L.orc_particle_pass.argtypes = [C.c_void_p]
+        L.orc_fine_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_coarse_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_move_grid_back.argtypes = [C.c_void_p, f32p]
+        L.orc_delete_particles.argtypes = [C.c_void_p]
+        L.orc_step_out.argtypes = [C.c_void_p, C.c_float, C.POINTER(P3MStepOut)]
+        L.orc_particle_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(P3MStepOut)]
+        L.orc_tile_density.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, f32p]
+        L.orc_tile_force.argtypes = [C.c_void_p, f32p, f32p, C.POINTER(C.c_float)]
+        L.orc_coarse_density.argtypes = [C.c_void_p, C.c_float]
+        L.orc_rho_c.restype = C.POINTER(C.c_float)
+        L.orc_rho_c.argtypes = [C.c_void_p, C.c_int]
+        L.orc_force_c.restype = C.POINTER(C.c_float)
+        L.orc_force_c.argtypes = [C.c_void_p, C.c_int]
+        L.orc_coarse_force.argtypes = [C.c_void_p]
+        L.orc_fft3d.argtypes = [f32p, C.c_int, C.c_int]
+        L.orc_fft3d_rect.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _vec3(v):
+    if v is None:
+        return None
+    a = np.ascontiguousarray(v, np.float32)
+    return a.ctypes.data_as(C.c_void_p), a
+
+
+class Oracle:
+    """All nodes_dim^3 ranks of the reference simulated in one process."""
+
+    def __init__(self, params: Params):
+        self.p = params
+        self.L = lib()
+        self._cp = params.to_c()
+        self.h = self.L.orc_create(C.byref(self._cp))
+        assert self.h
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # kernels
+    def set_kernel_tables(self, fine, coarse):
+        self.L.orc_fine_kernel(self.h, np.ascontiguousarray(fine, np.float32))
+        self.L.orc_coarse_kernel(self.h, np.ascontiguousarray(coarse, np.float32))
+
+    def kern_f(self):
+        nf = self.p.nf_tile
+        return np.ctypeslib.as_array(self.L.orc_kern_f(self.h), shape=(nf, nf, nf // 2 + 1, 3)).copy()
+
+    def kern_c(self):
+        nc = self.p.nc_dim
+        return np.ctypeslib.as_array(self.L.orc_kern_c(self.h), shape=(nc, nc, nc // 2 + 1, 3)).copy()
+
+    # particles
+    def set_particles(self, rank, xv, pid=None):
+        xv = np.ascontiguousarray(xv, np.float32)
+        pp = None if pid is None else np.ascontiguousarray(pid, np.int64).ctypes.data_as(C.c_void_p)
+        r = self.L.orc_set_particles(self.h, rank, xv, pp, len(xv))
+        assert r == 0, "oracle capacity (max_np) exceeded"
+
+    def get_particles(self, rank=0):
+        n = self.L.orc_get_np(self.h, rank)
+        xv = np.empty((n, 6), np.float32)
+        pid = np.empty(n, np.int64)
+        self.L.orc_get_particles(self.h, rank, xv, pid)
+        return xv, pid
+
+    # phases
+    def update_position(self, dt, dt_old, offset=None):
+        o = _vec3(offset)
+        self.L.orc_update_position(self.h, dt, dt_old, o[0] if o else None)
+
+    def link_list(self):
+        self.L.orc_link_list(self.h)
+
+    def particle_pass(self):
+        return self.L.orc_particle_pass(self.h)
+
+    def fine_mesh(self, a_mid, dt, mass_p):
+        self.L.orc_fine_mesh(self.h, a_mid, dt, mass_p)
+
+    def coarse_mesh(self, a_mid, dt, mass_p):
+        self.L.orc_coarse_mesh(self.h, a_mid, dt, mass_p)
+
+    def delete_particles(self):
+        self.L.orc_delete_particles(self.h)
+
+    def step_out(self, a_mid=1.0):
+        o = P3MStepOut()
+        self.L.orc_step_out(self.h, a_mid, C.byref(o))
+        return o
+
+    def particle_mesh(self, a_mid, dt, dt_old, mass_p, offset=None, move_back=None):
+        o = P3MStepOut()
+        of, mb = _vec3(offset), _vec3(move_back)
+        r = self.L.orc_particle_mesh(self.h, a_mid, dt, dt_old, mass_p, of[0] if of else None, mb[0] if mb else None, C.byref(o))
+        assert r == 0, f"oracle particle_mesh failed {r}"
+        return o
+
+    # probes
+    def tile_density(self, rank, tile, mass_p):
+        nf = self.p.nf_tile
+        rho = np.empty((nf, nf, nf + 2), np.float32)
+        self.L.orc_tile_density(self.h, rank, tile[0], tile[1], tile[2], mass_p, rho)
+        return rho
+
+    def tile_force(self, rho):
+        pt = self.p.nf_physical_tile_dim
+        f = np.empty((pt + 3, pt + 3, pt + 3, 3), np.float32)
+        m = C.c_float()
+        self.L.orc_tile_force(self.h, np.ascontiguousarray(rho, np.float32), f, C.byref(m))
+        return f, m.value
+
+    def coarse_density(self, mass_p):
+        self.L.orc_coarse_density(self.h, mass_p)
+
+    def rho_c(self, rank=0):
+        n = self.p.nc_node_dim
+        return np.ctypeslib.as_array(self.L.orc_rho_c(self.h, rank), shape=(n, n, n)).copy()
+
+    def force_c(self, rank=0):
+        n = self.p.nc_node_dim + 2
+        return np.ctypeslib.as_array(self.L.orc_force_c(self.h, rank), shape=(n, n, n, 3)).copy()
+
+    def coarse_force(self):
+        self.L.orc_coarse_force(self.h)
+
+
+def fft3d(a, n, direction):
+    a = np.ascontiguousarray(a, np.float32)
+    lib().orc_fft3d(a, n, direction)
+    return a

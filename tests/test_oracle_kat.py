@@ -1,0 +1,110 @@
+"""Known-answer tests that pin the oracle end to end.
+
+The reference has no golden vectors.  The values below were RECORDED FROM A RUN
+OF THE REFERENCE FORTRAN ITSELF during the survey (flang build of the unmodified sources with MKL
+standing in for the absent FFTW 2.1.5) on inputs that are exactly
+reproducible here: `default_rng(12345).random((32768,3),float32)*64`, mass_p=8, a_mid=0.005,
+dt=0.2, dt_old=0, v=0, config 1 geometry (nf_tile=80, 2^3 tiles, nc=16), no LRCKCORR, no shake.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from common import COARSE_TABLE, FINE_TABLE, cfg1, rms, uniform_particles
+
+
+@pytest.fixture(scope="module")
+def ngp_run():
+    o = ol.Oracle(cfg1(ngp=True))
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    xv = uniform_particles(32768, 64.0)
+    o.set_particles(0, xv)
+    out = o.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    xo, pid = o.get_particles(0)
+    return o, xv, xo[np.argsort(pid)], out
+
+
+def test_kernel_samples_match_reference_run(ngp_run):
+    o = ngp_run[0]
+    kf, kc = o.kern_f(), o.kern_c()  # [k][j][i][c]
+    # kern_f(1,2,1,1)=kern_f(2,1,2,1)=kern_f(3,1,1,2)=20.61798, kern_f(1,5,3,2)=31.44519
+    assert kf[0, 0, 1, 0] == pytest.approx(20.61798, abs=2e-5)
+    assert kf[0, 1, 0, 1] == pytest.approx(20.61798, abs=2e-5)
+    assert kf[1, 0, 0, 2] == pytest.approx(20.61798, abs=2e-5)
+    assert kf[1, 2, 4, 0] == pytest.approx(31.44519, abs=2e-5)
+    assert np.abs(kf).max() == pytest.approx(41.24, abs=5e-3)
+    assert np.abs(kc).max() == pytest.approx(2.059, abs=5e-4)
+
+
+def test_pm_only_ngp_matches_reference_run(ngp_run):
+    _, xv, xo, out = ngp_run
+    assert out.dt_f_acc == pytest.approx(9.564716, rel=2e-6)   # oracle run printed 9.564716
+    assert out.dt_c_acc == pytest.approx(61.18163, rel=2e-6)   # 61.18163
+    assert out.sum_rho_f == 262144.0                           # "sum of rho_f = 262144."
+    assert out.sum_rho_c == pytest.approx(262144.0, rel=1e-7)
+    assert out.np_total == 32768
+    assert np.array_equal(xo[:, :3], xv[:, :3])                # dt_old=0, v=0: positions unchanged
+    # per-component rms of the kick: 3.453e-4
+    assert rms(xo[:, 3:]) == pytest.approx(3.453e-4, rel=5e-4)
+
+
+def test_pm_only_cic_matches_reference_run():
+    o = ol.Oracle(cfg1(ngp=False))
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    o.set_particles(0, uniform_particles(32768, 64.0))
+    out = o.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    xo, _ = o.get_particles(0)
+    assert out.dt_f_acc == pytest.approx(10.741141, rel=2e-6)
+    assert out.sum_rho_f == pytest.approx(262144.00002, abs=2e-5)
+    assert rms(xo[:, 3:]) == pytest.approx(2.657e-4, rel=5e-4)
+
+
+# --- pair force: report_pair.f90:50-63, F = -G r/r^3, G = 1/(6 pi); envelope of the reference itself
+#     (SURVEY.md "Pair-force envelope"): exactly 0 below rsoft, Newtonian to 1e-4 inside the PP range.
+def _pair_ratio(r, seed):
+    rng = np.random.default_rng(seed)
+    p = cfg1(ngp=True, ppint=True, pp_ext=True)
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    c = rng.random(3) * 40 + 12
+    u = rng.normal(size=3)
+    u /= np.linalg.norm(u)
+    xv = np.zeros((2, 6), np.float32)
+    xv[0, :3] = c - 0.5 * r * u
+    xv[1, :3] = c + 0.5 * r * u
+    o.set_particles(0, xv)
+    mass, a_mid, dt = 10000.0, 1.0, 1.0  # particle_initialization.f90:388, timestep.f90:200-217
+    o.particle_mesh(a_mid, dt, 0.0, mass)
+    xo, pid = o.get_particles(0)
+    xo = xo[np.argsort(pid)]
+    sep = (xv[0, :3] - xv[1, :3]).astype(np.float64)
+    rr = np.linalg.norm(sep)
+    G = 1.0 / 6.0 / 3.141592654
+    newton = G * mass * a_mid * dt / rr ** 2
+    radial = -np.dot(xo[0, 3:], sep / rr)  # attraction: particle 0 moves towards 1, i.e. along -sep
+    tang = np.linalg.norm(xo[0, 3:] + radial * sep / rr)
+    return radial / newton, tang / newton, xo
+
+
+@pytest.mark.parametrize("r", [0.3, 0.7, 1.0, 1.5, 2.0])
+def test_pair_force_is_newtonian_inside_pp_range(r):
+    for s in range(3):
+        ratio, tang, xo = _pair_ratio(r, 10 * s + int(10 * r))
+        assert ratio == pytest.approx(1.0, abs=3e-4), (r, ratio)
+        assert tang < 3e-4
+        assert np.allclose(xo[0, 3:], -xo[1, 3:], rtol=0, atol=2e-4 * np.abs(xo[0, 3:]).max())  # momentum
+
+
+def test_pair_force_vanishes_below_rsoft():
+    ratio, tang, xo = _pair_ratio(0.05, 3)
+    # inside one fine cell and r <= rsoft: no PP force; the mesh force of a cell on itself is zero
+    assert abs(ratio) < 1e-6 and tang < 1e-6
+
+
+# Outside the PP range the single-step NGP mesh force scatters with the sub-cell position (the
+# reference's own samples: 0.82-0.92 at r=4, 0.96-1.03 at r=8, 0.94-1.18 at r=12..16, 0.995-1.006 at
+# r=20, 1.0001-1.0011 at r=28); NGP bounds it by (r/(r-sqrt3))^2 .. (r/(r+sqrt3))^2.
+@pytest.mark.parametrize("r,lo,hi", [(4.0, 0.45, 3.2), (8.0, 0.65, 1.65), (20.0, 0.96, 1.04), (28.0, 0.99, 1.01)])
+def test_pair_force_mesh_envelope(r, lo, hi):
+    ratios = [_pair_ratio(r, 7 * s + int(r))[0] for s in range(3)]
+    assert all(lo <= q <= hi for q in ratios), ratios
