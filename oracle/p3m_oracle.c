@@ -889,6 +889,7 @@ void orc_coarse_density(orc_ctx *c, float mass_p) {
   }
 }
 
+void orc_distribute_force(orc_ctx *c, const float *fg);
 /* coarse_force.f90:18-90 + fftw3ds.f90 (cube<->slab is the identity once all ranks live in one
    address space) + coarse_force_buffer.f90:19-63 (periodic halo from the neighbour cubes) */
 void orc_coarse_force(orc_ctx *c) {
@@ -916,7 +917,16 @@ void orc_coarse_force(orc_ctx *c) {
       fg[(((size_t)(k - 1) * nc + (j - 1)) * nc + (i - 1)) * 3 + (cc - 1)] = SL(slab, i, j, k);
   }
 #undef SL
-  /* force_c(:,0:ncn+1,...) = own cube (coarse_force.f90:52) + 1-cell periodic halo (coarse_force_buffer.f90) */
+  (void)nd;
+  orc_distribute_force(c, fg);
+  free(slab); free(cr); free(fg);
+}
+
+/* force_c(:,0:ncn+1,...) = own cube (coarse_force.f90:52,71,90) + the 1-cell periodic halo that the six
+   mpi_sendrecv_replace calls of coarse_force_buffer.f90:19-63 deliver (x, then y incl. x-halo, then z:
+   edges and corners arrive too).  fg: global (3,nc,nc,nc), component fastest. */
+void orc_distribute_force(orc_ctx *c, const float *fg) {
+  int nc = c->nc_dim, ncn = c->nc_node_dim;
   for (int rk = 0; rk < c->nodes; rk++) {
     orc_rank *R = &c->r[rk]; int ox = R->cart[2] * ncn, oy = R->cart[1] * ncn, oz = R->cart[0] * ncn;
     for (int k = 0; k <= ncn + 1; k++) for (int j = 0; j <= ncn + 1; j++) for (int i = 0; i <= ncn + 1; i++) {
@@ -924,12 +934,10 @@ void orc_coarse_force(orc_ctx *c) {
       for (int cc = 1; cc <= 3; cc++) FC(R, cc, i, j, k) = fg[(((size_t)gk * nc + gj) * nc + gi) * 3 + (cc - 1)];
     }
   }
-  (void)nd;
-  free(slab); free(cr); free(fg);
 }
 
 /* coarse_max_dt.f90:17-37 and coarse_velocity.f90:137-179 */
-static void coarse_max_dt_and_velocity(orc_ctx *c, float a_mid, float dt) {
+void orc_coarse_max_dt_and_velocity(orc_ctx *c, float a_mid, float dt) {
   int ncn = c->nc_node_dim, ms = c->p.mesh_scale;
   float gmax = 0.f;
   for (int rk = 0; rk < c->nodes; rk++) {
@@ -969,7 +977,7 @@ void orc_coarse_mesh(orc_ctx *c, float a_mid, float dt, float mass_p) {   /* coa
   for (int rk = 0; rk < c->nodes; rk++) for (size_t i = 0; i < (size_t)ncn * ncn * ncn; i++) s += (double)c->r[rk].rho_c[i];
   c->sum_rho_c = s;
   orc_coarse_force(c);
-  coarse_max_dt_and_velocity(c, a_mid, dt);
+  orc_coarse_max_dt_and_velocity(c, a_mid, dt);
 }
 
 /* move_grid_back.f90:17-24 */

@@ -63,6 +63,8 @@ def lib():
         L.orc_force_c.restype = C.POINTER(C.c_float)
         L.orc_force_c.argtypes = [C.c_void_p, C.c_int]
         L.orc_coarse_force.argtypes = [C.c_void_p]
+        L.orc_distribute_force.argtypes = [C.c_void_p, f32p]
+        L.orc_coarse_max_dt_and_velocity.argtypes = [C.c_void_p, C.c_float, C.c_float]
         L.orc_fft3d.argtypes = [f32p, C.c_int, C.c_int]
         L.orc_fft3d_rect.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
@@ -183,6 +185,13 @@ class Oracle:
 
     def coarse_force(self):
         self.L.orc_coarse_force(self.h)
+
+    def distribute_force(self, fg):
+        """fg: global coarse force [k][j][i][3] -> every rank's force_c incl. halo."""
+        self.L.orc_distribute_force(self.h, np.ascontiguousarray(fg, np.float32))
+
+    def coarse_max_dt_and_velocity(self, a_mid, dt):
+        self.L.orc_coarse_max_dt_and_velocity(self.h, a_mid, dt)
 
 
 def fft3d(a, n, direction):

@@ -1,0 +1,66 @@
+"""Oracle vs the committed golden fixtures (tests/golden/ref_stages_*.npz), which hold outputs of the
+REFERENCE'S OWN OBJECT CODE for the FFT-free stages (generator: tests/golden/make_ref_fixtures.py).
+Runs anywhere (no /root/reference, no oracle/_ref needed).  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from common import cfg1
+from ref_stage_run import synth_force_c
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def dense(d, key, shape):
+    a = np.zeros(int(np.prod(shape)), np.float32)
+    a[d[key + "_idx"]] = d[key + "_val"]
+    return a.reshape(shape)
+
+
+@pytest.mark.parametrize("nd", [1, 2])
+def test_oracle_reproduces_reference_stage_outputs(nd):
+    d = np.load(os.path.join(G, "ref_stages_%drank.npz" % (nd ** 3)))
+    a_mid, dt, dt_old, mass_p = (float(v) for v in d["scal"])
+    tiles = [tuple(int(x) for x in t) for t in d["tiles"]]
+    nr = nd ** 3
+    key = (lambda r, k: k) if nd == 1 else (lambda r, k: "r%d_%s" % (r, k))
+    for ngp in (True, False):
+        p = cfg1(nodes_dim=nd, ngp=ngp)
+        o = ol.Oracle(p)
+        for r in range(nr):
+            o.set_particles(r, d[key(r, "xv_in")], d[key(r, "pid_in")])
+        o.update_position(dt, dt_old)
+        o.link_list()
+        assert o.particle_pass() == 0
+        nf = p.nf_tile
+        for r in range(nr):
+            x, q = o.get_particles(r)
+            assert np.array_equal(x, d[key(r, "xv_passed")])
+            if nd == 1:
+                assert np.array_equal(q, d["pid_passed"])
+            for t in tiles:
+                name = ("rho_ngp_%d%d%d" if ngp else "rho_cic_%d%d%d") % t
+                assert np.array_equal(o.tile_density(r, t, mass_p), dense(d, key(r, name), (nf, nf, nf + 2)))
+        o.coarse_density(mass_p)
+        for r in range(nr):
+            assert np.array_equal(o.rho_c(r), d[key(r, "rho_c")])
+    ncn, nc = p.nc_node_dim, p.nc_dim
+    fg = np.zeros((nc, nc, nc, 3), np.float32)
+    for r in range(nr):
+        c1, c2, c3 = r // (nd * nd), (r // nd) % nd, r % nd
+        fg[c1 * ncn:(c1 + 1) * ncn, c2 * ncn:(c2 + 1) * ncn, c3 * ncn:(c3 + 1) * ncn] = synth_force_c(ncn, r)
+    o.distribute_force(fg)
+    for r in range(nr):
+        assert np.array_equal(o.force_c(r), d[key(r, "force_c_halo")])
+    o.coarse_max_dt_and_velocity(a_mid, dt)
+    assert o.step_out().dt_c_acc == d[key(0, "dt_c_acc")]
+    for r in range(nr):
+        assert np.array_equal(o.get_particles(r)[0], d[key(r, "xv_kicked")])
+    o.delete_particles()
+    for r in range(nr):
+        x, q = o.get_particles(r)
+        assert np.array_equal(x, d[key(r, "xv_final")])
+        if nd == 1:
+            assert np.array_equal(q, d["pid_final"])
