@@ -1,0 +1,229 @@
+// coarse_mesh.hip -- long-range force on the mesh_scale-times coarser global mesh (coarse_mesh.f90):
+//   coarse_mass.f90 + coarse_cic_mass(.f90|_buffer.f90) -> k_coarse_deposit (gather, no atomics to HBM)
+//   coarse_force.f90 + fftw3ds.f90 (single rank: cube == slab)      -> coarse_force
+//   coarse_force_buffer.f90 (periodic 1-cell halo)                   -> k_coarse_unpack
+//   coarse_max_dt.f90                                                -> k_coarse_max
+//   coarse_velocity.f90:137-179                                      -> k_coarse_kick
+//   coarse_kernel (kernel_initialization.f90:272-732)                -> build_coarse_kernel
+#include "p3m_internal.h"
+#include <algorithm>
+
+struct CGeo { int nb, E, Nn, ms, ncn, nc; };
+
+// One 64-lane workgroup per coarse output row (J,K).  A particle's CIC footprint is the cells
+// i1 = floor(x/ms - 0.5) + 1 and i1+1 per axis (coarse_cic_mass.f90:18-21), clipped to 1..ncn
+// (coarse_cic_mass_buffer.f90:59-113); row J (0-based) is fed by particles with j1 in {J, J+1}
+// (1-based), which lie in the 2*ms fine cell rows [ms*J - ms/2, ms*J + 3*ms/2).
+__global__ __launch_bounds__(64) void k_coarse_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho_c, CGeo G,
+                                                       float mass_p, double *__restrict__ sum_out) {
+  extern __shared__ float row[];
+  const int J = blockIdx.x % G.ncn, K = blockIdx.x / G.ncn;
+  for (int i = threadIdx.x; i < G.ncn; i += 64) row[i] = 0.f;
+  __syncthreads();
+  const int h = G.ms / 2;
+  const float inv = 1.0f / (float)G.ms;
+  const int xlo = G.nb - G.ms, xhi = G.nb + G.Nn + G.ms;  // chains hoc(0:ncn+1) only (coarse_mass.f90:85-87)
+  for (int fz = G.ms * K - h; fz < G.ms * K + 3 * h; fz++)
+    for (int fy = G.ms * J - h; fy < G.ms * J + 3 * h; fy++) {
+      const int64_t rb = ((int64_t)(fz + G.nb) * G.E + (fy + G.nb)) * G.E;
+      const int p0 = cs[rb + xlo], p1 = cs[rb + xhi];
+      for (int s = p0 + threadIdx.x; s < p1; s += 64) {
+        const float4 p = spos[s];
+        const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;     // coarse_cic_mass.f90:18
+        const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;  // 1-based
+        float dx1 = (float)i1 - x, dy1 = (float)j1 - y, dz1 = (float)k1 - z;
+        float dx2 = 1.0f - dx1; const float dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+        float wy, wz;
+        if (j1 == J + 1) wy = dy1; else if (j1 == J) wy = dy2; else continue;
+        if (k1 == K + 1) wz = dz1; else if (k1 == K) wz = dz2; else continue;
+        dx1 = mass_p * dx1; dx2 = mass_p * dx2;                                             // :32-33
+        if (i1 >= 1 && i1 <= G.ncn) atomicAdd(&row[i1 - 1], dx1 * wy * wz);
+        if (i1 + 1 >= 1 && i1 + 1 <= G.ncn) atomicAdd(&row[i1], dx2 * wy * wz);
+      }
+    }
+  __syncthreads();
+  float part = 0.f;
+  for (int i = threadIdx.x; i < G.ncn; i += 64) { const float v = row[i]; rho_c[((int64_t)K * G.ncn + J) * G.ncn + i] = v; part += v; }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+  if (threadIdx.x == 0 && sum_out) atomicAdd(sum_out, (double)part);                        // coarse_mesh.f90:31-43
+}
+
+int coarse_deposit(p3m_ctx *c, float mass_p) {
+  const Geometry &g = c->g;
+  CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc};
+  hipLaunchKernelGGL(k_coarse_deposit, dim3(g.ncn * g.ncn), dim3(64), sizeof(float) * g.ncn, c->stream, (const float4 *)c->spos,
+                     (const int *)c->cell_end, c->rho_c, G, mass_p, c->d_sums + 1);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// cube -> slab (pack_slab, fftw3ds.f90:4-54); single rank: a pitch change only
+__global__ __launch_bounds__(256) void k_cube_to_slab(const float *__restrict__ cube, float *__restrict__ slab, int n) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tot = (int64_t)n * n * (n + 2);
+  if (idx >= tot) return;
+  const int i = (int)(idx % (n + 2)); const int64_t r = idx / (n + 2);
+  slab[idx] = (i < n) ? cube[r * n + i] : 0.f;
+}
+// slab -> force_c(comp, 0:ncn+1, ...) with the periodic 1-cell halo (unpack_slab + coarse_force_buffer.f90)
+__global__ __launch_bounds__(256) void k_slab_to_force(const float *__restrict__ slab, float *__restrict__ fc, int n) {
+  const int m = n + 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)m * m * m) return;
+  const int i = (int)(idx % m), j = (int)((idx / m) % m), k = (int)(idx / ((int64_t)m * m));
+  const int gi = (i - 1 + n) % n, gj = (j - 1 + n) % n, gk = (k - 1 + n) % n;
+  fc[idx] = slab[((int64_t)gk * n + gj) * (n + 2) + gi];
+}
+// coarse_max_dt.f90:24-31
+__global__ __launch_bounds__(256) void k_coarse_max(const float *__restrict__ fc, int n, float *__restrict__ out) {
+  const int m = n + 2; const int64_t cs = (int64_t)m * m * m;
+  float mx = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)n * n * n; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx % n), j = (int)((idx / n) % n), k = (int)(idx / ((int64_t)n * n));
+    const int64_t o = ((int64_t)(k + 1) * m + (j + 1)) * m + (i + 1);
+    const float a = fc[o], b = fc[o + cs], d = fc[o + 2 * cs];
+    mx = fmaxf(mx, sqrtf(a * a + b * b + d * d));
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(mx));
+}
+
+int coarse_force(p3m_ctx *c) {
+  const Geometry &g = c->g;
+  if (g.nodes != 1) { p3m_set_error("coarse_force: multi-rank path needs the slab transport"); return P3M_ECOMM; }
+  const int n = g.nc;
+  const int64_t tot = (int64_t)n * n * (n + 2);
+  hipLaunchKernelGGL(k_cube_to_slab, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, (const float *)c->rho_c, c->slab, n);
+  HIP_TRY(hipGetLastError());
+  P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));                                          // coarse_force.f90:18
+  const size_t kplane = (size_t)n * n * (n / 2 + 1);
+  const int64_t fcs = (int64_t)(n + 2) * (n + 2) * (n + 2);
+  for (int comp = 0; comp < 3; comp++) {
+    P3M_TRY(fft3d_inverse(c, c->plan_c, c->slab_w, 1, c->slab, c->kern_c + comp * kplane));  // :37-50
+    hipLaunchKernelGGL(k_slab_to_force, dim3(cdiv(fcs, 256)), dim3(256), 0, c->stream, (const float *)c->slab_w, c->force_c + comp * fcs, n);
+    HIP_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_coarse_max, dim3(std::min<int64_t>(1024, cdiv((int64_t)n * n * n, 256))), dim3(256), 0, c->stream, (const float *)c->force_c,
+                     n, c->d_red + 2);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// coarse_velocity.f90:137-179: CIC gather of force_c (with halo) at x/ms - 0.5, particles of hoc(1..ncn)
+__global__ __launch_bounds__(256) void k_coarse_kick(const float4 *__restrict__ spos, float4 *__restrict__ svel, int n, CGeo G,
+                                                     const float *__restrict__ fc, float a_mid, float dt) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const float4 p = spos[s];
+  const float fNn = (float)G.Nn;
+  if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) return;
+  const float inv = 1.0f / (float)G.ms;
+  const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;             // :143
+  const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;
+  const float dx1 = (float)i1 - x, dy1 = (float)j1 - y, dz1 = (float)k1 - z;
+  const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+  const int m = G.ncn + 2; const int64_t cs = (int64_t)m * m * m;
+  float4 v = svel[s];
+#pragma unroll
+  for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+    for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+      for (int cx = 0; cx < 2; cx++) {                                                        // :153-168
+        const float dV = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
+        const int64_t o = ((int64_t)(k1 + cz) * m + (j1 + cy)) * m + (i1 + cx);
+        v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + cs] * dV; v.z = v.z + fc[o + 2 * cs] * dV;
+      }
+  svel[s] = v;
+}
+
+int coarse_kick(p3m_ctx *c, float a_mid, float dt) {
+  const Geometry &g = c->g;
+  if (c->np_all == 0) return P3M_OK;
+  CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc};
+  hipLaunchKernelGGL(k_coarse_kick, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G,
+                     (const float *)c->force_c, a_mid, dt);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ coarse_kernel (kernel_initialization.f90:272-732), single rank
+// ck = -r/r^3 on the mesh_scale-spaced periodic lattice (:302-336), the 4^3 corner and its signed
+// mirror images from the table (:366-406): component d flips sign when axis d is mirrored.
+__global__ __launch_bounds__(256) void k_coarse_kernel_real(float *__restrict__ slab, const float *__restrict__ table, int n, int ms, int comp,
+                                                            int use_table) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tot = (int64_t)n * n * (n + 2);
+  if (idx >= tot) return;
+  const int i = (int)(idx % (n + 2)); const int64_t r = idx / (n + 2); const int j = (int)(r % n), k = (int)(r / n);
+  float v = 0.f;
+  if (i < n) {
+    const int c3[3] = {i, j, k};
+    float xs[3]; int t3[3]; bool in_table = use_table != 0; float sgn = 1.f;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const float w = (c3[d] < n / 2 + 1) ? (float)c3[d] : (float)(c3[d] - n);                // :304-308
+      xs[d] = (float)ms * w;
+      if (c3[d] < 4) t3[d] = c3[d];
+      else if (c3[d] > n - 4) { t3[d] = n - c3[d]; if (d == comp) sgn = -sgn; }
+      else in_table = false;
+    }
+    if (in_table) v = sgn * table[(((int64_t)t3[2] * 4 + t3[1]) * 4 + t3[0]) * 3 + comp];
+    else {
+      const float rr = sqrtf(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+      v = (rr == 0.0f) ? 0.f : -xs[comp] / (rr * rr * rr);                                    // :327-333
+    }
+  }
+  slab[idx] = v;
+}
+// LRCKCORR, :562-591: Im K_c <- Im K_c^{corr} * (wc / Im K_c^{uncorr}) for integer |k| <= 8, k_c != 0
+__global__ __launch_bounds__(256) void k_lrck(float *__restrict__ kern, const float *__restrict__ uncorr, int n, int comp) {
+  const int hx = n / 2 + 1;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)n * n * hx) return;
+  const int kx = (int)(idx % hx), j = (int)((idx / hx) % n), k = (int)(idx / ((int64_t)hx * n));
+  const int ky = (j < n / 2 + 1) ? j : j - n, kz = (k < n / 2 + 1) ? k : k - n;
+  const float kr = sqrtf((float)(kx * kx + ky * ky + kz * kz));
+  if (!(kr <= 8.f)) return;
+  const int kk = comp == 0 ? kx : (comp == 1 ? ky : kz);
+  if (kk == 0) return;
+  const float ka = 2 * sinf(P3M_PI_F * kx / (float)n), kb = 2 * sinf(P3M_PI_F * ky / (float)n), kc = 2 * sinf(P3M_PI_F * kz / (float)n);
+  const float kq = comp == 0 ? ka : (comp == 1 ? kb : kc);
+  const float wc = 4.f * P3M_PI_F * kq / (ka * ka + kb * kb + kc * kc) / 16.f;
+  kern[idx] = kern[idx] * (wc / uncorr[idx]);
+}
+__global__ __launch_bounds__(256) void k_take_imag_c(const float *__restrict__ hat, float *__restrict__ kern, int64_t ncomplex) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < ncomplex) kern[i] = hat[2 * i + 1];
+}
+
+int build_coarse_kernel(p3m_ctx *c, const float *table4_host) {
+  const Geometry &g = c->g;
+  if (g.nodes != 1) { p3m_set_error("build_coarse_kernel: multi-rank path needs the slab transport"); return P3M_ECOMM; }
+  const int n = g.nc;
+  float *d_table = nullptr;
+  HIP_TRY(hipMalloc(&d_table, sizeof(float) * 192));
+  HIP_TRY(hipMemcpyAsync(d_table, table4_host, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
+  const int64_t tot = (int64_t)n * n * (n + 2), ncx = (int64_t)n * n * (n / 2 + 1);
+  float *unc = nullptr;
+  const bool lr = (c->p.flags & P3M_FLAG_LRCKCORR) != 0;
+  if (lr) HIP_TRY(hipMalloc(&unc, sizeof(float) * ncx));
+  for (int comp = 0; comp < 3; comp++) {
+    if (lr) {
+      hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, g.ms, comp, 0);
+      P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));
+      hipLaunchKernelGGL(k_take_imag_c, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->slab, unc, ncx);
+    }
+    hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, g.ms, comp, 1);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));
+    hipLaunchKernelGGL(k_take_imag_c, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->slab, c->kern_c + comp * ncx, ncx);
+    if (lr) hipLaunchKernelGGL(k_lrck, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, c->kern_c + comp * ncx, (const float *)unc, n, comp);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  (void)hipFree(d_table);
+  if (unc) (void)hipFree(unc);
+  c->have_kc = true;
+  return P3M_OK;
+}

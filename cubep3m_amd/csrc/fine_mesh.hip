@@ -1,0 +1,248 @@
+// fine_mesh.hip -- per-tile fine particle-mesh force (particle_mesh_threaded.f90:85-319), all tiles
+// of a batch in one launch.
+//
+// Particles are sorted by extended fine cell (particles.hip); cs[c]..cs[c+1] is the record range of
+// cell c, and a whole x-row of cells is one contiguous record range.  Deposits are therefore
+// GATHERS: each output row of a tile is produced by one workgroup from the records of the (up to
+// four) cell rows that can touch it -- no global atomics, no memset, coalesced row stores.
+//
+// Cell assignment follows the reference's fp32 expressions exactly: the fine deposit and kick use
+// floor(xv + offset) with the TILE-dependent real offset = nf_buf - tile*nf_physical_tile_dim
+// (:134,:227,:248-249), which can round a coordinate within half an ulp below an integer up into
+// the next cell.  Since the parity metric (1e-5 relative rms over all particles) does not tolerate
+// even one mis-binned particle, every kernel here recomputes the reference expression per record.
+#include "p3m_internal.h"
+
+int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, int mode, float *box, int fb, int lo);
+int fft3d_inverse_zy(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const float *src, const float *kern);
+
+struct TileGeo { int T, nf, nb, pt, E, fb; };
+
+__device__ __forceinline__ void tile_xyz(int tile, int T, int &tx, int &ty, int &tz) {  // :86-90
+  tz = tile / (T * T); const int r = tile - tz * T * T; ty = r / T; tx = r - ty * T;
+}
+__device__ __forceinline__ float block_sum_f(float v, float *sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0) for (int i = 0; i < nw; i++) s += sh[i];
+  __syncthreads();
+  return s;
+}
+
+// ------------------------------------------------------------------ fine deposit, NGP (:119-151) and CIC (:153-160)
+// One 64-lane workgroup per output row (tile,k,j).  NGP: a record lands in this row iff its
+// tile-local cell (jt,kt) == (j,k); such records live in cell rows {j-1,j}x{k-1,k} (round-up).
+// Window of chains deposited: NGP x_loc in [4,nf-4), CIC x_loc in [0,nf) (cic_l/cic_h, :119-124),
+// membership by coarse cell = exact test on x because the boundaries are multiples of mesh_scale.
+template <bool NGP>
+__global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho,
+                                                     int tile0, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
+  extern __shared__ float row[];  // nf+2 floats
+  const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb;
+  const int j = blockIdx.x % nf, k = (blockIdx.x / nf) % nf, tl = blockIdx.x / (nf * nf);
+  int tx, ty, tz; tile_xyz(tile0 + tl, G.T, tx, ty, tz);
+  for (int i = threadIdx.x; i < nf + 2; i += 64) row[i] = 0.f;
+  __syncthreads();
+  const float offx = (float)(-tx * pt + nb), offy = (float)(-ty * pt + nb), offz = (float)(-tz * pt + nb);  // :134
+  const int wlo = NGP ? 4 : 0, whi = NGP ? nf - 4 : nf;                                                  // window [wlo,whi)
+  const bool row_possible = NGP ? (j >= wlo && j <= whi && k >= wlo && k <= whi) : true;
+  if (row_possible) {
+    for (int dk = -1; dk <= 0; dk++) {
+      const int ks = k + dk; if (ks < wlo || ks >= whi) continue;   // source cell row must be inside the window
+      for (int dj = -1; dj <= 0; dj++) {
+        const int js = j + dj; if (js < wlo || js >= whi) continue;
+        const int64_t rb = ((int64_t)(tz * pt + ks) * E + (ty * pt + js)) * E + tx * pt;
+        const int p0 = cs[rb + wlo], p1 = cs[rb + whi];
+        for (int s = p0 + threadIdx.x; s < p1; s += 64) {
+          const float4 p = spos[s];
+          const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                   // :139
+          const int i1 = (int)floorf(x), j1 = (int)floorf(y), k1 = (int)floorf(z);                     // 0-based (:143 minus 1)
+          if (NGP) {
+            if (j1 == j && k1 == k) atomicAdd(&row[i1], mass_p);                                         // :148
+          } else {
+            // fine_cic_mass.f90:17-43 / fine_cic_mass_buffer.f90:25-53 (clipped to 1..nf)
+            const float dx1 = (float)(i1 + 1) - x, dy1 = (float)(j1 + 1) - y, dz1 = (float)(k1 + 1) - z;
+            const float dx2 = 1.f - dx1, dy2 = 1.f - dy1, dz2 = 1.f - dz1;
+            float wy, wz;
+            if (j1 == j) wy = dy1; else if (j1 + 1 == j) wy = dy2; else continue;
+            if (k1 == k) wz = dz1; else if (k1 + 1 == k) wz = dz2; else continue;
+            const float mx1 = mass_p * dx1, mx2 = mass_p * dx2;                                          // :23-24
+            atomicAdd(&row[i1], mx1 * wy * wz);
+            if (i1 + 1 < nf) atomicAdd(&row[i1 + 1], mx2 * wy * wz);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float *out = rho + ((int64_t)tl * nf * nf + (int64_t)k * nf + j) * (nf + 2);
+  float part = 0.f;
+  const bool interior_row = (j >= nb && j < nf - nb && k >= nb && k < nf - nb);
+  for (int i = threadIdx.x; i < nf + 2; i += 64) {
+    const float v = row[i];
+    out[i] = v;
+    if (interior_row && i >= nb && i < nf - nb) part += v;                                               // :167-173
+  }
+  if (sum_interior) {
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if (threadIdx.x == 0 && interior_row && part != 0.f) atomicAdd(sum_interior, (double)part);
+  }
+}
+
+int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
+  const Geometry &g = c->g;
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb};
+  const unsigned blocks = (unsigned)((int64_t)ntile * g.nf * g.nf);
+  const size_t lds = sizeof(float) * (g.nf + 2);
+  if (c->p.flags & P3M_FLAG_NGP)
+    hipLaunchKernelGGL(k_fine_deposit<true>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
+                       tile0, G, mass_p, c->d_sums);
+  else
+    hipLaunchKernelGGL(k_fine_deposit<false>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
+                       tile0, G, mass_p, c->d_sums);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ :176-204 forward FFT, 3 x (i K_c multiply, inverse FFT, box extract)
+int fine_force(p3m_ctx *c, int tile0, int ntile) {
+  const Geometry &g = c->g;
+  P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, ntile));
+  const size_t kplane = (size_t)g.nf * g.nf * g.hx;
+  const size_t boxsz = (size_t)g.fb * g.fb * g.fb;
+  for (int comp = 0; comp < 3; comp++) {
+    P3M_TRY(fft3d_inverse_zy(c, c->plan_f, c->work, ntile, c->rho, c->kern_f + comp * kplane));
+    float *box = c->fbox + ((size_t)comp * g.ntiles + tile0) * boxsz;
+    P3M_TRY(fft_x_inverse(c, c->plan_f, c->work, ntile, 1, box, g.fb, g.nb - 2));
+  }
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ :208-223 max |F|^2 over every tile's force box
+__global__ __launch_bounds__(256) void k_force_max(const float *__restrict__ fbox, int64_t n, int64_t comp_stride, float *__restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = fbox[i], b = fbox[i + comp_stride], d = fbox[i + 2 * comp_stride];
+    const float f = a * a + b * b + d * d;                                                               // :217-218
+    m = fmaxf(m, f);
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(m));    // m >= 0
+}
+int fine_force_max(p3m_ctx *c) {
+  const Geometry &g = c->g;
+  const int64_t n = (int64_t)g.ntiles * g.fb * g.fb * g.fb;
+  hipLaunchKernelGGL(k_force_max, dim3(std::min<int64_t>(2048, cdiv(n, 256))), dim3(256), 0, c->stream, (const float *)c->fbox, n, n, c->d_red);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ :227-319 gather + kick of the physical particles
+template <bool NGP>
+__global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ spos, float4 *__restrict__ svel, int n, TileGeo G, int Nn, int ms,
+                                                   const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const float4 p = spos[s];
+  const float fNn = (float)Nn;
+  if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) return;  // chains of hoc(1..ncn) only (:234-236)
+  const int nct = G.pt / ms;
+  // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
+  const int tx = ((int)floorf(p.x / (float)ms)) / nct, ty = ((int)floorf(p.y / (float)ms)) / nct, tz = ((int)floorf(p.z / (float)ms)) / nct;
+  const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
+  const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
+  const int lo = G.nb - 2, fb = G.fb;
+  const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
+  const int tile = (tz * G.T + ty) * G.T + tx;
+  const float *f0 = fbox + (int64_t)tile * fb * fb * fb;
+  float4 v = svel[s];
+  if (NGP) {
+    const int64_t o = ((int64_t)k1 * fb + j1) * fb + i1;
+    v.x = v.x + f0[o] * a_mid * P3M_G_F * dt;                                                         // :265-266
+    v.y = v.y + f0[o + comp_stride] * a_mid * P3M_G_F * dt;
+    v.z = v.z + f0[o + 2 * comp_stride] * a_mid * P3M_G_F * dt;
+  } else {
+    const float dx1 = (float)(i1 + lo + 1) - x, dy1 = (float)(j1 + lo + 1) - y, dz1 = (float)(k1 + lo + 1) - z;  // :290
+    const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+#pragma unroll
+    for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+      for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+        for (int cx = 0; cx < 2; cx++) {                                                                // order of :293-316
+          const float dVc = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
+          const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * fb + (i1 + cx);
+          v.x = v.x + f0[o] * dVc; v.y = v.y + f0[o + comp_stride] * dVc; v.z = v.z + f0[o + 2 * comp_stride] * dVc;
+        }
+  }
+  svel[s] = v;
+}
+
+int fine_kick(p3m_ctx *c, float a_mid, float dt) {
+  const Geometry &g = c->g;
+  if (c->np_all == 0) return P3M_OK;
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb};
+  const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fb;
+  if (c->p.flags & P3M_FLAG_NGP)
+    hipLaunchKernelGGL(k_fine_kick<true>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G, g.Nn,
+                       g.ms, (const float *)c->fbox, cs, a_mid, dt);
+  else
+    hipLaunchKernelGGL(k_fine_kick<false>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G, g.Nn,
+                       g.ms, (const float *)c->fbox, cs, a_mid, dt);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ fine_kernel (kernel_initialization.f90:2-267)
+// real-space table mirrored into the nf^3 box (odd along the component's own axis, :69-85),
+// PP_EXT corner zeroed (:38-54); then r2c and keep the imaginary part (:93-99).
+__global__ __launch_bounds__(256) void k_fine_kernel_real(float *__restrict__ rho, const float *__restrict__ table, int nf, int ncut, int comp,
+                                                          int zero_corner) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tot = (int64_t)nf * nf * (nf + 2);
+  if (idx >= tot) return;
+  const int i = (int)(idx % (nf + 2)); const int64_t r = idx / (nf + 2); const int j = (int)(r % nf), k = (int)(r / nf);
+  float v = 0.f;
+  if (i < nf) {
+    int c3[3] = {i, j, k}, t3[3]; float sgn = 1.f; bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      if (c3[d] < ncut) t3[d] = c3[d];
+      else if (c3[d] > nf - ncut) { t3[d] = nf - c3[d]; if (d == comp) sgn = -sgn; }
+      else ok = false;
+    }
+    if (ok) {
+      if (!(zero_corner > 0 && t3[0] < zero_corner && t3[1] < zero_corner && t3[2] < zero_corner))
+        v = sgn * table[(((int64_t)t3[2] * ncut + t3[1]) * ncut + t3[0]) * 3 + comp];
+    }
+  }
+  rho[idx] = v;
+}
+__global__ __launch_bounds__(256) void k_take_imag(const float *__restrict__ hat, float *__restrict__ kern, int64_t ncomplex) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < ncomplex) kern[i] = hat[2 * i + 1];
+}
+
+int build_fine_kernel(p3m_ctx *c, const float *table16_host) {
+  const Geometry &g = c->g;
+  float *d_table = nullptr;
+  const size_t tb = sizeof(float) * 3 * g.ncut * g.ncut * g.ncut;
+  HIP_TRY(hipMalloc(&d_table, tb));
+  HIP_TRY(hipMemcpyAsync(d_table, table16_host, tb, hipMemcpyHostToDevice, c->stream));
+  const int64_t tot = (int64_t)g.nf * g.nf * (g.nf + 2), ncx = (int64_t)g.nf * g.nf * g.hx;
+  const int zc = (c->p.flags & P3M_FLAG_PP_EXT) ? g.pp_range + 1 : 0;
+  for (int comp = 0; comp < 3; comp++) {
+    hipLaunchKernelGGL(k_fine_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->rho, (const float *)d_table, g.nf, g.ncut, comp, zc);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, 1));
+    hipLaunchKernelGGL(k_take_imag, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->rho, c->kern_f + comp * ncx, ncx);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  (void)hipFree(d_table);
+  c->have_kf = true;
+  return P3M_OK;
+}

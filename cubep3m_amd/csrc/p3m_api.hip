@@ -1,0 +1,464 @@
+// p3m_api.hip -- the C ABI of include/p3m_hip.h: context lifecycle, particle upload/download,
+// the `particle_mesh` sequence (particle_mesh_threaded.f90:2-726) and the probes/timers.
+#include "p3m_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, int mode, float *box, int fb, int lo);
+
+static thread_local char g_err[1024] = "";
+void p3m_set_error(const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char *p3m_hip_last_error(void) { return g_err; }
+
+template <typename T> static int dalloc(T **p, size_t n) {
+  *p = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) { p3m_set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e)); return P3M_ENOMEM; }
+  return P3M_OK;
+}
+template <typename T> static void dfree(T *&p) { if (p) (void)hipFree(p); p = nullptr; }
+
+static int fill_geometry(const p3m_params *p, Geometry *g) {
+  if (p->nodes_dim < 1 || p->tiles_node_dim < 1 || p->mesh_scale < 2 || p->nf_buf < 0) { p3m_set_error("bad parameters"); return P3M_EINVAL; }
+  g->nodes_dim = p->nodes_dim; g->nodes = p->nodes_dim * p->nodes_dim * p->nodes_dim;
+  g->T = p->tiles_node_dim; g->ntiles = g->T * g->T * g->T;
+  g->nf = p->nf_tile; g->nb = p->nf_buf; g->ncut = p->nf_cutoff; g->ms = p->mesh_scale; g->pp_range = p->pp_range;
+  g->pt = g->nf - 2 * g->nb;
+  if (g->pt <= 0 || g->pt % g->ms || g->nb % g->ms || (g->nf & 1)) {
+    p3m_set_error("nf_tile=%d, nf_buf=%d: nf_tile-2*nf_buf must be a positive multiple of mesh_scale (parameters.example:25-31)", g->nf, g->nb);
+    return P3M_EINVAL;
+  }
+  if (g->ncut > g->nf / 2) { p3m_set_error("nf_cutoff too large for nf_tile"); return P3M_EINVAL; }
+  if (g->pp_range + 1 > g->ncut || g->pp_range > g->nb) { p3m_set_error("pp_range too large"); return P3M_EINVAL; }
+  g->Nn = g->pt * g->T; g->E = g->Nn + 2 * g->nb;
+  g->nc_buf = g->nb / g->ms; g->nct = g->pt / g->ms; g->ncn = g->nct * g->T; g->nc = g->ncn * g->nodes_dim;
+  if (g->nc % g->nodes) { p3m_set_error("cannot evenly decompose mesh into slabs (mpi_initialization.f90:26)"); return P3M_EINVAL; }
+  g->nc_slab = g->nc / g->nodes;
+  g->hx = g->nf / 2 + 1; g->fb = g->pt + 3;
+  if ((int64_t)g->E * g->E * g->E > 2000000000LL) { p3m_set_error("extended fine domain %d^3 exceeds int32 cell indices", g->E); return P3M_EINVAL; }
+  const int nd = g->nodes_dim, rk = p->rank;
+  if (rk < 0 || rk >= g->nodes) { p3m_set_error("rank %d out of range", rk); return P3M_EINVAL; }
+  g->cart[0] = rk / (nd * nd); g->cart[1] = (rk / nd) % nd; g->cart[2] = rk % nd;  // mpi_initialization.f90:60-64
+  for (int d = 0; d < 3; d++) {
+    int cm[3] = {g->cart[0], g->cart[1], g->cart[2]}, cp[3] = {g->cart[0], g->cart[1], g->cart[2]};
+    cm[d] = (cm[d] - 1 + nd) % nd; cp[d] = (cp[d] + 1) % nd;
+    g->nbr[2 * d] = cm[0] * nd * nd + cm[1] * nd + cm[2]; g->nbr[2 * d + 1] = cp[0] * nd * nd + cp[1] * nd + cp[2];
+  }
+  // cubepm.par:170-172
+  const double Nn = g->Nn, nb = g->nb;
+  const double inner = (double)((g->Nn / 2) * (int64_t)(g->Nn / 2)) * (g->Nn / 2) + (8.0 * nb * nb * nb + 6.0 * nb * Nn * Nn + 12.0 * nb * nb * Nn) / 8.0;
+  g->max_np = (int64_t)((double)p->density_buffer * inner);
+  if (g->max_np > 2000000000LL) { p3m_set_error("max_np exceeds int32"); return P3M_EINVAL; }
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
+  if (!params || !out) return P3M_EINVAL;
+  *out = nullptr;
+  p3m_ctx *c = new p3m_ctx();
+  c->p = *params;
+  int r = fill_geometry(params, &c->g);
+  if (r) { delete c; return r; }
+  const Geometry &g = c->g;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { p3m_set_error("no HIP device (this library has no CPU fallback)"); delete c; return P3M_EDEVICE; }
+  if (params->device >= 0) { c->device = params->device; } else { (void)hipGetDevice(&c->device); }
+  auto fail = [&](int code) { p3m_hip_destroy(c); return code; };
+  if (hipSetDevice(c->device) != hipSuccess) { p3m_set_error("hipSetDevice(%d) failed", c->device); return fail(P3M_EDEVICE); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { p3m_set_error("stream creation failed"); return fail(P3M_EDEVICE); }
+  c->cap = g.max_np;
+#define A(x) do { int _r = (x); if (_r) return fail(_r); } while (0)
+  A(dalloc(&c->pos, c->cap)); A(dalloc(&c->vel, c->cap)); A(dalloc(&c->pid, c->cap));
+  A(dalloc(&c->spos, c->cap)); A(dalloc(&c->svel, c->cap)); A(dalloc(&c->spid, c->cap));
+  A(dalloc(&c->cell_of, c->cap)); A(dalloc(&c->flags, c->cap + 8));
+  const int64_t ncell = (int64_t)g.E * g.E * g.E;
+  int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // (cell_end+1) is 16-byte aligned for the scan
+  A(dalloc(&c->d_counters, 16));
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 16 * sizeof(int)) != hipSuccess) return fail(P3M_ENOMEM);
+  // fine mesh: as many tiles per sweep as fit a 48 GiB budget for rho+work
+  const size_t S = (size_t)(g.nf + 2) * g.nf * g.nf;
+  size_t budget = (size_t)48 << 30;
+  c->tile_batch = (int)std::max<size_t>(1, std::min<size_t>(g.ntiles, budget / (2 * S * sizeof(float))));
+  A(dalloc(&c->rho, S * c->tile_batch)); A(dalloc(&c->work, S * c->tile_batch));
+  A(dalloc(&c->fbox, (size_t)3 * g.ntiles * g.fb * g.fb * g.fb));
+  A(dalloc(&c->kern_f, (size_t)3 * g.nf * g.nf * g.hx));
+  A(fft_plan_create(&c->plan_f, g.nf));
+  // coarse mesh
+  A(dalloc(&c->rho_c, (size_t)g.ncn * g.ncn * g.ncn));
+  A(dalloc(&c->force_c, (size_t)3 * (g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2)));
+  if (g.nodes == 1) {
+    A(dalloc(&c->slab, (size_t)g.nc * g.nc * (g.nc + 2))); A(dalloc(&c->slab_w, (size_t)g.nc * g.nc * (g.nc + 2)));
+    A(dalloc(&c->kern_c, (size_t)3 * g.nc * g.nc * (g.nc / 2 + 1)));
+    A(fft_plan_create(&c->plan_c, g.nc));
+  }
+  A(dalloc(&c->d_red, 8)); A(dalloc(&c->d_tile_ext, g.ntiles)); A(dalloc(&c->d_sums, 4));
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_red), 8 * sizeof(float)) != hipSuccess) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_tile_ext), g.ntiles * sizeof(float)) != hipSuccess) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sums), 4 * sizeof(double)) != hipSuccess) return fail(P3M_ENOMEM);
+#undef A
+  // variable_initialization.f90:22-29
+  c->last.dt_f_acc = c->last.dt_pp_acc = c->last.dt_pp_ext_acc = c->last.dt_c_acc = 1000.f;
+  *out = c;
+  return P3M_OK;
+}
+
+extern "C" void p3m_hip_destroy(p3m_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  dfree(c->pos); dfree(c->vel); dfree(c->pid); dfree(c->spos); dfree(c->svel); dfree(c->spid);
+  dfree(c->cell_of); dfree(c->flags); dfree(c->scan_tmp); dfree(c->d_counters);
+  if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
+  dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->kern_f);
+  dfree(c->rho_c); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->kern_c);
+  dfree(c->d_red); dfree(c->d_tile_ext); dfree(c->d_sums);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  if (c->h_red) (void)hipHostFree(c->h_red);
+  if (c->h_tile_ext) (void)hipHostFree(c->h_tile_ext);
+  if (c->h_sums) (void)hipHostFree(c->h_sums);
+  fft_plan_destroy(&c->plan_f); fft_plan_destroy(&c->plan_c);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int64_t p3m_hip_derived(const p3m_ctx *c, int32_t what) {
+  if (!c) return -1;
+  switch (what) {
+    case 0: return c->g.max_np; case 1: return c->g.nc; case 2: return c->g.ncn; case 3: return c->g.Nn; case 4: return c->g.nc_slab; case 5: return c->g.pt;
+    case 6: return c->tile_batch; case 7: return c->g.E;
+  }
+  return -1;
+}
+extern "C" void *p3m_hip_stream(p3m_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ------------------------------------------------------------------ kernels
+extern "C" int p3m_hip_set_kernel_tables(p3m_ctx *c, const float *fine_table, const float *coarse_table) {
+  if (!c || !fine_table || !coarse_table) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  P3M_TRY(build_fine_kernel(c, fine_table));
+  P3M_TRY(build_coarse_kernel(c, coarse_table));
+  return P3M_OK;
+}
+
+// reference layout (3, hx, n, n) component fastest  <->  device SoA planes [3][n][n][hx]
+static void aos_to_planes(const float *aos, float *planes, size_t ncx) {
+  for (int comp = 0; comp < 3; comp++) for (size_t i = 0; i < ncx; i++) planes[comp * ncx + i] = aos[i * 3 + comp];
+}
+static void planes_to_aos(const float *planes, float *aos, size_t ncx) {
+  for (int comp = 0; comp < 3; comp++) for (size_t i = 0; i < ncx; i++) aos[i * 3 + comp] = planes[comp * ncx + i];
+}
+
+extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const float *kern_c) {
+  if (!c || !kern_f || !kern_c) return P3M_EINVAL;
+  if (c->g.nodes != 1) { p3m_set_error("set_kernels_raw: single-rank contexts only"); return P3M_EINVAL; }
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t nf = (size_t)c->g.nf * c->g.nf * c->g.hx, ncx = (size_t)c->g.nc * c->g.nc * (c->g.nc / 2 + 1);
+  std::vector<float> tmp(3 * std::max(nf, ncx));
+  aos_to_planes(kern_f, tmp.data(), nf);
+  HIP_TRY(hipMemcpy(c->kern_f, tmp.data(), sizeof(float) * 3 * nf, hipMemcpyHostToDevice));
+  aos_to_planes(kern_c, tmp.data(), ncx);
+  HIP_TRY(hipMemcpy(c->kern_c, tmp.data(), sizeof(float) * 3 * ncx, hipMemcpyHostToDevice));
+  c->have_kf = c->have_kc = true;
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_get_kernels(p3m_ctx *c, float *kern_f, float *kern_c) {
+  if (!c) return P3M_EINVAL;
+  if (!c->have_kf || !c->have_kc) { p3m_set_error("kernels not set"); return P3M_ESTATE; }
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t nf = (size_t)c->g.nf * c->g.nf * c->g.hx, ncx = (size_t)c->g.nc * c->g.nc * (c->g.nc / 2 + 1);
+  std::vector<float> tmp(3 * std::max(nf, ncx));
+  if (kern_f) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_f, sizeof(float) * 3 * nf, hipMemcpyDeviceToHost)); planes_to_aos(tmp.data(), kern_f, nf); }
+  if (kern_c && c->kern_c) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_c, sizeof(float) * 3 * ncx, hipMemcpyDeviceToHost)); planes_to_aos(tmp.data(), kern_c, ncx); }
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ particle store
+__global__ __launch_bounds__(256) void k_unpack_xv(const float *__restrict__ xv6, float4 *__restrict__ pos, float4 *__restrict__ vel, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float *r = xv6 + (int64_t)i * 6;
+  pos[i] = make_float4(r[0], r[1], r[2], 0.f); vel[i] = make_float4(r[3], r[4], r[5], 0.f);
+}
+__global__ __launch_bounds__(256) void k_pack_xv(const float4 *__restrict__ pos, const float4 *__restrict__ vel, float *__restrict__ xv6, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pos[i], v = vel[i];
+  float *r = xv6 + (int64_t)i * 6;
+  r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = v.x; r[4] = v.y; r[5] = v.z;
+}
+__global__ __launch_bounds__(256) void k_iota_pid(int64_t *pid, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) pid[i] = (int64_t)i + 1;
+}
+
+extern "C" int p3m_hip_upload_particles(p3m_ctx *c, const float *xv6, const int64_t *pid, int32_t np_local) {
+  if (!c || np_local < 0 || (np_local > 0 && !xv6)) return P3M_EINVAL;
+  if (np_local > c->cap) { p3m_set_error("np_local %d exceeds max_np %lld", np_local, (long long)c->cap); return P3M_ECAPACITY; }
+  HIP_TRY(hipSetDevice(c->device));
+  c->np_local = np_local; c->np_all = 0;
+  if (np_local == 0) return P3M_OK;
+  float *stage = reinterpret_cast<float *>(c->spos);  // 16 B/record of scratch >= ... 24 B/record needs svel too
+  // spos and svel are separate allocations: stage through a temporary instead
+  float *tmp = nullptr; P3M_TRY(dalloc(&tmp, (size_t)np_local * 6));
+  (void)stage;
+  HIP_TRY(hipMemcpyAsync(tmp, xv6, sizeof(float) * 6 * (size_t)np_local, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_unpack_xv, dim3(cdiv(np_local, 256)), dim3(256), 0, c->stream, (const float *)tmp, c->pos, c->vel, np_local);
+  if (pid) HIP_TRY(hipMemcpyAsync(c->pid, pid, sizeof(int64_t) * (size_t)np_local, hipMemcpyHostToDevice, c->stream));
+  else hipLaunchKernelGGL(k_iota_pid, dim3(cdiv(np_local, 256)), dim3(256), 0, c->stream, c->pid, np_local);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  dfree(tmp);
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_download_particles(p3m_ctx *c, float *xv6, int64_t *pid, int32_t *np_local) {
+  if (!c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  if (np_local) *np_local = c->np_local;
+  const int n = c->np_local;
+  if (n == 0) return P3M_OK;
+  if (xv6) {
+    float *tmp = nullptr; P3M_TRY(dalloc(&tmp, (size_t)n * 6));
+    hipLaunchKernelGGL(k_pack_xv, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, tmp, n);
+    HIP_TRY(hipMemcpyAsync(xv6, tmp, sizeof(float) * 6 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(tmp);
+  }
+  if (pid) { HIP_TRY(hipMemcpyAsync(pid, c->pid, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ phases
+static int need_kernels(p3m_ctx *c) {
+  if (!c->have_kf || !c->have_kc) { p3m_set_error("particle_mesh before the Green's functions were set (fine_kernel/coarse_kernel, cubepm.f90:42-46)"); return P3M_ESTATE; }
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_update_position(p3m_ctx *c, float dt, float dt_old, const float *offset) {
+  if (!c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  return particles_drift(c, dt, dt_old, offset);
+}
+
+extern "C" int p3m_hip_link_list_and_pass(p3m_ctx *c) {
+  if (!c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  return particles_pass_and_sort(c);
+}
+
+static int fine_sweep(p3m_ctx *c, float mass_p) {
+  const Geometry &g = c->g;
+  for (int t0 = 0; t0 < g.ntiles; t0 += c->tile_batch) {
+    const int nt = std::min(c->tile_batch, g.ntiles - t0);
+    P3M_TRY(fine_deposit(c, t0, nt, mass_p));
+    P3M_TRY(fine_force(c, t0, nt));
+  }
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+  if (!c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  P3M_TRY(need_kernels(c));
+  HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * sizeof(double), c->stream));
+  P3M_TRY(fine_sweep(c, mass_p));
+  P3M_TRY(fine_force_max(c));
+  P3M_TRY(fine_kick(c, a_mid, dt));
+  if ((c->p.flags & P3M_FLAG_PPINT) && (c->p.flags & P3M_FLAG_NGP)) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
+  if (c->p.flags & P3M_FLAG_PP_EXT) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_coarse_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+  if (!c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  P3M_TRY(need_kernels(c));
+  P3M_TRY(coarse_deposit(c, mass_p));
+  P3M_TRY(coarse_force(c));
+  P3M_TRY(coarse_kick(c, a_mid, dt));   // coarse_vel_update = .true. (cubepm.par:87)
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_delete_particles(p3m_ctx *c, const float *move_back) {
+  if (!c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  return particles_finalize(c, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr);
+}
+
+extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) {
+  if (!c || !out) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  const Geometry &g = c->g;
+  HIP_TRY(hipMemcpyAsync(c->h_red, c->d_red, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_sums, c->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  p3m_step_out o; memset(&o, 0, sizeof(o));
+  float fmax = sqrtf(c->h_red[0]);                         // :643
+  float ppmax = c->h_red[1], cmax = c->h_red[2];
+  // :617 assigns pp_ext_force_max(thread) per tile: every OpenMP thread keeps its LAST tile of the
+  // static `!$omp do` chunk (:84-85); reproduce with `cores`.
+  float emax = 0.f;
+  if (c->p.flags & P3M_FLAG_PP_EXT) {
+    const int cores = std::max(1, c->p.cores), nt = std::min(cores, g.ntiles), base = g.ntiles / nt, rem = g.ntiles % nt;
+    int pos = 0;
+    for (int t = 0; t < nt; t++) { pos += base + (t < rem ? 1 : 0); emax = std::max(emax, c->h_tile_ext[pos - 1]); }
+  }
+  double sums[2] = {c->h_sums[0], c->h_sums[1]}; int64_t npt = c->np_local;
+  if (g.nodes > 1) {
+    if (!c->have_transport) { p3m_set_error("multi-rank context without transport"); return P3M_ECOMM; }
+    float v[4] = {fmax, ppmax, emax, cmax};
+    if (c->transport.allreduce_max_f32(c->transport.user, v, 4)) return P3M_ECOMM;
+    fmax = v[0]; ppmax = v[1]; emax = v[2]; cmax = v[3];
+    double s[3] = {sums[0], sums[1], (double)npt};
+    if (c->transport.allreduce_sum_f64(c->transport.user, s, 3)) return P3M_ECOMM;
+    sums[0] = s[0]; sums[1] = s[1]; npt = (int64_t)s[2];
+  }
+  o.f_force_max = fmax; o.pp_force_max = ppmax; o.pp_ext_force_max = emax; o.c_force_max = cmax;
+  o.dt_f_acc = 1.0f / sqrtf(fmaxf(0.0001f, fmax) * a_mid * P3M_G_F);                                  // :652
+  o.dt_pp_acc = (c->p.flags & P3M_FLAG_PPINT) ? sqrtf(c->p.dt_pp_scale * c->p.rsoft) / fmaxf(sqrtf(ppmax * a_mid * P3M_G_F), 1e-3f) : c->last.dt_pp_acc;      // :668
+  o.dt_pp_ext_acc = (c->p.flags & P3M_FLAG_PP_EXT) ? sqrtf(c->p.dt_pp_scale * c->p.rsoft) / fmaxf(sqrtf(emax * a_mid * P3M_G_F), 1e-3f) : c->last.dt_pp_ext_acc;  // :692
+  o.dt_c_acc = sqrtf((float)g.ms / (cmax * a_mid * P3M_G_F));                                          // coarse_max_dt.f90:36
+  o.sum_rho_f = sums[0]; o.sum_rho_c = sums[1];
+  o.np_total = npt; o.np_local = c->np_local; o.np_ghost = c->np_ghost; o.np_deleted = c->np_deleted;
+  c->last = o; *out = o;
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt_old, float mass_p, const float *offset,
+                                     const float *move_back, p3m_step_out *out) {
+  if (!c) return P3M_EINVAL;
+  P3M_TRY(need_kernels(c));
+  P3M_TRY(p3m_hip_update_position(c, dt, dt_old, offset));   // :56
+  P3M_TRY(p3m_hip_link_list_and_pass(c));                    // :61-63
+  P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));          // :72-628
+  P3M_TRY(p3m_hip_coarse_mesh(c, a_mid, dt, mass_p));        // :712
+  P3M_TRY(p3m_hip_delete_particles(c, move_back));           // :716-720
+  p3m_step_out o;
+  P3M_TRY(p3m_hip_get_step_out(c, a_mid, &o));               // :643-706
+  if (out) *out = o;
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ probes
+extern "C" int p3m_hip_probe_tile_density(p3m_ctx *c, int32_t tx, int32_t ty, int32_t tz, float mass_p, float *rho_f) {
+  if (!c || !rho_f) return P3M_EINVAL;
+  const Geometry &g = c->g;
+  if (tx < 0 || ty < 0 || tz < 0 || tx >= g.T || ty >= g.T || tz >= g.T) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  const int tile = (tz * g.T + ty) * g.T + tx;
+  P3M_TRY(fine_deposit(c, tile, 1, mass_p));
+  HIP_TRY(hipMemcpyAsync(rho_f, c->rho, sizeof(float) * (size_t)(g.nf + 2) * g.nf * g.nf, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_probe_tile_force(p3m_ctx *c, const float *rho_f, float *force_f, float *force_max2) {
+  if (!c || !rho_f || !force_f) return P3M_EINVAL;
+  if (!c->have_kf) { p3m_set_error("fine kernel not set"); return P3M_ESTATE; }
+  const Geometry &g = c->g;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->rho, rho_f, sizeof(float) * (size_t)(g.nf + 2) * g.nf * g.nf, hipMemcpyHostToDevice, c->stream));
+  P3M_TRY(fine_force(c, 0, 1));
+  const size_t boxsz = (size_t)g.fb * g.fb * g.fb;
+  std::vector<float> tmp(3 * boxsz);
+  for (int comp = 0; comp < 3; comp++)
+    HIP_TRY(hipMemcpyAsync(tmp.data() + comp * boxsz, c->fbox + (size_t)comp * g.ntiles * boxsz, sizeof(float) * boxsz, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float m2 = 0.f;
+  for (size_t i = 0; i < boxsz; i++) {
+    const float a = tmp[i], b = tmp[boxsz + i], d = tmp[2 * boxsz + i];
+    force_f[3 * i] = a; force_f[3 * i + 1] = b; force_f[3 * i + 2] = d;
+    m2 = std::max(m2, a * a + b * b + d * d);
+  }
+  if (force_max2) *force_max2 = m2;
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_probe_coarse(p3m_ctx *c, float mass_p, float *rho_c, float *force_c) {
+  if (!c) return P3M_EINVAL;
+  const Geometry &g = c->g;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * sizeof(float), c->stream));
+  P3M_TRY(coarse_deposit(c, mass_p));
+  if (rho_c) HIP_TRY(hipMemcpyAsync(rho_c, c->rho_c, sizeof(float) * (size_t)g.ncn * g.ncn * g.ncn, hipMemcpyDeviceToHost, c->stream));
+  if (force_c) {
+    P3M_TRY(need_kernels(c));
+    P3M_TRY(coarse_force(c));
+    const size_t fcs = (size_t)(g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2);
+    std::vector<float> tmp(3 * fcs);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), c->force_c, sizeof(float) * 3 * fcs, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    planes_to_aos(tmp.data(), force_c, fcs);
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_fft3d(p3m_ctx *c, float *data, int32_t n, int32_t dir) {
+  if (!c || !data) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  FftPlan pl; P3M_TRY(fft_plan_create(&pl, n));
+  float *d = nullptr; const size_t S = (size_t)(n + 2) * n * n;
+  int r = dalloc(&d, S);
+  if (!r) {
+    hipError_t e = hipMemcpyAsync(d, data, sizeof(float) * S, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) r = dir > 0 ? fft3d_forward(c, pl, d, 1) : fft3d_inverse(c, pl, d, 1, nullptr, nullptr);
+    if (!r) e = hipMemcpyAsync(data, d, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || e != hipSuccess) { p3m_set_error("fft3d probe: HIP error"); r = r ? r : P3M_EDEVICE; }
+  }
+  dfree(d); fft_plan_destroy(&pl);
+  return r;
+}
+
+extern "C" int p3m_hip_time_fine_sweep(p3m_ctx *c, float mass_p, int32_t reps, float *ms_per_sweep) {
+  if (!c || reps < 1 || !ms_per_sweep) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  P3M_TRY(need_kernels(c));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  P3M_TRY(fine_sweep(c, mass_p));  // warm-up
+  HIP_TRY(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < reps; i++) P3M_TRY(fine_sweep(c, mass_p));
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_per_sweep = ms / reps;
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ transport (multi-rank) -- see transport.hip
+extern "C" int p3m_hip_set_transport(p3m_ctx *c, const p3m_transport *t) {
+  if (!c || !t) return P3M_EINVAL;
+  c->transport = *t; c->have_transport = true;
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ F77-ABI wrapper (style of pp_force_c_, nbody-ueli.cu:368)
+extern "C" void particle_mesh_hip_(int64_t *handle, const p3m_params *params, const float *fine_table, const float *coarse_table,
+                                   float *xv, int64_t *pid, int32_t *np_local, const float *a_mid, const float *dt, const float *dt_old,
+                                   const float *mass_p, const float *offset, const float *move_back, float *dt_f_acc, float *dt_pp_acc,
+                                   float *dt_pp_ext_acc, float *dt_c_acc, int32_t *ierr) {
+  int r = P3M_OK;
+  p3m_ctx *c = reinterpret_cast<p3m_ctx *>(static_cast<intptr_t>(*handle));
+  if (!c) {
+    r = p3m_hip_create(params, &c);
+    if (!r) r = p3m_hip_set_kernel_tables(c, fine_table, coarse_table);
+    if (r) { if (c) p3m_hip_destroy(c); *ierr = r; return; }
+    *handle = static_cast<int64_t>(reinterpret_cast<intptr_t>(c));
+  }
+  p3m_step_out o;
+  r = p3m_hip_upload_particles(c, xv, pid, *np_local);
+  if (!r) r = p3m_hip_particle_mesh(c, *a_mid, *dt, *dt_old, *mass_p, offset, move_back, &o);
+  if (!r) r = p3m_hip_download_particles(c, xv, pid, np_local);
+  if (!r) { *dt_f_acc = o.dt_f_acc; *dt_pp_acc = o.dt_pp_acc; *dt_pp_ext_acc = o.dt_pp_ext_acc; *dt_c_acc = o.dt_c_acc; }
+  *ierr = r;
+}

@@ -1,0 +1,132 @@
+// p3m_internal.h -- context, geometry and launch helpers shared by the HIP translation units.
+// gfx950 only (wave64, 256 CUs / 8 XCDs, 160 KiB LDS per CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/p3m_hip.h"
+
+#define P3M_PI_F 3.141592654f                 /* cubepm.par:148 */
+#define P3M_G_F (1.0f / 6.0f / P3M_PI_F)      /* cubepm.par:149 */
+#define P3M_EPS_F 1.0e-03f                    /* cubepm.par:150 */
+
+void p3m_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      p3m_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));      \
+      return (_e == hipErrorOutOfMemory) ? P3M_ENOMEM : P3M_EDEVICE;                           \
+    }                                                                                          \
+  } while (0)
+#define P3M_TRY(expr)            \
+  do {                           \
+    int _r = (expr);             \
+    if (_r != P3M_OK) return _r; \
+  } while (0)
+
+// ------------------------------------------------------------------ FFT plan (fft.hip)
+struct FftPlan {
+  int n = 0;               // real transform length per axis
+  int nfac_full = 0, fac_full[16];  // radices of n      (strided c2c passes)
+  int nfac_half = 0, fac_half[16];  // radices of n/2    (packed real x pass)
+  float2 *d_tw = nullptr;  // exp(-2 pi i q / n), q in [0,n)
+};
+
+// Derived sizes of cubepm.par:186-208 plus the device layout.
+struct Geometry {
+  int nodes_dim, nodes, T, ntiles, nf, nb, ncut, ms, pp_range;
+  int pt;      // nf_physical_tile_dim
+  int Nn;      // nf_physical_node_dim
+  int E;       // extended fine cells per axis: Nn + 2*nb  (ghost zone included)
+  int nc_buf, nct, ncn, nc, nc_slab;
+  int hx;      // nf/2+1 complex per row
+  int fb;      // force box edge: pt+3   (force_f(3, nb-1:nf-nb+1,...), cubep3m.fh:36)
+  int cart[3]; // z,y,x rank coordinates (mpi_initialization.f90:60-64)
+  int nbr[6];  // -z,+z,-y,+y,-x,+x
+  int64_t max_np;
+};
+
+struct p3m_ctx {
+  p3m_params p;
+  Geometry g;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // ---- particle store (persistent between steps): cubep3m.fh:75-79 as SoA
+  int64_t cap = 0;        // capacity in records (physical + ghosts)
+  int np_local = 0;       // physical particles
+  int np_all = 0;         // after the ghost pass
+  float4 *pos = nullptr, *vel = nullptr; int64_t *pid = nullptr;       // unsorted (arrival order)
+  float4 *spos = nullptr, *svel = nullptr; int64_t *spid = nullptr;    // sorted by extended fine cell
+  int *cell_end = nullptr;     // [E^3+1] inclusive prefix of per-cell counts, shifted by one: start(c)=cell_end[c], end(c)=cell_end[c+1]
+  int *cell_of = nullptr;      // [cap] extended cell of each unsorted record (-1: dropped)
+  int *scan_tmp = nullptr; size_t scan_tmp_n = 0;
+  int *flags = nullptr;        // [cap] compaction flags / offsets
+  int *d_counters = nullptr;   // small device counter block
+  int *h_counters = nullptr;   // pinned mirror
+  // ---- fine mesh, all tiles batched
+  int tile_batch = 0;          // tiles processed per sweep
+  float *rho = nullptr;        // [batch][nf][nf][nf+2]  density -> rho-hat
+  float *work = nullptr;       // [batch][nf][nf][nf+2]  i*K_c*rho-hat -> force
+  float *fbox = nullptr;       // [3][ntiles][fb][fb][fb] extracted force (SoA planes)
+  float *kern_f = nullptr;     // [3][nf][nf][hx]  SoA planes of kern_f
+  FftPlan plan_f;
+  // ---- coarse mesh
+  float *rho_c = nullptr;      // [ncn][ncn][ncn]
+  float *slab = nullptr;       // [nc][nc][nc+2] (single rank) density -> hat
+  float *slab_w = nullptr;
+  float *force_c = nullptr;    // [3][ncn+2][ncn+2][ncn+2] SoA planes incl. halo
+  float *kern_c = nullptr;     // [3][nc][nc][nc/2+1]
+  FftPlan plan_c;
+  bool have_kf = false, have_kc = false;
+  // ---- per-step reductions (device) and results
+  float *d_red = nullptr;      // [0] f_force_max^2 [1] pp_force_max [2] c_force_max [3..] scratch
+  float *d_tile_ext = nullptr; // [ntiles] per-tile pp_ext max
+  double *d_sums = nullptr;    // [0] sum rho_f (interior) [1] sum rho_c
+  float *h_red = nullptr; float *h_tile_ext = nullptr; double *h_sums = nullptr;  // pinned
+  p3m_step_out last{};
+  int np_ghost = 0, np_deleted = 0;
+  // ---- transport
+  p3m_transport transport{}; bool have_transport = false;
+  void *rccl_comm = nullptr;
+};
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- fft.hip
+int fft_plan_create(FftPlan *pl, int n);
+void fft_plan_destroy(FftPlan *pl);
+// in-place batched 3-D r2c of `batch` arrays [n][n][n+2]
+int fft3d_forward(p3m_ctx *c, const FftPlan &pl, float *data, int batch);
+// data <- c2r( in ) / n^3 ; when kern != nullptr the first pass reads src=rho-hat and multiplies by
+// i*K (particle_mesh_threaded.f90:183-192) on the fly, writing into `data` (src is left intact)
+int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const float *src, const float *kern);
+
+// ---- particles.hip
+int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset);
+int particles_pass_and_sort(p3m_ctx *c);
+int particles_finalize(p3m_ctx *c, const float *move_back);
+
+// ---- fine_mesh.hip
+int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p);
+int fine_force(p3m_ctx *c, int tile0, int ntile);
+int fine_kick(p3m_ctx *c, float a_mid, float dt);
+int fine_force_max(p3m_ctx *c);
+int fine_sum_mass(p3m_ctx *c, int tile0, int ntile);
+int build_fine_kernel(p3m_ctx *c, const float *table16_host);
+
+// ---- pp.hip
+int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p);
+int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p);
+
+// ---- coarse_mesh.hip
+int coarse_deposit(p3m_ctx *c, float mass_p);
+int coarse_force(p3m_ctx *c);
+int coarse_kick(p3m_ctx *c, float a_mid, float dt);
+int build_coarse_kernel(p3m_ctx *c, const float *table4_host);
+
+// ---- scan.hip
+int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n);  // in place; data[n] (one past) receives the total

@@ -1,0 +1,183 @@
+// particles.hip -- particle bookkeeping of the gravity step on the device:
+//   update_position.f90:68-76   -> k_drift
+//   link_list.f90 + particle_pass.f90 (single rank: periodic self exchange) -> k_pass_axis
+//   link_list's chaining mesh hoc/ll (and llf, hoc_fine/ll_fine) -> counting sort by extended
+//     fine cell: k_cell_hist / exclusive scan / k_scatter
+//   delete_particles.f90 + move_grid_back.f90 -> k_flag_physical / scan / k_compact
+// Records are SoA float4 pos, float4 vel, int64 pid.  Everything here is HBM-bound streaming
+// except the cell histogram/scatter (one int atomic per particle).
+#include "p3m_internal.h"
+
+#define PT 256
+
+// ------------------------------------------------------------------ update_position.f90:68-76
+__global__ __launch_bounds__(PT) void k_drift(float4 *__restrict__ pos, const float4 *__restrict__ vel, int n, float dt, float dt_old,
+                                              float ox, float oy, float oz, int use_off) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pos[i]; const float4 v = vel[i];
+  const float hs = 0.5f * (dt + dt_old);
+  if (use_off) { p.x = p.x + v.x * hs + ox; p.y = p.y + v.y * hs + oy; p.z = p.z + v.z * hs + oz; }  // :71
+  else { p.x = p.x + v.x * hs; p.y = p.y + v.y * hs; p.z = p.z + v.z * hs; }                           // :73
+  pos[i] = p;
+}
+
+int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset) {
+  if (c->np_local == 0) return P3M_OK;
+  hipLaunchKernelGGL(k_drift, dim3(cdiv(c->np_local, PT)), dim3(PT), 0, c->stream, c->pos, (const float4 *)c->vel, c->np_local, dt, dt_old,
+                     offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+__device__ __forceinline__ float comp(const float4 &p, int a) { return a == 0 ? p.x : (a == 1 ? p.y : p.z); }
+__device__ __forceinline__ void setcomp(float4 &p, int a, float v) { if (a == 0) p.x = v; else if (a == 1) p.y = v; else p.z = v; }
+__device__ __forceinline__ bool in_hoc_range(const float4 &p, float lo, float hi) {
+  // link_list.f90:26-31: floor(x/mesh_scale)+1 within hoc_nc_l..hoc_nc_h  <=>  -nf_buf <= x < Nn+nf_buf
+  return p.x >= lo && p.x < hi && p.y >= lo && p.y < hi && p.z >= lo && p.z < hi;
+}
+
+// One axis of particle_pass.f90 on a single rank (the rank is its own +/- neighbour): every
+// valid record i < n_cur with x_a >= Nn-nb gets an image at max(x_a-Nn,-nb) (:83,:162) and every
+// record with x_a < nb an image at min(guard(x_a)+Nn, Nn+nb-eps) (:185,:257-265).  Records that
+// arrived in this axis' first direction are not re-sent in the second (they are not in hoc yet).
+__global__ __launch_bounds__(PT) void k_pass_axis_self(float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid,
+                                                       int n_cur, int cap, int axis, float Nn, float nb, int *__restrict__ counter,
+                                                       int *__restrict__ overflow) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n_cur) return;
+  const float4 p = pos[i];
+  if (!in_hoc_range(p, -nb, Nn + nb)) return;  // dropped by link_list ("PARTICLE DELETED")
+  const float x = comp(p, axis);
+  const bool hi = x >= Nn - nb, lo = x < nb;
+  if (!(hi || lo)) return;
+  const float4 v = vel[i]; const int64_t id = pid[i];
+  if (hi) {
+    const int s = n_cur + atomicAdd(counter, 1);
+    if (s < cap) { float4 q = p; setcomp(q, axis, fmaxf(x - Nn, -nb)); pos[s] = q; vel[s] = v; pid[s] = id; }
+    else *overflow = 1;
+  }
+  if (lo) {
+    float xs = x;
+    if (fabsf(xs) < P3M_EPS_F) xs = (xs < 0.0f) ? -P3M_EPS_F : P3M_EPS_F;
+    const int s = n_cur + atomicAdd(counter, 1);
+    if (s < cap) { float4 q = p; setcomp(q, axis, fminf(xs + Nn, Nn + nb - P3M_EPS_F)); pos[s] = q; vel[s] = v; pid[s] = id; }
+    else *overflow = 1;
+  }
+}
+
+// ------------------------------------------------------------------ counting sort by extended fine cell
+// cell = ((cz*E + cy)*E + cx), c_d = floor(x_d) + nb in [0,E).  cs[c] = start(c), cs[c+1] = end(c).
+__global__ __launch_bounds__(PT) void k_cell_hist(const float4 *__restrict__ pos, int n, int np_orig, float Nn, float nb, int E,
+                                                  int *__restrict__ cell_of, int *__restrict__ cs, int *__restrict__ ndeleted) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pos[i];
+  int cell = -1;
+  if (in_hoc_range(p, -nb, Nn + nb)) {
+    const int cx = (int)floorf(p.x) + (int)nb, cy = (int)floorf(p.y) + (int)nb, cz = (int)floorf(p.z) + (int)nb;
+    cell = (cz * E + cy) * E + cx;
+    atomicAdd(&cs[cell + 1], 1);
+  } else if (i < np_orig) {
+    atomicAdd(ndeleted, 1);
+  }
+  cell_of[i] = cell;
+}
+
+__global__ __launch_bounds__(PT) void k_scatter(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
+                                                const int *__restrict__ cell_of, int n, int *__restrict__ cs, float4 *__restrict__ spos,
+                                                float4 *__restrict__ svel, int64_t *__restrict__ spid) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n) return;
+  const int cell = cell_of[i];
+  if (cell < 0) return;
+  const int s = atomicAdd(&cs[cell + 1], 1);
+  spos[s] = pos[i]; svel[s] = vel[i]; spid[s] = pid[i];
+}
+
+int particles_pass_and_sort(p3m_ctx *c) {
+  const Geometry &g = c->g;
+  int *cnt = c->d_counters;  // [0..2] per-axis image counts, [3] overflow, [4] deleted
+  HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
+  int n_cur = c->np_local;
+  if (g.nodes == 1) {
+    for (int axis = 0; axis < 3; axis++) {
+      if (n_cur > 0) {
+        hipLaunchKernelGGL(k_pass_axis_self, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, axis,
+                           (float)g.Nn, (float)g.nb, cnt + axis, cnt + 3);
+        HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->h_counters[3] || (int64_t)n_cur + c->h_counters[axis] > c->cap) {
+        p3m_set_error("exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139); raise density_buffer",
+                      (long long)n_cur + c->h_counters[axis], (long long)c->cap);
+        return P3M_ECAPACITY;
+      }
+      n_cur += c->h_counters[axis];
+    }
+  } else {
+    p3m_set_error("multi-rank pass requires a transport (not initialised)");
+    return P3M_ECOMM;
+  }
+  c->np_all = n_cur;
+  c->np_ghost = n_cur - c->np_local;
+  const int64_t ncell = (int64_t)g.E * g.E * g.E;
+  HIP_TRY(hipMemsetAsync(c->cell_end - 3, 0, (size_t)(ncell + 8) * sizeof(int), c->stream));
+  if (n_cur > 0) {
+    hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, c->np_local, (float)g.Nn,
+                       (float)g.nb, g.E, c->cell_of, c->cell_end, cnt + 4);
+    HIP_TRY(hipGetLastError());
+  }
+  P3M_TRY(exclusive_scan_i32(c, c->cell_end + 1, ncell));
+  if (n_cur > 0) {
+    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel,
+                       (const int64_t *)c->pid, (const int *)c->cell_of, n_cur, c->cell_end, c->spos, c->svel, c->spid);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->np_deleted = c->h_counters[4];
+  c->np_all = n_cur - c->np_deleted;  // sorted records
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ delete_particles.f90:17-47 (+ move_grid_back.f90:17-24)
+// move_grid_back (xv -= shake_offset) runs BEFORE delete_particles (particle_mesh_threaded.f90:716-720),
+// so the range test is applied to the shifted-back positions.
+__global__ __launch_bounds__(PT) void k_flag_physical(const float4 *__restrict__ spos, int n, float Nn, int *__restrict__ flags,
+                                                      float mx, float my, float mz) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n) return;
+  float4 p = spos[i];
+  p.x -= mx; p.y -= my; p.z -= mz;
+  flags[i] = (p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn) ? 1 : 0;
+}
+__global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos, const float4 *__restrict__ svel, const int64_t *__restrict__ spid,
+                                                const int *__restrict__ offs, int n, float Nn, float4 *__restrict__ pos, float4 *__restrict__ vel,
+                                                int64_t *__restrict__ pid, float mx, float my, float mz) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n) return;
+  float4 p = spos[i];
+  p.x -= mx; p.y -= my; p.z -= mz;
+  if (!(p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn)) return;
+  const int o = offs[i];
+  pos[o] = p; vel[o] = svel[i]; pid[o] = spid[i];
+}
+
+int particles_finalize(p3m_ctx *c, const float *move_back) {
+  const int n = c->np_all;
+  if (n == 0) { c->np_local = 0; return P3M_OK; }
+  float mx = 0, my = 0, mz = 0;
+  if (move_back) { mx = move_back[0]; my = move_back[1]; mz = move_back[2]; }
+  hipLaunchKernelGGL(k_flag_physical, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, n, (float)c->g.Nn, c->flags, mx, my, mz);
+  HIP_TRY(hipGetLastError());
+  P3M_TRY(exclusive_scan_i32(c, c->flags, n));
+  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel,
+                     (const int64_t *)c->spid, (const int *)c->flags, n, (float)c->g.Nn, c->pos, c->vel, c->pid, mx, my, mz);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->h_counters, c->flags + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->np_local = c->h_counters[0];
+  return P3M_OK;
+}

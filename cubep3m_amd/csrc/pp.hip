@@ -1,0 +1,154 @@
+// pp.hip -- short-range particle-particle forces on the cell-sorted records.
+//   pp_intra    : -DPPINT, particle_mesh_threaded.f90:274-285 (bucketing) + :324-361 (pairs)
+//   pp_extended : -DPP_EXT, particle_mesh_threaded.f90:378-624
+// The sorted order (records of one fine cell contiguous, cells of one x-row contiguous) replaces
+// llf / hoc_fine / ll_fine: a cell's partners are index ranges.  FP32-ALU bound (about 20 flop per
+// pair incl. the reciprocal square root); reported as pairs/s, not against the HBM roofline.
+#include "p3m_internal.h"
+
+struct PPGeo { int T, nb, pt, E, Nn, ms, ppr; float rsoft, pp_bias, ncut; };
+
+__device__ __forceinline__ float3 pair_force(const float4 &a, const float4 &b, float mass_p, float rsoft, float pp_bias) {
+  // :336-344 : sep = x1-x2 ; rmag ; if (rmag>rsoft) force_pp = mass_p*(sep/(rmag*pp_bias)**3)
+  const float sx = a.x - b.x, sy = a.y - b.y, sz = a.z - b.z;
+  const float rmag = sqrtf(sx * sx + sy * sy + sz * sz);
+  if (!(rmag > rsoft)) return make_float3(0.f, 0.f, 0.f);
+  const float rb = rmag * pp_bias, rb3 = rb * rb * rb;
+  return make_float3(mass_p * (sx / rb3), mass_p * (sy / rb3), mass_p * (sz / rb3));
+}
+
+// ------------------------------------------------------------------ intra-cell PP
+// One thread per physical record.  Its bucket is the reference's: hoc coarse cell
+// floor(x/mesh_scale) and sub-cell mod(i1-1,mesh_scale) with i1 = floor(x + offset_tile) + 1
+// (:248-249,:276-278).  Partners: records of that fine cell whose own bucket is the same.
+__global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, int n,
+                                                  PPGeo G, float mass_p, float a_mid, float dt, float *__restrict__ fmax_out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  float mag = 0.f;
+  if (s < n) {
+    const float4 p = spos[s];
+    const float fNn = (float)G.Nn;
+    if (p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn) {
+      const int nct = G.pt / G.ms;
+      int cc[3], sub[3]; const float xs[3] = {p.x, p.y, p.z};
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        cc[d] = (int)floorf(xs[d] / (float)G.ms);                     // hoc coarse cell (0-based)
+        const int t = cc[d] / nct;
+        const float xl = xs[d] + ((float)G.nb - (float)(t * G.pt));   // :248
+        sub[d] = ((int)floorf(xl)) % G.ms;                            // :277  (i1-1) mod mesh_scale
+      }
+      const int bx = cc[0] * G.ms + sub[0] + G.nb, by = cc[1] * G.ms + sub[1] + G.nb, bz = cc[2] * G.ms + sub[2] + G.nb;
+      const int64_t cell = ((int64_t)bz * G.E + by) * G.E + bx;
+      const int q0 = cs[cell], q1 = cs[cell + 1];
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      for (int q = q0; q < q1; q++) {
+        if (q == s) continue;
+        const float4 o = spos[q];
+        // the partner must be bucketed here too (it is unless one of its coordinates rounds up)
+        bool same = true;
+        const float os[3] = {o.x, o.y, o.z};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const int oc = (int)floorf(os[d] / (float)G.ms);
+          const int t = oc / nct;
+          const float xl = os[d] + ((float)G.nb - (float)(t * G.pt));
+          same = same && (oc == cc[d]) && ((((int)floorf(xl)) % G.ms) == sub[d]);
+        }
+        if (!same) continue;
+        const float3 f = pair_force(p, o, mass_p, G.rsoft, G.pp_bias);
+        ax -= f.x; ay -= f.y; az -= f.z;                                // :346-347
+      }
+      if (q1 - q0 > 1 || true) {
+        float4 v = svel[s];
+        v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
+        svel[s] = v;
+      }
+      mag = sqrtf(ax * ax + ay * ay + az * az);                         // :356
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_down(mag, o, 64));
+  if ((threadIdx.x & 63) == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out), __float_as_uint(mag));
+}
+
+int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+  const Geometry &g = c->g;
+  if (c->np_all == 0) return P3M_OK;
+  PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
+  hipLaunchKernelGGL(k_pp_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end,
+                     c->np_all, G, mass_p, a_mid, dt, c->d_red + 1);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// ------------------------------------------------------------------ extended PP
+// One 64-lane workgroup per (tile, z, y) row of the tile's region extended by pp_range cells
+// (:397-402); one lane per record of the row.  Partner cells: Chebyshev distance 1..pp_range,
+// clipped to the extended region exactly as the reference's half-shell sweep is (:503-523), so the
+// per-tile maxval(|pp_ext_force_accum|) (:617) is reproduced including the partial sums of records
+// in the rim.  Only records whose cell is in the physical tile are kicked (:576-590).
+__global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G,
+                                               float mass_p, float a_mid, float dt, float *__restrict__ tile_max) {
+  const int e = G.pt + 2 * G.ppr;
+  const int ry = blockIdx.x % e, rz = (blockIdx.x / e) % e, tile = blockIdx.x / (e * e);
+  const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+  // extended region in extended-cell coordinates: [lo_d, lo_d + e)
+  const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
+  const int cy = loy + ry, cz = loz + rz;
+  const int64_t rowb = ((int64_t)cz * G.E + cy) * G.E;
+  const int p0 = cs[rowb + lox], p1 = cs[rowb + lox + e];
+  float mymax = 0.f;
+  const float tmax = G.ncut + sqrtf(3.0f);
+  for (int s = p0 + threadIdx.x; s < p1; s += 64) {
+    const float4 p = spos[s];
+    const int cx = (int)floorf(p.x) + G.nb;                                // :412 (floor(xv)+1, global)
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const int z0 = max(cz - G.ppr, loz), z1 = min(cz + G.ppr, loz + e - 1);
+    const int y0 = max(cy - G.ppr, loy), y1 = min(cy + G.ppr, loy + e - 1);
+    const int x0 = max(cx - G.ppr, lox), x1 = min(cx + G.ppr, lox + e - 1);
+    for (int zz = z0; zz <= z1; zz++)
+      for (int yy = y0; yy <= y1; yy++) {
+        const int64_t rb = ((int64_t)zz * G.E + yy) * G.E;
+        const bool own = (zz == cz && yy == cy);
+        const int q0 = cs[rb + x0], q1 = cs[rb + x1 + 1];
+        const int s0 = own ? cs[rb + cx] : 0, s1 = own ? cs[rb + cx + 1] : 0;  // own cell is excluded (:515-516)
+        for (int q = q0; q < q1; q++) {
+          if (own && q >= s0 && q < s1) { q = s1 - 1; continue; }
+          const float4 o = spos[q];
+          const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;            // :551
+          const float rmag = sqrtf(sx * sx + sy * sy + sz * sz);
+          if (rmag > G.rsoft) {                                                   // :558
+            const float rb1 = rmag * G.pp_bias, rb3 = rb1 * rb1 * rb1;
+            float fx = mass_p * (sx / rb3), fy = mass_p * (sy / rb3), fz = mass_p * (sz / rb3);
+            if (!(rmag > tmax)) {                                                 // :559-564
+              const float qq = rb1 / G.ncut;
+              const float taper = 1.f - (7.0f / 4.0f) * (qq * qq * qq) + (3.0f / 4.0f) * (qq * qq * qq * qq * qq);
+              fx *= taper; fy *= taper; fz *= taper;
+            }
+            ax -= fx; ay -= fy; az -= fz;                                         // :571
+          }
+        }
+      }
+    const bool phys = (cx >= lox + G.ppr && cx < lox + G.ppr + G.pt && ry >= G.ppr && ry < G.ppr + G.pt && rz >= G.ppr && rz < G.ppr + G.pt);
+    if (phys) {                                                                   // :576-582
+      float4 v = svel[s];
+      v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
+      svel[s] = v;
+    }
+    mymax = fmaxf(mymax, sqrtf(ax * ax + ay * ay + az * az));                     // :617
+  }
+  for (int o = 32; o > 0; o >>= 1) mymax = fmaxf(mymax, __shfl_down(mymax, o, 64));
+  if (threadIdx.x == 0 && mymax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(mymax));
+}
+
+int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+  const Geometry &g = c->g;
+  if (g.pp_range == 0) return P3M_OK;
+  PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
+  const int e = g.pt + 2 * g.pp_range;
+  const unsigned blocks = (unsigned)((int64_t)g.ntiles * e * e);
+  hipLaunchKernelGGL(k_pp_ext, dim3(blocks), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, mass_p, a_mid,
+                     dt, c->d_tile_ext);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}

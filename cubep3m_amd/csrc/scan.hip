@@ -1,0 +1,102 @@
+// scan.hip -- in-place exclusive prefix sum of int32 (cell offsets of the counting sort that
+// replaces link_list.f90's hoc/ll chains, and stream compaction for delete_particles.f90).
+// Three-kernel scheme (block sums -> recursive scan of the sums -> apply); HBM-bound:
+// 2 reads + 1 write of the array.
+#include "p3m_internal.h"
+
+#define SCAN_T 256
+#define SCAN_I 16
+#define SCAN_CH (SCAN_T * SCAN_I)
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if ((threadIdx.x & 63) >= o) v += t; }
+  return v;
+}
+// returns the exclusive prefix of `v` within the block and the block total in *total
+__device__ __forceinline__ int block_excl_scan(int v, int *total) {
+  __shared__ int wsum[SCAN_T / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int inc = wave_incl_scan(v);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_T / 64; i++) { if (i < w) off += wsum[i]; tot += wsum[i]; }
+  __syncthreads();
+  *total = tot;
+  return off + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(const int *__restrict__ d, int64_t n, int *__restrict__ sums) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CH + (int64_t)threadIdx.x * SCAN_I;
+  int s = 0;
+  if (base + SCAN_I <= n) {
+    const int4 *p = reinterpret_cast<const int4 *>(d + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_I / 4; i++) { int4 q = p[i]; s += q.x + q.y + q.z + q.w; }
+  } else {
+    for (int i = 0; i < SCAN_I; i++) if (base + i < n) s += d[base + i];
+  }
+  int tot; (void)block_excl_scan(s, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_apply(int *__restrict__ d, int64_t n, const int *__restrict__ sums, int *__restrict__ total_out) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CH + (int64_t)threadIdx.x * SCAN_I;
+  int v[SCAN_I];
+  const bool full = base + SCAN_I <= n;
+  if (full) {
+    const int4 *p = reinterpret_cast<const int4 *>(d + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_I / 4; i++) { int4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++) v[i] = (base + i < n) ? d[base + i] : 0;
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_I; i++) s += v[i];
+  int tot;
+  int run = block_excl_scan(s, &tot) + (sums ? sums[blockIdx.x] : 0);
+  if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = tot + (sums ? sums[blockIdx.x] : 0);
+#pragma unroll
+  for (int i = 0; i < SCAN_I; i++) { int t = v[i]; v[i] = run; run += t; }
+  if (full) {
+    int4 *p = reinterpret_cast<int4 *>(d + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_I / 4; i++) p[i] = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++) if (base + i < n) d[base + i] = v[i];
+  }
+}
+
+static int scan_rec(p3m_ctx *c, int *d, int64_t n, int *tmp, int *total_out) {
+  const int64_t nb = (n + SCAN_CH - 1) / SCAN_CH;
+  if (nb == 1) {
+    hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(SCAN_T), 0, c->stream, d, n, (const int *)nullptr, total_out);
+    HIP_TRY(hipGetLastError());
+    return P3M_OK;
+  }
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(SCAN_T), 0, c->stream, (const int *)d, n, tmp);
+  HIP_TRY(hipGetLastError());
+  const int64_t nb_al = (nb + 3) & ~(int64_t)3;  // keep the next level 16-byte aligned
+  P3M_TRY(scan_rec(c, tmp, nb, tmp + nb_al, nullptr));
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_T), 0, c->stream, d, n, (const int *)tmp, total_out);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+// data must be 16-byte aligned and hold n+1 ints: data[n] receives the total.
+int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n) {
+  size_t need = 0;
+  for (int64_t m = (n + SCAN_CH - 1) / SCAN_CH; m > 1; m = (m + SCAN_CH - 1) / SCAN_CH) need += (size_t)((m + 3) & ~(int64_t)3);
+  need += 8;
+  if (need > c->scan_tmp_n) {
+    if (c->scan_tmp) (void)hipFree(c->scan_tmp);
+    HIP_TRY(hipMalloc(&c->scan_tmp, need * sizeof(int)));
+    c->scan_tmp_n = need;
+  }
+  return scan_rec(c, data, n, c->scan_tmp, data + n);
+}

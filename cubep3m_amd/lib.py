@@ -1,0 +1,83 @@
+"""ctypes binding of cubep3m_amd/libp3m_hip.so (include/p3m_hip.h).
+
+There is no CPU fallback: if the HIP library is missing this module raises at first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .params import P3MParams, P3MStepOut
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libp3m_hip.so")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+
+# every entry point include/p3m_hip.h declares
+EXPORTS = [
+    "p3m_hip_create", "p3m_hip_destroy", "p3m_hip_last_error", "p3m_hip_derived", "p3m_hip_set_transport",
+    "p3m_hip_rccl_unique_id", "p3m_hip_comm_init_rccl", "p3m_hip_set_kernel_tables", "p3m_hip_set_kernels_raw",
+    "p3m_hip_get_kernels", "p3m_hip_upload_particles", "p3m_hip_download_particles", "p3m_hip_particle_mesh",
+    "p3m_hip_update_position", "p3m_hip_link_list_and_pass", "p3m_hip_fine_mesh", "p3m_hip_coarse_mesh",
+    "p3m_hip_delete_particles", "p3m_hip_get_step_out", "p3m_hip_probe_tile_density", "p3m_hip_probe_tile_force",
+    "p3m_hip_probe_coarse", "p3m_hip_fft3d", "p3m_hip_time_fine_sweep", "p3m_hip_stream", "particle_mesh_hip_",
+]
+
+
+class P3MError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"p3m_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + ([] if verbose else ["-s"]))
+    return SO_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: build it with `make -C cubep3m_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(SO_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    L.p3m_hip_create.argtypes = [C.POINTER(P3MParams), C.POINTER(vp)]
+    L.p3m_hip_destroy.argtypes = [vp]
+    L.p3m_hip_destroy.restype = None
+    L.p3m_hip_last_error.restype = C.c_char_p
+    L.p3m_hip_derived.argtypes = [vp, i32]
+    L.p3m_hip_derived.restype = C.c_int64
+    L.p3m_hip_set_kernel_tables.argtypes = [vp, f32p, f32p]
+    L.p3m_hip_set_kernels_raw.argtypes = [vp, f32p, f32p]
+    L.p3m_hip_get_kernels.argtypes = [vp, vp, vp]
+    L.p3m_hip_upload_particles.argtypes = [vp, vp, vp, i32]
+    L.p3m_hip_download_particles.argtypes = [vp, vp, vp, C.POINTER(i32)]
+    L.p3m_hip_particle_mesh.argtypes = [vp, f32, f32, f32, f32, vp, vp, C.POINTER(P3MStepOut)]
+    L.p3m_hip_update_position.argtypes = [vp, f32, f32, vp]
+    L.p3m_hip_link_list_and_pass.argtypes = [vp]
+    L.p3m_hip_fine_mesh.argtypes = [vp, f32, f32, f32]
+    L.p3m_hip_coarse_mesh.argtypes = [vp, f32, f32, f32]
+    L.p3m_hip_delete_particles.argtypes = [vp, vp]
+    L.p3m_hip_get_step_out.argtypes = [vp, f32, C.POINTER(P3MStepOut)]
+    L.p3m_hip_probe_tile_density.argtypes = [vp, i32, i32, i32, f32, f32p]
+    L.p3m_hip_probe_tile_force.argtypes = [vp, f32p, f32p, C.POINTER(f32)]
+    L.p3m_hip_probe_coarse.argtypes = [vp, f32, vp, vp]
+    L.p3m_hip_fft3d.argtypes = [vp, f32p, i32, i32]
+    L.p3m_hip_time_fine_sweep.argtypes = [vp, f32, i32, C.POINTER(f32)]
+    L.p3m_hip_stream.argtypes = [vp]
+    L.p3m_hip_stream.restype = vp
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise P3MError(code, load().p3m_hip_last_error().decode(errors="replace"))

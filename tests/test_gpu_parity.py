@@ -1,0 +1,297 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bars: particle count exact; positions max|dx| <= 1e-4 cells;
+kick rel. rms <= 1e-5 matched by PID; dt limits rel. 1e-5; integer/NGP mesh work bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from common import COARSE_TABLE, FINE_TABLE, by_pid, cfg1, clustered_particles, grid_jitter_particles, rel_rms, rms, uniform_particles
+from cubep3m_amd.params import Params
+
+pytestmark = pytest.mark.gpu
+
+KICK_TOL = 1e-5   # north_star: <= 1e-5 RMS relative force error vs the CPU reference
+POS_TOL = 1e-4
+DT_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def PM():
+    from cubep3m_amd.particle_mesh import ParticleMesh
+
+    return ParticleMesh
+
+
+def both(PM, p):
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    return g, o
+
+
+# ---------------------------------------------------------------------------------- FFT
+@pytest.mark.parametrize("n", [8, 16, 20, 28, 40, 44, 52, 68, 76, 80, 112, 176])
+def test_fft_forward_and_inverse_vs_oracle(PM, n):
+    g = PM(cfg1(), set_kernels=False)
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, n, n)).astype(np.float32)
+    a = np.zeros((n, n, n + 2), np.float32)
+    a[:, :, :n] = x
+    fg = g.fft3d(a, n, +1)
+    fo = ol.fft3d(a.copy(), n, +1)
+    scale = np.abs(fo).max()
+    assert np.abs(fg - fo).max() / scale < 2e-6
+    ref = np.fft.rfftn(x.astype(np.float64))
+    got = fg[:, :, 0::2] + 1j * fg[:, :, 1::2]
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+    back = g.fft3d(fg, n, -1)
+    assert np.abs(back[:, :, :n] - x).max() < 2e-5
+    assert np.all(back[:, :, n:] == 0)
+
+
+# ---------------------------------------------------------------------------------- Green's functions
+@pytest.mark.parametrize("pp_ext,lrck,T,nf", [(False, False, 2, 80), (True, False, 2, 80), (False, True, 2, 112)])
+def test_kernels_vs_oracle(PM, pp_ext, lrck, T, nf):
+    p = Params(tiles_node_dim=T, nf_tile=nf, ngp=True, ppint=pp_ext, pp_ext=pp_ext, lrckcorr=lrck)
+    g, o = both(PM, p)
+    kf, kc = g.get_kernels()
+    of, oc = o.kern_f(), o.kern_c()
+    assert np.abs(kf - of).max() / np.abs(of).max() < 2e-6
+    ok = np.isfinite(oc)  # LRCKCORR divides by zero at the Nyquist planes for tiny meshes
+    assert np.array_equal(np.isfinite(kc), ok)
+    assert np.abs(kc[ok] - oc[ok]).max() / np.abs(oc[ok]).max() < 5e-6
+
+
+# ---------------------------------------------------------------------------------- mesh stages
+@pytest.mark.parametrize("ngp", [True, False])
+def test_fine_deposit_vs_oracle(PM, ngp):
+    p = cfg1(ngp=ngp)
+    g, o = both(PM, p)
+    xv = clustered_particles(20000, 64.0, seed=5, frac=0.4, nblobs=10, sigma=0.8)
+    g.upload_particles(xv)
+    o.set_particles(0, xv)
+    g.link_list_and_pass()
+    o.link_list()
+    assert o.particle_pass() == 0
+    for tile in [(0, 0, 0), (1, 0, 1), (1, 1, 1)]:
+        rg, ro = g.tile_density(tile, 8.0), o.tile_density(0, tile, 8.0)
+        if ngp:
+            assert np.array_equal(rg, ro)          # integer counts times mass_p: bit-exact
+        else:
+            assert np.abs(rg - ro).max() <= 4e-6 * max(1.0, np.abs(ro).max())
+            assert abs(float(rg.sum(dtype=np.float64)) - float(ro.sum(dtype=np.float64))) < 1e-3
+
+
+def test_tile_force_vs_oracle(PM):
+    p = cfg1()
+    g, o = both(PM, p)
+    xv = uniform_particles(32768, 64.0)
+    o.set_particles(0, xv)
+    o.link_list()
+    o.particle_pass()
+    rho = o.tile_density(0, (1, 0, 1), 8.0)
+    fg, mg = g.tile_force(rho)
+    fo, mo = o.tile_force(rho)
+    assert rel_rms(fg, fo) < 2e-6
+    assert mg == pytest.approx(mo, rel=1e-5)
+
+
+def test_coarse_mesh_vs_oracle(PM):
+    p = cfg1()
+    g, o = both(PM, p)
+    xv = clustered_particles(30000, 64.0, seed=9)
+    g.upload_particles(xv)
+    o.set_particles(0, xv)
+    g.link_list_and_pass()
+    o.link_list()
+    o.particle_pass()
+    rg, fg = g.coarse(8.0)
+    o.coarse_density(8.0)
+    o.coarse_force()
+    ro, fo = o.rho_c(0), o.force_c(0)
+    assert np.abs(rg - ro).max() <= 4e-6 * np.abs(ro).max()
+    assert rel_rms(fg, fo) < 2e-6
+
+
+# ---------------------------------------------------------------------------------- whole step
+def run_step(PM, p, xv, scal, pid=None, steps=1):
+    a_mid, dt, dt_old, mass_p = scal
+    g, o = both(PM, p)
+    g.upload_particles(xv, pid)
+    o.set_particles(0, xv, pid)
+    outs = []
+    for s in range(steps):
+        og = g.particle_mesh(a_mid, dt, dt_old if s == 0 else dt, mass_p)
+        oo = o.particle_mesh(a_mid, dt, dt_old if s == 0 else dt, mass_p)
+        outs.append((og, oo))
+    xg, pg = by_pid(*g.download_particles())
+    xo, po = by_pid(*o.get_particles(0))
+    return xg, pg, xo, po, outs
+
+
+def check_step(xv, xg, pg, xo, po, outs, flags):
+    assert len(xg) == len(xo) and np.array_equal(pg, po)                      # particle count + identities exact
+    assert np.abs(xg[:, :3] - xo[:, :3]).max() <= POS_TOL
+    og, oo = outs[-1]
+    assert og.np_total == oo.np_total and og.np_ghost == oo.np_ghost and og.np_deleted == oo.np_deleted
+    assert og.dt_f_acc == pytest.approx(oo.dt_f_acc, rel=DT_TOL)
+    assert og.dt_c_acc == pytest.approx(oo.dt_c_acc, rel=DT_TOL)
+    if "pp" in flags:
+        assert og.dt_pp_acc == pytest.approx(oo.dt_pp_acc, rel=DT_TOL)
+    if "ext" in flags:
+        assert og.dt_pp_ext_acc == pytest.approx(oo.dt_pp_ext_acc, rel=DT_TOL)
+    assert og.sum_rho_f == pytest.approx(oo.sum_rho_f, rel=1e-6)
+    assert og.sum_rho_c == pytest.approx(oo.sum_rho_c, rel=1e-6)
+
+
+CASES = {
+    "pm_ngp_uniform": (dict(ngp=True), "uniform", ""),
+    "pm_cic_uniform": (dict(ngp=False), "uniform", ""),
+    "pm_ngp_grid": (dict(ngp=True), "grid", ""),
+    "p3m_intra_clustered": (dict(ngp=True, ppint=True), "clustered", "pp"),
+    "p3m_ext_clustered": (dict(ngp=True, ppint=True, pp_ext=True), "clustered", "pp ext"),
+    "p3m_ext_uniform": (dict(ngp=True, ppint=True, pp_ext=True), "uniform", "pp ext"),
+}
+
+
+def make_ic(kind, box=64.0, n=32768):
+    if kind == "uniform":
+        return uniform_particles(n, box)
+    if kind == "grid":
+        return grid_jitter_particles(32, box)
+    return clustered_particles(n, box, seed=2024, frac=0.3, nblobs=48, sigma=0.6)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_particle_mesh_config1_kick_parity(PM, case):
+    kw, ic, flags = CASES[case]
+    p = cfg1(**kw)
+    xv = make_ic(ic)
+    # first-step-like scalars of SURVEY section 8d: v=0, dt_old=0 -> output velocity is the pure kick
+    xg, pg, xo, po, outs = run_step(PM, p, xv, (0.005, 0.2, 0.0, 8.0))
+    check_step(xv, xg, pg, xo, po, outs, flags)
+    err = rel_rms(xg[:, 3:], xo[:, 3:])
+    assert err <= KICK_TOL, (case, err)
+    assert np.array_equal(xg[:, :3], xo[:, :3])   # no drift in this set-up: positions bit-identical
+
+
+def test_two_steps_with_drift_and_late_time_scalars(PM):
+    p = cfg1(ngp=True, ppint=True, pp_ext=True)
+    xv = clustered_particles(32768, 64.0, seed=11, frac=0.3, nblobs=40, sigma=0.7, vel_sigma=0.8)
+    pid = np.arange(len(xv), dtype=np.int64) * 3 + 17
+    xg, pg, xo, po, outs = run_step(PM, p, xv, (0.5, 0.05, 0.04, 8.0), pid=pid, steps=2)
+    check_step(xv, xg, pg, xo, po, outs, "pp ext")
+    # velocities now hold v0 + two kicks; compare the accumulated change
+    v0 = xv[np.argsort(pid), 3:]
+    assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
+
+
+def test_f77_wrapper_matches_context_api(PM):
+    from cubep3m_amd import lib
+
+    L = lib.load()
+    p = cfg1()
+    xv = uniform_particles(8192, 64.0, seed=3)
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    g.upload_particles(xv)
+    og = g.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    xr, pr = by_pid(*g.download_particles())
+    handle = C.c_int64(0)
+    cp = p.to_c()
+    xv2 = xv.copy()
+    pid = np.arange(1, len(xv) + 1, dtype=np.int64)
+    n = C.c_int32(len(xv))
+    f = lambda v: C.byref(C.c_float(v))
+    out = [C.c_float() for _ in range(4)]
+    ierr = C.c_int32(-99)
+    L.particle_mesh_hip_(C.byref(handle), C.byref(cp), FINE_TABLE.ctypes.data_as(C.c_void_p), COARSE_TABLE.ctypes.data_as(C.c_void_p),
+                         xv2.ctypes.data_as(C.c_void_p), pid.ctypes.data_as(C.c_void_p), C.byref(n), f(0.005), f(0.2), f(0.0), f(8.0),
+                         None, None, C.byref(out[0]), C.byref(out[1]), C.byref(out[2]), C.byref(out[3]), C.byref(ierr))
+    assert ierr.value == 0 and n.value == len(xv)
+    xw, pw = by_pid(xv2, pid)
+    assert rel_rms(xw[:, 3:], xr[:, 3:]) < 1e-6
+    assert out[0].value == pytest.approx(og.dt_f_acc, rel=1e-6) and out[3].value == pytest.approx(og.dt_c_acc, rel=1e-6)
+    L.p3m_hip_destroy(C.c_void_p(handle.value))
+
+
+# ---------------------------------------------------------------------------------- edge cases
+def test_empty_particle_set(PM):
+    g = PM(cfg1(), FINE_TABLE, COARSE_TABLE)
+    g.upload_particles(np.zeros((0, 6), np.float32))
+    out = g.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    assert out.np_total == 0 and out.sum_rho_f == 0.0 and g.np_local == 0
+
+
+def test_particles_leaving_the_chaining_mesh_are_dropped_and_reported(PM):
+    p = cfg1()
+    xv = uniform_particles(4096, 64.0, seed=8)
+    xv[:5, 0] = [-30.0, 95.0, 64.0 + 24.0, -24.0, 63.99]   # beyond +-nf_buf: deleted; exactly -24 / <88 kept
+    g, o = both(PM, p)
+    g.upload_particles(xv)
+    o.set_particles(0, xv)
+    og, oo = g.particle_mesh(0.005, 0.2, 0.0, 8.0), o.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    assert og.np_deleted == oo.np_deleted == 3
+    assert og.np_total == oo.np_total
+    xg, pg = by_pid(*g.download_particles())
+    xo, po = by_pid(*o.get_particles(0))
+    assert np.array_equal(pg, po) and rel_rms(xg[:, 3:], xo[:, 3:]) <= KICK_TOL
+
+
+def test_coordinates_half_an_ulp_below_a_cell_face(PM):
+    """xv + offset rounds up into the next cell in the reference's fp32 (particle_mesh_threaded.f90:139,248):
+    the deposit, the kick and the PP bucket must follow."""
+    p = cfg1(ngp=True, ppint=True, pp_ext=True)
+    xv = clustered_particles(16384, 64.0, seed=21, frac=0.5, nblobs=30, sigma=0.5)
+    k = np.arange(0, 4000)
+    faces = (np.arange(len(k)) % 60 + 2).astype(np.float32)
+    xv[k, 0] = np.nextafter(faces, np.float32(0))          # just below an integer, x
+    xv[k[::3], 1] = np.nextafter(faces[::3], np.float32(0))
+    xv[k[::7], 2] = np.nextafter(faces[::7] * 0 + 31, np.float32(0))
+    xg, pg, xo, po, outs = run_step(PM, p, xv, (0.005, 0.2, 0.0, 8.0))
+    check_step(xv, xg, pg, xo, po, outs, "pp ext")
+    assert rel_rms(xg[:, 3:], xo[:, 3:]) <= KICK_TOL
+
+
+def test_capacity_overflow_is_an_error_not_an_abort(PM):
+    from cubep3m_amd import lib
+
+    p = cfg1(density_buffer=0.3)
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    cap = g.derived(0)
+    with pytest.raises(lib.P3MError) as e:
+        g.upload_particles(uniform_particles(cap + 1, 64.0))
+    assert e.value.code == -3
+    g.upload_particles(uniform_particles(cap - 10, 64.0))
+    with pytest.raises(lib.P3MError) as e:
+        g.particle_mesh(0.005, 0.2, 0.0, 8.0)             # ghosts do not fit: "exceeded max_np in pass"
+    assert e.value.code == -3 and "max_np" in str(e.value)
+
+
+def test_step_before_kernels_is_a_state_error(PM):
+    from cubep3m_amd import lib
+
+    g = PM(cfg1(), set_kernels=False)
+    g.upload_particles(uniform_particles(100, 64.0))
+    with pytest.raises(lib.P3MError) as e:
+        g.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    assert e.value.code == -5
+
+
+# ---------------------------------------------------------------------------------- config 2 geometry, size-independent properties
+def test_config2_mass_conservation_and_momentum(PM):
+    p = Params(tiles_node_dim=4, nf_tile=112, ngp=True, ppint=True, pp_ext=True, density_buffer=1.5)
+    n = 128 ** 3
+    xv = uniform_particles(n, 256.0, seed=12345)
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    g.upload_particles(xv)
+    out = g.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    assert out.np_total == n
+    assert out.sum_rho_f == pytest.approx(8.0 * n, rel=1e-9)     # sum of rho_f = N*mass_p (NGP, exact)
+    assert out.sum_rho_c == pytest.approx(8.0 * n, rel=1e-6)
+    xo, pid = g.download_particles()
+    assert np.array_equal(np.sort(pid), np.arange(1, n + 1))
+    dv = xo[:, 3:].astype(np.float64)
+    # total momentum change ~ 0 (antisymmetric kernels, pairwise PP): compare with the rms kick
+    assert np.abs(dv.mean(0)).max() < 2e-3 * rms(dv)
