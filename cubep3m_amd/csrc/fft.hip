@@ -371,3 +371,17 @@ int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const f
   P3M_TRY(fft3d_inverse_zy(c, pl, data, batch, src, kern));
   return fft_x_inverse(c, pl, data, batch, 0, nullptr, 0, 0);
 }
+
+// benchmark hook: one pass kernel over `batch` tiles (see p3m_hip_time_fft_pass)
+int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float *work, const float *kern, int batch, float *box, int fb, int lo) {
+  switch (which) {
+    case 0: return fft_x_forward(c, pl, data, batch);
+    case 1: return lines_any<false, false>(c, pl, data, data, nullptr, 1, batch);
+    case 2: return lines_any<false, false>(c, pl, data, data, nullptr, 2, batch);
+    case 3: return lines_any<true, true>(c, pl, work, data, kern, 2, batch);
+    case 4: return lines_any<true, false>(c, pl, work, work, nullptr, 1, batch);
+    case 5: return fft_x_inverse(c, pl, work, batch, 1, box, fb, lo);
+  }
+  p3m_set_error("fft_single_pass: bad selector %d", which);
+  return P3M_EINVAL;
+}

@@ -78,6 +78,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   const int64_t ncell = (int64_t)g.E * g.E * g.E;
   int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // (cell_end+1) is 16-byte aligned for the scan
   A(dalloc(&c->d_counters, 16));
+  { const int64_t ec = g.E / g.ms; A(dalloc(&c->cflag, (size_t)(ec * ec * ec + 16))); }
   if (hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 16 * sizeof(int)) != hipSuccess) return fail(P3M_ENOMEM);
   // fine mesh: as many tiles per sweep as fit a 48 GiB budget for rho+work
   const size_t S = (size_t)(g.nf + 2) * g.nf * g.nf;
@@ -111,7 +112,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->pid); dfree(c->spos); dfree(c->svel); dfree(c->spid);
-  dfree(c->cell_of); dfree(c->flags); dfree(c->scan_tmp); dfree(c->d_counters);
+  dfree(c->cell_of); dfree(c->flags); dfree(c->cflag); dfree(c->scan_tmp); dfree(c->d_counters);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->kern_f);
   dfree(c->rho_c); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->kern_c);
@@ -432,6 +433,28 @@ extern "C" int p3m_hip_time_fine_sweep(p3m_ctx *c, float mass_p, int32_t reps, f
   float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *ms_per_sweep = ms / reps;
+  return P3M_OK;
+}
+
+int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float *work, const float *kern, int batch, float *box, int fb, int lo);
+
+extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch) {
+  if (!c || reps < 1 || !ms_per_launch) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  P3M_TRY(need_kernels(c));
+  const Geometry &g = c->g;
+  const int nt = std::min(c->tile_batch, g.ntiles);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2));  // warm-up
+  HIP_TRY(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < reps; i++) P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2));
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / reps;
+  if (batch) *batch = nt;
   return P3M_OK;
 }
 

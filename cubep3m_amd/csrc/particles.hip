@@ -68,8 +68,12 @@ __global__ __launch_bounds__(PT) void k_pass_axis_self(float4 *__restrict__ pos,
 
 // ------------------------------------------------------------------ counting sort by extended fine cell
 // cell = ((cz*E + cy)*E + cx), c_d = floor(x_d) + nb in [0,E).  cs[c] = start(c), cs[c+1] = end(c).
+// Also flags the coarse (hoc) cells that hold a physical record whose TILE-LOCAL fine cell
+// floor(x + offset_tile) (particle_mesh_threaded.f90:248-249) differs from floor(x): the intra-cell PP
+// buckets of such a coarse cell (:276-284) are not the sorted fine cells and take the slow path.
 __global__ __launch_bounds__(PT) void k_cell_hist(const float4 *__restrict__ pos, int n, int np_orig, float Nn, float nb, int E,
-                                                  int *__restrict__ cell_of, int *__restrict__ cs, int *__restrict__ ndeleted) {
+                                                  int *__restrict__ cell_of, int *__restrict__ cs, int *__restrict__ ndeleted,
+                                                  unsigned char *__restrict__ cflag, int ms, int pt) {
   const int i = blockIdx.x * PT + threadIdx.x;
   if (i >= n) return;
   const float4 p = pos[i];
@@ -78,6 +82,17 @@ __global__ __launch_bounds__(PT) void k_cell_hist(const float4 *__restrict__ pos
     const int cx = (int)floorf(p.x) + (int)nb, cy = (int)floorf(p.y) + (int)nb, cz = (int)floorf(p.z) + (int)nb;
     cell = (cz * E + cy) * E + cx;
     atomicAdd(&cs[cell + 1], 1);
+    if (cflag && p.x >= 0.f && p.x < Nn && p.y >= 0.f && p.y < Nn && p.z >= 0.f && p.z < Nn) {
+      const int nct = pt / ms; const float xs[3] = {p.x, p.y, p.z}; bool displaced = false; int cc[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        cc[d] = (int)floorf(xs[d] / (float)ms);
+        const int t = cc[d] / nct;
+        const float xl = xs[d] + (nb - (float)(t * pt));
+        displaced = displaced || ((int)floorf(xl) != (int)floorf(xs[d]) + (int)nb - t * pt);
+      }
+      if (displaced) { const int Ec = E / ms, cb = (int)nb / ms; cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] = 1; }
+    }
   } else if (i < np_orig) {
     atomicAdd(ndeleted, 1);
   }
@@ -124,9 +139,11 @@ int particles_pass_and_sort(p3m_ctx *c) {
   c->np_ghost = n_cur - c->np_local;
   const int64_t ncell = (int64_t)g.E * g.E * g.E;
   HIP_TRY(hipMemsetAsync(c->cell_end - 3, 0, (size_t)(ncell + 8) * sizeof(int), c->stream));
+  const bool want_cflag = (c->p.flags & P3M_FLAG_PPINT) != 0;
+  if (want_cflag) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
   if (n_cur > 0) {
     hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, c->np_local, (float)g.Nn,
-                       (float)g.nb, g.E, c->cell_of, c->cell_end, cnt + 4);
+                       (float)g.nb, g.E, c->cell_of, c->cell_end, cnt + 4, want_cflag ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
     HIP_TRY(hipGetLastError());
   }
   P3M_TRY(exclusive_scan_i32(c, c->cell_end + 1, ncell));

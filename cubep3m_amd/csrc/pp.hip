@@ -18,53 +18,68 @@ __device__ __forceinline__ float3 pair_force(const float4 &a, const float4 &b, f
 }
 
 // ------------------------------------------------------------------ intra-cell PP
-// One thread per physical record.  Its bucket is the reference's: hoc coarse cell
-// floor(x/mesh_scale) and sub-cell mod(i1-1,mesh_scale) with i1 = floor(x + offset_tile) + 1
-// (:248-249,:276-278).  Partners: records of that fine cell whose own bucket is the same.
-__global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, int n,
-                                                  PPGeo G, float mass_p, float a_mid, float dt, float *__restrict__ fmax_out) {
+// One thread per physical record.  The reference buckets the chain of hoc coarse cell
+// floor(x/mesh_scale) by sub-cell mod(i1-1,mesh_scale), i1 = floor(x + offset_tile) + 1
+// (:248-249,:276-278), and sums all pairs of one bucket.  For every coarse cell in which no
+// coordinate rounds across a cell face under the tile offset (cflag == 0, the overwhelmingly
+// common case) a bucket IS a sorted fine cell: partners are the index range of the own cell.
+// Flagged coarse cells take the slow path: scan the whole coarse cell (ms*ms x-rows) and compare
+// the reference's bucket of every candidate.
+__device__ __forceinline__ void ref_bucket(const float4 &p, const PPGeo &G, int cc[3], int sub[3]) {
+  const int nct = G.pt / G.ms; const float xs[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    cc[d] = (int)floorf(xs[d] / (float)G.ms);                     // hoc coarse cell, 0-based (link_list.f90:19-21)
+    const int t = cc[d] / nct;
+    const float xl = xs[d] + ((float)G.nb - (float)(t * G.pt));   // :248
+    sub[d] = ((int)floorf(xl)) % G.ms;                            // :277, (i1-1) mod mesh_scale
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs,
+                                                  const unsigned char *__restrict__ cflag, int n, PPGeo G, float mass_p, float a_mid, float dt,
+                                                  float *__restrict__ fmax_out) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   float mag = 0.f;
   if (s < n) {
     const float4 p = spos[s];
     const float fNn = (float)G.Nn;
     if (p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn) {
-      const int nct = G.pt / G.ms;
-      int cc[3], sub[3]; const float xs[3] = {p.x, p.y, p.z};
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        cc[d] = (int)floorf(xs[d] / (float)G.ms);                     // hoc coarse cell (0-based)
-        const int t = cc[d] / nct;
-        const float xl = xs[d] + ((float)G.nb - (float)(t * G.pt));   // :248
-        sub[d] = ((int)floorf(xl)) % G.ms;                            // :277  (i1-1) mod mesh_scale
-      }
-      const int bx = cc[0] * G.ms + sub[0] + G.nb, by = cc[1] * G.ms + sub[1] + G.nb, bz = cc[2] * G.ms + sub[2] + G.nb;
-      const int64_t cell = ((int64_t)bz * G.E + by) * G.E + bx;
-      const int q0 = cs[cell], q1 = cs[cell + 1];
+      int cc[3], sub[3];
+      ref_bucket(p, G, cc, sub);
+      const int Ec = G.E / G.ms, cb = G.nb / G.ms;
+      const bool slow = cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] != 0;
       float ax = 0.f, ay = 0.f, az = 0.f;
-      for (int q = q0; q < q1; q++) {
-        if (q == s) continue;
-        const float4 o = spos[q];
-        // the partner must be bucketed here too (it is unless one of its coordinates rounds up)
-        bool same = true;
-        const float os[3] = {o.x, o.y, o.z};
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          const int oc = (int)floorf(os[d] / (float)G.ms);
-          const int t = oc / nct;
-          const float xl = os[d] + ((float)G.nb - (float)(t * G.pt));
-          same = same && (oc == cc[d]) && ((((int)floorf(xl)) % G.ms) == sub[d]);
+      if (!slow) {
+        const int bx = (int)floorf(p.x) + G.nb, by = (int)floorf(p.y) + G.nb, bz = (int)floorf(p.z) + G.nb;
+        const int64_t cell = ((int64_t)bz * G.E + by) * G.E + bx;
+        const int q0 = cs[cell], q1 = cs[cell + 1];
+        for (int q = q0; q < q1; q++) {
+          if (q == s) continue;
+          const float3 f = pair_force(p, spos[q], mass_p, G.rsoft, G.pp_bias);
+          ax -= f.x; ay -= f.y; az -= f.z;                            // :346-347
         }
-        if (!same) continue;
-        const float3 f = pair_force(p, o, mass_p, G.rsoft, G.pp_bias);
-        ax -= f.x; ay -= f.y; az -= f.z;                                // :346-347
+      } else {
+        const int x0 = cc[0] * G.ms + G.nb;
+        for (int dz = 0; dz < G.ms; dz++)
+          for (int dy = 0; dy < G.ms; dy++) {
+            const int64_t rb = ((int64_t)(cc[2] * G.ms + G.nb + dz) * G.E + (cc[1] * G.ms + G.nb + dy)) * G.E;
+            const int q0 = cs[rb + x0], q1 = cs[rb + x0 + G.ms];
+            for (int q = q0; q < q1; q++) {
+              if (q == s) continue;
+              const float4 o = spos[q];
+              int oc[3], os[3];
+              ref_bucket(o, G, oc, os);
+              if (oc[0] != cc[0] || oc[1] != cc[1] || oc[2] != cc[2] || os[0] != sub[0] || os[1] != sub[1] || os[2] != sub[2]) continue;
+              const float3 f = pair_force(p, o, mass_p, G.rsoft, G.pp_bias);
+              ax -= f.x; ay -= f.y; az -= f.z;
+            }
+          }
       }
-      if (q1 - q0 > 1 || true) {
-        float4 v = svel[s];
-        v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
-        svel[s] = v;
-      }
-      mag = sqrtf(ax * ax + ay * ay + az * az);                         // :356
+      float4 v = svel[s];
+      v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
+      svel[s] = v;
+      mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356
     }
   }
   for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_down(mag, o, 64));
@@ -76,7 +91,7 @@ int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (c->np_all == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   hipLaunchKernelGGL(k_pp_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end,
-                     c->np_all, G, mass_p, a_mid, dt, c->d_red + 1);
+                     (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "p3m_hip_get_kernels", "p3m_hip_upload_particles", "p3m_hip_download_particles", "p3m_hip_particle_mesh",
     "p3m_hip_update_position", "p3m_hip_link_list_and_pass", "p3m_hip_fine_mesh", "p3m_hip_coarse_mesh",
     "p3m_hip_delete_particles", "p3m_hip_get_step_out", "p3m_hip_probe_tile_density", "p3m_hip_probe_tile_force",
-    "p3m_hip_probe_coarse", "p3m_hip_fft3d", "p3m_hip_time_fine_sweep", "p3m_hip_stream", "particle_mesh_hip_",
+    "p3m_hip_probe_coarse", "p3m_hip_fft3d", "p3m_hip_time_fine_sweep", "p3m_hip_time_fft_pass", "p3m_hip_stream", "particle_mesh_hip_",
 ]
 
 
@@ -72,6 +72,7 @@ def load():
     L.p3m_hip_probe_coarse.argtypes = [vp, f32, vp, vp]
     L.p3m_hip_fft3d.argtypes = [vp, f32p, i32, i32]
     L.p3m_hip_time_fine_sweep.argtypes = [vp, f32, i32, C.POINTER(f32)]
+    L.p3m_hip_time_fft_pass.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(i32)]
     L.p3m_hip_stream.argtypes = [vp]
     L.p3m_hip_stream.restype = vp
     _lib = L

@@ -155,3 +155,11 @@ class ParticleMesh:
         ms = C.c_float()
         _lib.check(self.L.p3m_hip_time_fine_sweep(self.h, mass_p, reps, C.byref(ms)))
         return ms.value
+
+    FFT_PASSES = ("x_fwd", "y_fwd", "z_fwd", "z_inv_fused", "y_inv", "x_inv_extract")
+
+    def time_fft_pass(self, which, reps=20):
+        """Average ms per launch of one FFT pass kernel over the tile batch (HIP events on the library stream)."""
+        ms, nb = C.c_float(), C.c_int32()
+        _lib.check(self.L.p3m_hip_time_fft_pass(self.h, which, reps, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value

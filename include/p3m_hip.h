@@ -185,6 +185,12 @@ int p3m_hip_fft3d(p3m_ctx *ctx, float *data, int32_t n, int32_t dir);
 /* Fine-mesh sweep over all tiles `reps` times with device-resident inputs, timed with HIP
    events on the library's stream; returns average milliseconds per sweep (benchmark leg). */
 int p3m_hip_time_fine_sweep(p3m_ctx *ctx, float mass_p, int32_t reps, float *ms_per_sweep);
+/* One pass kernel of the fine-mesh FFT over the whole tile batch, launched `reps` times between
+   HIP events on the library's stream; returns the average milliseconds per launch.
+   which: 0 x-forward (r2c rows), 1 y-forward lines, 2 z-forward lines, 3 z-inverse lines fused with
+   the i*K multiply, 4 y-inverse lines, 5 x-inverse (c2r rows) + force-box extraction.  *batch returns
+   the number of tiles one launch processed. */
+int p3m_hip_time_fft_pass(p3m_ctx *ctx, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch);
 /* HIP stream the kernels are launched on (for hipEvent timing by the host). */
 void *p3m_hip_stream(p3m_ctx *ctx);
 

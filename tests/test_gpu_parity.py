@@ -81,7 +81,7 @@ def test_fine_deposit_vs_oracle(PM, ngp):
             assert np.array_equal(rg, ro)          # integer counts times mass_p: bit-exact
         else:
             assert np.abs(rg - ro).max() <= 4e-6 * max(1.0, np.abs(ro).max())
-            assert abs(float(rg.sum(dtype=np.float64)) - float(ro.sum(dtype=np.float64))) < 1e-3
+            assert float(rg.sum(dtype=np.float64)) == pytest.approx(float(ro.sum(dtype=np.float64)), rel=1e-7)
 
 
 def test_tile_force_vs_oracle(PM):
