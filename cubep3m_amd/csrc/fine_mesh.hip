@@ -12,6 +12,7 @@
 // the next cell.  Since the parity metric (1e-5 relative rms over all particles) does not tolerate
 // even one mis-binned particle, every kernel here recomputes the reference expression per record.
 #include "p3m_internal.h"
+#include <algorithm>
 
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, int mode, float *box, int fb, int lo);
 int fft3d_inverse_zy(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const float *src, const float *kern);
@@ -92,17 +93,84 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ NGP deposit from the cell counts
+// rho(cell) = mass_p added count(cell) times (:148), count = cs[c+1]-cs[c]: a streaming pass over the
+// sorted cell offsets, no particle reads, no atomics.  Cells outside the NGP chain window [4,nf-4)
+// (:120-121) are zero.  The handful of records whose xv+offset rounds into the next cell are moved
+// afterwards by k_ngp_fixup.
+__global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, float *__restrict__ rho, int tile0, int ntile, TileGeo G,
+                                                    float mass_p, double *__restrict__ sum_interior) {
+  __shared__ float sh[4];
+  const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb, pitch = nf + 2;
+  const int64_t tot = (int64_t)ntile * nf * nf * pitch;
+  float part = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx % pitch); int64_t r = idx / pitch;
+    const int j = (int)(r % nf); r /= nf; const int k = (int)(r % nf); const int tl = (int)(r / nf);
+    float v = 0.f;
+    if (i >= 4 && i < nf - 4 && j >= 4 && j < nf - 4 && k >= 4 && k < nf - 4) {
+      int tx, ty, tz; tile_xyz(tile0 + tl, G.T, tx, ty, tz);
+      const int64_t cell = ((int64_t)(tz * pt + k) * E + (ty * pt + j)) * E + (tx * pt + i);
+      const int cnt = cs[cell + 1] - cs[cell];
+      for (int q = 0; q < cnt; q++) v = v + mass_p;                                                // :148, same partial sums
+      if (i >= nb && i < nf - nb && j >= nb && j < nf - nb && k >= nb && k < nf - nb) part += v;      // :167-173
+    }
+    rho[idx] = v;
+  }
+  if (sum_interior) {
+    const float s = block_sum_f(part, sh);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(sum_interior, (double)s);
+  }
+}
+// candidates: sorted indices of records within 2^-10 below a cell face in some coordinate (k_scatter)
+__global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, const int *__restrict__ cand, int ncand, float *__restrict__ rho,
+                                                   int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)ncand * ntile) return;
+  const int tl = (int)(id / ncand); const int ci = (int)(id - (int64_t)tl * ncand);
+  const float4 p = spos[cand[ci]];
+  const int nf = G.nf, pt = G.pt, nb = G.nb;
+  int t3[3]; tile_xyz(tile0 + tl, G.T, t3[0], t3[1], t3[2]);
+  const float xs[3] = {p.x, p.y, p.z};
+  int gl[3], rr[3]; bool member = true, moved = false;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    gl[d] = (int)floorf(xs[d]) + nb - t3[d] * pt;                       // cell the count-based deposit used
+    member = member && gl[d] >= 4 && gl[d] < nf - 4;                     // chain window (:120-121)
+    rr[d] = (int)floorf(xs[d] + (float)(-t3[d] * pt + nb));             // the reference's cell (:134,:139,:143)
+    moved = moved || (rr[d] != gl[d]);
+  }
+  if (!member || !moved) return;
+  float *base = rho + (int64_t)tl * nf * nf * (nf + 2);
+  atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * (nf + 2) + gl[0]], -mass_p);
+  atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * (nf + 2) + rr[0]], mass_p);
+  if (sum_interior) {
+    const bool ig = gl[0] >= nb && gl[0] < nf - nb && gl[1] >= nb && gl[1] < nf - nb && gl[2] >= nb && gl[2] < nf - nb;
+    const bool ir = rr[0] >= nb && rr[0] < nf - nb && rr[1] >= nb && rr[1] < nf - nb && rr[2] >= nb && rr[2] < nf - nb;
+    if (ig != ir) atomicAdd(sum_interior, ir ? (double)mass_p : -(double)mass_p);
+  }
+}
+
 int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   const Geometry &g = c->g;
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb};
+  if (c->p.flags & P3M_FLAG_NGP) {
+    const int64_t tot = (int64_t)ntile * g.nf * g.nf * (g.nf + 2);
+    hipLaunchKernelGGL(k_ngp_counts, dim3((unsigned)std::min<int64_t>(cdiv(tot, 256), 256 * 32)), dim3(256), 0, c->stream, (const int *)c->cell_end,
+                       c->rho, tile0, ntile, G, mass_p, c->d_sums);
+    HIP_TRY(hipGetLastError());
+    if (c->ncand > 0) {
+      const int64_t work = (int64_t)c->ncand * ntile;
+      hipLaunchKernelGGL(k_ngp_fixup, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cand,
+                         c->ncand, c->rho, tile0, ntile, G, mass_p, c->d_sums);
+      HIP_TRY(hipGetLastError());
+    }
+    return P3M_OK;
+  }
   const unsigned blocks = (unsigned)((int64_t)ntile * g.nf * g.nf);
   const size_t lds = sizeof(float) * (g.nf + 2);
-  if (c->p.flags & P3M_FLAG_NGP)
-    hipLaunchKernelGGL(k_fine_deposit<true>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
-                       tile0, G, mass_p, c->d_sums);
-  else
-    hipLaunchKernelGGL(k_fine_deposit<false>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
-                       tile0, G, mass_p, c->d_sums);
+  hipLaunchKernelGGL(k_fine_deposit<false>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
+                     tile0, G, mass_p, c->d_sums);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

@@ -66,6 +66,7 @@ struct p3m_ctx {
   int *scan_tmp = nullptr; size_t scan_tmp_n = 0;
   int *flags = nullptr;        // [cap] compaction flags / offsets
   unsigned char *cflag = nullptr; // [(E/ms)^3] coarse cells holding a record whose tile-local cell differs from floor(x)
+  int *cand = nullptr; int ncand = 0; // [cap] sorted indices of records within 2^-10 below a cell face
   int *d_counters = nullptr;   // small device counter block
   int *h_counters = nullptr;   // pinned mirror
   // ---- fine mesh, all tiles batched

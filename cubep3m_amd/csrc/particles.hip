@@ -7,6 +7,7 @@
 // Records are SoA float4 pos, float4 vel, int64 pid.  Everything here is HBM-bound streaming
 // except the cell histogram/scatter (one int atomic per particle).
 #include "p3m_internal.h"
+#include <algorithm>
 
 #define PT 256
 
@@ -37,33 +38,60 @@ __device__ __forceinline__ bool in_hoc_range(const float4 &p, float lo, float hi
   return p.x >= lo && p.x < hi && p.y >= lo && p.y < hi && p.z >= lo && p.z < hi;
 }
 
-// One axis of particle_pass.f90 on a single rank (the rank is its own +/- neighbour): every
-// valid record i < n_cur with x_a >= Nn-nb gets an image at max(x_a-Nn,-nb) (:83,:162) and every
-// record with x_a < nb an image at min(guard(x_a)+Nn, Nn+nb-eps) (:185,:257-265).  Records that
-// arrived in this axis' first direction are not re-sent in the second (they are not in hoc yet).
-__global__ __launch_bounds__(PT) void k_pass_axis_self(float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid,
-                                                       int n_cur, int cap, int axis, float Nn, float nb, int *__restrict__ counter,
-                                                       int *__restrict__ overflow) {
-  const int i = blockIdx.x * PT + threadIdx.x;
-  if (i >= n_cur) return;
-  const float4 p = pos[i];
-  if (!in_hoc_range(p, -nb, Nn + nb)) return;  // dropped by link_list ("PARTICLE DELETED")
-  const float x = comp(p, axis);
-  const bool hi = x >= Nn - nb, lo = x < nb;
-  if (!(hi || lo)) return;
-  const float4 v = vel[i]; const int64_t id = pid[i];
-  if (hi) {
-    const int s = n_cur + atomicAdd(counter, 1);
-    if (s < cap) { float4 q = p; setcomp(q, axis, fmaxf(x - Nn, -nb)); pos[s] = q; vel[s] = v; pid[s] = id; }
-    else *overflow = 1;
-  }
-  if (lo) {
+// particle_pass.f90 on a single rank (the rank is its own +/- neighbour in every direction).
+// The three sequential axis exchanges (+x,-x | re-link | -y,+y | re-link | +z,-z) deliver, for every
+// record, the Cartesian product of its per-axis image sets: coordinate a contributes itself, plus
+// max(x_a-Nn,-nb) if x_a >= Nn-nb (:83,:162), plus min(guard(x_a)+Nn, Nn+nb-eps) if x_a < nb
+// (:185,:257-265); an axis' second direction never re-sends what its first direction delivered (not
+// yet in hoc), and the later axes see all earlier arrivals (re-link :274-298).  One kernel writes all
+// images: per-block exclusive scan of the image counts, one atomic per block for the base.
+__device__ __forceinline__ int axis_images(float x, float Nn, float nb, float out[3]) {
+  int n = 0;
+  out[n++] = x;
+  if (x >= Nn - nb) out[n++] = fmaxf(x - Nn, -nb);
+  if (x < nb) {
     float xs = x;
     if (fabsf(xs) < P3M_EPS_F) xs = (xs < 0.0f) ? -P3M_EPS_F : P3M_EPS_F;
-    const int s = n_cur + atomicAdd(counter, 1);
-    if (s < cap) { float4 q = p; setcomp(q, axis, fminf(xs + Nn, Nn + nb - P3M_EPS_F)); pos[s] = q; vel[s] = v; pid[s] = id; }
-    else *overflow = 1;
+    out[n++] = fminf(xs + Nn, Nn + nb - P3M_EPS_F);
   }
+  return n;
+}
+__global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid, int n_cur,
+                                                    int cap, float Nn, float nb, int *__restrict__ counter, int *__restrict__ overflow) {
+  __shared__ int wsum[PT / 64];
+  __shared__ int base_sh;
+  const int i = blockIdx.x * PT + threadIdx.x;
+  float ox[3], oy[3], oz[3]; int nx = 1, ny = 1, nz = 1, cnt = 0;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n_cur) {
+    p = pos[i];
+    if (in_hoc_range(p, -nb, Nn + nb)) {  // else dropped by link_list ("PARTICLE DELETED")
+      nx = axis_images(p.x, Nn, nb, ox); ny = axis_images(p.y, Nn, nb, oy); nz = axis_images(p.z, Nn, nb, oz);
+      cnt = nx * ny * nz - 1;
+    }
+  }
+  // block exclusive scan of cnt
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < PT / 64; k++) { if (k < w) off += wsum[k]; tot += wsum[k]; }
+  if (threadIdx.x == 0) base_sh = tot ? atomicAdd(counter, tot) : 0;
+  __syncthreads();
+  if (cnt == 0) return;
+  int s = n_cur + base_sh + off + inc - cnt;
+  const float4 v = vel[i]; const int64_t id = pid[i];
+  for (int c = 0; c < nz; c++)
+    for (int b = 0; b < ny; b++)
+      for (int a = 0; a < nx; a++) {
+        if ((a | b | c) == 0) continue;
+        if (s < cap) { pos[s] = make_float4(ox[a], oy[b], oz[c], p.w); vel[s] = v; pid[s] = id; } else *overflow = 1;
+        s++;
+      }
 }
 
 // ------------------------------------------------------------------ counting sort by extended fine cell
@@ -101,13 +129,22 @@ __global__ __launch_bounds__(PT) void k_cell_hist(const float4 *__restrict__ pos
 
 __global__ __launch_bounds__(PT) void k_scatter(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
                                                 const int *__restrict__ cell_of, int n, int *__restrict__ cs, float4 *__restrict__ spos,
-                                                float4 *__restrict__ svel, int64_t *__restrict__ spid) {
+                                                float4 *__restrict__ svel, int64_t *__restrict__ spid, int *__restrict__ cand,
+                                                int *__restrict__ ncand, int cand_cap) {
   const int i = blockIdx.x * PT + threadIdx.x;
   if (i >= n) return;
   const int cell = cell_of[i];
   if (cell < 0) return;
   const int s = atomicAdd(&cs[cell + 1], 1);
-  spos[s] = pos[i]; svel[s] = vel[i]; spid[s] = pid[i];
+  const float4 p = pos[i];
+  spos[s] = p; svel[s] = vel[i]; spid[s] = pid[i];
+  // records with a coordinate within 2^-10 below a cell face: only these can be moved into the next
+  // cell by the rounding of xv + offset_tile (fine_mesh.hip, count-based NGP deposit fix-up)
+  const float thr = 1.0f - 0.0009765625f;
+  if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
+    const int k = atomicAdd(ncand, 1);
+    if (k < cand_cap) cand[k] = s;
+  }
 }
 
 int particles_pass_and_sort(p3m_ctx *c) {
@@ -116,21 +153,19 @@ int particles_pass_and_sort(p3m_ctx *c) {
   HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
   int n_cur = c->np_local;
   if (g.nodes == 1) {
-    for (int axis = 0; axis < 3; axis++) {
-      if (n_cur > 0) {
-        hipLaunchKernelGGL(k_pass_axis_self, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, axis,
-                           (float)g.Nn, (float)g.nb, cnt + axis, cnt + 3);
-        HIP_TRY(hipGetLastError());
-      }
-      HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      if (c->h_counters[3] || (int64_t)n_cur + c->h_counters[axis] > c->cap) {
-        p3m_set_error("exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139); raise density_buffer",
-                      (long long)n_cur + c->h_counters[axis], (long long)c->cap);
-        return P3M_ECAPACITY;
-      }
-      n_cur += c->h_counters[axis];
+    if (n_cur > 0) {
+      hipLaunchKernelGGL(k_make_images, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
+                         (float)g.nb, cnt, cnt + 3);
+      HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_counters[3] || (int64_t)n_cur + c->h_counters[0] > c->cap) {
+      p3m_set_error("exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139); raise density_buffer",
+                    (long long)n_cur + c->h_counters[0], (long long)c->cap);
+      return P3M_ECAPACITY;
+    }
+    n_cur += c->h_counters[0];
   } else {
     p3m_set_error("multi-rank pass requires a transport (not initialised)");
     return P3M_ECOMM;
@@ -149,12 +184,13 @@ int particles_pass_and_sort(p3m_ctx *c) {
   P3M_TRY(exclusive_scan_i32(c, c->cell_end + 1, ncell));
   if (n_cur > 0) {
     hipLaunchKernelGGL(k_scatter, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel,
-                       (const int64_t *)c->pid, (const int *)c->cell_of, n_cur, c->cell_end, c->spos, c->svel, c->spid);
+                       (const int64_t *)c->pid, (const int *)c->cell_of, n_cur, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5, (int)c->cap);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->np_deleted = c->h_counters[4];
+  c->ncand = std::min<int64_t>(c->h_counters[5], c->cap);
   c->np_all = n_cur - c->np_deleted;  // sorted records
   return P3M_OK;
 }
