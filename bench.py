@@ -136,14 +136,15 @@ def main():
     for i, name in enumerate(pm.FFT_PASSES):
         ms, nb = pm.time_fft_pass(i, reps=20)
         passes[name] = ms
-    # per sweep over the batch: 1 x_fwd, 1 y_fwd, 1 z_fwd, then per component z_inv_fused, y_inv, x_inv_extract
-    per_sweep = {k: v * (1 if k.endswith("fwd") else 3) for k, v in passes.items()}
+    # per sweep over the batch, one launch each: x_fwd, y_fwd, z_fwd, z_inv_fused (3 components), y_inv (3), x_inv_extract (3)
     dom = max(("y_fwd", "z_fwd", "z_inv_fused", "y_inv"), key=lambda k: passes[k])
     sweep_ms = pm.time_fine_sweep(mass_p, reps=5)
     ntile = p.tiles_node_dim ** 3
-    # one 3-D transform of one tile is 2*S algorithmic bytes (one read + one write); this
-    # implementation spends three axis passes on it, so one pass launch over `nb` tiles carries (2/3)*S*nb.
-    alg_bytes = (2.0 / 3.0) * S * nb
+    # the forward 3-D transform of one tile is 2*S algorithmic bytes (one read + one write), one force
+    # component is 2.5*S (read rho-hat, read half-size kernel, write).  This implementation spends three axis passes on a
+    # transform, so a forward pass launch over `nb` tiles carries (2/3)*S*nb and an inverse pass launch (all three
+    # components in one launch) 3*(2.5/3)*S*nb.
+    alg_bytes = ((2.0 / 3.0) if dom.endswith("fwd") else 2.5) * S * nb
     achieved = alg_bytes / (passes[dom] * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -58,21 +58,21 @@ int coarse_deposit(p3m_ctx *c, float mass_p) {
 }
 
 // cube -> slab (pack_slab, fftw3ds.f90:4-54); single rank: a pitch change only
-__global__ __launch_bounds__(256) void k_cube_to_slab(const float *__restrict__ cube, float *__restrict__ slab, int n) {
+__global__ __launch_bounds__(256) void k_cube_to_slab(const float *__restrict__ cube, float *__restrict__ slab, int n, int rp) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t tot = (int64_t)n * n * (n + 2);
+  const int64_t tot = (int64_t)n * n * rp;
   if (idx >= tot) return;
-  const int i = (int)(idx % (n + 2)); const int64_t r = idx / (n + 2);
+  const int i = (int)(idx % rp); const int64_t r = idx / rp;
   slab[idx] = (i < n) ? cube[r * n + i] : 0.f;
 }
 // slab -> force_c(comp, 0:ncn+1, ...) with the periodic 1-cell halo (unpack_slab + coarse_force_buffer.f90)
-__global__ __launch_bounds__(256) void k_slab_to_force(const float *__restrict__ slab, float *__restrict__ fc, int n) {
+__global__ __launch_bounds__(256) void k_slab_to_force(const float *__restrict__ slab, float *__restrict__ fc, int n, int rp) {
   const int m = n + 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)m * m * m) return;
   const int i = (int)(idx % m), j = (int)((idx / m) % m), k = (int)(idx / ((int64_t)m * m));
   const int gi = (i - 1 + n) % n, gj = (j - 1 + n) % n, gk = (k - 1 + n) % n;
-  fc[idx] = slab[((int64_t)gk * n + gj) * (n + 2) + gi];
+  fc[idx] = slab[((int64_t)gk * n + gj) * rp + gi];
 }
 // coarse_max_dt.f90:24-31
 __global__ __launch_bounds__(256) void k_coarse_max(const float *__restrict__ fc, int n, float *__restrict__ out) {
@@ -92,15 +92,16 @@ int coarse_force(p3m_ctx *c) {
   const Geometry &g = c->g;
   if (g.nodes != 1) { p3m_set_error("coarse_force: multi-rank path needs the slab transport"); return P3M_ECOMM; }
   const int n = g.nc;
-  const int64_t tot = (int64_t)n * n * (n + 2);
-  hipLaunchKernelGGL(k_cube_to_slab, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, (const float *)c->rho_c, c->slab, n);
+  const int rp = 2 * g.pxc;
+  const int64_t tot = (int64_t)n * n * rp;
+  hipLaunchKernelGGL(k_cube_to_slab, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, (const float *)c->rho_c, c->slab, n, rp);
   HIP_TRY(hipGetLastError());
   P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));                                          // coarse_force.f90:18
-  const size_t kplane = (size_t)n * n * (n / 2 + 1);
+  const size_t kplane = (size_t)n * n * g.pxc;
   const int64_t fcs = (int64_t)(n + 2) * (n + 2) * (n + 2);
   for (int comp = 0; comp < 3; comp++) {
     P3M_TRY(fft3d_inverse(c, c->plan_c, c->slab_w, 1, c->slab, c->kern_c + comp * kplane));  // :37-50
-    hipLaunchKernelGGL(k_slab_to_force, dim3(cdiv(fcs, 256)), dim3(256), 0, c->stream, (const float *)c->slab_w, c->force_c + comp * fcs, n);
+    hipLaunchKernelGGL(k_slab_to_force, dim3(cdiv(fcs, 256)), dim3(256), 0, c->stream, (const float *)c->slab_w, c->force_c + comp * fcs, n, rp);
     HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(k_coarse_max, dim3(std::min<int64_t>(1024, cdiv((int64_t)n * n * n, 256))), dim3(256), 0, c->stream, (const float *)c->force_c,
@@ -150,12 +151,12 @@ int coarse_kick(p3m_ctx *c, float a_mid, float dt) {
 // ------------------------------------------------------------------ coarse_kernel (kernel_initialization.f90:272-732), single rank
 // ck = -r/r^3 on the mesh_scale-spaced periodic lattice (:302-336), the 4^3 corner and its signed
 // mirror images from the table (:366-406): component d flips sign when axis d is mirrored.
-__global__ __launch_bounds__(256) void k_coarse_kernel_real(float *__restrict__ slab, const float *__restrict__ table, int n, int ms, int comp,
+__global__ __launch_bounds__(256) void k_coarse_kernel_real(float *__restrict__ slab, const float *__restrict__ table, int n, int rp, int ms, int comp,
                                                             int use_table) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t tot = (int64_t)n * n * (n + 2);
+  const int64_t tot = (int64_t)n * n * rp;
   if (idx >= tot) return;
-  const int i = (int)(idx % (n + 2)); const int64_t r = idx / (n + 2); const int j = (int)(r % n), k = (int)(r / n);
+  const int i = (int)(idx % rp); const int64_t r = idx / rp; const int j = (int)(r % n), k = (int)(r / n);
   float v = 0.f;
   if (i < n) {
     const int c3[3] = {i, j, k};
@@ -177,11 +178,11 @@ __global__ __launch_bounds__(256) void k_coarse_kernel_real(float *__restrict__ 
   slab[idx] = v;
 }
 // LRCKCORR, :562-591: Im K_c <- Im K_c^{corr} * (wc / Im K_c^{uncorr}) for integer |k| <= 8, k_c != 0
-__global__ __launch_bounds__(256) void k_lrck(float *__restrict__ kern, const float *__restrict__ uncorr, int n, int comp) {
-  const int hx = n / 2 + 1;
+__global__ __launch_bounds__(256) void k_lrck(float *__restrict__ kern, const float *__restrict__ uncorr, int n, int px, int comp) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)n * n * hx) return;
-  const int kx = (int)(idx % hx), j = (int)((idx / hx) % n), k = (int)(idx / ((int64_t)hx * n));
+  if (idx >= (int64_t)n * n * px) return;
+  const int kx = (int)(idx % px), j = (int)((idx / px) % n), k = (int)(idx / ((int64_t)px * n));
+  if (kx > n / 2) return;  // pad columns
   const int ky = (j < n / 2 + 1) ? j : j - n, kz = (k < n / 2 + 1) ? k : k - n;
   const float kr = sqrtf((float)(kx * kx + ky * ky + kz * kz));
   if (!(kr <= 8.f)) return;
@@ -204,21 +205,22 @@ int build_coarse_kernel(p3m_ctx *c, const float *table4_host) {
   float *d_table = nullptr;
   HIP_TRY(hipMalloc(&d_table, sizeof(float) * 192));
   HIP_TRY(hipMemcpyAsync(d_table, table4_host, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
-  const int64_t tot = (int64_t)n * n * (n + 2), ncx = (int64_t)n * n * (n / 2 + 1);
+  const int rp = 2 * g.pxc;
+  const int64_t tot = (int64_t)n * n * rp, ncx = (int64_t)n * n * g.pxc;
   float *unc = nullptr;
   const bool lr = (c->p.flags & P3M_FLAG_LRCKCORR) != 0;
   if (lr) HIP_TRY(hipMalloc(&unc, sizeof(float) * ncx));
   for (int comp = 0; comp < 3; comp++) {
     if (lr) {
-      hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, g.ms, comp, 0);
+      hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, rp, g.ms, comp, 0);
       P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));
       hipLaunchKernelGGL(k_take_imag_c, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->slab, unc, ncx);
     }
-    hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, g.ms, comp, 1);
+    hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, rp, g.ms, comp, 1);
     HIP_TRY(hipGetLastError());
     P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));
     hipLaunchKernelGGL(k_take_imag_c, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->slab, c->kern_c + comp * ncx, ncx);
-    if (lr) hipLaunchKernelGGL(k_lrck, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, c->kern_c + comp * ncx, (const float *)unc, n, comp);
+    if (lr) hipLaunchKernelGGL(k_lrck, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, c->kern_c + comp * ncx, (const float *)unc, n, g.pxc, comp);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(c->stream));

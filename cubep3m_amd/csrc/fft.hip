@@ -153,20 +153,26 @@ __device__ __forceinline__ float2 *fft_lds(float2 *A, float2 *B, int n, int nl, 
   return in;
 }
 
+// ------------------------------------------------------------------ memory layout
+// One array is [n][n][px] complex (= [n][n][2*px] real), px = n/2+1 rounded up to 16 so that every
+// row starts on a 128-byte line and a bundle of BX=16 columns is exactly one line.  The pad
+// columns hold zeros and are transformed along (independent lines).
+
 // ------------------------------------------------------------------ x pass, forward (r2c)
-// rows_total real rows of length n (row pitch n+2 floats); RB rows per workgroup.
+// rows_total real rows of length n (row pitch 2*px floats); RB rows per workgroup.
 template <int RB>
-__global__ __launch_bounds__(256) void k_fft_x_fwd(float *__restrict__ data, int n, int rows_total, Factors fac,
+__global__ __launch_bounds__(256) void k_fft_x_fwd(float *__restrict__ data, int n, int px, int rows_total, Factors fac,
                                                    const float2 *__restrict__ tw_g) {
   extern __shared__ float2 lds[];
-  const int h = n >> 1, LP = h + 1;
+  const int h = n >> 1, LP = h + 2, h2 = h >> 1;
   float2 *A = lds, *B = A + RB * LP, *tw = B + RB * LP;
   for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
   const int64_t row0 = (int64_t)blockIdx.x * RB;
   const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
-  for (int e = threadIdx.x; e < nrows * h; e += blockDim.x) {
-    const int r = e / h, m = e - r * h;
-    A[r * LP + m] = reinterpret_cast<const float2 *>(data + (row0 + r) * (int64_t)(n + 2))[m];
+  for (int e = threadIdx.x; e < nrows * h2; e += blockDim.x) {
+    const int r = e / h2, m = e - r * h2;
+    const float4 v = reinterpret_cast<const float4 *>(data + (row0 + r) * (int64_t)(2 * px))[m];
+    *reinterpret_cast<float4 *>(&A[r * LP + 2 * m]) = v;
   }
   __syncthreads();
   const float2 *Z = fft_lds<true>(A, B, h, nrows, 1, LP, fac, tw, 2);
@@ -179,20 +185,20 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd(float *__restrict__ data, int
     const float2 O = make_float2(0.5f * (zk.y - zc.y), -0.5f * (zk.x - zc.x));
     const float2 w = (k == h) ? make_float2(-1.f, 0.f) : tw[k];
     const float2 X = cadd(E, cmul(O, w));
-    reinterpret_cast<float2 *>(data + (row0 + r) * (int64_t)(n + 2))[k] = X;
+    reinterpret_cast<float2 *>(data + (row0 + r) * (int64_t)(2 * px))[k] = X;
   }
 }
 
 // ------------------------------------------------------------------ x pass, inverse (c2r) + /n^3
-// mode 0: in place, all rows.  mode 1: only the rows/columns of the force box
-// force_f(c, nb-1:nf-nb+1,...) (particle_mesh_threaded.f90:202) are produced and written to
-// box[tile][fb][fb][fb]; lo = nb-2 (0-based first cell of the box).
+// mode 0: in place, all rows.  mode 1: rows enumerate (b, kk, jj) over the force box
+// force_f(c, nb-1:nf-nb+1,...) (particle_mesh_threaded.f90:202); b = comp*ntile + tile; only the box
+// columns are written, to box + comp*box_comp_stride + tile*fb^3; lo = nb-2 (first box cell).
 template <int RB>
-__global__ __launch_bounds__(256) void k_fft_x_inv(float *__restrict__ data, int n, int rows_total, Factors fac,
+__global__ __launch_bounds__(256) void k_fft_x_inv(float *__restrict__ data, int n, int px, int rows_total, Factors fac,
                                                    const float2 *__restrict__ tw_g, float inv_scale, int mode,
-                                                   float *__restrict__ box, int fb, int lo) {
+                                                   float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
   extern __shared__ float2 lds[];
-  const int h = n >> 1, LP = h + 1;
+  const int h = n >> 1, LP = h + 2;
   float2 *A = lds, *B = A + RB * LP, *tw = B + RB * LP;
   for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
   const int64_t row0 = (int64_t)blockIdx.x * RB;
@@ -200,14 +206,21 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(float *__restrict__ data, int
   __syncthreads();
   // Z'[m] = (X[m] + conj X[h-m]) + i (X[m] - conj X[h-m]) W_n^{-m}; conj() on the way in: the
   // forward machinery then yields conj(IFFT), undone on the way out.
+  __shared__ int64_t src_row[RB], dst_off[RB];
+  if (threadIdx.x < nrows) {
+    int64_t srow = row0 + threadIdx.x, dofs = 0;
+    if (mode == 1) {
+      const int jj = (int)(srow % fb); const int64_t t2 = srow / fb; const int kk = (int)(t2 % fb); const int64_t b = t2 / fb;
+      const int comp = (int)(b / ntile), tl = (int)(b % ntile);
+      srow = (b * n + (kk + lo)) * n + (jj + lo);
+      dofs = comp * box_comp_stride + (((int64_t)tl * fb + kk) * fb + jj) * fb;
+    }
+    src_row[threadIdx.x] = srow; dst_off[threadIdx.x] = dofs;
+  }
+  __syncthreads();
   for (int e = threadIdx.x; e < nrows * h; e += blockDim.x) {
     const int r = e / h, m = e - r * h;
-    int64_t srow = row0 + r;
-    if (mode == 1) {  // row index enumerates (tile, kk, jj) of the box
-      const int jj = (int)(srow % fb); const int64_t t2 = srow / fb; const int kk = (int)(t2 % fb); const int64_t tile = t2 / fb;
-      srow = (tile * n + (kk + lo)) * n + (jj + lo);
-    }
-    const float2 *X = reinterpret_cast<const float2 *>(data + srow * (int64_t)(n + 2));
+    const float2 *X = reinterpret_cast<const float2 *>(data + src_row[r] * (int64_t)(2 * px));
     const float2 xk = X[m], xc = cconj(X[h - m]);
     const float2 e2 = cadd(xk, xc), d = csub(xk, xc);
     const float2 o = cmul(d, cconj(tw[m]));
@@ -216,11 +229,11 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(float *__restrict__ data, int
   __syncthreads();
   const float2 *Z = fft_lds<true>(A, B, h, nrows, 1, LP, fac, tw, 2);
   if (mode == 0) {
-    for (int e = threadIdx.x; e < nrows * (h + 1); e += blockDim.x) {
-      const int r = e / (h + 1), m = e - r * (h + 1);
+    for (int e = threadIdx.x; e < nrows * px; e += blockDim.x) {
+      const int r = e / px, m = e - r * px;
       float2 z = make_float2(0.f, 0.f);
       if (m < h) { z = Z[r * LP + m]; z = make_float2(z.x / inv_scale, -z.y / inv_scale); }
-      reinterpret_cast<float2 *>(data + (row0 + r) * (int64_t)(n + 2))[m] = z;
+      reinterpret_cast<float2 *>(data + (row0 + r) * (int64_t)(2 * px))[m] = z;
     }
   } else {
     for (int e = threadIdx.x; e < nrows * fb; e += blockDim.x) {
@@ -228,46 +241,85 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(float *__restrict__ data, int
       const int x = ii + lo;
       const float2 z = Z[r * LP + (x >> 1)];
       const float val = (x & 1) ? -z.y : z.x;
-      box[(row0 + r) * (int64_t)fb + ii] = val / inv_scale;
+      box[dst_off[r] + ii] = val / inv_scale;
     }
   }
 }
 
 // ------------------------------------------------------------------ y / z passes (strided lines)
-// layout [b][z][y][x], x in [0,hx).  axis 1: lines along y (one z per workgroup), axis 2: along z.
-// A workgroup owns BX adjacent x columns.  FUSE: read src, multiply by i*K on the fly.
-template <int BX, bool INV, bool FUSE>
-__global__ __launch_bounds__(256) void k_fft_lines(float2 *__restrict__ dst, const float2 *__restrict__ src,
-                                                   const float *__restrict__ kern, int n, int hx, int axis, int nchunk,
-                                                   Factors fac, const float2 *__restrict__ tw_g) {
+// layout [b][z][y][x], x in [0,px).  axis 1: lines along y (one z per workgroup), axis 2: along z.
+// A workgroup owns BX adjacent x columns = BX/2 float4 per row segment.
+// NC = 0: plain transform src -> dst.
+// NC = 1|3: fused k-space multiply (particle_mesh_threaded.f90:183-192): the bundle of rho-hat is
+//   read ONCE into registers; for each component c the bundle times i*K_c is transformed and
+//   written to dst + c*dst_comp_stride.
+// Pruning: only `ocount` values of the other axis starting at `olo` are processed, and only line
+//   elements [slo, slo+scount) are stored (the inverse only needs the force box).
+struct LinesArgs {
+  float2 *dst; const float2 *src; const float *kern;
+  int64_t kern_comp_stride, dst_comp_stride, dst_batch_stride;
+  int n, px, axis, nchunk, olo, ocount, slo, scount;
+};
+template <int BX, bool INV, int NC>
+__global__ __launch_bounds__(256) void k_fft_lines(LinesArgs a, Factors fac, const float2 *__restrict__ tw_g) {
   extern __shared__ float2 lds[];
+  constexpr int L4 = BX / 2;
+  const int n = a.n, px = a.px;
   float2 *A = lds, *B = A + n * BX, *tw = B + n * BX;
   for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
-  const int ch = blockIdx.x % nchunk;
-  const int64_t rest = blockIdx.x / nchunk;
-  const int o = (int)(rest % n);
-  const int64_t b = rest / n;
-  const int x0 = ch * BX, nl = min(BX, hx - x0);
-  const int64_t plane = (int64_t)n * hx;
-  int64_t base, stride;
-  if (axis == 1) { base = (b * n + o) * plane + x0; stride = hx; }
-  else { base = b * n * plane + (int64_t)o * hx + x0; stride = plane; }
-  int64_t kbase = 0;
-  if (FUSE) kbase = base - b * n * plane;  // kern has no batch dimension
-  for (int e = threadIdx.x; e < n * nl; e += blockDim.x) {
-    const int idx = e / nl, l = e - idx * nl;
-    float2 v = src[base + idx * stride + l];
-    if (FUSE) { const float K = kern[kbase + idx * stride + l]; v = make_float2(-v.y * K, v.x * K); }
-    if (INV) v.y = -v.y;
-    A[idx * nl + l] = v;
-  }
-  __syncthreads();
-  const float2 *Z = fft_lds<false>(A, B, n, nl, nl, 1, fac, tw, 1);
-  for (int e = threadIdx.x; e < n * nl; e += blockDim.x) {
-    const int idx = e / nl, l = e - idx * nl;
-    float2 v = Z[idx * nl + l];
-    if (INV) v.y = -v.y;
-    dst[base + idx * stride + l] = v;
+  const int ch = blockIdx.x % a.nchunk;
+  const int64_t rest = blockIdx.x / a.nchunk;
+  const int o = a.olo + (int)(rest % a.ocount);
+  const int64_t b = rest / a.ocount;
+  const int x0 = ch * BX;
+  const int64_t plane = (int64_t)n * px;
+  int64_t inb, stride;   // offsets inside one array, in float2 units
+  if (a.axis == 1) { inb = (int64_t)o * plane + x0; stride = px; }
+  else { inb = (int64_t)o * px + x0; stride = plane; }
+  const float4 *src4 = reinterpret_cast<const float4 *>(a.src + b * n * plane + inb);
+  const int64_t st4 = stride / 2;
+  const int ne = n * L4;
+  if (NC == 0) {
+    for (int e = threadIdx.x; e < ne; e += 256) {
+      const int idx = e / L4, l4 = e - idx * L4;
+      float4 v = src4[idx * st4 + l4];
+      if (INV) { v.y = -v.y; v.w = -v.w; }
+      *reinterpret_cast<float4 *>(&A[idx * BX + 2 * l4]) = v;
+    }
+    __syncthreads();
+    const float2 *Z = fft_lds<false>(A, B, n, BX, BX, 1, fac, tw, 1);
+    float4 *dst4 = reinterpret_cast<float4 *>(a.dst + b * a.dst_batch_stride + inb);
+    for (int e = threadIdx.x; e < ne; e += 256) {
+      const int idx = e / L4, l4 = e - idx * L4;
+      if (idx < a.slo || idx >= a.slo + a.scount) continue;
+      float4 v = *reinterpret_cast<const float4 *>(&Z[idx * BX + 2 * l4]);
+      if (INV) { v.y = -v.y; v.w = -v.w; }
+      dst4[idx * st4 + l4] = v;
+    }
+  } else {
+    // the bundle of rho-hat is re-read per component: the 2nd and 3rd reads hit this XCD's L2
+#pragma unroll 1
+    for (int comp = 0; comp < NC; comp++) {
+      const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + inb);
+      for (int e = threadIdx.x; e < ne; e += 256) {
+        const int idx = e / L4, l4 = e - idx * L4;
+        const float4 r = src4[idx * st4 + l4];
+        const float2 K = k2[idx * st4 + l4];
+        // (re,im) * i*K = (-im*K, re*K); then conj for the inverse-by-forward trick
+        *reinterpret_cast<float4 *>(&A[idx * BX + 2 * l4]) = make_float4(-r.y * K.x, -(r.x * K.x), -r.w * K.y, -(r.z * K.y));
+      }
+      __syncthreads();
+      const float2 *Z = fft_lds<false>(A, B, n, BX, BX, 1, fac, tw, 1);
+      float4 *dst4 = reinterpret_cast<float4 *>(a.dst + comp * a.dst_comp_stride + b * a.dst_batch_stride + inb);
+      for (int e = threadIdx.x; e < ne; e += 256) {
+        const int idx = e / L4, l4 = e - idx * L4;
+        if (idx < a.slo || idx >= a.slo + a.scount) continue;
+        float4 v = *reinterpret_cast<const float4 *>(&Z[idx * BX + 2 * l4]);
+        v.y = -v.y; v.w = -v.w;
+        dst4[idx * st4 + l4] = v;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -284,8 +336,10 @@ static bool factorize(int n, int *nfac, int *fac) {
 }
 
 int fft_plan_create(FftPlan *pl, int n) {
-  if (n < 4 || (n & 1)) { p3m_set_error("fft: n=%d must be even and >= 4", n); return P3M_EINVAL; }
+  if (n < 4 || (n & 3)) { p3m_set_error("fft: n=%d must be a multiple of 4", n); return P3M_EINVAL; }
+  if (n > 1024) { p3m_set_error("fft: n=%d > 1024 not supported by the LDS line kernels", n); return P3M_EINVAL; }
   pl->n = n;
+  pl->px = ((n / 2 + 1) + 15) / 16 * 16;
   if (!factorize(n, &pl->nfac_full, pl->fac_full) || !factorize(n / 2, &pl->nfac_half, pl->fac_half)) {
     p3m_set_error("fft: n=%d has a prime factor > 19 (supported radices 2,3,4,5,7,8,11,13,17,19)", n);
     return P3M_EINVAL;
@@ -309,78 +363,100 @@ template <typename K> static int set_lds(K kern, size_t bytes) {
 }
 
 template <int RB> static int launch_x_fwd(p3m_ctx *c, const FftPlan &pl, float *data, int64_t rows) {
-  const int n = pl.n; const size_t lds = sizeof(float2) * ((size_t)2 * RB * (n / 2 + 1) + n);
+  const int n = pl.n; const size_t lds = sizeof(float2) * ((size_t)2 * RB * (n / 2 + 2) + n);
   P3M_TRY(set_lds(k_fft_x_fwd<RB>, lds));
-  hipLaunchKernelGGL(k_fft_x_fwd<RB>, dim3(cdiv(rows, RB)), dim3(256), lds, c->stream, data, n, (int)rows,
+  hipLaunchKernelGGL(k_fft_x_fwd<RB>, dim3(cdiv(rows, RB)), dim3(256), lds, c->stream, data, n, pl.px, (int)rows,
                      mkfac(pl.nfac_half, pl.fac_half), pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-template <int RB> static int launch_x_inv(p3m_ctx *c, const FftPlan &pl, float *data, int64_t rows, int mode, float *box, int fb, int lo) {
-  const int n = pl.n; const size_t lds = sizeof(float2) * ((size_t)2 * RB * (n / 2 + 1) + n);
+template <int RB>
+static int launch_x_inv(p3m_ctx *c, const FftPlan &pl, float *data, int64_t rows, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
+  const int n = pl.n; const size_t lds = sizeof(float2) * ((size_t)2 * RB * (n / 2 + 2) + n);
   const float scale = (float)n * (float)n * (float)n;  // real(nf_tile)**3, fftw2.f90:22
   P3M_TRY(set_lds(k_fft_x_inv<RB>, lds));
-  hipLaunchKernelGGL(k_fft_x_inv<RB>, dim3(cdiv(rows, RB)), dim3(256), lds, c->stream, data, n, (int)rows,
-                     mkfac(pl.nfac_half, pl.fac_half), pl.d_tw, scale, mode, box, fb, lo);
+  hipLaunchKernelGGL(k_fft_x_inv<RB>, dim3(cdiv(rows, RB)), dim3(256), lds, c->stream, data, n, pl.px, (int)rows,
+                     mkfac(pl.nfac_half, pl.fac_half), pl.d_tw, scale, mode, box, fb, lo, ntile, bcs);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-template <int BX, bool INV, bool FUSE>
-static int launch_lines(p3m_ctx *c, const FftPlan &pl, float *dst, const float *src, const float *kern, int axis, int batch) {
-  const int n = pl.n, hx = n / 2 + 1, nchunk = cdiv(hx, BX);
+template <int BX, bool INV, int NC> static int launch_lines(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
+  const int n = pl.n;
+  a.n = n; a.px = pl.px; a.nchunk = pl.px / BX;
   const size_t lds = sizeof(float2) * ((size_t)2 * n * BX + n);
-  P3M_TRY(set_lds(k_fft_lines<BX, INV, FUSE>, lds));
-  const int64_t blocks = (int64_t)batch * n * nchunk;
-  hipLaunchKernelGGL((k_fft_lines<BX, INV, FUSE>), dim3((unsigned)blocks), dim3(256), lds, c->stream,
-                     reinterpret_cast<float2 *>(dst), reinterpret_cast<const float2 *>(src), kern, n, hx, axis, nchunk,
-                     mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
+  P3M_TRY(set_lds(k_fft_lines<BX, INV, NC>, lds));
+  const int64_t blocks = (int64_t)batch * a.ocount * a.nchunk;
+  hipLaunchKernelGGL((k_fft_lines<BX, INV, NC>), dim3((unsigned)blocks), dim3(256), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
+}
+template <bool INV, int NC> static int lines_any(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
+  return pl.n <= 320 ? launch_lines<16, INV, NC>(c, pl, a, batch) : launch_lines<8, INV, NC>(c, pl, a, batch);
+}
+static LinesArgs full_args(const FftPlan &pl, float *dst, const float *src, int axis) {
+  LinesArgs a{};
+  a.dst = reinterpret_cast<float2 *>(dst); a.src = reinterpret_cast<const float2 *>(src); a.kern = nullptr;
+  a.dst_batch_stride = (int64_t)pl.n * pl.n * pl.px; a.axis = axis; a.olo = 0; a.ocount = pl.n; a.slo = 0; a.scount = pl.n;
+  return a;
 }
 
 int fft_x_forward(p3m_ctx *c, const FftPlan &pl, float *data, int batch) {
   const int64_t rows = (int64_t)batch * pl.n * pl.n;
   return pl.n <= 256 ? launch_x_fwd<8>(c, pl, data, rows) : launch_x_fwd<4>(c, pl, data, rows);
 }
-int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, int mode, float *box, int fb, int lo) {
+int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
   const int64_t rows = mode == 0 ? (int64_t)batch * pl.n * pl.n : (int64_t)batch * fb * fb;
-  return pl.n <= 256 ? launch_x_inv<8>(c, pl, data, rows, mode, box, fb, lo) : launch_x_inv<4>(c, pl, data, rows, mode, box, fb, lo);
-}
-template <bool INV, bool FUSE>
-static int lines_any(p3m_ctx *c, const FftPlan &pl, float *dst, const float *src, const float *kern, int axis, int batch) {
-  return pl.n <= 320 ? launch_lines<16, INV, FUSE>(c, pl, dst, src, kern, axis, batch)
-                     : launch_lines<8, INV, FUSE>(c, pl, dst, src, kern, axis, batch);
+  return pl.n <= 256 ? launch_x_inv<8>(c, pl, data, rows, mode, box, fb, lo, ntile, bcs)
+                     : launch_x_inv<4>(c, pl, data, rows, mode, box, fb, lo, ntile, bcs);
 }
 
 int fft3d_forward(p3m_ctx *c, const FftPlan &pl, float *data, int batch) {
   P3M_TRY(fft_x_forward(c, pl, data, batch));
-  P3M_TRY((lines_any<false, false>(c, pl, data, data, nullptr, 1, batch)));
-  P3M_TRY((lines_any<false, false>(c, pl, data, data, nullptr, 2, batch)));
+  P3M_TRY((lines_any<false, 0>(c, pl, full_args(pl, data, data, 1), batch)));
+  P3M_TRY((lines_any<false, 0>(c, pl, full_args(pl, data, data, 2), batch)));
   return P3M_OK;
 }
 
-// z, y strided passes of the inverse (shared by the in-place and the force-box variants)
-int fft3d_inverse_zy(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const float *src, const float *kern) {
-  if (kern) P3M_TRY((lines_any<true, true>(c, pl, data, src, kern, 2, batch)));
-  else P3M_TRY((lines_any<true, false>(c, pl, data, src ? src : data, nullptr, 2, batch)));
-  P3M_TRY((lines_any<true, false>(c, pl, data, data, nullptr, 1, batch)));
-  return P3M_OK;
-}
-
+// full-size inverse (coarse mesh, probes): data <- c2r(src [* i*kern]) / n^3
 int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const float *src, const float *kern) {
-  P3M_TRY(fft3d_inverse_zy(c, pl, data, batch, src, kern));
-  return fft_x_inverse(c, pl, data, batch, 0, nullptr, 0, 0);
+  LinesArgs z = full_args(pl, data, src ? src : data, 2);
+  if (kern) { z.kern = kern; P3M_TRY((lines_any<true, 1>(c, pl, z, batch))); }
+  else P3M_TRY((lines_any<true, 0>(c, pl, z, batch)));
+  P3M_TRY((lines_any<true, 0>(c, pl, full_args(pl, data, data, 1), batch)));
+  return fft_x_inverse(c, pl, data, batch, 0, nullptr, 0, 0, 1, 0);
+}
+
+// fine mesh: the three force components of `batch` tiles from rho-hat, pruned to the force box.
+// work holds 3*batch arrays ([comp][tile]); box points at tile0 of component 0, bcs = component stride.
+int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, int fb, int lo) {
+  LinesArgs z = full_args(pl, work, rho_hat, 2);
+  z.kern = kern3; z.kern_comp_stride = (int64_t)pl.n * pl.n * pl.px;      // one float per complex element, same pitch
+  z.dst_comp_stride = (int64_t)batch * pl.n * pl.n * pl.px;
+  z.slo = lo; z.scount = fb;                                              // only box planes are stored
+  return lines_any<true, 3>(c, pl, z, batch);
+}
+int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, int fb, int lo) {
+  LinesArgs y = full_args(pl, work, work, 1);
+  y.olo = lo; y.ocount = fb; y.slo = lo; y.scount = fb;                   // only box planes, only box rows
+  return lines_any<true, 0>(c, pl, y, 3 * batch);
+}
+int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, float *box, int fb, int lo,
+                     int64_t bcs) {
+  P3M_TRY(fft_inverse3_box_z(c, pl, rho_hat, work, kern3, batch, fb, lo));
+  P3M_TRY(fft_inverse3_box_y(c, pl, work, batch, fb, lo));
+  return fft_x_inverse(c, pl, work, 3 * batch, 1, box, fb, lo, batch, bcs);
 }
 
 // benchmark hook: one pass kernel over `batch` tiles (see p3m_hip_time_fft_pass)
-int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float *work, const float *kern, int batch, float *box, int fb, int lo) {
+int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float *work, const float *kern, int batch, float *box, int fb, int lo,
+                    int64_t bcs) {
   switch (which) {
     case 0: return fft_x_forward(c, pl, data, batch);
-    case 1: return lines_any<false, false>(c, pl, data, data, nullptr, 1, batch);
-    case 2: return lines_any<false, false>(c, pl, data, data, nullptr, 2, batch);
-    case 3: return lines_any<true, true>(c, pl, work, data, kern, 2, batch);
-    case 4: return lines_any<true, false>(c, pl, work, work, nullptr, 1, batch);
-    case 5: return fft_x_inverse(c, pl, work, batch, 1, box, fb, lo);
+    case 1: return lines_any<false, 0>(c, pl, full_args(pl, data, data, 1), batch);
+    case 2: return lines_any<false, 0>(c, pl, full_args(pl, data, data, 2), batch);
+    case 3: return fft_inverse3_box_z(c, pl, data, work, kern, batch, fb, lo);
+    case 4: return fft_inverse3_box_y(c, pl, work, batch, fb, lo);
+    case 5: return fft_x_inverse(c, pl, work, 3 * batch, 1, box, fb, lo, batch, bcs);
   }
   p3m_set_error("fft_single_pass: bad selector %d", which);
   return P3M_EINVAL;

@@ -14,10 +14,10 @@
 #include "p3m_internal.h"
 #include <algorithm>
 
-int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, int mode, float *box, int fb, int lo);
-int fft3d_inverse_zy(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const float *src, const float *kern);
+int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, float *box, int fb, int lo,
+                     int64_t bcs);
 
-struct TileGeo { int T, nf, nb, pt, E, fb; };
+struct TileGeo { int T, nf, nb, pt, E, fb, rp; };  // rp: real row pitch of a fine array (2*px)
 
 __device__ __forceinline__ void tile_xyz(int tile, int T, int &tx, int &ty, int &tz) {  // :86-90
   tz = tile / (T * T); const int r = tile - tz * T * T; ty = r / T; tx = r - ty * T;
@@ -41,11 +41,11 @@ __device__ __forceinline__ float block_sum_f(float v, float *sh) {
 template <bool NGP>
 __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho,
                                                      int tile0, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
-  extern __shared__ float row[];  // nf+2 floats
+  extern __shared__ float row[];  // rp floats
   const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb;
   const int j = blockIdx.x % nf, k = (blockIdx.x / nf) % nf, tl = blockIdx.x / (nf * nf);
   int tx, ty, tz; tile_xyz(tile0 + tl, G.T, tx, ty, tz);
-  for (int i = threadIdx.x; i < nf + 2; i += 64) row[i] = 0.f;
+  for (int i = threadIdx.x; i < G.rp; i += 64) row[i] = 0.f;
   __syncthreads();
   const float offx = (float)(-tx * pt + nb), offy = (float)(-ty * pt + nb), offz = (float)(-tz * pt + nb);  // :134
   const int wlo = NGP ? 4 : 0, whi = NGP ? nf - 4 : nf;                                                  // window [wlo,whi)
@@ -79,10 +79,10 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
     }
   }
   __syncthreads();
-  float *out = rho + ((int64_t)tl * nf * nf + (int64_t)k * nf + j) * (nf + 2);
+  float *out = rho + ((int64_t)tl * nf * nf + (int64_t)k * nf + j) * G.rp;
   float part = 0.f;
   const bool interior_row = (j >= nb && j < nf - nb && k >= nb && k < nf - nb);
-  for (int i = threadIdx.x; i < nf + 2; i += 64) {
+  for (int i = threadIdx.x; i < G.rp; i += 64) {
     const float v = row[i];
     out[i] = v;
     if (interior_row && i >= nb && i < nf - nb) part += v;                                               // :167-173
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
 __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, float *__restrict__ rho, int tile0, int ntile, TileGeo G,
                                                     float mass_p, double *__restrict__ sum_interior) {
   __shared__ float sh[4];
-  const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb, pitch = nf + 2;
+  const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb, pitch = G.rp;
   const int64_t tot = (int64_t)ntile * nf * nf * pitch;
   float part = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ sp
     moved = moved || (rr[d] != gl[d]);
   }
   if (!member || !moved) return;
-  float *base = rho + (int64_t)tl * nf * nf * (nf + 2);
-  atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * (nf + 2) + gl[0]], -mass_p);
-  atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * (nf + 2) + rr[0]], mass_p);
+  float *base = rho + (int64_t)tl * nf * nf * G.rp;
+  atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0]], -mass_p);
+  atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0]], mass_p);
   if (sum_interior) {
     const bool ig = gl[0] >= nb && gl[0] < nf - nb && gl[1] >= nb && gl[1] < nf - nb && gl[2] >= nb && gl[2] < nf - nb;
     const bool ir = rr[0] >= nb && rr[0] < nf - nb && rr[1] >= nb && rr[1] < nf - nb && rr[2] >= nb && rr[2] < nf - nb;
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ sp
 
 int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   const Geometry &g = c->g;
-  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb};
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px};
   if (c->p.flags & P3M_FLAG_NGP) {
-    const int64_t tot = (int64_t)ntile * g.nf * g.nf * (g.nf + 2);
+    const int64_t tot = (int64_t)ntile * g.nf * g.nf * (2 * g.px);
     hipLaunchKernelGGL(k_ngp_counts, dim3((unsigned)std::min<int64_t>(cdiv(tot, 256), 256 * 32)), dim3(256), 0, c->stream, (const int *)c->cell_end,
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
     HIP_TRY(hipGetLastError());
@@ -168,7 +168,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
     return P3M_OK;
   }
   const unsigned blocks = (unsigned)((int64_t)ntile * g.nf * g.nf);
-  const size_t lds = sizeof(float) * (g.nf + 2);
+  const size_t lds = sizeof(float) * (2 * g.px);
   hipLaunchKernelGGL(k_fine_deposit<false>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
                      tile0, G, mass_p, c->d_sums);
   HIP_TRY(hipGetLastError());
@@ -179,14 +179,10 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
 int fine_force(p3m_ctx *c, int tile0, int ntile) {
   const Geometry &g = c->g;
   P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, ntile));
-  const size_t kplane = (size_t)g.nf * g.nf * g.hx;
   const size_t boxsz = (size_t)g.fb * g.fb * g.fb;
-  for (int comp = 0; comp < 3; comp++) {
-    P3M_TRY(fft3d_inverse_zy(c, c->plan_f, c->work, ntile, c->rho, c->kern_f + comp * kplane));
-    float *box = c->fbox + ((size_t)comp * g.ntiles + tile0) * boxsz;
-    P3M_TRY(fft_x_inverse(c, c->plan_f, c->work, ntile, 1, box, g.fb, g.nb - 2));
-  }
-  return P3M_OK;
+  // one fused launch per axis for all three components (rho-hat is read once)
+  return fft_inverse3_box(c, c->plan_f, c->rho, c->work, c->kern_f, ntile, c->fbox + (size_t)tile0 * boxsz, g.fb, g.nb - 2,
+                          (int64_t)g.ntiles * boxsz);
 }
 
 // ------------------------------------------------------------------ :208-223 max |F|^2 over every tile's force box
@@ -252,7 +248,7 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 int fine_kick(p3m_ctx *c, float a_mid, float dt) {
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
-  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb};
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fb;
   if (c->p.flags & P3M_FLAG_NGP)
     hipLaunchKernelGGL(k_fine_kick<true>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G, g.Nn,
@@ -267,12 +263,12 @@ int fine_kick(p3m_ctx *c, float a_mid, float dt) {
 // ------------------------------------------------------------------ fine_kernel (kernel_initialization.f90:2-267)
 // real-space table mirrored into the nf^3 box (odd along the component's own axis, :69-85),
 // PP_EXT corner zeroed (:38-54); then r2c and keep the imaginary part (:93-99).
-__global__ __launch_bounds__(256) void k_fine_kernel_real(float *__restrict__ rho, const float *__restrict__ table, int nf, int ncut, int comp,
+__global__ __launch_bounds__(256) void k_fine_kernel_real(float *__restrict__ rho, const float *__restrict__ table, int nf, int rp, int ncut, int comp,
                                                           int zero_corner) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t tot = (int64_t)nf * nf * (nf + 2);
+  const int64_t tot = (int64_t)nf * nf * rp;
   if (idx >= tot) return;
-  const int i = (int)(idx % (nf + 2)); const int64_t r = idx / (nf + 2); const int j = (int)(r % nf), k = (int)(r / nf);
+  const int i = (int)(idx % rp); const int64_t r = idx / rp; const int j = (int)(r % nf), k = (int)(r / nf);
   float v = 0.f;
   if (i < nf) {
     int c3[3] = {i, j, k}, t3[3]; float sgn = 1.f; bool ok = true;
@@ -300,10 +296,10 @@ int build_fine_kernel(p3m_ctx *c, const float *table16_host) {
   const size_t tb = sizeof(float) * 3 * g.ncut * g.ncut * g.ncut;
   HIP_TRY(hipMalloc(&d_table, tb));
   HIP_TRY(hipMemcpyAsync(d_table, table16_host, tb, hipMemcpyHostToDevice, c->stream));
-  const int64_t tot = (int64_t)g.nf * g.nf * (g.nf + 2), ncx = (int64_t)g.nf * g.nf * g.hx;
+  const int64_t tot = (int64_t)g.nf * g.nf * (2 * g.px), ncx = (int64_t)g.nf * g.nf * g.px;
   const int zc = (c->p.flags & P3M_FLAG_PP_EXT) ? g.pp_range + 1 : 0;
   for (int comp = 0; comp < 3; comp++) {
-    hipLaunchKernelGGL(k_fine_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->rho, (const float *)d_table, g.nf, g.ncut, comp, zc);
+    hipLaunchKernelGGL(k_fine_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->rho, (const float *)d_table, g.nf, 2 * g.px, g.ncut, comp, zc);
     HIP_TRY(hipGetLastError());
     P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, 1));
     hipLaunchKernelGGL(k_take_imag, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->rho, c->kern_f + comp * ncx, ncx);

@@ -6,7 +6,6 @@
 #include <cstdarg>
 #include <cstring>
 
-int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, int mode, float *box, int fb, int lo);
 
 static thread_local char g_err[1024] = "";
 void p3m_set_error(const char *fmt, ...) {
@@ -39,6 +38,7 @@ static int fill_geometry(const p3m_params *p, Geometry *g) {
   if (g->nc % g->nodes) { p3m_set_error("cannot evenly decompose mesh into slabs (mpi_initialization.f90:26)"); return P3M_EINVAL; }
   g->nc_slab = g->nc / g->nodes;
   g->hx = g->nf / 2 + 1; g->fb = g->pt + 3;
+  g->px = (g->hx + 15) / 16 * 16; g->pxc = ((g->nc / 2 + 1) + 15) / 16 * 16;
   if ((int64_t)g->E * g->E * g->E > 2000000000LL) { p3m_set_error("extended fine domain %d^3 exceeds int32 cell indices", g->E); return P3M_EINVAL; }
   const int nd = g->nodes_dim, rk = p->rank;
   if (rk < 0 || rk >= g->nodes) { p3m_set_error("rank %d out of range", rk); return P3M_EINVAL; }
@@ -81,19 +81,24 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   { const int64_t ec = g.E / g.ms; A(dalloc(&c->cflag, (size_t)(ec * ec * ec + 16))); }
   if (hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 16 * sizeof(int)) != hipSuccess) return fail(P3M_ENOMEM);
   // fine mesh: as many tiles per sweep as fit a 48 GiB budget for rho+work
-  const size_t S = (size_t)(g.nf + 2) * g.nf * g.nf;
-  size_t budget = (size_t)48 << 30;
-  c->tile_batch = (int)std::max<size_t>(1, std::min<size_t>(g.ntiles, budget / (2 * S * sizeof(float))));
-  A(dalloc(&c->rho, S * c->tile_batch)); A(dalloc(&c->work, S * c->tile_batch));
+  const size_t S = (size_t)(2 * g.px) * g.nf * g.nf;
+  size_t budget = (size_t)64 << 30;
+  c->tile_batch = (int)std::max<size_t>(1, std::min<size_t>(g.ntiles, budget / (4 * S * sizeof(float))));
+  A(dalloc(&c->rho, S * c->tile_batch)); A(dalloc(&c->work, 3 * S * c->tile_batch));
+  if (hipMemset(c->rho, 0, S * c->tile_batch * sizeof(float)) != hipSuccess || hipMemset(c->work, 0, 3 * S * c->tile_batch * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
   A(dalloc(&c->fbox, (size_t)3 * g.ntiles * g.fb * g.fb * g.fb));
-  A(dalloc(&c->kern_f, (size_t)3 * g.nf * g.nf * g.hx));
+  A(dalloc(&c->kern_f, (size_t)3 * g.nf * g.nf * g.px));
+  if (hipMemset(c->kern_f, 0, (size_t)3 * g.nf * g.nf * g.px * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
   A(fft_plan_create(&c->plan_f, g.nf));
   // coarse mesh
   A(dalloc(&c->rho_c, (size_t)g.ncn * g.ncn * g.ncn));
   A(dalloc(&c->force_c, (size_t)3 * (g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2)));
   if (g.nodes == 1) {
-    A(dalloc(&c->slab, (size_t)g.nc * g.nc * (g.nc + 2))); A(dalloc(&c->slab_w, (size_t)g.nc * g.nc * (g.nc + 2)));
-    A(dalloc(&c->kern_c, (size_t)3 * g.nc * g.nc * (g.nc / 2 + 1)));
+    const size_t Sc = (size_t)g.nc * g.nc * (2 * g.pxc);
+    A(dalloc(&c->slab, Sc)); A(dalloc(&c->slab_w, Sc));
+    A(dalloc(&c->kern_c, (size_t)3 * g.nc * g.nc * g.pxc));
+    if (hipMemset(c->slab, 0, Sc * sizeof(float)) != hipSuccess || hipMemset(c->slab_w, 0, Sc * sizeof(float)) != hipSuccess ||
+        hipMemset(c->kern_c, 0, (size_t)3 * g.nc * g.nc * g.pxc * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
     A(fft_plan_create(&c->plan_c, g.nc));
   }
   A(dalloc(&c->d_red, 8)); A(dalloc(&c->d_tile_ext, g.ntiles)); A(dalloc(&c->d_sums, 4));
@@ -152,16 +157,26 @@ static void aos_to_planes(const float *aos, float *planes, size_t ncx) {
 static void planes_to_aos(const float *planes, float *aos, size_t ncx) {
   for (int comp = 0; comp < 3; comp++) for (size_t i = 0; i < ncx; i++) aos[i * 3 + comp] = planes[comp * ncx + i];
 }
+// kernels: reference rows hold hx values, device rows px (zero padded)
+static void kern_to_device(const float *aos, float *planes, size_t rows, int hx, int px) {
+  for (int comp = 0; comp < 3; comp++) for (size_t r = 0; r < rows; r++) for (int i = 0; i < px; i++)
+    planes[(comp * rows + r) * px + i] = i < hx ? aos[(r * hx + i) * 3 + comp] : 0.f;
+}
+static void kern_from_device(const float *planes, float *aos, size_t rows, int hx, int px) {
+  for (int comp = 0; comp < 3; comp++) for (size_t r = 0; r < rows; r++) for (int i = 0; i < hx; i++)
+    aos[(r * hx + i) * 3 + comp] = planes[(comp * rows + r) * px + i];
+}
 
 extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const float *kern_c) {
   if (!c || !kern_f || !kern_c) return P3M_EINVAL;
   if (c->g.nodes != 1) { p3m_set_error("set_kernels_raw: single-rank contexts only"); return P3M_EINVAL; }
   HIP_TRY(hipSetDevice(c->device));
-  const size_t nf = (size_t)c->g.nf * c->g.nf * c->g.hx, ncx = (size_t)c->g.nc * c->g.nc * (c->g.nc / 2 + 1);
+  const Geometry &g = c->g;
+  const size_t nf = (size_t)g.nf * g.nf * g.px, ncx = (size_t)g.nc * g.nc * g.pxc;
   std::vector<float> tmp(3 * std::max(nf, ncx));
-  aos_to_planes(kern_f, tmp.data(), nf);
+  kern_to_device(kern_f, tmp.data(), (size_t)g.nf * g.nf, g.hx, g.px);
   HIP_TRY(hipMemcpy(c->kern_f, tmp.data(), sizeof(float) * 3 * nf, hipMemcpyHostToDevice));
-  aos_to_planes(kern_c, tmp.data(), ncx);
+  kern_to_device(kern_c, tmp.data(), (size_t)g.nc * g.nc, g.nc / 2 + 1, g.pxc);
   HIP_TRY(hipMemcpy(c->kern_c, tmp.data(), sizeof(float) * 3 * ncx, hipMemcpyHostToDevice));
   c->have_kf = c->have_kc = true;
   return P3M_OK;
@@ -171,10 +186,11 @@ extern "C" int p3m_hip_get_kernels(p3m_ctx *c, float *kern_f, float *kern_c) {
   if (!c) return P3M_EINVAL;
   if (!c->have_kf || !c->have_kc) { p3m_set_error("kernels not set"); return P3M_ESTATE; }
   HIP_TRY(hipSetDevice(c->device));
-  const size_t nf = (size_t)c->g.nf * c->g.nf * c->g.hx, ncx = (size_t)c->g.nc * c->g.nc * (c->g.nc / 2 + 1);
+  const Geometry &g = c->g;
+  const size_t nf = (size_t)g.nf * g.nf * g.px, ncx = (size_t)g.nc * g.nc * g.pxc;
   std::vector<float> tmp(3 * std::max(nf, ncx));
-  if (kern_f) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_f, sizeof(float) * 3 * nf, hipMemcpyDeviceToHost)); planes_to_aos(tmp.data(), kern_f, nf); }
-  if (kern_c && c->kern_c) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_c, sizeof(float) * 3 * ncx, hipMemcpyDeviceToHost)); planes_to_aos(tmp.data(), kern_c, ncx); }
+  if (kern_f) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_f, sizeof(float) * 3 * nf, hipMemcpyDeviceToHost)); kern_from_device(tmp.data(), kern_f, (size_t)g.nf * g.nf, g.hx, g.px); }
+  if (kern_c && c->kern_c) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_c, sizeof(float) * 3 * ncx, hipMemcpyDeviceToHost)); kern_from_device(tmp.data(), kern_c, (size_t)g.nc * g.nc, g.nc / 2 + 1, g.pxc); }
   return P3M_OK;
 }
 
@@ -355,7 +371,8 @@ extern "C" int p3m_hip_probe_tile_density(p3m_ctx *c, int32_t tx, int32_t ty, in
   HIP_TRY(hipSetDevice(c->device));
   const int tile = (tz * g.T + ty) * g.T + tx;
   P3M_TRY(fine_deposit(c, tile, 1, mass_p));
-  HIP_TRY(hipMemcpyAsync(rho_f, c->rho, sizeof(float) * (size_t)(g.nf + 2) * g.nf * g.nf, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpy2DAsync(rho_f, sizeof(float) * (g.nf + 2), c->rho, sizeof(float) * 2 * g.px, sizeof(float) * (g.nf + 2), (size_t)g.nf * g.nf,
+                           hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return P3M_OK;
 }
@@ -365,7 +382,8 @@ extern "C" int p3m_hip_probe_tile_force(p3m_ctx *c, const float *rho_f, float *f
   if (!c->have_kf) { p3m_set_error("fine kernel not set"); return P3M_ESTATE; }
   const Geometry &g = c->g;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemcpyAsync(c->rho, rho_f, sizeof(float) * (size_t)(g.nf + 2) * g.nf * g.nf, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpy2DAsync(c->rho, sizeof(float) * 2 * g.px, rho_f, sizeof(float) * (g.nf + 2), sizeof(float) * (g.nf + 2), (size_t)g.nf * g.nf,
+                           hipMemcpyHostToDevice, c->stream));
   P3M_TRY(fine_force(c, 0, 1));
   const size_t boxsz = (size_t)g.fb * g.fb * g.fb;
   std::vector<float> tmp(3 * boxsz);
@@ -407,12 +425,13 @@ extern "C" int p3m_hip_fft3d(p3m_ctx *c, float *data, int32_t n, int32_t dir) {
   if (!c || !data) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
   FftPlan pl; P3M_TRY(fft_plan_create(&pl, n));
-  float *d = nullptr; const size_t S = (size_t)(n + 2) * n * n;
+  float *d = nullptr; const size_t S = (size_t)(2 * pl.px) * n * n;
   int r = dalloc(&d, S);
   if (!r) {
-    hipError_t e = hipMemcpyAsync(d, data, sizeof(float) * S, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(float) * S, c->stream);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(d, sizeof(float) * 2 * pl.px, data, sizeof(float) * (n + 2), sizeof(float) * (n + 2), (size_t)n * n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) r = dir > 0 ? fft3d_forward(c, pl, d, 1) : fft3d_inverse(c, pl, d, 1, nullptr, nullptr);
-    if (!r) e = hipMemcpyAsync(data, d, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream);
+    if (!r) e = hipMemcpy2DAsync(data, sizeof(float) * (n + 2), d, sizeof(float) * 2 * pl.px, sizeof(float) * (n + 2), (size_t)n * n, hipMemcpyDeviceToHost, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess || e != hipSuccess) { p3m_set_error("fft3d probe: HIP error"); r = r ? r : P3M_EDEVICE; }
   }
   dfree(d); fft_plan_destroy(&pl);
@@ -436,7 +455,8 @@ extern "C" int p3m_hip_time_fine_sweep(p3m_ctx *c, float mass_p, int32_t reps, f
   return P3M_OK;
 }
 
-int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float *work, const float *kern, int batch, float *box, int fb, int lo);
+int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float *work, const float *kern, int batch, float *box, int fb, int lo,
+                    int64_t bcs);
 
 extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch) {
   if (!c || reps < 1 || !ms_per_launch) return P3M_EINVAL;
@@ -446,9 +466,10 @@ extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, fl
   const int nt = std::min(c->tile_batch, g.ntiles);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-  P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2));  // warm-up
+  const int64_t bcs = (int64_t)g.ntiles * g.fb * g.fb * g.fb;
+  P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2, bcs));  // warm-up
   HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < reps; i++) P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2));
+  for (int i = 0; i < reps; i++) P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2, bcs));
   HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));

@@ -31,6 +31,7 @@ void p3m_set_error(const char *fmt, ...);
 // ------------------------------------------------------------------ FFT plan (fft.hip)
 struct FftPlan {
   int n = 0;               // real transform length per axis
+  int px = 0;              // complex row pitch: n/2+1 rounded up to 16 (128-byte lines)
   int nfac_full = 0, fac_full[16];  // radices of n      (strided c2c passes)
   int nfac_half = 0, fac_half[16];  // radices of n/2    (packed real x pass)
   float2 *d_tw = nullptr;  // exp(-2 pi i q / n), q in [0,n)
@@ -43,7 +44,9 @@ struct Geometry {
   int Nn;      // nf_physical_node_dim
   int E;       // extended fine cells per axis: Nn + 2*nb  (ghost zone included)
   int nc_buf, nct, ncn, nc, nc_slab;
-  int hx;      // nf/2+1 complex per row
+  int hx;      // nf/2+1 complex per row (reference layout)
+  int px;      // device complex row pitch of a fine array (fft plan), real pitch = 2*px
+  int pxc;     // same for the coarse mesh
   int fb;      // force box edge: pt+3   (force_f(3, nb-1:nf-nb+1,...), cubep3m.fh:36)
   int cart[3]; // z,y,x rank coordinates (mpi_initialization.f90:60-64)
   int nbr[6];  // -z,+z,-y,+y,-x,+x
@@ -71,17 +74,17 @@ struct p3m_ctx {
   int *h_counters = nullptr;   // pinned mirror
   // ---- fine mesh, all tiles batched
   int tile_batch = 0;          // tiles processed per sweep
-  float *rho = nullptr;        // [batch][nf][nf][nf+2]  density -> rho-hat
-  float *work = nullptr;       // [batch][nf][nf][nf+2]  i*K_c*rho-hat -> force
+  float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
+  float *work = nullptr;       // [3][batch][nf][nf][2*px]  i*K_c*rho-hat -> force, all three components
   float *fbox = nullptr;       // [3][ntiles][fb][fb][fb] extracted force (SoA planes)
-  float *kern_f = nullptr;     // [3][nf][nf][hx]  SoA planes of kern_f
+  float *kern_f = nullptr;     // [3][nf][nf][px]  SoA planes of kern_f
   FftPlan plan_f;
   // ---- coarse mesh
   float *rho_c = nullptr;      // [ncn][ncn][ncn]
-  float *slab = nullptr;       // [nc][nc][nc+2] (single rank) density -> hat
+  float *slab = nullptr;       // [nc][nc][2*pxc] (single rank) density -> hat
   float *slab_w = nullptr;
   float *force_c = nullptr;    // [3][ncn+2][ncn+2][ncn+2] SoA planes incl. halo
-  float *kern_c = nullptr;     // [3][nc][nc][nc/2+1]
+  float *kern_c = nullptr;     // [3][nc][nc][pxc]
   FftPlan plan_c;
   bool have_kf = false, have_kc = false;
   // ---- per-step reductions (device) and results
