@@ -96,12 +96,12 @@ int coarse_force(p3m_ctx *c) {
   const int64_t tot = (int64_t)n * n * rp;
   hipLaunchKernelGGL(k_cube_to_slab, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, (const float *)c->rho_c, c->slab, n, rp);
   HIP_TRY(hipGetLastError());
-  P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));                                          // coarse_force.f90:18
+  P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, c->slab_w, 1));                               // coarse_force.f90:18
   const size_t kplane = (size_t)n * n * g.pxc;
   const int64_t fcs = (int64_t)(n + 2) * (n + 2) * (n + 2);
   for (int comp = 0; comp < 3; comp++) {
-    P3M_TRY(fft3d_inverse(c, c->plan_c, c->slab_w, 1, c->slab, c->kern_c + comp * kplane));  // :37-50
-    hipLaunchKernelGGL(k_slab_to_force, dim3(cdiv(fcs, 256)), dim3(256), 0, c->stream, (const float *)c->slab_w, c->force_c + comp * fcs, n, rp);
+    P3M_TRY(fft3d_inverse(c, c->plan_c, c->slab, c->slab_w, c->slab_o, 1, c->kern_c + comp * kplane));  // :37-50
+    hipLaunchKernelGGL(k_slab_to_force, dim3(cdiv(fcs, 256)), dim3(256), 0, c->stream, (const float *)c->slab_o, c->force_c + comp * fcs, n, rp);
     HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(k_coarse_max, dim3(std::min<int64_t>(1024, cdiv((int64_t)n * n * n, 256))), dim3(256), 0, c->stream, (const float *)c->force_c,
@@ -179,9 +179,12 @@ __global__ __launch_bounds__(256) void k_coarse_kernel_real(float *__restrict__ 
 }
 // LRCKCORR, :562-591: Im K_c <- Im K_c^{corr} * (wc / Im K_c^{uncorr}) for integer |k| <= 8, k_c != 0
 __global__ __launch_bounds__(256) void k_lrck(float *__restrict__ kern, const float *__restrict__ uncorr, int n, int px, int comp) {
+  // kern / uncorr are in the bundle layout LZ: [y][chunk][z][16]
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)n * n * px) return;
-  const int kx = (int)(idx % px), j = (int)((idx / px) % n), k = (int)(idx / ((int64_t)px * n));
+  const int l = (int)(idx % 16), k = (int)((idx / 16) % n), nchunk = px / 16;
+  const int chunk = (int)((idx / (16 * (int64_t)n)) % nchunk), j = (int)(idx / (16 * (int64_t)n * nchunk));
+  const int kx = chunk * 16 + l;
   if (kx > n / 2) return;  // pad columns
   const int ky = (j < n / 2 + 1) ? j : j - n, kz = (k < n / 2 + 1) ? k : k - n;
   const float kr = sqrtf((float)(kx * kx + ky * ky + kz * kz));
@@ -213,12 +216,12 @@ int build_coarse_kernel(p3m_ctx *c, const float *table4_host) {
   for (int comp = 0; comp < 3; comp++) {
     if (lr) {
       hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, rp, g.ms, comp, 0);
-      P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));
+      P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, c->slab_w, 1));
       hipLaunchKernelGGL(k_take_imag_c, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->slab, unc, ncx);
     }
     hipLaunchKernelGGL(k_coarse_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->slab, (const float *)d_table, n, rp, g.ms, comp, 1);
     HIP_TRY(hipGetLastError());
-    P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, 1));
+    P3M_TRY(fft3d_forward(c, c->plan_c, c->slab, c->slab_w, 1));
     hipLaunchKernelGGL(k_take_imag_c, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->slab, c->kern_c + comp * ncx, ncx);
     if (lr) hipLaunchKernelGGL(k_lrck, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, c->kern_c + comp * ncx, (const float *)unc, n, g.pxc, comp);
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,147 @@
+// fft_core.h -- in-LDS mixed-radix Stockham machinery shared by the FFT kernels (see fft.hip).
+#pragma once
+struct Factors { int nfac; int f[12]; };
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// ---- compile-time trig for the odd-radix butterflies -----------------------------------------
+constexpr double ct_sin(double x) {  // |x| <= pi
+  double term = x, sum = x;
+  for (int i = 1; i < 24; i++) { term *= -x * x / ((2.0 * i) * (2.0 * i + 1.0)); sum += term; }
+  return sum;
+}
+constexpr double ct_cos(double x) {
+  double term = 1.0, sum = 1.0;
+  for (int i = 1; i < 24; i++) { term *= -x * x / ((2.0 * i - 1.0) * (2.0 * i)); sum += term; }
+  return sum;
+}
+template <int R> struct TrigTab {
+  float c[R], s[R];
+  constexpr TrigTab() : c(), s() {
+    for (int k = 0; k < R; k++) {
+      double a = 2.0 * 3.14159265358979323846 * k / R;
+      if (a > 3.14159265358979323846) a -= 2.0 * 3.14159265358979323846;
+      c[k] = (float)ct_cos(a); s[k] = (float)ct_sin(a);
+    }
+  }
+};
+
+// forward DFT (sign -1) of R values held in registers
+template <int R> __device__ __forceinline__ void dft(float2 (&v)[R]);
+
+template <> __device__ __forceinline__ void dft<2>(float2 (&v)[2]) {
+  float2 a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b);
+}
+template <> __device__ __forceinline__ void dft<4>(float2 (&v)[4]) {
+  float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+  float2 jd = make_float2(d.y, -d.x);  // -i*d
+  v[0] = cadd(a, c); v[1] = cadd(b, jd); v[2] = csub(a, c); v[3] = csub(b, jd);
+}
+template <> __device__ __forceinline__ void dft<8>(float2 (&v)[8]) {
+  const float r = 0.70710678118654752440f;
+  float2 a[4], b[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { a[k] = cadd(v[k], v[k + 4]); b[k] = csub(v[k], v[k + 4]); }
+  b[1] = make_float2(r * (b[1].x + b[1].y), r * (b[1].y - b[1].x));    // * (1-i)/sqrt2
+  b[2] = make_float2(b[2].y, -b[2].x);                                 // * -i
+  b[3] = make_float2(r * (b[3].y - b[3].x), -r * (b[3].x + b[3].y));   // * (-1-i)/sqrt2
+  dft<4>(a); dft<4>(b);
+#pragma unroll
+  for (int q = 0; q < 4; q++) { v[2 * q] = a[q]; v[2 * q + 1] = b[q]; }
+}
+template <int R> __device__ __forceinline__ void dft_odd(float2 (&v)[R]) {
+  constexpr int H = (R - 1) / 2;
+  constexpr TrigTab<R> tab{};
+  float2 t[H + 1], u[H + 1];
+#pragma unroll
+  for (int p = 1; p <= H; p++) { t[p] = cadd(v[p], v[R - p]); u[p] = csub(v[p], v[R - p]); }
+  float2 v0 = v[0], s0 = v[0];
+#pragma unroll
+  for (int p = 1; p <= H; p++) s0 = cadd(s0, t[p]);
+  v[0] = s0;
+#pragma unroll
+  for (int a = 1; a <= H; a++) {
+    float2 A = v0, B = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int p = 1; p <= H; p++) {
+      const float cc = tab.c[(a * p) % R], ss = tab.s[(a * p) % R];
+      A.x += cc * t[p].x; A.y += cc * t[p].y; B.x += ss * u[p].x; B.y += ss * u[p].y;
+    }
+    v[a] = make_float2(A.x + B.y, A.y - B.x);      // A - iB
+    v[R - a] = make_float2(A.x - B.y, A.y + B.x);  // A + iB
+  }
+}
+template <> __device__ __forceinline__ void dft<3>(float2 (&v)[3]) { dft_odd<3>(v); }
+template <> __device__ __forceinline__ void dft<5>(float2 (&v)[5]) { dft_odd<5>(v); }
+template <> __device__ __forceinline__ void dft<7>(float2 (&v)[7]) { dft_odd<7>(v); }
+template <> __device__ __forceinline__ void dft<11>(float2 (&v)[11]) { dft_odd<11>(v); }
+template <> __device__ __forceinline__ void dft<13>(float2 (&v)[13]) { dft_odd<13>(v); }
+template <> __device__ __forceinline__ void dft<17>(float2 (&v)[17]) { dft_odd<17>(v); }
+template <> __device__ __forceinline__ void dft<19>(float2 (&v)[19]) { dft_odd<19>(v); }
+
+// One radix-R Stockham stage on `nl` lines of length n held in LDS.
+// element (idx,line) lives at idx*sI + line*sL.  ROWS: lanes run along the line (x pass);
+// otherwise lanes run across lines (strided passes).  tw[q*twm] = exp(-2 pi i q / n).
+template <int R, bool ROWS>
+__device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 *__restrict__ out, int n, int Ns, int nl,
+                                          int sI, int sL, const float2 *__restrict__ tw, int twm) {
+  const int nb = n / R, ntask = nb * nl;
+  const int tstep = (n / (Ns * R)) * twm;
+  for (int task = threadIdx.x; task < ntask; task += blockDim.x) {
+    int j, line;
+    if (ROWS) { line = task / nb; j = task - line * nb; } else { j = task / nl; line = task - j * nl; }
+    const int k = j % Ns;
+    const float2 *pin = in + line * sL;
+    float2 v[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) v[m] = pin[(j + m * nb) * sI];
+    if (Ns > 1) {
+      const int ts = tstep * k;
+#pragma unroll
+      for (int m = 1; m < R; m++) v[m] = cmul(v[m], tw[m * ts]);
+    }
+    dft<R>(v);
+    const int j0 = (j - k) * R + k;
+    float2 *pout = out + line * sL;
+#pragma unroll
+    for (int m = 0; m < R; m++) pout[(j0 + m * Ns) * sI] = v[m];
+  }
+}
+
+// RSET selects which odd radices are compiled in (their butterflies set the kernel's VGPR count):
+// 0: 2,3,4,5,7,8   1: + 11,13   2: + 17,19
+template <bool ROWS, int RSET>
+__device__ __forceinline__ float2 *fft_lds(float2 *A, float2 *B, int n, int nl, int sI, int sL, const Factors &fac,
+                                           const float2 *tw, int twm) {
+  int Ns = 1;
+  float2 *in = A, *out = B;
+  for (int s = 0; s < fac.nfac; s++) {
+    const int R = fac.f[s];
+    switch (R) {
+      case 2: fft_stage<2, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 3: fft_stage<3, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 4: fft_stage<4, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 5: fft_stage<5, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 7: fft_stage<7, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 8: fft_stage<8, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      default:
+        if constexpr (RSET >= 1) {
+          if (R == 11) fft_stage<11, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          else if (R == 13) fft_stage<13, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
+        }
+        if constexpr (RSET >= 2) {
+          if (R == 17) fft_stage<17, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          else if (R == 19) fft_stage<19, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
+        }
+        break;
+    }
+    Ns *= R;
+    __syncthreads();
+    float2 *t = in; in = out; out = t;
+  }
+  return in;
+}
+

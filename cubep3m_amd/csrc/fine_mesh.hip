@@ -178,7 +178,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
 // ------------------------------------------------------------------ :176-204 forward FFT, 3 x (i K_c multiply, inverse FFT, box extract)
 int fine_force(p3m_ctx *c, int tile0, int ntile) {
   const Geometry &g = c->g;
-  P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, ntile));
+  P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, c->work, ntile));
   const size_t boxsz = (size_t)g.fb * g.fb * g.fb;
   // one fused launch per axis for all three components (rho-hat is read once)
   return fft_inverse3_box(c, c->plan_f, c->rho, c->work, c->kern_f, ntile, c->fbox + (size_t)tile0 * boxsz, g.fb, g.nb - 2,
@@ -301,7 +301,7 @@ int build_fine_kernel(p3m_ctx *c, const float *table16_host) {
   for (int comp = 0; comp < 3; comp++) {
     hipLaunchKernelGGL(k_fine_kernel_real, dim3(cdiv(tot, 256)), dim3(256), 0, c->stream, c->rho, (const float *)d_table, g.nf, 2 * g.px, g.ncut, comp, zc);
     HIP_TRY(hipGetLastError());
-    P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, 1));
+    P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, c->work, 1));   // rho-hat in the bundle layout LZ; so is kern_f
     hipLaunchKernelGGL(k_take_imag, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->rho, c->kern_f + comp * ncx, ncx);
     HIP_TRY(hipGetLastError());
   }

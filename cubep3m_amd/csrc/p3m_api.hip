@@ -95,7 +95,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   A(dalloc(&c->force_c, (size_t)3 * (g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2)));
   if (g.nodes == 1) {
     const size_t Sc = (size_t)g.nc * g.nc * (2 * g.pxc);
-    A(dalloc(&c->slab, Sc)); A(dalloc(&c->slab_w, Sc));
+    A(dalloc(&c->slab, Sc)); A(dalloc(&c->slab_w, Sc)); A(dalloc(&c->slab_o, Sc));
     A(dalloc(&c->kern_c, (size_t)3 * g.nc * g.nc * g.pxc));
     if (hipMemset(c->slab, 0, Sc * sizeof(float)) != hipSuccess || hipMemset(c->slab_w, 0, Sc * sizeof(float)) != hipSuccess ||
         hipMemset(c->kern_c, 0, (size_t)3 * g.nc * g.nc * g.pxc * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
@@ -120,7 +120,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   dfree(c->cell_of); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->kern_f);
-  dfree(c->rho_c); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->kern_c);
+  dfree(c->rho_c); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->slab_o); dfree(c->kern_c);
   dfree(c->d_red); dfree(c->d_tile_ext); dfree(c->d_sums);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   if (c->h_red) (void)hipHostFree(c->h_red);
@@ -158,13 +158,21 @@ static void planes_to_aos(const float *planes, float *aos, size_t ncx) {
   for (int comp = 0; comp < 3; comp++) for (size_t i = 0; i < ncx; i++) aos[i * 3 + comp] = planes[comp * ncx + i];
 }
 // kernels: reference rows hold hx values, device rows px (zero padded)
-static void kern_to_device(const float *aos, float *planes, size_t rows, int hx, int px) {
-  for (int comp = 0; comp < 3; comp++) for (size_t r = 0; r < rows; r++) for (int i = 0; i < px; i++)
-    planes[(comp * rows + r) * px + i] = i < hx ? aos[(r * hx + i) * 3 + comp] : 0.f;
+// kernels: reference (3, hx, n, n) component fastest  <->  device SoA planes in the FFT's bundle layout
+// LZ [y][chunk][z][16] (fft.hip "memory layouts"), zero in the pad columns
+static inline size_t lz_index(int n, int px, int x, int y, int z) {
+  return ((((size_t)y * (px / 16) + x / 16) * n + z) * 16) + x % 16;
 }
-static void kern_from_device(const float *planes, float *aos, size_t rows, int hx, int px) {
-  for (int comp = 0; comp < 3; comp++) for (size_t r = 0; r < rows; r++) for (int i = 0; i < hx; i++)
-    aos[(r * hx + i) * 3 + comp] = planes[(comp * rows + r) * px + i];
+static void kern_to_device(const float *aos, float *planes, int n, int hx, int px) {
+  const size_t plane = (size_t)n * n * px;
+  for (size_t i = 0; i < 3 * plane; i++) planes[i] = 0.f;
+  for (int comp = 0; comp < 3; comp++) for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < hx; x++)
+    planes[comp * plane + lz_index(n, px, x, y, z)] = aos[((((size_t)z * n + y) * hx) + x) * 3 + comp];
+}
+static void kern_from_device(const float *planes, float *aos, int n, int hx, int px) {
+  const size_t plane = (size_t)n * n * px;
+  for (int comp = 0; comp < 3; comp++) for (int z = 0; z < n; z++) for (int y = 0; y < n; y++) for (int x = 0; x < hx; x++)
+    aos[((((size_t)z * n + y) * hx) + x) * 3 + comp] = planes[comp * plane + lz_index(n, px, x, y, z)];
 }
 
 extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const float *kern_c) {
@@ -174,9 +182,9 @@ extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const fl
   const Geometry &g = c->g;
   const size_t nf = (size_t)g.nf * g.nf * g.px, ncx = (size_t)g.nc * g.nc * g.pxc;
   std::vector<float> tmp(3 * std::max(nf, ncx));
-  kern_to_device(kern_f, tmp.data(), (size_t)g.nf * g.nf, g.hx, g.px);
+  kern_to_device(kern_f, tmp.data(), g.nf, g.hx, g.px);
   HIP_TRY(hipMemcpy(c->kern_f, tmp.data(), sizeof(float) * 3 * nf, hipMemcpyHostToDevice));
-  kern_to_device(kern_c, tmp.data(), (size_t)g.nc * g.nc, g.nc / 2 + 1, g.pxc);
+  kern_to_device(kern_c, tmp.data(), g.nc, g.nc / 2 + 1, g.pxc);
   HIP_TRY(hipMemcpy(c->kern_c, tmp.data(), sizeof(float) * 3 * ncx, hipMemcpyHostToDevice));
   c->have_kf = c->have_kc = true;
   return P3M_OK;
@@ -189,8 +197,8 @@ extern "C" int p3m_hip_get_kernels(p3m_ctx *c, float *kern_f, float *kern_c) {
   const Geometry &g = c->g;
   const size_t nf = (size_t)g.nf * g.nf * g.px, ncx = (size_t)g.nc * g.nc * g.pxc;
   std::vector<float> tmp(3 * std::max(nf, ncx));
-  if (kern_f) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_f, sizeof(float) * 3 * nf, hipMemcpyDeviceToHost)); kern_from_device(tmp.data(), kern_f, (size_t)g.nf * g.nf, g.hx, g.px); }
-  if (kern_c && c->kern_c) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_c, sizeof(float) * 3 * ncx, hipMemcpyDeviceToHost)); kern_from_device(tmp.data(), kern_c, (size_t)g.nc * g.nc, g.nc / 2 + 1, g.pxc); }
+  if (kern_f) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_f, sizeof(float) * 3 * nf, hipMemcpyDeviceToHost)); kern_from_device(tmp.data(), kern_f, g.nf, g.hx, g.px); }
+  if (kern_c && c->kern_c) { HIP_TRY(hipMemcpy(tmp.data(), c->kern_c, sizeof(float) * 3 * ncx, hipMemcpyDeviceToHost)); kern_from_device(tmp.data(), kern_c, g.nc, g.nc / 2 + 1, g.pxc); }
   return P3M_OK;
 }
 
@@ -425,16 +433,19 @@ extern "C" int p3m_hip_fft3d(p3m_ctx *c, float *data, int32_t n, int32_t dir) {
   if (!c || !data) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
   FftPlan pl; P3M_TRY(fft_plan_create(&pl, n));
-  float *d = nullptr; const size_t S = (size_t)(2 * pl.px) * n * n;
-  int r = dalloc(&d, S);
+  float *d = nullptr, *t1 = nullptr, *t2 = nullptr; const size_t S = (size_t)(2 * pl.px) * n * n;
+  int r = dalloc(&d, S); if (!r) r = dalloc(&t1, S); if (!r) r = dalloc(&t2, S);
   if (!r) {
     hipError_t e = hipMemsetAsync(d, 0, sizeof(float) * S, c->stream);
     if (e == hipSuccess) e = hipMemcpy2DAsync(d, sizeof(float) * 2 * pl.px, data, sizeof(float) * (n + 2), sizeof(float) * (n + 2), (size_t)n * n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) r = dir > 0 ? fft3d_forward(c, pl, d, 1) : fft3d_inverse(c, pl, d, 1, nullptr, nullptr);
-    if (!r) e = hipMemcpy2DAsync(data, sizeof(float) * (n + 2), d, sizeof(float) * 2 * pl.px, sizeof(float) * (n + 2), (size_t)n * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) {
+      if (dir > 0) { r = fft3d_forward(c, pl, d, t1, 1); if (!r) r = fft_lz_to_rows(c, pl, d, t2); }               // reference rows <- LZ
+      else { r = fft_rows_to_lz(c, pl, d, t1); if (!r) r = fft3d_inverse(c, pl, t1, d, t2, 1, nullptr); }
+    }
+    if (!r) e = hipMemcpy2DAsync(data, sizeof(float) * (n + 2), t2, sizeof(float) * 2 * pl.px, sizeof(float) * (n + 2), (size_t)n * n, hipMemcpyDeviceToHost, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess || e != hipSuccess) { p3m_set_error("fft3d probe: HIP error"); r = r ? r : P3M_EDEVICE; }
   }
-  dfree(d); fft_plan_destroy(&pl);
+  dfree(d); dfree(t1); dfree(t2); fft_plan_destroy(&pl);
   return r;
 }
 

@@ -82,7 +82,7 @@ struct p3m_ctx {
   // ---- coarse mesh
   float *rho_c = nullptr;      // [ncn][ncn][ncn]
   float *slab = nullptr;       // [nc][nc][2*pxc] (single rank) density -> hat
-  float *slab_w = nullptr;
+  float *slab_w = nullptr, *slab_o = nullptr;  // scratch (LY) and real output of the inverse
   float *force_c = nullptr;    // [3][ncn+2][ncn+2][ncn+2] SoA planes incl. halo
   float *kern_c = nullptr;     // [3][nc][nc][pxc]
   FftPlan plan_c;
@@ -104,11 +104,14 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // ---- fft.hip
 int fft_plan_create(FftPlan *pl, int n);
 void fft_plan_destroy(FftPlan *pl);
-// in-place batched 3-D r2c of `batch` arrays [n][n][n+2]
-int fft3d_forward(p3m_ctx *c, const FftPlan &pl, float *data, int batch);
-// data <- c2r( in ) / n^3 ; when kern != nullptr the first pass reads src=rho-hat and multiplies by
-// i*K (particle_mesh_threaded.f90:183-192) on the fly, writing into `data` (src is left intact)
-int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, float *data, int batch, const float *src, const float *kern);
+// batched 3-D r2c: data holds real ROWS ([n][n][2*px]) on entry and rho-hat in the bundle layout LZ on
+// exit (see fft.hip "memory layouts"); scratch is one more array of the same size
+int fft3d_forward(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch);
+// out (real ROWS) <- c2r(hat [* i*kern]) / n^3 ; hat and kern in LZ; tmp: scratch array; out != tmp
+// (the multiply is particle_mesh_threaded.f90:183-192; hat is left intact)
+int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, const float *hat, float *tmp, float *out, int batch, const float *kern);
+int fft_rows_to_lz(p3m_ctx *c, const FftPlan &pl, const float *rows, float *lz);
+int fft_lz_to_rows(p3m_ctx *c, const FftPlan &pl, const float *lz, float *rows);
 
 // ---- particles.hip
 int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset);
