@@ -230,7 +230,7 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
     }
   }
   __syncthreads();
-  const float2 *Z = fft_lds<false, RSET>(A, B, n, BXC, BXC, 1, fac, tw, 1);
+  const float2 *Z = fft_lds<false, RSET, BXC>(A, B, n, BXC, BXC, 1, fac, tw, 1);
   float2 *dbase = a.dst + comp * a.dst_comp_stride;
   const int e0 = a.slo * (BXC / 2), e1 = (a.slo + a.scount) * (BXC / 2);
   if (!TR) {
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void k_lz_to_rows(const float2 *__restrict__ l
 // ================================================================== host side
 static bool factorize(int n, int *nfac, int *fac) {
   int m = n, k = 0;
+  while (m % 16 == 0) { fac[k++] = 16; m /= 16; }
   while (m % 8 == 0) { fac[k++] = 8; m /= 8; }
   while (m % 4 == 0) { fac[k++] = 4; m /= 4; }
   while (m % 2 == 0) { fac[k++] = 2; m /= 2; }

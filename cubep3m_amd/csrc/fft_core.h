@@ -52,6 +52,31 @@ template <> __device__ __forceinline__ void dft<8>(float2 (&v)[8]) {
 #pragma unroll
   for (int q = 0; q < 4; q++) { v[2 * q] = a[q]; v[2 * q + 1] = b[q]; }
 }
+// radix 16 = 4 x 4: Y_{n1} = DFT4 over n2 of v[n1+4*n2]; twiddle W16^{n1*k2}; X[4*k1+k2] = DFT4 over n1
+template <> __device__ __forceinline__ void dft<16>(float2 (&v)[16]) {
+  const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r = 0.70710678118654752440f;
+  float2 y[4][4];
+#pragma unroll
+  for (int n1 = 0; n1 < 4; n1++) {
+    float2 t[4] = {v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]};
+    dft<4>(t);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) y[n1][k2] = t[k2];
+  }
+  // W16^m = exp(-2 pi i m/16): m = n1*k2
+  const float2 w1 = make_float2(c1, -s1), w2 = make_float2(r, -r), w3 = make_float2(s1, -c1);
+  const float2 w6 = make_float2(-r, -r), w9 = make_float2(-c1, s1);
+  y[1][1] = cmul(y[1][1], w1); y[1][2] = cmul(y[1][2], w2); y[1][3] = cmul(y[1][3], w3);
+  y[2][1] = cmul(y[2][1], w2); y[2][2] = make_float2(y[2][2].y, -y[2][2].x); y[2][3] = cmul(y[2][3], w6);
+  y[3][1] = cmul(y[3][1], w3); y[3][2] = cmul(y[3][2], w6); y[3][3] = cmul(y[3][3], w9);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; k2++) {
+    float2 t[4] = {y[0][k2], y[1][k2], y[2][k2], y[3][k2]};
+    dft<4>(t);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) v[4 * k1 + k2] = t[k1];
+  }
+}
 template <int R> __device__ __forceinline__ void dft_odd(float2 (&v)[R]) {
   constexpr int H = (R - 1) / 2;
   constexpr TrigTab<R> tab{};
@@ -85,15 +110,19 @@ template <> __device__ __forceinline__ void dft<19>(float2 (&v)[19]) { dft_odd<1
 // One radix-R Stockham stage on `nl` lines of length n held in LDS.
 // element (idx,line) lives at idx*sI + line*sL.  ROWS: lanes run along the line (x pass);
 // otherwise lanes run across lines (strided passes).  tw[q*twm] = exp(-2 pi i q / n).
-template <int R, bool ROWS>
-__device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 *__restrict__ out, int n, int Ns, int nl,
+// The position k = j mod Ns inside the sub-transform needs no division in the first stage (Ns = 1,
+// k = 0) nor in the last (Ns = n/R > j, k = j); NL > 0 makes the line count a compile-time constant.
+template <int R, bool ROWS, int NL>
+__device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 *__restrict__ out, int n, int Ns, int nl_rt,
                                           int sI, int sL, const float2 *__restrict__ tw, int twm) {
+  const int nl = NL > 0 ? NL : nl_rt;
   const int nb = n / R, ntask = nb * nl;
   const int tstep = (n / (Ns * R)) * twm;
+  const bool last = (Ns == nb);
   for (int task = threadIdx.x; task < ntask; task += blockDim.x) {
     int j, line;
     if (ROWS) { line = task / nb; j = task - line * nb; } else { j = task / nl; line = task - j * nl; }
-    const int k = j % Ns;
+    const int k = (Ns == 1) ? 0 : (last ? j : j % Ns);
     const float2 *pin = in + line * sL;
     float2 v[R];
 #pragma unroll
@@ -113,28 +142,32 @@ __device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 
 
 // RSET selects which odd radices are compiled in (their butterflies set the kernel's VGPR count):
 // 0: 2,3,4,5,7,8   1: + 11,13   2: + 17,19
-template <bool ROWS, int RSET>
+template <bool ROWS, int RSET, int NL = 0>
 __device__ __forceinline__ float2 *fft_lds(float2 *A, float2 *B, int n, int nl, int sI, int sL, const Factors &fac,
                                            const float2 *tw, int twm) {
   int Ns = 1;
   float2 *in = A, *out = B;
+#ifdef P3M_ABLATE_NOFFT   // timing-only build: global<->LDS traffic without the butterflies (outputs are wrong)
+  return in;
+#endif
   for (int s = 0; s < fac.nfac; s++) {
     const int R = fac.f[s];
     switch (R) {
-      case 2: fft_stage<2, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 3: fft_stage<3, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 4: fft_stage<4, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 5: fft_stage<5, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 7: fft_stage<7, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 8: fft_stage<8, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 2: fft_stage<2, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 3: fft_stage<3, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 4: fft_stage<4, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 5: fft_stage<5, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 7: fft_stage<7, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 8: fft_stage<8, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 16: fft_stage<16, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
       default:
         if constexpr (RSET >= 1) {
-          if (R == 11) fft_stage<11, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
-          else if (R == 13) fft_stage<13, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          if (R == 11) fft_stage<11, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          else if (R == 13) fft_stage<13, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
         }
         if constexpr (RSET >= 2) {
-          if (R == 17) fft_stage<17, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
-          else if (R == 19) fft_stage<19, ROWS>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          if (R == 17) fft_stage<17, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          else if (R == 19) fft_stage<19, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
         }
         break;
     }

@@ -13,7 +13,7 @@ import numpy as np
 from .params import P3MParams, P3MStepOut
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libp3m_hip.so")
+SO_PATH = os.environ.get("P3M_HIP_LIB") or os.path.join(_HERE, "libp3m_hip.so")  # override: timing-only ablation builds
 _lib = None
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
