@@ -16,6 +16,7 @@
 // produce the planes/rows of the force box.  Bound: HBM (no MFMA: nothing here is a dense contraction).
 #include "p3m_internal.h"
 #include <math.h>
+#include <algorithm>
 #include "fft_core.h"
 
 // ------------------------------------------------------------------ memory layouts
@@ -177,76 +178,89 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(const float2 *__restrict__ sr
 // z forward, y inverse) or, element idx of bundle (o,chunk), to element o of bundle (idx,chunk) of
 // the other bundle layout (TR = true: y forward LY->LZ, z inverse LZ->LY).
 // NC = 0: plain.  NC = 1|3: fused k-space multiply (particle_mesh_threaded.f90:183-192); the kernels
-// K_c are stored in LZ like rho-hat; component c goes to dst + c*dst_comp_stride.  With NC = 3 the
-// three workgroups of one bundle sit 8 block ids apart, i.e. on the same XCD, so rho-hat is fetched
-// from HBM once and re-read from that XCD's L2 (placement is a speed hint only, never correctness).
+// K_c are stored in LZ like rho-hat; component c goes to dst + c*dst_comp_stride.
 // Pruning: bundles o in [olo, olo+ocount) only; line elements [slo, slo+scount) are stored.
 struct LinesArgs {
   float2 *dst; const float2 *src; const float *kern;
   int64_t kern_comp_stride, dst_comp_stride;
   int n, nchunk, olo, ocount, slo, scount, nbundles;
 };
-template <bool INV, bool TR, int NC, int RSET, int TB>
+// Each workgroup walks a grid-stride list of work items and is software-pipelined: the next
+// item's global loads are issued into registers (LUX 16-byte loads per lane) before the butterflies
+// of the current one run, so HBM latency hides under the LDS stages.  With NC = 3 a work item is
+// (bundle, component); the three components of one bundle are 8 item numbers apart, i.e. on the
+// same XCD under round-robin placement, so rho-hat comes from HBM once and from that XCD's L2
+// twice (a speed hint only, never correctness).
+template <bool INV, bool TR, int NC, int RSET, int TB, int LUX>
 __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, const float2 *__restrict__ tw_g) {
   extern __shared__ float2 lds[];
   const int n = a.n;
+  constexpr int T = TB;
   float2 *A = lds, *B = A + n * BXC, *tw = B + n * BXC;
-  int bid = blockIdx.x, comp = 0;
-  if (NC == 3) { const int g = bid / 24, s = bid - g * 24; comp = s >> 3; bid = g * 8 + (s & 7); }
-  if (bid >= a.nbundles) return;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
-  const int chunk = bid % a.nchunk;
-  const int rest = bid / a.nchunk;
-  const int o = a.olo + rest % a.ocount;
-  const int64_t b = rest / a.ocount;
-  const int64_t soff = bundle_off(b, n, a.nchunk, o, chunk);
-  const float4 *src4 = reinterpret_cast<const float4 *>(a.src + soff);
+  for (int i = threadIdx.x; i < n; i += T) tw[i] = tw_g[i];
   const int ne = n * (BXC / 2);
-  // all of a thread's loads are issued before the first use (LU independent 16-byte loads in flight
-  // per lane): the pass is latency-bound otherwise
-  constexpr int LU = 6;
-  const int T = blockDim.x;
-  if (NC == 0) {
-    for (int e0 = threadIdx.x; e0 < ne; e0 += LU * T) {
-      float4 v[LU];
+  const int nwork = (NC == 3) ? ((a.nbundles + 7) / 8) * 24 : a.nbundles;
+  float4 v[LUX]; float2 K[LUX];
+  auto decode = [&](int w, int &comp, int &bid) {
+    if (NC == 3) { const int g = w / 24, s = w - g * 24; comp = s >> 3; bid = g * 8 + (s & 7); } else { comp = 0; bid = w; }
+  };
+  auto locate = [&](int bid, int &o, int &chunk, int64_t &b) {
+    chunk = bid % a.nchunk; const int rest = bid / a.nchunk; o = a.olo + rest % a.ocount; b = rest / a.ocount;
+  };
+  auto fetch = [&](int w) {
+    int comp, bid; decode(w, comp, bid);
+    bid = min(bid, a.nbundles - 1);
+    int o, chunk; int64_t b; locate(bid, o, chunk, b);
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.src + bundle_off(b, n, a.nchunk, o, chunk));
 #pragma unroll
-      for (int u = 0; u < LU; u++) v[u] = src4[min(e0 + u * T, ne - 1)];   // unconditional: keeps v[] in registers
+    for (int u = 0; u < LUX; u++) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if ((int)threadIdx.x + u * T < ne) v[u] = src4[(int)threadIdx.x + u * T]; }
+    if (NC != 0) {
+      const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + bundle_off(0, n, a.nchunk, o, chunk));
 #pragma unroll
-      for (int u = 0; u < LU; u++) if (e0 + u * T < ne) {
-        if (INV) { v[u].y = -v[u].y; v[u].w = -v[u].w; }
-        reinterpret_cast<float4 *>(A)[e0 + u * T] = v[u];
+      for (int u = 0; u < LUX; u++) { K[u] = make_float2(0.f, 0.f); if ((int)threadIdx.x + u * T < ne) K[u] = k2[(int)threadIdx.x + u * T]; }
+    }
+  };
+  int w = blockIdx.x;
+  if (w < nwork) fetch(w);
+  for (; w < nwork; w += gridDim.x) {
+    int comp, bid; decode(w, comp, bid);
+    const bool valid = bid < a.nbundles;   // uniform over the workgroup
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < LUX; u++) {
+        const int e = (int)threadIdx.x + u * T;
+        if (e < ne) {
+          float4 r = v[u];
+          if (NC != 0) r = make_float4(-r.y * K[u].x, -(r.x * K[u].x), -r.w * K[u].y, -(r.z * K[u].y));  // (re,im)*i*K, then conj
+          else if (INV) { r.y = -r.y; r.w = -r.w; }
+          reinterpret_cast<float4 *>(A)[e] = r;
+        }
       }
     }
-  } else {
-    const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + bundle_off(0, n, a.nchunk, o, chunk));
-    for (int e0 = threadIdx.x; e0 < ne; e0 += LU * T) {
-      float4 r[LU]; float2 K[LU];
-#pragma unroll
-      for (int u = 0; u < LU; u++) { const int ec = min(e0 + u * T, ne - 1); r[u] = src4[ec]; K[u] = k2[ec]; }
-#pragma unroll
-      for (int u = 0; u < LU; u++) if (e0 + u * T < ne)
-        // (re,im) * i*K = (-im*K, re*K); then conj for the inverse-by-forward trick
-        reinterpret_cast<float4 *>(A)[e0 + u * T] = make_float4(-r[u].y * K[u].x, -(r[u].x * K[u].x), -r[u].w * K[u].y, -(r[u].z * K[u].y));
+    __syncthreads();
+    { const int wn = w + gridDim.x; if (wn < nwork) fetch(wn); }   // in flight during the butterflies
+    if (valid) {
+      int o, chunk; int64_t b; locate(bid, o, chunk, b);
+      const float2 *Z = fft_lds<false, RSET, BXC>(A, B, n, BXC, BXC, 1, fac, tw, 1);
+      float2 *dbase = a.dst + comp * a.dst_comp_stride;
+      const int e0 = a.slo * (BXC / 2), e1 = (a.slo + a.scount) * (BXC / 2);
+      if (!TR) {
+        float4 *dst4 = reinterpret_cast<float4 *>(dbase + bundle_off(b, n, a.nchunk, o, chunk));
+        for (int e = e0 + threadIdx.x; e < e1; e += T) {
+          float4 r = reinterpret_cast<const float4 *>(Z)[e];
+          if (INV) { r.y = -r.y; r.w = -r.w; }
+          dst4[e] = r;
+        }
+      } else {
+        for (int e = e0 + threadIdx.x; e < e1; e += T) {
+          const int idx = e >> 3, l4 = e & 7;
+          float4 r = reinterpret_cast<const float4 *>(Z)[e];
+          if (INV) { r.y = -r.y; r.w = -r.w; }
+          reinterpret_cast<float4 *>(dbase + bundle_off(b, n, a.nchunk, idx, chunk) + (int64_t)o * BXC)[l4] = r;
+        }
+      }
     }
-  }
-  __syncthreads();
-  const float2 *Z = fft_lds<false, RSET, BXC>(A, B, n, BXC, BXC, 1, fac, tw, 1);
-  float2 *dbase = a.dst + comp * a.dst_comp_stride;
-  const int e0 = a.slo * (BXC / 2), e1 = (a.slo + a.scount) * (BXC / 2);
-  if (!TR) {
-    float4 *dst4 = reinterpret_cast<float4 *>(dbase + soff);
-    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-      float4 v = reinterpret_cast<const float4 *>(Z)[e];
-      if (INV) { v.y = -v.y; v.w = -v.w; }
-      dst4[e] = v;
-    }
-  } else {
-    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-      const int idx = e >> 3, l4 = e & 7;
-      float4 v = reinterpret_cast<const float4 *>(Z)[e];
-      if (INV) { v.y = -v.y; v.w = -v.w; }
-      reinterpret_cast<float4 *>(dbase + bundle_off(b, n, a.nchunk, idx, chunk) + (int64_t)o * BXC)[l4] = v;
-    }
+    __syncthreads();
   }
 }
 
@@ -351,27 +365,50 @@ int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, i
     default: return x_inv_impl<2>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
   }
 }
-template <bool INV, bool TR, int NC, int RSET, int TB> static int lines_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
+template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
   const int n = pl.n;
   a.n = n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
   const size_t lds = sizeof(float2) * ((size_t)2 * n * BXC + n);
-  P3M_TRY((set_lds(k_fft_lines<INV, TR, NC, RSET, TB>, lds)));
-  const int64_t blocks = NC == 3 ? (int64_t)((a.nbundles + 7) / 8) * 24 : a.nbundles;
-  hipLaunchKernelGGL((k_fft_lines<INV, TR, NC, RSET, TB>), dim3((unsigned)blocks), dim3(TB), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
+  P3M_TRY((set_lds(k_fft_lines<INV, TR, NC, RSET, TB, LUX>, lds)));
+  // persistent grid: as many workgroups as are resident at once, a multiple of 24 (XCD/component map)
+  const int nwork = NC == 3 ? ((a.nbundles + 7) / 8) * 24 : a.nbundles;
+  // never more than fit at once (a straggler wave of workgroups would double the time)
+  static int occ_cache = 0, occ_lds = 0;
+  if (occ_cache == 0 || occ_lds != (int)lds) {
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines<INV, TR, NC, RSET, TB, LUX>), TB, lds));
+    occ_cache = occ < 1 ? 1 : occ; occ_lds = (int)lds;
+  }
+  hipDeviceProp_t prop; int ncu = 256;
+  (void)prop;
+  int grid = ncu * occ_cache;
+  if (NC == 3) grid = nwork;   // one (bundle, component) per workgroup: measured faster than the persistent form here
+  if (grid > nwork) grid = nwork;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_fft_lines<INV, TR, NC, RSET, TB, LUX>), dim3((unsigned)grid), dim3(TB), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
 template <bool INV, bool TR, int NC> static int launch_lines(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
   const int rs = rset_of(pl.nfac_full, pl.fac_full);
-  if (pl.n <= 320) {   // 256 threads, several workgroups per CU
-    if (rs == 0) return lines_impl<INV, TR, NC, 0, 256>(c, pl, a, batch);
-    if (rs == 1) return lines_impl<INV, TR, NC, 1, 256>(c, pl, a, batch);
-    return lines_impl<INV, TR, NC, 2, 256>(c, pl, a, batch);
+  if (pl.n <= 128) {   // 256 threads hold a bundle in 4 float4 per lane
+    if (rs == 0) return lines_impl<INV, TR, NC, 0, 256, 4>(c, pl, a, batch);
+    if (rs == 1) return lines_impl<INV, TR, NC, 1, 256, 4>(c, pl, a, batch);
+    return lines_impl<INV, TR, NC, 2, 256, 4>(c, pl, a, batch);
   }
-  // the bundle fills most of the LDS: one workgroup per CU, 1024 threads
-  if (rs == 0) return lines_impl<INV, TR, NC, 0, 1024>(c, pl, a, batch);
-  if (rs == 1) return lines_impl<INV, TR, NC, 1, 1024>(c, pl, a, batch);
-  return lines_impl<INV, TR, NC, 2, 1024>(c, pl, a, batch);
+  if (pl.n <= 192) {   // ... in 6
+    if (rs == 0) return lines_impl<INV, TR, NC, 0, 256, 6>(c, pl, a, batch);
+    if (rs == 1) return lines_impl<INV, TR, NC, 1, 256, 6>(c, pl, a, batch);
+    return lines_impl<INV, TR, NC, 2, 256, 6>(c, pl, a, batch);
+  }
+  if (pl.n <= 320) {
+    if (rs == 0) return lines_impl<INV, TR, NC, 0, 512, 5>(c, pl, a, batch);
+    if (rs == 1) return lines_impl<INV, TR, NC, 1, 512, 5>(c, pl, a, batch);
+    return lines_impl<INV, TR, NC, 2, 512, 5>(c, pl, a, batch);
+  }
+  if (rs == 0) return lines_impl<INV, TR, NC, 0, 1024, 5>(c, pl, a, batch);
+  if (rs == 1) return lines_impl<INV, TR, NC, 1, 1024, 5>(c, pl, a, batch);
+  return lines_impl<INV, TR, NC, 2, 1024, 5>(c, pl, a, batch);
 }
 static LinesArgs full_args(const FftPlan &pl, float *dst, const float *src) {
   LinesArgs a{};
