@@ -34,6 +34,10 @@
 __device__ __forceinline__ int64_t bundle_off(int64_t b, int n, int nchunk, int o, int chunk) {
   return (((b * n + o) * nchunk + chunk) * (int64_t)n) * BXC;
 }
+// general form: `planes` bundles-planes per batch element, lines of `line` elements
+__device__ __forceinline__ int64_t bundle_off2(int64_t b, int planes, int line, int nchunk, int o, int chunk) {
+  return (((b * planes + o) * nchunk + chunk) * (int64_t)line) * BXC;
+}
 
 // ------------------------------------------------------------------ x pass, forward (r2c): ROWS -> LY
 // RB consecutive rows per workgroup; LDS holds element m of row r at m*RBP + r with RBP odd
@@ -180,10 +184,13 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(const float2 *__restrict__ sr
 // NC = 0: plain.  NC = 1|3: fused k-space multiply (particle_mesh_threaded.f90:183-192); the kernels
 // K_c are stored in LZ like rho-hat; component c goes to dst + c*dst_comp_stride.
 // Pruning: bundles o in [olo, olo+ocount) only; line elements [slo, slo+scount) are stored.
+// Distributed (slab) transforms use src_planes / dst_planes / dst_line != n: a rank then holds only
+// its nc_slab planes, and the transposing store writes straight into the all-to-all send layout.
 struct LinesArgs {
   float2 *dst; const float2 *src; const float *kern;
   int64_t kern_comp_stride, dst_comp_stride;
   int n, nchunk, olo, ocount, slo, scount, nbundles;
+  int src_planes, dst_planes, dst_line;
 };
 // Each workgroup walks a grid-stride list of work items and is software-pipelined: the next
 // item's global loads are issued into registers (LUX 16-byte loads per lane) before the butterflies
@@ -211,11 +218,11 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
     int comp, bid; decode(w, comp, bid);
     bid = min(bid, a.nbundles - 1);
     int o, chunk; int64_t b; locate(bid, o, chunk, b);
-    const float4 *src4 = reinterpret_cast<const float4 *>(a.src + bundle_off(b, n, a.nchunk, o, chunk));
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.src + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk));
 #pragma unroll
     for (int u = 0; u < LUX; u++) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if ((int)threadIdx.x + u * T < ne) v[u] = src4[(int)threadIdx.x + u * T]; }
     if (NC != 0) {
-      const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + bundle_off(0, n, a.nchunk, o, chunk));
+      const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk));
 #pragma unroll
       for (int u = 0; u < LUX; u++) { K[u] = make_float2(0.f, 0.f); if ((int)threadIdx.x + u * T < ne) K[u] = k2[(int)threadIdx.x + u * T]; }
     }
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
       float2 *dbase = a.dst + comp * a.dst_comp_stride;
       const int e0 = a.slo * (BXC / 2), e1 = (a.slo + a.scount) * (BXC / 2);
       if (!TR) {
-        float4 *dst4 = reinterpret_cast<float4 *>(dbase + bundle_off(b, n, a.nchunk, o, chunk));
+        float4 *dst4 = reinterpret_cast<float4 *>(dbase + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk));
         for (int e = e0 + threadIdx.x; e < e1; e += T) {
           float4 r = reinterpret_cast<const float4 *>(Z)[e];
           if (INV) { r.y = -r.y; r.w = -r.w; }
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
           const int idx = e >> 3, l4 = e & 7;
           float4 r = reinterpret_cast<const float4 *>(Z)[e];
           if (INV) { r.y = -r.y; r.w = -r.w; }
-          reinterpret_cast<float4 *>(dbase + bundle_off(b, n, a.nchunk, idx, chunk) + (int64_t)o * BXC)[l4] = r;
+          reinterpret_cast<float4 *>(dbase + bundle_off2(b, a.dst_planes, a.dst_line, a.nchunk, idx, chunk) + (int64_t)o * BXC)[l4] = r;
         }
       }
     }
@@ -328,9 +335,8 @@ static int rset_of(int nfac, const int *fac) {
   for (int i = 0; i < nfac; i++) { if (fac[i] >= 17) r = 2; else if (fac[i] >= 11 && r < 1) r = 1; }
   return r;
 }
-template <int RSET> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int batch) {
+template <int RSET> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
   const int n = pl.n; int RB, RBP; x_rows(n, &RB, &RBP);
-  const int64_t rows = (int64_t)batch * n * n;
   const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2) * RBP + n);
   P3M_TRY(set_lds(k_fft_x_fwd<RSET>, lds));
   hipLaunchKernelGGL(k_fft_x_fwd<RSET>, dim3(cdiv(rows, RB)), dim3(256), lds, c->stream, src, reinterpret_cast<float2 *>(dst), n, pl.px, (int)rows, RB,
@@ -338,17 +344,21 @@ template <int RSET> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const f
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-int fft_x_forward(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int batch) {
+int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
   switch (rset_of(pl.nfac_half, pl.fac_half)) {
-    case 0: return x_fwd_impl<0>(c, pl, src, dst, batch);
-    case 1: return x_fwd_impl<1>(c, pl, src, dst, batch);
-    default: return x_fwd_impl<2>(c, pl, src, dst, batch);
+    case 0: return x_fwd_impl<0>(c, pl, src, dst, rows);
+    case 1: return x_fwd_impl<1>(c, pl, src, dst, rows);
+    default: return x_fwd_impl<2>(c, pl, src, dst, rows);
   }
+}
+int fft_x_forward(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int batch) {
+  return fft_x_forward_rows(c, pl, src, dst, (int64_t)batch * pl.n * pl.n);
 }
 template <int RSET>
 static int x_inv_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
   const int n = pl.n; int RB, RBP; x_rows(n, &RB, &RBP);
-  const int64_t rows = mode == 0 ? (int64_t)batch * n * n : (int64_t)batch * fb * fb;
+  // mode 0: `batch` counts ROWS when negative (distributed slabs), whole n^2 arrays otherwise
+  const int64_t rows = mode == 0 ? (batch < 0 ? -(int64_t)batch : (int64_t)batch * n * n) : (int64_t)batch * fb * fb;
   const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2 + 1) * RBP + n);
   const float scale = (float)n * (float)n * (float)n;  // real(nf_tile)**3, fftw2.f90:22
   P3M_TRY(set_lds(k_fft_x_inv<RSET>, lds));
@@ -414,6 +424,7 @@ static LinesArgs full_args(const FftPlan &pl, float *dst, const float *src) {
   LinesArgs a{};
   a.dst = reinterpret_cast<float2 *>(dst); a.src = reinterpret_cast<const float2 *>(src); a.kern = nullptr;
   a.olo = 0; a.ocount = pl.n; a.slo = 0; a.scount = pl.n;
+  a.src_planes = pl.n; a.dst_planes = pl.n; a.dst_line = pl.n;
   return a;
 }
 
@@ -481,4 +492,30 @@ int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float
   }
   p3m_set_error("fft_single_pass: bad selector %d", which);
   return P3M_EINVAL;
+}
+
+// ------------------------------------------------------------------ entry points for the distributed (slab) transforms, group.hip
+// planes: bundle planes held locally (nc_slab); the transposing passes write the all-to-all send layout
+// [line element][chunk][plane][16] directly.
+int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes) {
+  LinesArgs a = full_args(pl, send, ly);
+  a.ocount = planes; a.src_planes = planes; a.dst_planes = pl.n; a.dst_line = planes;
+  return launch_lines<false, true, 0>(c, pl, a, 1);
+}
+int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, float *lz, int planes) {
+  LinesArgs a = full_args(pl, lz, lz);
+  a.ocount = planes; a.src_planes = planes;
+  return launch_lines<false, false, 0>(c, pl, a, 1);
+}
+int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3, const float *kern3, int planes, int64_t kern_comp_stride,
+                    int64_t send_comp_stride) {
+  LinesArgs a = full_args(pl, send3, lz);
+  a.ocount = planes; a.src_planes = planes; a.dst_planes = pl.n; a.dst_line = planes;
+  a.kern = kern3; a.kern_comp_stride = kern_comp_stride; a.dst_comp_stride = send_comp_stride;
+  return launch_lines<true, true, 3>(c, pl, a, 1);
+}
+int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, float *ly3, int planes, int batch) {
+  LinesArgs a = full_args(pl, ly3, ly3);
+  a.ocount = planes; a.src_planes = planes;
+  return launch_lines<true, false, 0>(c, pl, a, batch);
 }

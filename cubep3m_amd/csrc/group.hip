@@ -1,0 +1,651 @@
+// group.hip -- multi-rank gravity step: the reference's nodes_dim^3 cubic sub-volumes ("logical
+// ranks", mpi_initialization.f90:42-76) distributed over the GPUs of one node.  One process drives
+// one GPU and owns a contiguous block of logical ranks (1, 2, 4 or 8 of the 8 when nodes_dim = 2);
+// exchanges between ranks of the same process are device-to-device copies, exchanges between
+// processes are RCCL send/recv over xGMI.  Replaces the MPI traffic of
+//   particle_pass.f90            -> ghost_pass()        3 axes x 2 directions, counts first
+//   fftw3ds.f90 pack/unpack_slab -> cube_to_slab() / slab_to_cube()  (all-to-all inside a z-layer)
+//   rfftwnd_f77_mpi (FFTW-MPI)   -> slab FFT: local x,y passes, ONE global all-to-all transpose per
+//                                   transform written directly by the y/z pass kernels, local z pass
+//   coarse_force_buffer.f90      -> force_halo()        3 axes x 2 directions
+//   mpi_reduce/bcast of dt limits-> reduce_step_out()   one max all-reduce + one sum all-reduce
+// k-space stays in "transposed order" (each rank owns a ky-slab with all kz), which saves the second
+// transpose FFTW's NORMAL_ORDER pays; kern_c is built through the same pipeline and is therefore
+// stored consistently.
+#include "p3m_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <rccl/rccl.h>
+
+int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows);
+int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs);
+int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes);
+int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, float *lz, int planes);
+int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3, const float *kern3, int planes, int64_t kern_comp_stride,
+                    int64_t send_comp_stride);
+int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, float *ly3, int planes, int batch);
+
+#define NCCL_TRY(expr)                                                                             \
+  do {                                                                                             \
+    ncclResult_t _r = (expr);                                                                      \
+    if (_r != ncclSuccess) { p3m_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); return P3M_ECOMM; } \
+  } while (0)
+
+struct CoarseDist {            // per local logical rank
+  float *blocks_in = nullptr;  // [nd^2][s][ncn][ncn]      cube -> slab arrivals
+  float *rows = nullptr;       // [3][s][nc][2*pxc]        real slab rows
+  float *ly = nullptr;         // [3][s][nchunk][nc][16]   complex, LY of the local planes
+  float *send = nullptr;       // [3][nc][nchunk][s][16]   complex, all-to-all send layout
+  float *recv = nullptr;       // same
+  float *lz = nullptr;         // [s][nchunk][nc][16]      complex rho-hat, own ky slab
+  float *kern = nullptr;       // [3][s*nchunk*nc*16]      Im K_c, same order as lz
+  float *blocks_out = nullptr; // [nd^2][3][s][ncn][ncn]   slab -> cube departures
+  float *blocks_back = nullptr;// [nd^2][3][s][ncn][ncn]   arrivals at the cube
+  float *halo_s[2] = {nullptr, nullptr}, *halo_r[2] = {nullptr, nullptr};  // [3][(ncn+2)^2]
+  float4 *sb[2] = {nullptr, nullptr}, *rb[2] = {nullptr, nullptr};         // ghost records, 48 B each
+  int *d_cnt = nullptr;        // [0..1] own send counts, [2..3] counts announced by the neighbours
+};
+
+struct p3m_group {
+  p3m_params base{};
+  int proc = 0, nprocs = 1, nodes = 1, nd = 1, device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<p3m_ctx *> ctx; std::vector<int> lrank, owner, lidx;
+  std::vector<CoarseDist> cd;
+  ncclComm_t comm = nullptr; bool force_nccl = false;
+  FftPlan plan_c; int s = 0, nchunk = 0, cap_buf = 0;
+  int *h_cnt = nullptr;        // pinned [nlocal*4]
+  float *d_red4 = nullptr; double *d_sum3 = nullptr; float *h_red4 = nullptr; double *h_sum3 = nullptr;
+  bool have_k = false;
+  p3m_step_out last{};
+};
+
+struct XMsg { int src, dst; const void *sptr; void *rptr; size_t bytes; };
+
+// every process builds the SAME global message list (same order); pointers are only needed for local ends
+static int do_exchange(p3m_group *G, const std::vector<XMsg> &msgs) {
+  bool any_remote = false;
+  for (const XMsg &m : msgs) {
+    const bool sl = G->owner[m.src] == G->proc, dl = G->owner[m.dst] == G->proc;
+    if (m.bytes == 0) continue;
+    if (sl && dl && !G->force_nccl) HIP_TRY(hipMemcpyAsync(m.rptr, m.sptr, m.bytes, hipMemcpyDeviceToDevice, G->stream));
+    else if (sl || dl) any_remote = true;
+  }
+  if (!any_remote) return P3M_OK;
+  if (!G->comm) { p3m_set_error("group exchange needs RCCL (p3m_hip_group_comm_init_rccl)"); return P3M_ECOMM; }
+  NCCL_TRY(ncclGroupStart());
+  for (const XMsg &m : msgs) {
+    if (m.bytes == 0) continue;
+    const bool sl = G->owner[m.src] == G->proc, dl = G->owner[m.dst] == G->proc;
+    if (sl && dl && !G->force_nccl) continue;
+    if (sl) NCCL_TRY(ncclSend(m.sptr, m.bytes, ncclChar, G->owner[m.dst], G->comm, G->stream));
+    if (dl) NCCL_TRY(ncclRecv(m.rptr, m.bytes, ncclChar, G->owner[m.src], G->comm, G->stream));
+  }
+  NCCL_TRY(ncclGroupEnd());
+  return P3M_OK;
+}
+
+template <typename T> static int galloc(T **p, size_t n) {
+  *p = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) { p3m_set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e)); return P3M_ENOMEM; }
+  return P3M_OK;
+}
+template <typename T> static void gfree(T *&p) { if (p) (void)hipFree(p); p = nullptr; }
+
+// ================================================================== lifecycle
+extern "C" void p3m_hip_group_destroy(p3m_group *G) {
+  if (!G) return;
+  (void)hipSetDevice(G->device);
+  if (G->stream) (void)hipStreamSynchronize(G->stream);
+  for (CoarseDist &d : G->cd) {
+    gfree(d.blocks_in); gfree(d.rows); gfree(d.ly); gfree(d.send); gfree(d.recv); gfree(d.lz); gfree(d.kern);
+    gfree(d.blocks_out); gfree(d.blocks_back);
+    for (int i = 0; i < 2; i++) { gfree(d.halo_s[i]); gfree(d.halo_r[i]); gfree(d.sb[i]); gfree(d.rb[i]); }
+    gfree(d.d_cnt);
+  }
+  for (p3m_ctx *c : G->ctx) { if (c) { c->stream = nullptr; p3m_hip_destroy(c); } }
+  if (G->comm) (void)ncclCommDestroy(G->comm);
+  gfree(G->d_red4); gfree(G->d_sum3);
+  if (G->h_cnt) (void)hipHostFree(G->h_cnt);
+  if (G->h_red4) (void)hipHostFree(G->h_red4);
+  if (G->h_sum3) (void)hipHostFree(G->h_sum3);
+  fft_plan_destroy(&G->plan_c);
+  if (G->stream) (void)hipStreamDestroy(G->stream);
+  delete G;
+}
+
+extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_t nprocs, p3m_group **out) {
+  if (!base || !out || nprocs < 1 || proc < 0 || proc >= nprocs) return P3M_EINVAL;
+  *out = nullptr;
+  const int nd = base->nodes_dim, nodes = nd * nd * nd;
+  if (nodes % nprocs) { p3m_set_error("nodes_dim^3 = %d logical ranks cannot be split evenly over %d processes", nodes, nprocs); return P3M_EINVAL; }
+  p3m_group *G = new p3m_group();
+  G->base = *base; G->proc = proc; G->nprocs = nprocs; G->nodes = nodes; G->nd = nd;
+  auto fail = [&](int code) { p3m_hip_group_destroy(G); return code; };
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { p3m_set_error("no HIP device (this library has no CPU fallback)"); delete G; return P3M_EDEVICE; }
+  if (base->device >= 0) G->device = base->device; else (void)hipGetDevice(&G->device);
+  if (hipSetDevice(G->device) != hipSuccess) { p3m_set_error("hipSetDevice(%d) failed", G->device); delete G; return P3M_EDEVICE; }
+  if (hipStreamCreateWithFlags(&G->stream, hipStreamNonBlocking) != hipSuccess) { delete G; return P3M_EDEVICE; }
+  const int per = nodes / nprocs;
+  G->owner.resize(nodes); G->lidx.assign(nodes, -1);
+  for (int r = 0; r < nodes; r++) G->owner[r] = r / per;   // contiguous blocks: whole z-layers stay on one GPU where possible
+  for (int r = proc * per; r < (proc + 1) * per; r++) {
+    p3m_params p = *base; p.rank = r; p.device = G->device;
+    p3m_ctx *c = nullptr;
+    int rc = p3m_hip_create(&p, &c);
+    if (rc) return fail(rc);
+    (void)hipStreamDestroy(c->stream); c->stream = G->stream;   // one stream for the whole group
+    G->lidx[r] = (int)G->ctx.size(); G->ctx.push_back(c); G->lrank.push_back(r);
+  }
+  const Geometry &g = G->ctx[0]->g;
+  if (nodes > 1) {
+    G->s = g.nc_slab;
+    int rc = fft_plan_create(&G->plan_c, g.nc);
+    if (rc) return fail(rc);
+    G->nchunk = G->plan_c.px / 16;
+    // ghost buffers: the largest single-axis face shell, sized from the rank's capacity
+    G->cap_buf = (int)std::min<int64_t>(g.max_np, (int64_t)(g.max_np / 2) + 1024);
+    const size_t NB = (size_t)G->s * G->nchunk * g.nc * 16 * 2;          // floats of one component's complex slab
+    const size_t blk = (size_t)G->s * g.ncn * g.ncn;
+    G->cd.resize(G->ctx.size());
+    for (CoarseDist &d : G->cd) {
+#define A(x) do { int _r = (x); if (_r) return fail(_r); } while (0)
+      A(galloc(&d.blocks_in, (size_t)nd * nd * blk)); A(galloc(&d.rows, (size_t)3 * G->s * g.nc * 2 * G->plan_c.px));
+      A(galloc(&d.ly, 3 * NB)); A(galloc(&d.send, 3 * NB)); A(galloc(&d.recv, 3 * NB)); A(galloc(&d.lz, NB)); A(galloc(&d.kern, 3 * NB / 2));
+      A(galloc(&d.blocks_out, (size_t)nd * nd * 3 * blk)); A(galloc(&d.blocks_back, (size_t)nd * nd * 3 * blk));
+      for (int i = 0; i < 2; i++) {
+        A(galloc(&d.halo_s[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2))); A(galloc(&d.halo_r[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2)));
+        A(galloc(&d.sb[i], (size_t)3 * G->cap_buf)); A(galloc(&d.rb[i], (size_t)3 * G->cap_buf));
+      }
+      A(galloc(&d.d_cnt, 8));
+#undef A
+      if (hipMemset(d.rows, 0, sizeof(float) * 3 * G->s * g.nc * 2 * G->plan_c.px) != hipSuccess) return fail(P3M_EDEVICE);
+    }
+  }
+  if (galloc(&G->d_red4, 8) || galloc(&G->d_sum3, 4)) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&G->h_cnt), sizeof(int) * 8 * G->ctx.size()) != hipSuccess) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&G->h_red4), sizeof(float) * 8) != hipSuccess) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&G->h_sum3), sizeof(double) * 4) != hipSuccess) return fail(P3M_ENOMEM);
+  G->last.dt_f_acc = G->last.dt_pp_acc = G->last.dt_pp_ext_acc = G->last.dt_c_acc = 1000.f;
+  *out = G;
+  return P3M_OK;
+}
+
+extern "C" int p3m_hip_rccl_unique_id(void *unique_id_128) {
+  if (!unique_id_128) return P3M_EINVAL;
+  static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the 128-byte buffer of the ABI");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  memset(unique_id_128, 0, 128);
+  memcpy(unique_id_128, &id, sizeof(id));
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_comm_init_rccl(p3m_group *G, const void *unique_id_128, int32_t force_for_local_peers) {
+  if (!G || !unique_id_128) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  ncclUniqueId id; memcpy(&id, unique_id_128, sizeof(id));
+  NCCL_TRY(ncclCommInitRank(&G->comm, G->nprocs, id, G->proc));
+  G->force_nccl = force_for_local_peers != 0;
+  return P3M_OK;
+}
+extern "C" int p3m_hip_comm_init_rccl(p3m_ctx *ctx, const void *unique_id_128) {
+  (void)ctx; (void)unique_id_128;
+  p3m_set_error("multi-rank contexts are driven through p3m_hip_group_* (p3m_hip_group_comm_init_rccl)");
+  return P3M_ECOMM;
+}
+extern "C" int32_t p3m_hip_group_nlocal(const p3m_group *G) { return G ? (int32_t)G->ctx.size() : -1; }
+extern "C" int32_t p3m_hip_group_local_rank(const p3m_group *G, int32_t i) { return (G && i >= 0 && i < (int)G->lrank.size()) ? G->lrank[i] : -1; }
+extern "C" p3m_ctx *p3m_hip_group_ctx(p3m_group *G, int32_t i) { return (G && i >= 0 && i < (int)G->ctx.size()) ? G->ctx[i] : nullptr; }
+
+// ================================================================== ghost pass (particle_pass.f90)
+static int ghost_pass(p3m_group *G) {
+  const int nl = (int)G->ctx.size();
+  if (G->nodes == 1) return particles_pass_self(G->ctx[0]);
+  std::vector<int> n_cur(nl);
+  for (int i = 0; i < nl; i++) n_cur[i] = G->ctx[i]->np_local;
+  for (int axis = 0; axis < 3; axis++) {
+    // 1. pack both directions, fetch the counts
+    for (int i = 0; i < nl; i++) {
+      CoarseDist &d = G->cd[i];
+      HIP_TRY(hipMemsetAsync(d.d_cnt, 0, 8 * sizeof(int), G->stream));
+      P3M_TRY(particles_pass_pack(G->ctx[i], n_cur[i], axis, d.sb[0], d.sb[1], G->cap_buf, d.d_cnt));
+    }
+    // 2. announce counts: +dir buffer goes to the +axis neighbour, which receives it as "from its -axis side"
+    //    nbr[] = {-z,+z,-y,+y,-x,+x}; axis 0 = x
+    std::vector<XMsg> cm;
+    for (int r = 0; r < G->nodes; r++) {
+      const int nd = G->nd, c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
+      int cp[3] = {c1, c2, c3}, cmn[3] = {c1, c2, c3};
+      const int dim = 2 - axis;  // x <-> cart dim 3 (index 2), y <-> 1, z <-> 0
+      cp[dim] = (cp[dim] + 1) % nd; cmn[dim] = (cmn[dim] - 1 + nd) % nd;
+      const int rp = cp[0] * nd * nd + cp[1] * nd + cp[2], rm = cmn[0] * nd * nd + cmn[1] * nd + cmn[2];
+      const int li = G->lidx[r], lp = G->lidx[rp], lm = G->lidx[rm];
+      cm.push_back({r, rp, li >= 0 ? (const void *)(G->cd[li].d_cnt + 0) : nullptr, lp >= 0 ? (void *)(G->cd[lp].d_cnt + 2) : nullptr, sizeof(int)});
+      cm.push_back({r, rm, li >= 0 ? (const void *)(G->cd[li].d_cnt + 1) : nullptr, lm >= 0 ? (void *)(G->cd[lm].d_cnt + 3) : nullptr, sizeof(int)});
+    }
+    P3M_TRY(do_exchange(G, cm));
+    for (int i = 0; i < nl; i++) HIP_TRY(hipMemcpyAsync(G->h_cnt + 4 * i, G->cd[i].d_cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    for (int i = 0; i < nl; i++) {
+      const int *h = G->h_cnt + 4 * i;
+      if (h[0] > G->cap_buf || h[1] > G->cap_buf || h[2] > G->cap_buf || h[3] > G->cap_buf) {
+        p3m_set_error("rank %d: not enough buffer space in pass (%d,%d,%d,%d > %d) (particle_pass.f90:96-99)", G->lrank[i], h[0], h[1], h[2], h[3], G->cap_buf);
+        return P3M_ECAPACITY;
+      }
+      if ((int64_t)n_cur[i] + h[2] + h[3] > G->ctx[i]->cap) {
+        p3m_set_error("rank %d: exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139)", G->lrank[i], (long long)n_cur[i] + h[2] + h[3], (long long)G->ctx[i]->cap);
+        return P3M_ECAPACITY;
+      }
+    }
+    // 3. payloads.  Sizes: the sender knows its own counts, the receiver the announced ones.
+    std::vector<XMsg> pm;
+    for (int r = 0; r < G->nodes; r++) {
+      const int nd = G->nd, c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
+      int cp[3] = {c1, c2, c3}, cmn[3] = {c1, c2, c3};
+      const int dim = 2 - axis;
+      cp[dim] = (cp[dim] + 1) % nd; cmn[dim] = (cmn[dim] - 1 + nd) % nd;
+      const int rp = cp[0] * nd * nd + cp[1] * nd + cp[2], rm = cmn[0] * nd * nd + cmn[1] * nd + cmn[2];
+      const int li = G->lidx[r], lp = G->lidx[rp], lm = G->lidx[rm];
+      // bytes: take whichever end is local (both agree)
+      size_t bp = 0, bm = 0;
+      if (li >= 0) { bp = (size_t)G->h_cnt[4 * li + 0] * 48; bm = (size_t)G->h_cnt[4 * li + 1] * 48; }
+      if (lp >= 0) bp = (size_t)G->h_cnt[4 * lp + 2] * 48;
+      if (lm >= 0) bm = (size_t)G->h_cnt[4 * lm + 3] * 48;
+      pm.push_back({r, rp, li >= 0 ? (const void *)G->cd[li].sb[0] : nullptr, lp >= 0 ? (void *)G->cd[lp].rb[0] : nullptr, bp});
+      pm.push_back({r, rm, li >= 0 ? (const void *)G->cd[li].sb[1] : nullptr, lm >= 0 ? (void *)G->cd[lm].rb[1] : nullptr, bm});
+    }
+    P3M_TRY(do_exchange(G, pm));
+    // 4. append: arrivals from the -axis neighbour's +buffer first (as the reference: +x then -x, :160-168,:252-268)
+    for (int i = 0; i < nl; i++) {
+      const int *h = G->h_cnt + 4 * i;
+      P3M_TRY(particles_pass_unpack(G->ctx[i], G->cd[i].rb[0], h[2], axis, 1, n_cur[i]));
+      P3M_TRY(particles_pass_unpack(G->ctx[i], G->cd[i].rb[1], h[3], axis, 0, n_cur[i] + h[2]));
+      n_cur[i] += h[2] + h[3];
+    }
+  }
+  for (int i = 0; i < nl; i++) G->ctx[i]->np_all = n_cur[i];
+  return P3M_OK;
+}
+
+// ================================================================== coarse mesh, distributed
+__global__ __launch_bounds__(256) void k_blocks_to_rows(const float *__restrict__ blocks, float *__restrict__ rows, int s, int nc, int ncn, int nd, int rp) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)s * nc * rp) return;
+  const int x = (int)(idx % rp), y = (int)((idx / rp) % nc), zl = (int)(idx / ((int64_t)rp * nc));
+  float v = 0.f;
+  if (x < nc) {
+    const int i = x / ncn, j = y / ncn;
+    v = blocks[(((int64_t)(j * nd + i) * s + zl) * ncn + (y - j * ncn)) * ncn + (x - i * ncn)];
+  }
+  rows[idx] = v;
+}
+// recv [comp][t][p][chunk][q][16] -> out [comp][p][chunk][t*s+q][16]   (complex)
+__global__ __launch_bounds__(256) void k_a2a_permute(const float2 *__restrict__ recv, float2 *__restrict__ out, int s, int nchunk, int nc, int ncomp) {
+  const int64_t per = (int64_t)s * nchunk * nc * 16;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= per * ncomp) return;
+  const int comp = (int)(idx / per); const int64_t r = idx - comp * per;
+  const int l = (int)(r % 16), q = (int)((r / 16) % s), chunk = (int)((r / (16 * s)) % nchunk), p = (int)((r / ((int64_t)16 * s * nchunk)) % s);
+  const int t = (int)(r / ((int64_t)16 * s * nchunk * s));
+  out[comp * per + (((int64_t)p * nchunk + chunk) * nc + (t * s + q)) * 16 + l] = recv[idx];
+}
+// rows [comp][zl][y][x] -> blocks_out [(j*nd+i)][comp][zl][yy][xx]
+__global__ __launch_bounds__(256) void k_rows_to_blocks(const float *__restrict__ rows, float *__restrict__ blocks, int s, int nc, int ncn, int nd, int rp) {
+  const int64_t tot = (int64_t)nd * nd * 3 * s * ncn * ncn;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= tot) return;
+  const int xx = (int)(idx % ncn), yy = (int)((idx / ncn) % ncn), zl = (int)((idx / ((int64_t)ncn * ncn)) % s);
+  const int comp = (int)((idx / ((int64_t)ncn * ncn * s)) % 3), ji = (int)(idx / ((int64_t)ncn * ncn * s * 3));
+  const int j = ji / nd, i = ji % nd;
+  blocks[idx] = rows[(((int64_t)comp * s + zl) * nc + (j * ncn + yy)) * rp + (i * ncn + xx)];
+}
+// blocks_back [q][comp][zl][yy][xx] -> force_c[comp][1+q*s+zl][1+yy][1+xx]
+__global__ __launch_bounds__(256) void k_blocks_to_force(const float *__restrict__ blocks, float *__restrict__ fc, int s, int ncn, int nq) {
+  const int64_t tot = (int64_t)nq * 3 * s * ncn * ncn;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= tot) return;
+  const int xx = (int)(idx % ncn), yy = (int)((idx / ncn) % ncn), zl = (int)((idx / ((int64_t)ncn * ncn)) % s);
+  const int comp = (int)((idx / ((int64_t)ncn * ncn * s)) % 3), q = (int)(idx / ((int64_t)ncn * ncn * s * 3));
+  const int m = ncn + 2;
+  fc[(int64_t)comp * m * m * m + ((int64_t)(1 + q * s + zl) * m + (1 + yy)) * m + (1 + xx)] = blocks[idx];
+}
+// coarse_force_buffer.f90: face `pl` of axis (0=x,1=y,2=z), full extent (0..ncn+1) of the other two
+__global__ __launch_bounds__(256) void k_halo_pack(const float *__restrict__ fc, float *__restrict__ buf, int ncn, int axis, int pl) {
+  const int m = ncn + 2; const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)3 * m * m) return;
+  const int a = (int)(idx % m), b = (int)((idx / m) % m), comp = (int)(idx / ((int64_t)m * m));
+  int i, j, k;
+  if (axis == 0) { i = pl; j = a; k = b; } else if (axis == 1) { i = a; j = pl; k = b; } else { i = a; j = b; k = pl; }
+  buf[idx] = fc[(int64_t)comp * m * m * m + ((int64_t)k * m + j) * m + i];
+}
+__global__ __launch_bounds__(256) void k_halo_unpack(float *__restrict__ fc, const float *__restrict__ buf, int ncn, int axis, int pl) {
+  const int m = ncn + 2; const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)3 * m * m) return;
+  const int a = (int)(idx % m), b = (int)((idx / m) % m), comp = (int)(idx / ((int64_t)m * m));
+  int i, j, k;
+  if (axis == 0) { i = pl; j = a; k = b; } else if (axis == 1) { i = a; j = pl; k = b; } else { i = a; j = b; k = pl; }
+  fc[(int64_t)comp * m * m * m + ((int64_t)k * m + j) * m + i] = buf[idx];
+}
+__global__ __launch_bounds__(256) void k_gmax_interior(const float *__restrict__ fc, int n, float *__restrict__ out) {
+  const int m = n + 2; const int64_t cs = (int64_t)m * m * m;
+  float mx = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < (int64_t)n * n * n; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx % n), j = (int)((idx / n) % n), k = (int)(idx / ((int64_t)n * n));
+    const int64_t o = ((int64_t)(k + 1) * m + (j + 1)) * m + (i + 1);
+    const float a = fc[o], b = fc[o + cs], d = fc[o + 2 * cs];
+    mx = fmaxf(mx, sqrtf(a * a + b * b + d * d));                        // coarse_max_dt.f90:24-31
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(mx));
+}
+// real-space coarse kernel on this rank's cube, global coordinates (kernel_initialization.f90:293-336, :366-457)
+__global__ __launch_bounds__(256) void k_ck_cube(float *__restrict__ cube, const float *__restrict__ table, int ncn, int nc, int ox, int oy, int oz, int ms,
+                                                 int comp, int use_table) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)ncn * ncn * ncn) return;
+  const int c3[3] = {(int)(idx % ncn) + ox, (int)((idx / ncn) % ncn) + oy, (int)(idx / ((int64_t)ncn * ncn)) + oz};
+  float xs[3]; int t3[3]; bool in_table = use_table != 0; float sgn = 1.f;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const float w = (c3[d] < nc / 2 + 1) ? (float)c3[d] : (float)(c3[d] - nc);
+    xs[d] = (float)ms * w;
+    if (c3[d] < 4) t3[d] = c3[d];
+    else if (c3[d] > nc - 4) { t3[d] = nc - c3[d]; if (d == comp) sgn = -sgn; }
+    else in_table = false;
+  }
+  float v;
+  if (in_table) v = sgn * table[(((int64_t)t3[2] * 4 + t3[1]) * 4 + t3[0]) * 3 + comp];
+  else { const float rr = sqrtf(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]); v = (rr == 0.0f) ? 0.f : -xs[comp] / (rr * rr * rr); }
+  cube[idx] = v;
+}
+__global__ __launch_bounds__(256) void k_take_imag_g(const float *__restrict__ hat, float *__restrict__ kern, int64_t ncomplex) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < ncomplex) kern[i] = hat[2 * i + 1];
+}
+// LRCKCORR (kernel_initialization.f90:562-591) on the local ky-slab: kern/uncorr in [yl][chunk][z][16]
+__global__ __launch_bounds__(256) void k_lrck_slab(float *__restrict__ kern, const float *__restrict__ uncorr, int n, int s, int nchunk, int ky0, int comp) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)s * nchunk * n * 16) return;
+  const int l = (int)(idx % 16), k = (int)((idx / 16) % n), chunk = (int)((idx / (16 * (int64_t)n)) % nchunk), yl = (int)(idx / (16 * (int64_t)n * nchunk));
+  const int kx = chunk * 16 + l, j = ky0 + yl;
+  if (kx > n / 2) return;
+  const int ky = (j < n / 2 + 1) ? j : j - n, kz = (k < n / 2 + 1) ? k : k - n;
+  const float kr = sqrtf((float)(kx * kx + ky * ky + kz * kz));
+  if (!(kr <= 8.f)) return;
+  const int kk = comp == 0 ? kx : (comp == 1 ? ky : kz);
+  if (kk == 0) return;
+  const float ka = 2 * sinf(P3M_PI_F * kx / (float)n), kb = 2 * sinf(P3M_PI_F * ky / (float)n), kc = 2 * sinf(P3M_PI_F * kz / (float)n);
+  const float kq = comp == 0 ? ka : (comp == 1 ? kb : kc);
+  const float wc = 4.f * P3M_PI_F * kq / (ka * ka + kb * kb + kc * kc) / 16.f;
+  kern[idx] = kern[idx] * (wc / uncorr[idx]);
+}
+
+// forward distributed transform of every rank's cube `cube_of(i)` (ncn^3 floats) into d.lz (rho-hat, own ky slab)
+template <typename F> static int dist_forward(p3m_group *G, F cube_of) {
+  const Geometry &g = G->ctx[0]->g;
+  const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, nchunk = G->nchunk;
+  const size_t blk = (size_t)s * ncn * ncn;
+  // cube -> slab (pack_slab, fftw3ds.f90:24-52): to every slab rank of the own z-layer
+  std::vector<XMsg> m1;
+  for (int r = 0; r < G->nodes; r++) {
+    const int c1 = r / (nd * nd), ji = r % (nd * nd);
+    for (int q = 0; q < nd * nd; q++) {
+      const int t = c1 * nd * nd + q;
+      const int li = G->lidx[r], lt = G->lidx[t];
+      m1.push_back({r, t, li >= 0 ? (const void *)(cube_of(li) + (size_t)q * blk) : nullptr, lt >= 0 ? (void *)(G->cd[lt].blocks_in + (size_t)ji * blk) : nullptr,
+                    blk * sizeof(float)});
+    }
+  }
+  P3M_TRY(do_exchange(G, m1));
+  const size_t NBc = (size_t)s * nchunk * nc * 16;   // complex elements of one component's slab
+  for (int i = 0; i < nl; i++) {
+    p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
+    const int64_t tot = (int64_t)s * nc * rp;
+    hipLaunchKernelGGL(k_blocks_to_rows, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)d.blocks_in, d.rows, s, nc, ncn, nd, rp);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(fft_x_forward_rows(c, G->plan_c, d.rows, d.ly, (int64_t)s * nc));        // ROWS -> LY (local planes)
+    P3M_TRY(fft_slab_y_fwd(c, G->plan_c, d.ly, d.send, s));                           // LY -> send layout [y][chunk][zl][16]
+  }
+  // the one global transpose: block r' (ky in r'*s..) of every rank t goes to r'
+  std::vector<XMsg> m2;
+  const size_t ab = (size_t)s * nchunk * s * 16 * sizeof(float2);
+  for (int t = 0; t < G->nodes; t++) for (int r2 = 0; r2 < G->nodes; r2++) {
+    const int lt = G->lidx[t], lr = G->lidx[r2];
+    m2.push_back({t, r2, lt >= 0 ? (const void *)((const char *)G->cd[lt].send + (size_t)r2 * ab) : nullptr,
+                  lr >= 0 ? (void *)((char *)G->cd[lr].recv + (size_t)t * ab) : nullptr, ab});
+  }
+  P3M_TRY(do_exchange(G, m2));
+  for (int i = 0; i < nl; i++) {
+    p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
+    hipLaunchKernelGGL(k_a2a_permute, dim3(cdiv((int64_t)NBc, 256)), dim3(256), 0, G->stream, reinterpret_cast<const float2 *>(d.recv),
+                       reinterpret_cast<float2 *>(d.lz), s, nchunk, nc, 1);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(fft_slab_z_fwd(c, G->plan_c, d.lz, s));                                   // LZ in place: rho-hat(ky slab, all kz)
+  }
+  return P3M_OK;
+}
+
+static int build_coarse_kernel_dist(p3m_group *G, const float *table4_host) {
+  const Geometry &g = G->ctx[0]->g;
+  const int nl = (int)G->ctx.size(), s = G->s, nc = g.nc, ncn = g.ncn, nchunk = G->nchunk;
+  float *d_table = nullptr; P3M_TRY(galloc(&d_table, 192));
+  HIP_TRY(hipMemcpyAsync(d_table, table4_host, sizeof(float) * 192, hipMemcpyHostToDevice, G->stream));
+  const int64_t NBc = (int64_t)s * nchunk * nc * 16;
+  const bool lr = (G->base.flags & P3M_FLAG_LRCKCORR) != 0;
+  std::vector<float *> unc(nl, nullptr);
+  if (lr) for (int i = 0; i < nl; i++) P3M_TRY(galloc(&unc[i], (size_t)NBc));
+  for (int comp = 0; comp < 3; comp++) {
+    for (int pass = lr ? 0 : 1; pass < 2; pass++) {   // pass 0: uncorrected analytic kernel (LRCKCORR only); pass 1: with the table
+      for (int i = 0; i < nl; i++) {
+        const Geometry &gi = G->ctx[i]->g;
+        hipLaunchKernelGGL(k_ck_cube, dim3(cdiv((int64_t)ncn * ncn * ncn, 256)), dim3(256), 0, G->stream, G->ctx[i]->rho_c, (const float *)d_table, ncn, nc,
+                           gi.cart[2] * ncn, gi.cart[1] * ncn, gi.cart[0] * ncn, g.ms, comp, pass);
+        HIP_TRY(hipGetLastError());
+      }
+      P3M_TRY(dist_forward(G, [&](int li) { return G->ctx[li]->rho_c; }));
+      for (int i = 0; i < nl; i++) {
+        float *dst = pass == 0 ? unc[i] : G->cd[i].kern + (size_t)comp * NBc;
+        hipLaunchKernelGGL(k_take_imag_g, dim3(cdiv(NBc, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].lz, dst, NBc);
+        if (pass == 1 && lr)
+          hipLaunchKernelGGL(k_lrck_slab, dim3(cdiv(NBc, 256)), dim3(256), 0, G->stream, dst, (const float *)unc[i], nc, s, nchunk, G->lrank[i] * s, comp);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  gfree(d_table);
+  for (float *&u : unc) gfree(u);
+  for (p3m_ctx *c : G->ctx) c->have_kc = true;
+  return P3M_OK;
+}
+
+// coarse_force.f90 + coarse_force_buffer.f90 + coarse_max_dt.f90 for all local ranks
+static int coarse_force_dist(p3m_group *G) {
+  const Geometry &g = G->ctx[0]->g;
+  const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, nchunk = G->nchunk;
+  const size_t NBc = (size_t)s * nchunk * nc * 16, blk = (size_t)s * ncn * ncn;
+  P3M_TRY(dist_forward(G, [&](int li) { return G->ctx[li]->rho_c; }));                  // coarse_force.f90:18
+  for (int i = 0; i < nl; i++)                                                           // :37-50 x3, fused multiply
+    P3M_TRY(fft_slab_z_inv3(G->ctx[i], G->plan_c, G->cd[i].lz, G->cd[i].send, G->cd[i].kern, s, (int64_t)NBc, (int64_t)NBc));
+  std::vector<XMsg> m2;                                                                  // transpose back, 3 components
+  const size_t ab = (size_t)s * nchunk * s * 16 * sizeof(float2);
+  for (int comp = 0; comp < 3; comp++)
+    for (int t = 0; t < G->nodes; t++) for (int r2 = 0; r2 < G->nodes; r2++) {
+      const int lt = G->lidx[t], lr = G->lidx[r2];
+      const size_t co = (size_t)comp * NBc * sizeof(float2);
+      m2.push_back({t, r2, lt >= 0 ? (const void *)((const char *)G->cd[lt].send + co + (size_t)r2 * ab) : nullptr,
+                    lr >= 0 ? (void *)((char *)G->cd[lr].recv + co + (size_t)t * ab) : nullptr, ab});
+    }
+  P3M_TRY(do_exchange(G, m2));
+  for (int i = 0; i < nl; i++) {
+    p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
+    hipLaunchKernelGGL(k_a2a_permute, dim3(cdiv((int64_t)3 * NBc, 256)), dim3(256), 0, G->stream, reinterpret_cast<const float2 *>(d.recv),
+                       reinterpret_cast<float2 *>(d.ly), s, nchunk, nc, 3);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(fft_slab_y_inv(c, G->plan_c, d.ly, s, 3));
+    P3M_TRY(fft_x_inverse(c, G->plan_c, d.ly, d.rows, -(3 * s * nc), 0, nullptr, 0, 0, 1, 0));   // incl. /nc^3 (fftw3ds.f90:161)
+    const int64_t tot = (int64_t)nd * nd * 3 * blk;
+    hipLaunchKernelGGL(k_rows_to_blocks, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)d.rows, d.blocks_out, s, nc, ncn, nd, rp);
+    HIP_TRY(hipGetLastError());
+  }
+  // slab -> cube (unpack_slab, fftw3ds.f90:69-99)
+  std::vector<XMsg> m3;
+  for (int t = 0; t < G->nodes; t++) {
+    const int c1 = t / (nd * nd), q = t % (nd * nd);
+    for (int ji = 0; ji < nd * nd; ji++) {
+      const int r = c1 * nd * nd + ji;
+      const int lt = G->lidx[t], lr = G->lidx[r];
+      m3.push_back({t, r, lt >= 0 ? (const void *)(G->cd[lt].blocks_out + (size_t)ji * 3 * blk) : nullptr,
+                    lr >= 0 ? (void *)(G->cd[lr].blocks_back + (size_t)q * 3 * blk) : nullptr, 3 * blk * sizeof(float)});
+    }
+  }
+  P3M_TRY(do_exchange(G, m3));
+  const int m = ncn + 2; const size_t face = (size_t)3 * m * m;
+  for (int i = 0; i < nl; i++) {
+    const int64_t tot = (int64_t)nd * nd * 3 * blk;
+    hipLaunchKernelGGL(k_blocks_to_force, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].blocks_back, G->ctx[i]->force_c, s, ncn, nd * nd);
+    HIP_TRY(hipGetLastError());
+  }
+  // one-cell halo: x, then y (carrying the x halo), then z (coarse_force_buffer.f90:19-63)
+  for (int axis = 0; axis < 3; axis++) {
+    for (int i = 0; i < nl; i++) {
+      hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[0], ncn, axis, 1);    // to -axis
+      hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[1], ncn, axis, ncn);  // to +axis
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<XMsg> hm;
+    for (int r = 0; r < G->nodes; r++) {
+      const int c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
+      int cp[3] = {c1, c2, c3}, cmn[3] = {c1, c2, c3};
+      const int dim = 2 - axis;
+      cp[dim] = (cp[dim] + 1) % nd; cmn[dim] = (cmn[dim] - 1 + nd) % nd;
+      const int rpl = cp[0] * nd * nd + cp[1] * nd + cp[2], rmn = cmn[0] * nd * nd + cmn[1] * nd + cmn[2];
+      const int li = G->lidx[r], lp = G->lidx[rpl], lm = G->lidx[rmn];
+      hm.push_back({r, rmn, li >= 0 ? (const void *)G->cd[li].halo_s[0] : nullptr, lm >= 0 ? (void *)G->cd[lm].halo_r[0] : nullptr, face * sizeof(float)});  // plane 1 -> their ncn+1
+      hm.push_back({r, rpl, li >= 0 ? (const void *)G->cd[li].halo_s[1] : nullptr, lp >= 0 ? (void *)G->cd[lp].halo_r[1] : nullptr, face * sizeof(float)});  // plane ncn -> their 0
+    }
+    P3M_TRY(do_exchange(G, hm));
+    for (int i = 0; i < nl; i++) {
+      hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[0], ncn, axis, ncn + 1);
+      hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[1], ncn, axis, 0);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  for (int i = 0; i < nl; i++) {
+    hipLaunchKernelGGL(k_gmax_interior, dim3(std::min<int64_t>(1024, cdiv((int64_t)ncn * ncn * ncn, 256))), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, ncn,
+                       G->ctx[i]->d_red + 2);
+    HIP_TRY(hipGetLastError());
+  }
+  return P3M_OK;
+}
+
+// ================================================================== public group API
+extern "C" int p3m_hip_group_set_kernel_tables(p3m_group *G, const float *fine_table, const float *coarse_table) {
+  if (!G || !fine_table || !coarse_table) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  if (G->nodes == 1) return p3m_hip_set_kernel_tables(G->ctx[0], fine_table, coarse_table);
+  // kern_f is identical on every rank: build once, copy
+  P3M_TRY(build_fine_kernel(G->ctx[0], fine_table));
+  const Geometry &g = G->ctx[0]->g;
+  for (size_t i = 1; i < G->ctx.size(); i++) {
+    HIP_TRY(hipMemcpyAsync(G->ctx[i]->kern_f, G->ctx[0]->kern_f, sizeof(float) * 3 * g.nf * g.nf * g.px, hipMemcpyDeviceToDevice, G->stream));
+    G->ctx[i]->have_kf = true;
+  }
+  P3M_TRY(build_coarse_kernel_dist(G, coarse_table));
+  G->have_k = true;
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_upload_particles(p3m_group *G, int32_t i, const float *xv6, const int64_t *pid, int32_t np) {
+  if (!G || i < 0 || i >= (int)G->ctx.size()) return P3M_EINVAL;
+  return p3m_hip_upload_particles(G->ctx[i], xv6, pid, np);
+}
+extern "C" int p3m_hip_group_download_particles(p3m_group *G, int32_t i, float *xv6, int64_t *pid, int32_t *np) {
+  if (!G || i < 0 || i >= (int)G->ctx.size()) return P3M_EINVAL;
+  return p3m_hip_download_particles(G->ctx[i], xv6, pid, np);
+}
+
+static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out) {
+  const Geometry &g = G->ctx[0]->g;
+  float v[4] = {0, 0, 0, 0}; double sums[3] = {0, 0, 0}; int ng = 0, ndel = 0;
+  for (p3m_ctx *c : G->ctx) {
+    HIP_TRY(hipMemcpyAsync(c->h_red, c->d_red, 8 * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_sums, c->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, G->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  for (p3m_ctx *c : G->ctx) {
+    v[0] = std::max(v[0], sqrtf(c->h_red[0])); v[1] = std::max(v[1], c->h_red[1]); v[3] = std::max(v[3], c->h_red[2]);
+    if (c->p.flags & P3M_FLAG_PP_EXT) {   // per-thread "last tile" overwrite, particle_mesh_threaded.f90:617
+      const int cores = std::max(1, c->p.cores), nt = std::min(cores, g.ntiles), base = g.ntiles / nt, rem = g.ntiles % nt;
+      int pos = 0;
+      for (int t = 0; t < nt; t++) { pos += base + (t < rem ? 1 : 0); v[2] = std::max(v[2], c->h_tile_ext[pos - 1]); }
+    }
+    sums[0] += c->h_sums[0]; sums[1] += c->h_sums[1]; sums[2] += (double)c->np_local; ng += c->np_ghost; ndel += c->np_deleted;
+  }
+  if (G->nprocs > 1) {   // mpi_reduce + mpi_bcast pairs (:646-696, coarse_max_dt.f90:34-37) as two all-reduces
+    memcpy(G->h_red4, v, sizeof(v)); memcpy(G->h_sum3, sums, sizeof(sums));
+    HIP_TRY(hipMemcpyAsync(G->d_red4, G->h_red4, 4 * sizeof(float), hipMemcpyHostToDevice, G->stream));
+    HIP_TRY(hipMemcpyAsync(G->d_sum3, G->h_sum3, 3 * sizeof(double), hipMemcpyHostToDevice, G->stream));
+    NCCL_TRY(ncclAllReduce(G->d_red4, G->d_red4, 4, ncclFloat, ncclMax, G->comm, G->stream));
+    NCCL_TRY(ncclAllReduce(G->d_sum3, G->d_sum3, 3, ncclDouble, ncclSum, G->comm, G->stream));
+    HIP_TRY(hipMemcpyAsync(G->h_red4, G->d_red4, 4 * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipMemcpyAsync(G->h_sum3, G->d_sum3, 3 * sizeof(double), hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    memcpy(v, G->h_red4, sizeof(v)); memcpy(sums, G->h_sum3, sizeof(sums));
+  }
+  p3m_step_out o; memset(&o, 0, sizeof(o));
+  const uint32_t fl = G->base.flags;
+  o.f_force_max = v[0]; o.pp_force_max = v[1]; o.pp_ext_force_max = v[2]; o.c_force_max = v[3];
+  o.dt_f_acc = 1.0f / sqrtf(fmaxf(0.0001f, v[0]) * a_mid * P3M_G_F);
+  o.dt_pp_acc = (fl & P3M_FLAG_PPINT) ? sqrtf(G->base.dt_pp_scale * G->base.rsoft) / fmaxf(sqrtf(v[1] * a_mid * P3M_G_F), 1e-3f) : G->last.dt_pp_acc;
+  o.dt_pp_ext_acc = (fl & P3M_FLAG_PP_EXT) ? sqrtf(G->base.dt_pp_scale * G->base.rsoft) / fmaxf(sqrtf(v[2] * a_mid * P3M_G_F), 1e-3f) : G->last.dt_pp_ext_acc;
+  o.dt_c_acc = sqrtf((float)g.ms / (v[3] * a_mid * P3M_G_F));
+  o.sum_rho_f = sums[0]; o.sum_rho_c = sums[1]; o.np_total = (int64_t)llround(sums[2]);
+  o.np_local = G->ctx[0]->np_local; o.np_ghost = ng; o.np_deleted = ndel;
+  G->last = o; *out = o;
+  return P3M_OK;
+}
+
+// subroutine particle_mesh on every local rank (particle_mesh_threaded.f90:2-726)
+extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, float dt_old, float mass_p, const float *offset,
+                                           const float *move_back, p3m_step_out *out) {
+  if (!G) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  if (G->nodes == 1) return p3m_hip_particle_mesh(G->ctx[0], a_mid, dt, dt_old, mass_p, offset, move_back, out);
+  for (p3m_ctx *c : G->ctx) if (!c->have_kf || !c->have_kc) { p3m_set_error("particle_mesh before the Green's functions were set"); return P3M_ESTATE; }
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
+  P3M_TRY(ghost_pass(G));                                                                           // :61-63
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort(c));
+  for (p3m_ctx *c : G->ctx) P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));                       // :72-628
+  for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                     // coarse_mass
+  P3M_TRY(coarse_force_dist(G));                                                                    // coarse_force, _buffer, max
+  for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt));                                     // coarse_velocity
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));  // :716-720
+  p3m_step_out o;
+  P3M_TRY(reduce_step_out(G, a_mid, &o));
+  if (out) *out = o;
+  return P3M_OK;
+}
+
+// probes for the parity tests: local coarse density / force of local rank i in the reference layout
+extern "C" int p3m_hip_group_probe_coarse(p3m_group *G, float mass_p, int32_t i, float *rho_c, float *force_c) {
+  if (!G || i < 0 || i >= (int)G->ctx.size()) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  const Geometry &g = G->ctx[0]->g;
+  if (G->nodes == 1) return p3m_hip_probe_coarse(G->ctx[0], mass_p, rho_c, force_c);
+  for (p3m_ctx *c : G->ctx) { HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * sizeof(double), G->stream)); HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * sizeof(float), G->stream)); P3M_TRY(coarse_deposit(c, mass_p)); }
+  if (rho_c) HIP_TRY(hipMemcpyAsync(rho_c, G->ctx[i]->rho_c, sizeof(float) * (size_t)g.ncn * g.ncn * g.ncn, hipMemcpyDeviceToHost, G->stream));
+  if (force_c) {
+    P3M_TRY(coarse_force_dist(G));
+    const size_t fcs = (size_t)(g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2);
+    std::vector<float> tmp(3 * fcs);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), G->ctx[i]->force_c, sizeof(float) * 3 * fcs, hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    for (int comp = 0; comp < 3; comp++) for (size_t k = 0; k < fcs; k++) force_c[k * 3 + comp] = tmp[comp * fcs + k];
+  }
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  return P3M_OK;
+}

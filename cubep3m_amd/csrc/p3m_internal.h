@@ -116,6 +116,10 @@ int fft_lz_to_rows(p3m_ctx *c, const FftPlan &pl, const float *lz, float *rows);
 // ---- particles.hip
 int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset);
 int particles_pass_and_sort(p3m_ctx *c);
+int particles_pass_self(p3m_ctx *c);
+int particles_sort(p3m_ctx *c);
+int particles_pass_pack(p3m_ctx *c, int n_cur, int axis, float4 *sbuf_plus, float4 *sbuf_minus, int cap_buf, int *d_counts);
+int particles_pass_unpack(p3m_ctx *c, const float4 *rbuf, int nrecv, int axis, int from_plus_dir, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);
 
 // ---- fine_mesh.hip

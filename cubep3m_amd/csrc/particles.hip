@@ -147,31 +147,35 @@ __global__ __launch_bounds__(PT) void k_scatter(const float4 *__restrict__ pos, 
   }
 }
 
-int particles_pass_and_sort(p3m_ctx *c) {
+// single rank: all ghost images in one kernel; leaves c->np_all = records incl. ghosts (unsorted)
+int particles_pass_self(p3m_ctx *c) {
   const Geometry &g = c->g;
-  int *cnt = c->d_counters;  // [0..2] per-axis image counts, [3] overflow, [4] deleted
+  int *cnt = c->d_counters;  // [0] image count, [3] overflow, [4] deleted, [5] candidates
   HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
   int n_cur = c->np_local;
-  if (g.nodes == 1) {
-    if (n_cur > 0) {
-      hipLaunchKernelGGL(k_make_images, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
-                         (float)g.nb, cnt, cnt + 3);
-      HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->h_counters[3] || (int64_t)n_cur + c->h_counters[0] > c->cap) {
-      p3m_set_error("exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139); raise density_buffer",
-                    (long long)n_cur + c->h_counters[0], (long long)c->cap);
-      return P3M_ECAPACITY;
-    }
-    n_cur += c->h_counters[0];
-  } else {
-    p3m_set_error("multi-rank pass requires a transport (not initialised)");
-    return P3M_ECOMM;
+  if (n_cur > 0) {
+    hipLaunchKernelGGL(k_make_images, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
+                       (float)g.nb, cnt, cnt + 3);
+    HIP_TRY(hipGetLastError());
   }
-  c->np_all = n_cur;
+  HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->h_counters[3] || (int64_t)n_cur + c->h_counters[0] > c->cap) {
+    p3m_set_error("exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139); raise density_buffer",
+                  (long long)n_cur + c->h_counters[0], (long long)c->cap);
+    return P3M_ECAPACITY;
+  }
+  c->np_all = n_cur + c->h_counters[0];
+  return P3M_OK;
+}
+
+// counting sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell
+int particles_sort(p3m_ctx *c) {
+  const Geometry &g = c->g;
+  int *cnt = c->d_counters;
+  const int n_cur = c->np_all;
   c->np_ghost = n_cur - c->np_local;
+  HIP_TRY(hipMemsetAsync(cnt + 4, 0, 2 * sizeof(int), c->stream));
   const int64_t ncell = (int64_t)g.E * g.E * g.E;
   HIP_TRY(hipMemsetAsync(c->cell_end - 3, 0, (size_t)(ncell + 8) * sizeof(int), c->stream));
   const bool want_cflag = (c->p.flags & P3M_FLAG_PPINT) != 0;
@@ -190,8 +194,62 @@ int particles_pass_and_sort(p3m_ctx *c) {
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->np_deleted = c->h_counters[4];
-  c->ncand = std::min<int64_t>(c->h_counters[5], c->cap);
+  c->ncand = (int)std::min<int64_t>(c->h_counters[5], c->cap);
   c->np_all = n_cur - c->np_deleted;  // sorted records
+  return P3M_OK;
+}
+
+int particles_pass_and_sort(p3m_ctx *c) {
+  if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }
+  P3M_TRY(particles_pass_self(c));
+  return particles_sort(c);
+}
+
+// ------------------------------------------------------------------ multi-rank ghost pass: pack / unpack one axis
+// Records travel as 48-byte AoS {x,y,z,w, vx,vy,vz,w, pid(8 B), pad(8 B)}.
+// dir_plus: records with x_a >= Nn-nb go to the +a neighbour (particle_pass.f90:83), dir_minus: x_a < nb to the
+// -a neighbour (:185).  Only records that existed before this axis (i < n_cur) are offered.
+__global__ __launch_bounds__(PT) void k_pass_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
+                                                  int n_cur, int axis, float Nn, float nb, float4 *__restrict__ sbuf_plus,
+                                                  float4 *__restrict__ sbuf_minus, int cap_buf, int *__restrict__ counts) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n_cur) return;
+  const float4 p = pos[i];
+  if (!in_hoc_range(p, -nb, Nn + nb)) return;
+  const float x = comp(p, axis);
+  const bool hi = x >= Nn - nb, lo = x < nb;
+  if (!(hi || lo)) return;
+  const float4 v = vel[i]; const int64_t id = pid[i];
+  float4 idv; idv.x = __int_as_float((int)(id & 0xffffffffLL)); idv.y = __int_as_float((int)(id >> 32)); idv.z = 0.f; idv.w = 0.f;
+  if (hi) { const int s = atomicAdd(&counts[0], 1); if (s < cap_buf) { sbuf_plus[3 * s] = p; sbuf_plus[3 * s + 1] = v; sbuf_plus[3 * s + 2] = idv; } }
+  if (lo) { const int s = atomicAdd(&counts[1], 1); if (s < cap_buf) { sbuf_minus[3 * s] = p; sbuf_minus[3 * s + 1] = v; sbuf_minus[3 * s + 2] = idv; } }
+}
+// from_plus_dir: the buffer was sent towards +a by the -a neighbour: x_a <- max(x_a - Nn, -nb) (:162);
+// otherwise it came from the +a neighbour: eps guard, x_a <- min(x_a + Nn, Nn+nb-eps) (:257-265).
+__global__ __launch_bounds__(PT) void k_pass_unpack(const float4 *__restrict__ rbuf, int nrecv, int axis, int from_plus_dir, float Nn, float nb,
+                                                    float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid, int base) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= nrecv) return;
+  float4 p = rbuf[3 * i]; const float4 v = rbuf[3 * i + 1], idv = rbuf[3 * i + 2];
+  float x = comp(p, axis);
+  if (from_plus_dir) x = fmaxf(x - Nn, -nb);
+  else { if (fabsf(x) < P3M_EPS_F) x = (x < 0.0f) ? -P3M_EPS_F : P3M_EPS_F; x = fminf(x + Nn, Nn + nb - P3M_EPS_F); }
+  setcomp(p, axis, x);
+  pos[base + i] = p; vel[base + i] = v;
+  pid[base + i] = (int64_t)(unsigned int)__float_as_int(idv.x) | ((int64_t)__float_as_int(idv.y) << 32);
+}
+int particles_pass_pack(p3m_ctx *c, int n_cur, int axis, float4 *sp, float4 *sm, int cap_buf, int *d_counts) {
+  if (n_cur == 0) return P3M_OK;
+  hipLaunchKernelGGL(k_pass_pack, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
+                     n_cur, axis, (float)c->g.Nn, (float)c->g.nb, sp, sm, cap_buf, d_counts);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+int particles_pass_unpack(p3m_ctx *c, const float4 *rbuf, int nrecv, int axis, int from_plus_dir, int base) {
+  if (nrecv == 0) return P3M_OK;
+  hipLaunchKernelGGL(k_pass_unpack, dim3(cdiv(nrecv, PT)), dim3(PT), 0, c->stream, rbuf, nrecv, axis, from_plus_dir, (float)c->g.Nn, (float)c->g.nb,
+                     c->pos, c->vel, c->pid, base);
+  HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
 

@@ -1,0 +1,118 @@
+"""Multi-rank host: the reference's nodes_dim^3 MPI ranks as a group of logical ranks spread over the
+GPUs of one node (include/p3m_hip.h, p3m_hip_group_*).  One process drives one GPU.
+
+    g = ParticleMeshGroup(Params(nodes_dim=2, ...), proc=rank, nprocs=world, unique_id=uid)
+    g.scatter_global(xv_global, pid)      # rank r gets the particles of its cube, in local coordinates
+    out = g.particle_mesh(a_mid, dt, dt_old, mass_p)
+
+Rank numbering and coordinates follow mpi_initialization.f90:42-76: rank = c1*nd^2 + c2*nd + c3 with
+x <-> c3, y <-> c2, z <-> c1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .kernels import default_tables
+from .params import P3MStepOut, Params
+
+
+def rccl_unique_id() -> bytes:
+    """128-byte ncclUniqueId; call on process 0 and broadcast (torch.distributed / MPI_Bcast)."""
+    buf = (C.c_ubyte * 128)()
+    _lib.check(_lib.load().p3m_hip_rccl_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
+
+
+def rank_coords(rank, nd):
+    return rank // (nd * nd), (rank // nd) % nd, rank % nd  # c1 (z), c2 (y), c3 (x)
+
+
+class ParticleMeshGroup:
+    def __init__(self, params: Params, proc=0, nprocs=1, fine_table=None, coarse_table=None, unique_id=None,
+                 force_rccl=False, set_kernels=True):
+        self.params = params
+        self.L = _lib.load()
+        self._cp = params.to_c()
+        h = C.c_void_p()
+        _lib.check(self.L.p3m_hip_group_create(C.byref(self._cp), proc, nprocs, C.byref(h)))
+        self.h = h
+        self.proc, self.nprocs = proc, nprocs
+        if unique_id is not None:
+            buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id)[:128].ljust(128, b"\0"))
+            _lib.check(self.L.p3m_hip_group_comm_init_rccl(self.h, C.cast(buf, C.c_void_p), 1 if force_rccl else 0))
+        self.nlocal = self.L.p3m_hip_group_nlocal(self.h)
+        self.local_ranks = [self.L.p3m_hip_group_local_rank(self.h, i) for i in range(self.nlocal)]
+        if set_kernels:
+            if fine_table is None or coarse_table is None:
+                fine_table, coarse_table = default_tables()
+            _lib.check(self.L.p3m_hip_group_set_kernel_tables(self.h, np.ascontiguousarray(fine_table, np.float32),
+                                                              np.ascontiguousarray(coarse_table, np.float32)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.p3m_hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- particles -------------------------------------------------------------------------
+    def upload_particles(self, i, xv, pid=None):
+        xv = np.ascontiguousarray(xv, np.float32).reshape(-1, 6)
+        pp = None
+        if pid is not None:
+            pid = np.ascontiguousarray(pid, np.int64)
+            pp = pid.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L.p3m_hip_group_upload_particles(self.h, i, xv.ctypes.data_as(C.c_void_p), pp, len(xv)))
+
+    def download_particles(self, i):
+        n = C.c_int32()
+        _lib.check(self.L.p3m_hip_group_download_particles(self.h, i, None, None, C.byref(n)))
+        xv = np.empty((n.value, 6), np.float32)
+        pid = np.empty(n.value, np.int64)
+        _lib.check(self.L.p3m_hip_group_download_particles(self.h, i, xv.ctypes.data_as(C.c_void_p), pid.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return xv, pid
+
+    def split_global(self, xv, pid):
+        """Particles of the global box -> {logical rank: (xv_local, pid)} for the ranks this process owns."""
+        nd, Nn = self.params.nodes_dim, self.params.nf_physical_node_dim
+        out = {}
+        cell = np.floor(xv[:, :3] / np.float32(Nn)).astype(np.int64)
+        owner = cell[:, 2] * nd * nd + cell[:, 1] * nd + cell[:, 0]
+        for r in self.local_ranks:
+            m = owner == r
+            c1, c2, c3 = rank_coords(r, nd)
+            loc = xv[m].copy()
+            loc[:, :3] -= np.array([c3, c2, c1], np.float32) * np.float32(Nn)
+            out[r] = (loc, pid[m])
+        return out
+
+    def scatter_global(self, xv, pid):
+        parts = self.split_global(xv, pid)
+        for i, r in enumerate(self.local_ranks):
+            self.upload_particles(i, *parts[r])
+        return parts
+
+    # -- subroutine particle_mesh on every rank ----------------------------------------------
+    def particle_mesh(self, a_mid, dt, dt_old, mass_p, offset=None, move_back=None) -> P3MStepOut:
+        o = P3MStepOut()
+        po = None if offset is None else np.ascontiguousarray(offset, np.float32)
+        pm = None if move_back is None else np.ascontiguousarray(move_back, np.float32)
+        _lib.check(self.L.p3m_hip_group_particle_mesh(self.h, a_mid, dt, dt_old, mass_p,
+                                                      None if po is None else po.ctypes.data_as(C.c_void_p),
+                                                      None if pm is None else pm.ctypes.data_as(C.c_void_p), C.byref(o)))
+        return o
+
+    def coarse(self, mass_p, i, want_force=True):
+        p = self.params
+        rho = np.empty((p.nc_node_dim,) * 3, np.float32)
+        f = np.empty((p.nc_node_dim + 2,) * 3 + (3,), np.float32) if want_force else None
+        _lib.check(self.L.p3m_hip_group_probe_coarse(self.h, mass_p, i, rho.ctypes.data_as(C.c_void_p),
+                                                     f.ctypes.data_as(C.c_void_p) if want_force else None))
+        return rho, f

@@ -134,7 +134,7 @@ int p3m_hip_set_transport(p3m_ctx *ctx, const p3m_transport *t);
 /* RCCL over xGMI: unique_id is the 128-byte ncclUniqueId the host broadcast from rank 0
    (p3m_hip_rccl_unique_id fills it on rank 0). */
 int p3m_hip_rccl_unique_id(void *unique_id_128);
-int p3m_hip_comm_init_rccl(p3m_ctx *ctx, const void *unique_id_128);
+int p3m_hip_comm_init_rccl(p3m_ctx *ctx, const void *unique_id_128); /* always P3M_ECOMM: use p3m_hip_group_comm_init_rccl */
 
 /* -- Green's functions (kernel_initialization.f90) -------------------------------------- */
 /* fine_table: the 16^3 rows of kernels/wfxyzf.3.ascii as float[16][16][16][3] with the file's
@@ -193,6 +193,29 @@ int p3m_hip_time_fine_sweep(p3m_ctx *ctx, float mass_p, int32_t reps, float *ms_
 int p3m_hip_time_fft_pass(p3m_ctx *ctx, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch);
 /* HIP stream the kernels are launched on (for hipEvent timing by the host). */
 void *p3m_hip_stream(p3m_ctx *ctx);
+
+/* -- multi-rank: a group of logical ranks (the reference's nodes_dim^3 MPI ranks) ---------
+ * One process drives one GPU and owns nodes_dim^3 / nprocs consecutive logical ranks; ranks on the
+ * same GPU exchange by device copies, ranks on different GPUs by RCCL send/recv over xGMI
+ * (replaces the MPI calls of particle_pass.f90, fftw3ds.f90, coarse_force_buffer.f90 and the
+ * mpi_reduce/mpi_bcast pairs of particle_mesh_threaded.f90:646-696, coarse_max_dt.f90:34-37).
+ * params->rank is ignored (set per logical rank), params->device selects the GPU. */
+typedef struct p3m_group p3m_group;
+int p3m_hip_group_create(const p3m_params *params, int32_t proc, int32_t nprocs, p3m_group **out);
+void p3m_hip_group_destroy(p3m_group *g);
+/* nprocs > 1: every process calls this with the id rank 0 obtained from p3m_hip_rccl_unique_id and the
+   host broadcast.  force_for_local_peers != 0 routes even same-GPU exchanges through RCCL (test mode). */
+int p3m_hip_group_comm_init_rccl(p3m_group *g, const void *unique_id_128, int32_t force_for_local_peers);
+int32_t p3m_hip_group_nlocal(const p3m_group *g);                 /* logical ranks owned by this process */
+int32_t p3m_hip_group_local_rank(const p3m_group *g, int32_t i);  /* logical rank id of the i-th local one */
+p3m_ctx *p3m_hip_group_ctx(p3m_group *g, int32_t i);              /* its context (probes, derived sizes) */
+int p3m_hip_group_set_kernel_tables(p3m_group *g, const float *fine_table, const float *coarse_table);
+int p3m_hip_group_upload_particles(p3m_group *g, int32_t i, const float *xv6, const int64_t *pid, int32_t np_local);
+int p3m_hip_group_download_particles(p3m_group *g, int32_t i, float *xv6, int64_t *pid, int32_t *np_local);
+/* `particle_mesh` on all ranks; `out` holds the global dt limits and DIAG sums (identical on every process) */
+int p3m_hip_group_particle_mesh(p3m_group *g, float a_mid, float dt, float dt_old, float mass_p,
+                                const float *offset, const float *move_back, p3m_step_out *out);
+int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho_c, float *force_c);
 
 /* -- F77-ABI one-call wrapper in the style of pp_force_c_ (nbody-ueli.cu:368) ------------ */
 /* Single-rank hosts: uploads xv/PID, runs the step, downloads, returns the four dt limits.

@@ -1,0 +1,90 @@
+"""GPU parity of the multi-rank path: 2x2x2 logical ranks on ONE GPU (device-to-device exchanges, and
+again with every exchange forced through RCCL send/recv to self) against the oracle's 8 simulated ranks."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from common import COARSE_TABLE, FINE_TABLE, by_pid, cfg1, clustered_particles, rel_rms, uniform_particles
+
+pytestmark = pytest.mark.gpu
+
+
+def global_ic(kind, n, box, seed):
+    xv = uniform_particles(n, box, seed=seed) if kind == "uniform" else clustered_particles(n, box, seed=seed, frac=0.3, nblobs=40, sigma=0.7, vel_sigma=0.5)
+    pid = np.arange(1, n + 1, dtype=np.int64) * 3 + 1
+    return xv, pid
+
+
+def run_both(p, xv, pid, scal, force_rccl=False, steps=1):
+    from cubep3m_amd.group import ParticleMeshGroup, rccl_unique_id
+
+    uid = rccl_unique_id() if force_rccl else None
+    g = ParticleMeshGroup(p, 0, 1, FINE_TABLE, COARSE_TABLE, unique_id=uid, force_rccl=force_rccl)
+    assert g.nlocal == p.nodes and g.local_ranks == list(range(p.nodes))
+    parts = g.scatter_global(xv, pid)
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    for r in range(p.nodes):
+        o.set_particles(r, *parts[r])
+    a_mid, dt, dt_old, mass_p = scal
+    for s in range(steps):
+        og = g.particle_mesh(a_mid, dt, dt_old if s == 0 else dt, mass_p)
+        oo = o.particle_mesh(a_mid, dt, dt_old if s == 0 else dt, mass_p)
+    return g, o, og, oo
+
+
+@pytest.mark.parametrize("kind,kw,force_rccl", [
+    ("uniform", dict(ngp=True), False),
+    ("clustered", dict(ngp=True, ppint=True, pp_ext=True), False),
+    ("clustered", dict(ngp=True, ppint=True, pp_ext=True, lrckcorr=True), False),
+    ("uniform", dict(ngp=False), True),
+    ("clustered", dict(ngp=True, ppint=True, pp_ext=True), True),
+])
+def test_eight_logical_ranks_match_oracle(kind, kw, force_rccl):
+    p = cfg1(nodes_dim=2, **kw)
+    box = float(p.nf_physical_dim)  # 128
+    xv, pid = global_ic(kind, 60000, box, 99)
+    # v != 0 and dt_old != 0: particles cross rank boundaries in the drift
+    g, o, og, oo = run_both(p, xv, pid, (0.01, 0.3, 0.3, 8.0), force_rccl=force_rccl)
+    assert og.np_total == oo.np_total == len(xv)
+    assert og.np_ghost == oo.np_ghost and og.np_deleted == oo.np_deleted
+    for name in ("dt_f_acc", "dt_c_acc") + (("dt_pp_acc", "dt_pp_ext_acc") if kw.get("pp_ext") else ()):
+        assert getattr(og, name) == pytest.approx(getattr(oo, name), rel=1e-5), name
+    assert og.sum_rho_f == pytest.approx(oo.sum_rho_f, rel=1e-6) and og.sum_rho_c == pytest.approx(oo.sum_rho_c, rel=1e-6)
+    v0 = dict(zip(pid.tolist(), xv[:, 3:]))
+    num = den = 0.0
+    for i, r in enumerate(g.local_ranks):
+        xg, pg = by_pid(*g.download_particles(i))
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
+        assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 1e-4
+        vin = np.stack([v0[q] for q in pg.tolist()])
+        dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
+        num += ((dg - do) ** 2).sum()
+        den += (do ** 2).sum()
+    assert np.sqrt(num / den) <= 1e-5, np.sqrt(num / den)
+
+
+def test_distributed_coarse_mesh_vs_oracle():
+    """Slab FFT with the all-to-all transpose, cube<->slab redistribution and the force halo, rank by rank."""
+    from cubep3m_amd.group import ParticleMeshGroup
+
+    p = cfg1(nodes_dim=2, lrckcorr=True)
+    xv, pid = global_ic("clustered", 40000, float(p.nf_physical_dim), 5)
+    g = ParticleMeshGroup(p, 0, 1, FINE_TABLE, COARSE_TABLE)
+    parts = g.scatter_global(xv, pid)
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    for r in range(8):
+        o.set_particles(r, *parts[r])
+    # dt = dt_old = 0: no drift; the step leaves the cell-sorted records (with ghosts) on the device for the probe
+    g.particle_mesh(0.01, 0.0, 0.0, 8.0)
+    o.link_list()
+    assert o.particle_pass() == 0
+    o.coarse_density(8.0)
+    o.coarse_force()
+    for i in range(8):
+        rg, fg = g.coarse(8.0, i)
+        ro, fo = o.rho_c(i), o.force_c(i)
+        assert np.abs(rg - ro).max() <= 4e-6 * np.abs(ro).max(), i
+        assert rel_rms(fg, fo) < 3e-6, i      # interior and the one-cell halo from the neighbours
