@@ -1,14 +1,19 @@
 #!/usr/bin/env python
 """Benchmark of the P3M gravity step (`particle_mesh`) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg1|big512] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg2|cfg3|...] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
 
-A "step" is one full `particle_mesh` call (drift -> ghost pass + cell sort -> per-tile fine PM
-[+PP] -> coarse PM -> ghost removal) on synthetic uniform particles that are resident in HBM when
-the timed region starts.  Prints ONE JSON line (see the task contract): metric particle-updates/s,
-plus `roofline` for the dominant kernel (the strided FFT line pass) measured live with HIP events on
-the library's stream, and `cpu_baseline` (the CPU oracle, a port of the reference path, timed on the
-same workload on this box's host cores).
+A "step" is one full `particle_mesh` call (drift -> ghost pass + cell sort -> per-tile fine PM [+PP]
+-> coarse PM with the slab FFT -> ghost removal) on synthetic uniform particles that are resident in
+HBM when the timed region starts.  Default workload = BASELINE.json configs[3]: 1024^3 fine mesh /
+512^3 particles in the reference's 2x2x2 cubic decomposition (8 logical ranks); with N GPUs each
+process drives one GPU and owns 8/N logical ranks (strong scaling; exchanges between ranks on one GPU
+are device copies, between GPUs RCCL send/recv over xGMI).
+Prints ONE JSON line: metric particle-updates/s (whole job), `roofline` for the dominant kernel (an FFT
+line pass) measured live with HIP events on the library's stream, and, at N=1, `cpu_baseline` (the CPU
+oracle -- a C port of the reference path -- timed on a bounded sample on this box's host cores).
 """
 from __future__ import annotations
 
@@ -29,20 +34,27 @@ from cubep3m_amd.params import Params  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 CONFIGS = {
-    # BASELINE.json configs[0]: 64^3 fine / 32^3 particles, PM-only
-    "cfg1": dict(params=dict(tiles_node_dim=2, nf_tile=80, ngp=True), nside=32,
+    # BASELINE.json configs[3]: 1024^3 fine / 512^3 particles, 2x2x2 ranks, one 560^3 tile per rank, 256^3 coarse slab FFT
+    "cfg4": dict(params=dict(nodes_dim=2, tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3), nside_rank=256,
+                 workload="1024^3 fine mesh / 512^3 particles, PM-only (NGP), 2x2x2 logical ranks, nf_tile=560 (one tile per rank), "
+                          "256^3 coarse mesh with slab FFT + all-to-all transpose"),
+    # configs[0]: 64^3 fine / 32^3 particles, PM-only
+    "cfg1": dict(params=dict(tiles_node_dim=2, nf_tile=80, ngp=True), nside_rank=32,
                  workload="64^3 fine mesh / 32^3 particles, PM-only (NGP), nf_tile=80, 2^3 tiles"),
     # configs[1]: 256^3 / 128^3, PM-only
-    "cfg2": dict(params=dict(tiles_node_dim=2, nf_tile=176, ngp=True, density_buffer=1.5), nside=128,
+    "cfg2": dict(params=dict(tiles_node_dim=2, nf_tile=176, ngp=True, density_buffer=1.5), nside_rank=128,
                  workload="256^3 fine mesh / 128^3 particles, PM-only (NGP), nf_tile=176, 2^3 tiles, 64^3 coarse"),
-    "cfg2_t4": dict(params=dict(tiles_node_dim=4, nf_tile=112, ngp=True, density_buffer=1.5), nside=128,
+    "cfg2_t4": dict(params=dict(tiles_node_dim=4, nf_tile=112, ngp=True, density_buffer=1.5), nside_rank=128,
                     workload="256^3 fine mesh / 128^3 particles, PM-only (NGP), nf_tile=112, 4^3 tiles, 64^3 coarse"),
     # configs[2]: 256^3 / 128^3, PM+PP+extended PP
-    "cfg3": dict(params=dict(tiles_node_dim=2, nf_tile=176, ngp=True, ppint=True, pp_ext=True, density_buffer=1.5), nside=128,
+    "cfg3": dict(params=dict(tiles_node_dim=2, nf_tile=176, ngp=True, ppint=True, pp_ext=True, density_buffer=1.5), nside_rank=128,
                  workload="256^3 fine mesh / 128^3 particles, PM+PP+PP_EXT, nf_tile=176, 2^3 tiles"),
-    # one GPU's share of configs[3] (1024^3 fine / 512^3 particles on 8 GPUs): 512^3 fine, 256^3 particles
-    "big512": dict(params=dict(tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3), nside=256,
-                   workload="512^3 fine mesh / 256^3 particles (one GPU's share of 1024^3/512^3), PM-only, nf_tile=560, 1 tile"),
+    # one rank's share of configs[3] on its own
+    "big512": dict(params=dict(tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3), nside_rank=256,
+                   workload="512^3 fine mesh / 256^3 particles (one rank's share of 1024^3/512^3), PM-only, nf_tile=560, 1 tile"),
+    # small multi-rank problem for quick checks
+    "cfg4_small": dict(params=dict(nodes_dim=2, tiles_node_dim=1, nf_tile=112, ngp=True, density_buffer=1.5), nside_rank=32,
+                       workload="128^3 fine mesh / 64^3 particles, PM-only, 2x2x2 logical ranks, nf_tile=112"),
 }
 
 
@@ -56,16 +68,19 @@ def make_particles(nside, box, seed=12345):
     return xv
 
 
-def cpu_baseline(p: Params, xv, scal, budget_s=30.0):
-    """Times the CPU oracle (tests/oracle_lib.py; a C port of the reference path, OpenMP over tiles like the
-    reference's `!$omp do`) on the same workload.  Checker-side code, used here only as the reported baseline."""
+def cpu_baseline(scal):
+    """The CPU oracle (tests/oracle_lib.py: a C port of the reference path, OpenMP like the reference's `!$omp do`)
+    on a bounded sample: a 256^3-cell sub-volume (BASELINE configs[1]: 128^3 particles of the same uniform density,
+    nf_tile=176, 2^3 tiles), full particle_mesh steps.  Checker-side code, used here only as the reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
+    p = Params(**CONFIGS["cfg2"]["params"])
     fine, coarse = default_tables()
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, p.tiles_node_dim ** 3))
+    threads = max(1, min(cores, 8))
     os.environ["OMP_NUM_THREADS"] = str(threads)
+    xv = make_particles(128, 256.0)
     o = ol.Oracle(p)
     o.set_kernel_tables(fine, coarse)
     o.set_particles(0, xv)
@@ -75,12 +90,12 @@ def cpu_baseline(p: Params, xv, scal, budget_s=30.0):
     while True:
         o.particle_mesh(a_mid, dt, dt_old, mass_p)
         steps += 1
-        if time.perf_counter() - t0 > 0.4 * budget_s or steps >= 3:
+        if time.perf_counter() - t0 > 12.0 or steps >= 3:
             break
     el = time.perf_counter() - t0
     return {"value": len(xv) * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "sample": "%d full particle_mesh step(s) of the same workload on the CPU oracle (C port of the reference path, "
-                      "OpenMP over fine tiles as the reference does), %.1f s" % (steps, el)}
+            "sample": "%d full particle_mesh step(s) of a 256^3-cell / 128^3-particle sub-volume (same density, nf_tile=176, 2^3 tiles) on the "
+                      "CPU oracle (C port of the reference path, OpenMP over fine tiles as the reference does), %.1f s" % (steps, el)}
 
 
 def main():
@@ -88,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -98,79 +113,113 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-    if world > 1:
-        raise SystemExit("multi-rank bench not available in this revision (see DESIGN.md 'Multi-GPU')")
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
 
-    from cubep3m_amd.particle_mesh import ParticleMesh
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from cubep3m_amd.group import ParticleMeshGroup, rccl_unique_id
 
     cfg = CONFIGS[args.config]
     p = Params(**cfg["params"])
     p.device = local_rank
-    fine, coarse = default_tables()
-    box = float(p.nf_physical_node_dim)
-    xv = make_particles(cfg["nside"], box)
-    n = len(xv)
-    mass_p = float((p.nf_physical_node_dim / cfg["nside"]) ** 3)  # (fine cells)/np = 8
-    scal = (0.5, 0.05, 0.05, mass_p)  # late-time scalar set of SURVEY section 8d
-    a_mid, dt, dt_old, _ = scal
+    if p.nodes % world:
+        raise SystemExit("%d logical ranks cannot be split over %d GPUs" % (p.nodes, world))
+    uid = None
+    if world > 1:   # rank 0 creates the RCCL id, torch.distributed (RCCL) broadcasts it
+        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        uid = bytes(t.cpu().numpy().tobytes())
 
-    pm = ParticleMesh(p, fine, coarse)
-    pm.upload_particles(xv)           # inputs resident in HBM before the timed region
+    fine, coarse = default_tables()
+    grp = ParticleMeshGroup(p, rank, world, fine, coarse, unique_id=uid)
+    box = float(p.nf_physical_node_dim)
+    nside = cfg["nside_rank"]
+    mass_p = float((p.nf_physical_node_dim / nside) ** 3)  # fine cells per particle = 8
+    scal = (0.5, 0.05, 0.05, mass_p)                       # late-time scalar set of SURVEY section 8d
+    a_mid, dt, dt_old, _ = scal
+    n_local = 0
+    for i, r in enumerate(grp.local_ranks):               # every logical rank gets its own uniform cube
+        xv = make_particles(nside, box, seed=12345 + r)
+        grp.upload_particles(i, xv, np.arange(1, len(xv) + 1, dtype=np.int64) + r * len(xv))
+        n_local += len(xv)
+        del xv
+    n_total = nside ** 3 * p.nodes
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
-        pm.particle_mesh(a_mid, dt, dt_old, mass_p)
-    torch.cuda.synchronize()
+        grp.particle_mesh(a_mid, dt, dt_old, mass_p)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pm.particle_mesh(a_mid, dt, dt_old, mass_p)   # each call ends with a stream sync (dt limits are returned)
-    torch.cuda.synchronize()
+        out = grp.particle_mesh(a_mid, dt, dt_old, mass_p)   # ends with a stream sync: the dt limits are returned to the host
+    sync()
     el = time.perf_counter() - t0
-    assert out.np_total == n, (out.np_total, n)
-    value = n * args.steps / el
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    assert out.np_total == n_total, (out.np_total, n_total)
+    value = n_total * args.steps / el
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream
-    S = 4.0 * (p.nf_tile + 2) * p.nf_tile ** 2                  # bytes of one fine real/complex array
-    passes = {}
-    for i, name in enumerate(pm.FFT_PASSES):
-        ms, nb = pm.time_fft_pass(i, reps=20)
-        passes[name] = ms
-    # per sweep over the batch, one launch each: x_fwd, y_fwd, z_fwd, z_inv_fused (3 components), y_inv (3), x_inv_extract (3)
-    dom = max(("y_fwd", "z_fwd", "z_inv_fused", "y_inv"), key=lambda k: passes[k])
-    sweep_ms = pm.time_fine_sweep(mass_p, reps=5)
-    ntile = p.tiles_node_dim ** 3
-    # the forward 3-D transform of one tile is 2*S algorithmic bytes (one read + one write), one force
-    # component is 2.5*S (read rho-hat, read half-size kernel, write).  This implementation spends three axis passes on a
-    # transform, so a forward pass launch over `nb` tiles carries (2/3)*S*nb and an inverse pass launch (all three
-    # components in one launch) 3*(2.5/3)*S*nb.
-    alg_bytes = ((2.0 / 3.0) if dom.endswith("fwd") else 2.5) * S * nb
-    achieved = alg_bytes / (passes[dom] * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get(args.config, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_fft_lines (%s pass, %d tiles/launch)" % (dom, nb), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "ms_per_launch": passes[dom], "pass_ms": passes,
-                "fine_sweep": {"ms": sweep_ms, "algorithmic_bytes": 10.5 * S * ntile,
-                               "achieved_GBs": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9,
-                               "frac": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-
-    res = {
-        "metric": "particle_updates_per_sec", "value": value, "unit": "particle-updates/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["workload"], "name": args.config, "particles": n, "tiles": ntile, "nf_tile": p.nf_tile,
-                   "flags": {"ngp": p.ngp, "ppint": p.ppint, "pp_ext": p.pp_ext}},
-        "roofline": roofline,
-    }
-    if not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(p, xv, scal)
-    print(json.dumps(res))
+    if rank == 0:
+        # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream (rank 0's first context)
+        pm = grp.rank_context(0)
+        S = 4.0 * (p.nf_tile + 2) * p.nf_tile ** 2              # bytes of one fine real/complex array
+        passes = {}
+        nb = 1
+        for i, name in enumerate(pm.FFT_PASSES):
+            ms, nb = pm.time_fft_pass(i, reps=10)
+            passes[name] = ms
+        # per sweep over the batch, one launch each: x_fwd, y_fwd, z_fwd, z_inv_fused (3 components), y_inv (3), x_inv_extract (3)
+        dom = max(("y_fwd", "z_fwd", "z_inv_fused", "y_inv"), key=lambda k: passes[k])
+        sweep_ms = pm.time_fine_sweep(mass_p, reps=3)
+        ntile = p.tiles_node_dim ** 3
+        # the forward 3-D transform of one tile is 2*S algorithmic bytes (one read + one write), one force
+        # component is 2.5*S (read rho-hat, read half-size kernel, write).  Three axis passes per transform: a forward pass
+        # launch over `nb` tiles carries (2/3)*S*nb, an inverse pass launch (all three components) 3*(2.5/3)*S*nb.
+        alg_bytes = ((2.0 / 3.0) if dom.endswith("fwd") else 2.5) * S * nb
+        achieved = alg_bytes / (passes[dom] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_fft_lines (%s pass, %d tile(s)/launch, nf_tile=%d)" % (dom, nb, p.nf_tile), "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "ms_per_launch": passes[dom], "pass_ms": passes,
+                    "fine_sweep": {"ms": sweep_ms, "algorithmic_bytes": 10.5 * S * ntile,
+                                   "achieved_GBs": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9,
+                                   "frac": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        res = {
+            "metric": "particle_updates_per_sec", "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["workload"], "name": args.config, "particles": n_total, "logical_ranks": p.nodes,
+                       "ranks_per_gpu": p.nodes // world, "tiles_per_rank": ntile, "nf_tile": p.nf_tile,
+                       "flags": {"ngp": p.ngp, "ppint": p.ppint, "pp_ext": p.pp_ext}},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(scal)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        grp.close()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

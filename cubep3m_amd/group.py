@@ -109,6 +109,12 @@ class ParticleMeshGroup:
                                                       None if pm is None else pm.ctypes.data_as(C.c_void_p), C.byref(o)))
         return o
 
+    def rank_context(self, i):
+        """The i-th local rank's context as a ParticleMesh (probes, kernel timers)."""
+        from .particle_mesh import ParticleMesh
+
+        return ParticleMesh.from_handle(self.L.p3m_hip_group_ctx(self.h, i), self.params)
+
     def coarse(self, mass_p, i, want_force=True):
         p = self.params
         rho = np.empty((p.nc_node_dim,) * 3, np.float32)

@@ -39,11 +39,18 @@ class ParticleMesh:
                 fine_table, coarse_table = default_tables()
             self.set_kernel_tables(fine_table, coarse_table)
 
+    @classmethod
+    def from_handle(cls, handle, params: Params):
+        """Wrap a context owned by someone else (a rank of a ParticleMeshGroup); close() is a no-op."""
+        self = cls.__new__(cls)
+        self.params, self.L, self.h, self.last, self._borrowed = params, _lib.load(), C.c_void_p(handle), None, True
+        return self
+
     # -- lifecycle ---------------------------------------------------------------------
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
             self.L.p3m_hip_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
