@@ -212,17 +212,32 @@ int particles_pass_and_sort(p3m_ctx *c) {
 __global__ __launch_bounds__(PT) void k_pass_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
                                                   int n_cur, int axis, float Nn, float nb, float4 *__restrict__ sbuf_plus,
                                                   float4 *__restrict__ sbuf_minus, int cap_buf, int *__restrict__ counts) {
+  // one atomic per block and direction (a per-record atomic on one address serialises the whole chip)
+  __shared__ int wsum[2][PT / 64];
+  __shared__ int base_sh[2];
   const int i = blockIdx.x * PT + threadIdx.x;
-  if (i >= n_cur) return;
-  const float4 p = pos[i];
-  if (!in_hoc_range(p, -nb, Nn + nb)) return;
-  const float x = comp(p, axis);
-  const bool hi = x >= Nn - nb, lo = x < nb;
+  bool hi = false, lo = false;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n_cur) {
+    p = pos[i];
+    if (in_hoc_range(p, -nb, Nn + nb)) { const float x = comp(p, axis); hi = x >= Nn - nb; lo = x < nb; }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long mh = __ballot(hi), ml = __ballot(lo);
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int ph = __popcll(mh & below), pl = __popcll(ml & below);
+  if (lane == 0) { wsum[0][w] = __popcll(mh); wsum[1][w] = __popcll(ml); }
+  __syncthreads();
+  int offh = 0, offl = 0, toth = 0, totl = 0;
+#pragma unroll
+  for (int k = 0; k < PT / 64; k++) { if (k < w) { offh += wsum[0][k]; offl += wsum[1][k]; } toth += wsum[0][k]; totl += wsum[1][k]; }
+  if (threadIdx.x == 0) { base_sh[0] = toth ? atomicAdd(&counts[0], toth) : 0; base_sh[1] = totl ? atomicAdd(&counts[1], totl) : 0; }
+  __syncthreads();
   if (!(hi || lo)) return;
   const float4 v = vel[i]; const int64_t id = pid[i];
   float4 idv; idv.x = __int_as_float((int)(id & 0xffffffffLL)); idv.y = __int_as_float((int)(id >> 32)); idv.z = 0.f; idv.w = 0.f;
-  if (hi) { const int s = atomicAdd(&counts[0], 1); if (s < cap_buf) { sbuf_plus[3 * s] = p; sbuf_plus[3 * s + 1] = v; sbuf_plus[3 * s + 2] = idv; } }
-  if (lo) { const int s = atomicAdd(&counts[1], 1); if (s < cap_buf) { sbuf_minus[3 * s] = p; sbuf_minus[3 * s + 1] = v; sbuf_minus[3 * s + 2] = idv; } }
+  if (hi) { const int s = base_sh[0] + offh + ph; if (s < cap_buf) { sbuf_plus[3 * s] = p; sbuf_plus[3 * s + 1] = v; sbuf_plus[3 * s + 2] = idv; } }
+  if (lo) { const int s = base_sh[1] + offl + pl; if (s < cap_buf) { sbuf_minus[3 * s] = p; sbuf_minus[3 * s + 1] = v; sbuf_minus[3 * s + 2] = idv; } }
 }
 // from_plus_dir: the buffer was sent towards +a by the -a neighbour: x_a <- max(x_a - Nn, -nb) (:162);
 // otherwise it came from the +a neighbour: eps guard, x_a <- min(x_a + Nn, Nn+nb-eps) (:257-265).
