@@ -30,6 +30,32 @@ def rank_coords(rank, nd):
     return rank // (nd * nd), (rank // nd) % nd, rank % nd  # c1 (z), c2 (y), c3 (x)
 
 
+def owner_of_rank(rank, nodes, nprocs):
+    """Process that drives logical rank `rank`: contiguous blocks, so whole z-layers share a GPU where possible
+    (same rule as p3m_hip_group_create)."""
+    return rank // (nodes // nprocs)
+
+
+def local_ranks_of(proc, nodes, nprocs):
+    per = nodes // nprocs
+    return list(range(proc * per, (proc + 1) * per))
+
+
+def split_global(params: Params, xv, pid, ranks):
+    """Particles of the global periodic box -> {logical rank: (xv in the rank's local coordinates, pid)}."""
+    nd, Nn = params.nodes_dim, params.nf_physical_node_dim
+    out = {}
+    cell = np.floor(xv[:, :3] / np.float32(Nn)).astype(np.int64)
+    owner = cell[:, 2] * nd * nd + cell[:, 1] * nd + cell[:, 0]
+    for r in ranks:
+        m = owner == r
+        c1, c2, c3 = rank_coords(r, nd)
+        loc = xv[m].copy()
+        loc[:, :3] -= np.array([c3, c2, c1], np.float32) * np.float32(Nn)
+        out[r] = (loc, pid[m])
+    return out
+
+
 class ParticleMeshGroup:
     def __init__(self, params: Params, proc=0, nprocs=1, fine_table=None, coarse_table=None, unique_id=None,
                  force_rccl=False, set_kernels=True):
@@ -81,17 +107,7 @@ class ParticleMeshGroup:
 
     def split_global(self, xv, pid):
         """Particles of the global box -> {logical rank: (xv_local, pid)} for the ranks this process owns."""
-        nd, Nn = self.params.nodes_dim, self.params.nf_physical_node_dim
-        out = {}
-        cell = np.floor(xv[:, :3] / np.float32(Nn)).astype(np.int64)
-        owner = cell[:, 2] * nd * nd + cell[:, 1] * nd + cell[:, 0]
-        for r in self.local_ranks:
-            m = owner == r
-            c1, c2, c3 = rank_coords(r, nd)
-            loc = xv[m].copy()
-            loc[:, :3] -= np.array([c3, c2, c1], np.float32) * np.float32(Nn)
-            out[r] = (loc, pid[m])
-        return out
+        return split_global(self.params, xv, pid, self.local_ranks)
 
     def scatter_global(self, xv, pid):
         parts = self.split_global(xv, pid)
