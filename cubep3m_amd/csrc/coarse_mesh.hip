@@ -10,48 +10,70 @@
 
 struct CGeo { int nb, E, Nn, ms, ncn, nc; };
 
-// One 64-lane workgroup per coarse output row (J,K).  A particle's CIC footprint is the cells
-// i1 = floor(x/ms - 0.5) + 1 and i1+1 per axis (coarse_cic_mass.f90:18-21), clipped to 1..ncn
-// (coarse_cic_mass_buffer.f90:59-113); row J (0-based) is fed by particles with j1 in {J, J+1}
-// (1-based), which lie in the 2*ms fine cell rows [ms*J - ms/2, ms*J + 3*ms/2).
-__global__ __launch_bounds__(64) void k_coarse_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho_c, CGeo G,
+// One 256-thread workgroup per CT x CT block of coarse output rows (J0..J0+3, K0..K0+3).  A particle's CIC
+// footprint is the cells i1 = floor(x/ms - 0.5) + 1 and i1+1 per axis (coarse_cic_mass.f90:18-21), clipped
+// to 1..ncn (coarse_cic_mass_buffer.f90:59-113); the block is fed by the fine cell rows
+// [ms*J0 - ms/2, ms*(J0+CT) + ms/2) x same in z, each read once per block (re-read factor (1+1/CT)^2).
+#define CT 4
+__global__ __launch_bounds__(256) void k_coarse_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho_c, CGeo G,
                                                        float mass_p, double *__restrict__ sum_out) {
-  extern __shared__ float row[];
-  const int J = blockIdx.x % G.ncn, K = blockIdx.x / G.ncn;
-  for (int i = threadIdx.x; i < G.ncn; i += 64) row[i] = 0.f;
+  extern __shared__ float rows[];   // [CT][CT][ncn]
+  const int nJ = (G.ncn + CT - 1) / CT;
+  const int J0 = (blockIdx.x % nJ) * CT, K0 = (blockIdx.x / nJ) * CT;
+  for (int i = threadIdx.x; i < CT * CT * G.ncn; i += 256) rows[i] = 0.f;
   __syncthreads();
   const int h = G.ms / 2;
   const float inv = 1.0f / (float)G.ms;
   const int xlo = G.nb - G.ms, xhi = G.nb + G.Nn + G.ms;  // chains hoc(0:ncn+1) only (coarse_mass.f90:85-87)
-  for (int fz = G.ms * K - h; fz < G.ms * K + 3 * h; fz++)
-    for (int fy = G.ms * J - h; fy < G.ms * J + 3 * h; fy++) {
-      const int64_t rb = ((int64_t)(fz + G.nb) * G.E + (fy + G.nb)) * G.E;
-      const int p0 = cs[rb + xlo], p1 = cs[rb + xhi];
-      for (int s = p0 + threadIdx.x; s < p1; s += 64) {
-        const float4 p = spos[s];
-        const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;     // coarse_cic_mass.f90:18
-        const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;  // 1-based
-        float dx1 = (float)i1 - x, dy1 = (float)j1 - y, dz1 = (float)k1 - z;
-        float dx2 = 1.0f - dx1; const float dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
-        float wy, wz;
-        if (j1 == J + 1) wy = dy1; else if (j1 == J) wy = dy2; else continue;
-        if (k1 == K + 1) wz = dz1; else if (k1 == K) wz = dz2; else continue;
-        dx1 = mass_p * dx1; dx2 = mass_p * dx2;                                             // :32-33
-        if (i1 >= 1 && i1 <= G.ncn) atomicAdd(&row[i1 - 1], dx1 * wy * wz);
-        if (i1 + 1 >= 1 && i1 + 1 <= G.ncn) atomicAdd(&row[i1], dx2 * wy * wz);
+  // The fine cell rows fy0..fy1 of one z-plane are ONE contiguous record range (whole rows incl. the few
+  // ghost-zone cells beyond the chain window, which the clipping below discards): two offset loads per
+  // plane instead of two per row, and all 256 lanes stream the range.
+  const int ny = G.ms * CT + G.ms;
+  const int fy0 = max(G.ms * J0 - h + G.nb, 0), fy1 = min(G.ms * J0 - h + ny + G.nb, G.E);   // extended-cell rows [fy0, fy1)
+  for (int zz = 0; zz < ny; zz++) {
+    const int cz0 = G.ms * K0 - h + zz + G.nb;
+    if (cz0 < 0 || cz0 >= G.E) continue;
+    const int p0 = cs[((int64_t)cz0 * G.E + fy0) * G.E], p1 = cs[((int64_t)cz0 * G.E + fy1) * G.E];
+    for (int s = p0 + (int)threadIdx.x; s < p1; s += 256) {
+      const float4 p = spos[s];
+      { const int cx = (int)floorf(p.x) + G.nb; if (cx < xlo || cx >= xhi) continue; }      // chain window hoc(0:ncn+1)
+      const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;     // coarse_cic_mass.f90:18
+      const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;  // 1-based
+      float dx1 = (float)i1 - x; const float dy1 = (float)j1 - y, dz1 = (float)k1 - z;
+      float dx2 = 1.0f - dx1; const float dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+      dx1 = mass_p * dx1; dx2 = mass_p * dx2;                                             // :32-33
+#pragma unroll
+      for (int cz = 0; cz < 2; cz++) {
+        const int K = k1 - 1 + cz - K0;                       // 0-based output row, relative to the block
+        if (K < 0 || K >= CT || K + K0 >= G.ncn) continue;
+        const float wz = cz ? dz2 : dz1;
+#pragma unroll
+        for (int cy = 0; cy < 2; cy++) {
+          const int J = j1 - 1 + cy - J0;
+          if (J < 0 || J >= CT || J + J0 >= G.ncn) continue;
+          const float wy = cy ? dy2 : dy1;
+          float *row = rows + (K * CT + J) * G.ncn;
+          if (i1 >= 1 && i1 <= G.ncn) atomicAdd(&row[i1 - 1], dx1 * wy * wz);
+          if (i1 + 1 >= 1 && i1 + 1 <= G.ncn) atomicAdd(&row[i1], dx2 * wy * wz);
+        }
       }
     }
+  }
   __syncthreads();
   float part = 0.f;
-  for (int i = threadIdx.x; i < G.ncn; i += 64) { const float v = row[i]; rho_c[((int64_t)K * G.ncn + J) * G.ncn + i] = v; part += v; }
+  for (int e = threadIdx.x; e < CT * CT * G.ncn; e += 256) {
+    const int i = e % G.ncn, J = (e / G.ncn) % CT, K = e / (G.ncn * CT);
+    if (J0 + J < G.ncn && K0 + K < G.ncn) { const float v = rows[e]; rho_c[((int64_t)(K0 + K) * G.ncn + (J0 + J)) * G.ncn + i] = v; part += v; }
+  }
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-  if (threadIdx.x == 0 && sum_out) atomicAdd(sum_out, (double)part);                        // coarse_mesh.f90:31-43
+  if ((threadIdx.x & 63) == 0 && sum_out && part != 0.f) atomicAdd(sum_out, (double)part);  // coarse_mesh.f90:31-43
 }
 
 int coarse_deposit(p3m_ctx *c, float mass_p) {
   const Geometry &g = c->g;
   CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc};
-  hipLaunchKernelGGL(k_coarse_deposit, dim3(g.ncn * g.ncn), dim3(64), sizeof(float) * g.ncn, c->stream, (const float4 *)c->spos,
+  const int nJ = (g.ncn + CT - 1) / CT;
+  hipLaunchKernelGGL(k_coarse_deposit, dim3(nJ * nJ), dim3(256), sizeof(float) * CT * CT * g.ncn, c->stream, (const float4 *)c->spos,
                      (const int *)c->cell_end, c->rho_c, G, mass_p, c->d_sums + 1);
   HIP_TRY(hipGetLastError());
   return P3M_OK;

@@ -100,22 +100,29 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
 // afterwards by k_ngp_fixup.
 __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, float *__restrict__ rho, int tile0, int ntile, TileGeo G,
                                                     float mass_p, double *__restrict__ sum_interior) {
+  // grid: (row groups of RG rows, nf planes, tiles); lanes run along x: coalesced 4-byte loads and stores
+  constexpr int RG = 8;
   __shared__ float sh[4];
   const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb, pitch = G.rp;
-  const int64_t tot = (int64_t)ntile * nf * nf * pitch;
+  const int k = blockIdx.y, tl = blockIdx.z;
+  int tx, ty, tz; tile_xyz(tile0 + tl, G.T, tx, ty, tz);
   float part = 0.f;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
-    const int i = (int)(idx % pitch); int64_t r = idx / pitch;
-    const int j = (int)(r % nf); r /= nf; const int k = (int)(r % nf); const int tl = (int)(r / nf);
-    float v = 0.f;
-    if (i >= 4 && i < nf - 4 && j >= 4 && j < nf - 4 && k >= 4 && k < nf - 4) {
-      int tx, ty, tz; tile_xyz(tile0 + tl, G.T, tx, ty, tz);
-      const int64_t cell = ((int64_t)(tz * pt + k) * E + (ty * pt + j)) * E + (tx * pt + i);
-      const int cnt = cs[cell + 1] - cs[cell];
-      for (int q = 0; q < cnt; q++) v = v + mass_p;                                                // :148, same partial sums
-      if (i >= nb && i < nf - nb && j >= nb && j < nf - nb && k >= nb && k < nf - nb) part += v;      // :167-173
+  for (int jr = 0; jr < RG; jr++) {
+    const int j = blockIdx.x * RG + jr;
+    if (j >= nf) break;
+    float *out = rho + (((int64_t)tl * nf + k) * nf + j) * pitch;
+    const bool row_in = (j >= 4 && j < nf - 4 && k >= 4 && k < nf - 4);
+    const bool row_int = (j >= nb && j < nf - nb && k >= nb && k < nf - nb);
+    const int *row = cs + ((int64_t)(tz * pt + k) * E + (ty * pt + j)) * E + tx * pt;
+    for (int i = threadIdx.x; i < pitch; i += 256) {
+      float r = 0.f;
+      if (row_in && i >= 4 && i < nf - 4) {
+        const int cnt = row[i + 1] - row[i];
+        for (int q = 0; q < cnt; q++) r = r + mass_p;                      // :148, same partial sums
+        if (row_int && i >= nb && i < nf - nb) part += r;                    // :167-173
+      }
+      out[i] = r;
     }
-    rho[idx] = v;
   }
   if (sum_interior) {
     const float s = block_sum_f(part, sh);
@@ -155,8 +162,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   const Geometry &g = c->g;
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px};
   if (c->p.flags & P3M_FLAG_NGP) {
-    const int64_t tot = (int64_t)ntile * g.nf * g.nf * (2 * g.px);
-    hipLaunchKernelGGL(k_ngp_counts, dim3((unsigned)std::min<int64_t>(cdiv(tot, 256), 256 * 32)), dim3(256), 0, c->stream, (const int *)c->cell_end,
+    hipLaunchKernelGGL(k_ngp_counts, dim3(cdiv(g.nf, 8), g.nf, ntile), dim3(256), 0, c->stream, (const int *)c->cell_end,
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
     HIP_TRY(hipGetLastError());
     if (c->ncand > 0) {

@@ -10,6 +10,7 @@
 #include <algorithm>
 
 #define PT 256
+#define RPT 4   // records per thread in the histogram / scatter kernels
 
 // ------------------------------------------------------------------ update_position.f90:68-76
 __global__ __launch_bounds__(PT) void k_drift(float4 *__restrict__ pos, const float4 *__restrict__ vel, int n, float dt, float dt_old,
@@ -102,8 +103,11 @@ __global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, fl
 __global__ __launch_bounds__(PT) void k_cell_hist(const float4 *__restrict__ pos, int n, int np_orig, float Nn, float nb, int E,
                                                   int *__restrict__ cell_of, int *__restrict__ cs, int *__restrict__ ndeleted,
                                                   unsigned char *__restrict__ cflag, int ms, int pt) {
-  const int i = blockIdx.x * PT + threadIdx.x;
-  if (i >= n) return;
+  // RPT records per thread, a block stride apart: several independent atomics in flight per lane
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {
+  const int i = (blockIdx.x * RPT + u) * PT + threadIdx.x;
+  if (i >= n) continue;
   const float4 p = pos[i];
   int cell = -1;
   if (in_hoc_range(p, -nb, Nn + nb)) {
@@ -125,17 +129,24 @@ __global__ __launch_bounds__(PT) void k_cell_hist(const float4 *__restrict__ pos
     atomicAdd(ndeleted, 1);
   }
   cell_of[i] = cell;
+  }
 }
 
 __global__ __launch_bounds__(PT) void k_scatter(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
                                                 const int *__restrict__ cell_of, int n, int *__restrict__ cs, float4 *__restrict__ spos,
                                                 float4 *__restrict__ svel, int64_t *__restrict__ spid, int *__restrict__ cand,
                                                 int *__restrict__ ncand, int cand_cap) {
-  const int i = blockIdx.x * PT + threadIdx.x;
-  if (i >= n) return;
-  const int cell = cell_of[i];
-  if (cell < 0) return;
-  const int s = atomicAdd(&cs[cell + 1], 1);
+  int idx[RPT], slot[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {                    // issue all the cursor atomics first
+    const int i = (blockIdx.x * RPT + u) * PT + threadIdx.x;
+    idx[u] = i; slot[u] = -1;
+    if (i < n) { const int cell = cell_of[i]; if (cell >= 0) slot[u] = atomicAdd(&cs[cell + 1], 1); }
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {
+  const int i = idx[u], s = slot[u];
+  if (s < 0) continue;
   const float4 p = pos[i];
   spos[s] = p; svel[s] = vel[i]; spid[s] = pid[i];
   // records with a coordinate within 2^-10 below a cell face: only these can be moved into the next
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(PT) void k_scatter(const float4 *__restrict__ pos, 
   if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
     const int k = atomicAdd(ncand, 1);
     if (k < cand_cap) cand[k] = s;
+  }
   }
 }
 
@@ -181,13 +193,13 @@ int particles_sort(p3m_ctx *c) {
   const bool want_cflag = (c->p.flags & P3M_FLAG_PPINT) != 0;
   if (want_cflag) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
   if (n_cur > 0) {
-    hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, c->np_local, (float)g.Nn,
+    hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(n_cur, PT * RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, c->np_local, (float)g.Nn,
                        (float)g.nb, g.E, c->cell_of, c->cell_end, cnt + 4, want_cflag ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
     HIP_TRY(hipGetLastError());
   }
   P3M_TRY(exclusive_scan_i32(c, c->cell_end + 1, ncell));
   if (n_cur > 0) {
-    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel,
+    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n_cur, PT * RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel,
                        (const int64_t *)c->pid, (const int *)c->cell_of, n_cur, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5, (int)c->cap);
     HIP_TRY(hipGetLastError());
   }
