@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(const float2 *__restrict__ sr
                                                    int RBP, Factors fac, const float2 *__restrict__ tw_g, float inv_scale, int mode,
                                                    float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
   extern __shared__ float2 lds[];
-  const int h = n >> 1, nchunk = px / BXC;
+  const int h = n >> 1, nchunk = px / BXC, fbp = (fb + 3) & ~3;
   float2 *A = lds, *B = A + (h + 1) * RBP, *tw = B + (h + 1) * RBP;
   __shared__ int64_t src_bz[64], dst_off[64];
   __shared__ int src_y[64];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(const float2 *__restrict__ sr
       const int jj = (int)(srow % fb); const int64_t t2 = srow / fb; const int kk = (int)(t2 % fb); const int64_t b = t2 / fb;
       const int comp = (int)(b / ntile), tl = (int)(b % ntile);
       src_bz[threadIdx.x] = b * n + (kk + lo); src_y[threadIdx.x] = jj + lo;
-      dst_off[threadIdx.x] = comp * box_comp_stride + (((int64_t)tl * fb + kk) * fb + jj) * fb;
+      dst_off[threadIdx.x] = comp * box_comp_stride + (((int64_t)tl * fb + kk) * fb + jj) * fbp;
     } else {
       src_bz[threadIdx.x] = srow / n; src_y[threadIdx.x] = (int)(srow % n);
       dst_off[threadIdx.x] = srow * (int64_t)(2 * px);
@@ -166,12 +166,18 @@ __global__ __launch_bounds__(256) void k_fft_x_inv(const float2 *__restrict__ sr
       reinterpret_cast<float2 *>(out + dst_off[r])[m] = z;
     }
   } else {
-    for (int e = threadIdx.x; e < nrows * fb; e += blockDim.x) {
-      const int r = e / fb, ii = e - r * fb;
-      const int x = ii + lo;
-      const float2 z = Z[(x >> 1) * RBP + r];
-      const float val = (x & 1) ? -z.y : z.x;
-      box[dst_off[r] + ii] = val / inv_scale;
+    // 4 consecutive box cells = 2 complex values per lane, one 16-byte store (lo is even, fbp % 4 == 0)
+    const int nq = fbp >> 2;
+    for (int e = threadIdx.x; e < nrows * nq; e += blockDim.x) {
+      const int r = e / nq, q = e - r * nq;
+      const int cx = (4 * q + lo) >> 1;
+      const float2 z0 = Z[cx * RBP + r], z1 = Z[(cx + 1) * RBP + r];
+      float4 o = make_float4(z0.x / inv_scale, -z0.y / inv_scale, z1.x / inv_scale, -z1.y / inv_scale);
+      if (4 * q + 0 >= fb) o.x = 0.f;
+      if (4 * q + 1 >= fb) o.y = 0.f;
+      if (4 * q + 2 >= fb) o.z = 0.f;
+      if (4 * q + 3 >= fb) o.w = 0.f;
+      *reinterpret_cast<float4 *>(box + dst_off[r] + 4 * q) = o;
     }
   }
 }

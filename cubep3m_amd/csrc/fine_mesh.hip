@@ -17,7 +17,7 @@
 int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, float *box, int fb, int lo,
                      int64_t bcs);
 
-struct TileGeo { int T, nf, nb, pt, E, fb, rp; };  // rp: real row pitch of a fine array (2*px)
+struct TileGeo { int T, nf, nb, pt, E, fb, rp, fbp; };  // rp: real row pitch of a fine array (2*px); fbp: force box row pitch
 
 __device__ __forceinline__ void tile_xyz(int tile, int T, int &tx, int &ty, int &tz) {  // :86-90
   tz = tile / (T * T); const int r = tile - tz * T * T; ty = r / T; tx = r - ty * T;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ sp
 
 int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   const Geometry &g = c->g;
-  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px};
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   if (c->p.flags & P3M_FLAG_NGP) {
     hipLaunchKernelGGL(k_ngp_counts, dim3(cdiv(g.nf, 8), g.nf, ntile), dim3(256), 0, c->stream, (const int *)c->cell_end,
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
@@ -185,7 +185,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
 int fine_force(p3m_ctx *c, int tile0, int ntile) {
   const Geometry &g = c->g;
   P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, c->work, ntile));
-  const size_t boxsz = (size_t)g.fb * g.fb * g.fb;
+  const size_t boxsz = (size_t)g.fb * g.fb * g.fbp;
   // one fused launch per axis for all three components (rho-hat is read once)
   return fft_inverse3_box(c, c->plan_f, c->rho, c->work, c->kern_f, ntile, c->fbox + (size_t)tile0 * boxsz, g.fb, g.nb - 2,
                           (int64_t)g.ntiles * boxsz);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_force_max(const float *__restrict__ fbo
 }
 int fine_force_max(p3m_ctx *c) {
   const Geometry &g = c->g;
-  const int64_t n = (int64_t)g.ntiles * g.fb * g.fb * g.fb;
+  const int64_t n = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;   // pad columns hold zeros
   hipLaunchKernelGGL(k_force_max, dim3(std::min<int64_t>(2048, cdiv(n, 256))), dim3(256), 0, c->stream, (const float *)c->fbox, n, n, c->d_red);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
@@ -227,10 +227,10 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
   const int lo = G.nb - 2, fb = G.fb;
   const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
   const int tile = (tz * G.T + ty) * G.T + tx;
-  const float *f0 = fbox + (int64_t)tile * fb * fb * fb;
+  const float *f0 = fbox + (int64_t)tile * fb * fb * G.fbp;
   float4 v = svel[s];
   if (NGP) {
-    const int64_t o = ((int64_t)k1 * fb + j1) * fb + i1;
+    const int64_t o = ((int64_t)k1 * fb + j1) * G.fbp + i1;
     v.x = v.x + f0[o] * a_mid * P3M_G_F * dt;                                                         // :265-266
     v.y = v.y + f0[o + comp_stride] * a_mid * P3M_G_F * dt;
     v.z = v.z + f0[o + 2 * comp_stride] * a_mid * P3M_G_F * dt;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 #pragma unroll
         for (int cx = 0; cx < 2; cx++) {                                                                // order of :293-316
           const float dVc = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
-          const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * fb + (i1 + cx);
+          const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * G.fbp + (i1 + cx);
           v.x = v.x + f0[o] * dVc; v.y = v.y + f0[o + comp_stride] * dVc; v.z = v.z + f0[o + 2 * comp_stride] * dVc;
         }
   }
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 int fine_kick(p3m_ctx *c, float a_mid, float dt) {
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
-  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px};
-  const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fb;
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
+  const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   if (c->p.flags & P3M_FLAG_NGP)
     hipLaunchKernelGGL(k_fine_kick<true>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G, g.Nn,
                        g.ms, (const float *)c->fbox, cs, a_mid, dt);

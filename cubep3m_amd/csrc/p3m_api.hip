@@ -38,6 +38,7 @@ static int fill_geometry(const p3m_params *p, Geometry *g) {
   if (g->nc % g->nodes) { p3m_set_error("cannot evenly decompose mesh into slabs (mpi_initialization.f90:26)"); return P3M_EINVAL; }
   g->nc_slab = g->nc / g->nodes;
   g->hx = g->nf / 2 + 1; g->fb = g->pt + 3;
+  g->fbp = (g->fb + 3) / 4 * 4;
   g->px = (g->hx + 15) / 16 * 16; g->pxc = ((g->nc / 2 + 1) + 15) / 16 * 16;
   if ((int64_t)g->E * g->E * g->E > 2000000000LL) { p3m_set_error("extended fine domain %d^3 exceeds int32 cell indices", g->E); return P3M_EINVAL; }
   const int nd = g->nodes_dim, rk = p->rank;
@@ -86,7 +87,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   c->tile_batch = (int)std::max<size_t>(1, std::min<size_t>(g.ntiles, budget / (4 * S * sizeof(float))));
   A(dalloc(&c->rho, S * c->tile_batch)); A(dalloc(&c->work, 3 * S * c->tile_batch));
   if (hipMemset(c->rho, 0, S * c->tile_batch * sizeof(float)) != hipSuccess || hipMemset(c->work, 0, 3 * S * c->tile_batch * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
-  A(dalloc(&c->fbox, (size_t)3 * g.ntiles * g.fb * g.fb * g.fb));
+  A(dalloc(&c->fbox, (size_t)3 * g.ntiles * g.fb * g.fb * g.fbp));
   A(dalloc(&c->kern_f, (size_t)3 * g.nf * g.nf * g.px));
   if (hipMemset(c->kern_f, 0, (size_t)3 * g.nf * g.nf * g.px * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
   A(fft_plan_create(&c->plan_f, g.nf));
@@ -393,10 +394,11 @@ extern "C" int p3m_hip_probe_tile_force(p3m_ctx *c, const float *rho_f, float *f
   HIP_TRY(hipMemcpy2DAsync(c->rho, sizeof(float) * 2 * g.px, rho_f, sizeof(float) * (g.nf + 2), sizeof(float) * (g.nf + 2), (size_t)g.nf * g.nf,
                            hipMemcpyHostToDevice, c->stream));
   P3M_TRY(fine_force(c, 0, 1));
-  const size_t boxsz = (size_t)g.fb * g.fb * g.fb;
+  const size_t boxsz = (size_t)g.fb * g.fb * g.fb, boxp = (size_t)g.fb * g.fb * g.fbp;
   std::vector<float> tmp(3 * boxsz);
   for (int comp = 0; comp < 3; comp++)
-    HIP_TRY(hipMemcpyAsync(tmp.data() + comp * boxsz, c->fbox + (size_t)comp * g.ntiles * boxsz, sizeof(float) * boxsz, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(tmp.data() + comp * boxsz, sizeof(float) * g.fb, c->fbox + (size_t)comp * g.ntiles * boxp, sizeof(float) * g.fbp,
+                             sizeof(float) * g.fb, (size_t)g.fb * g.fb, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   float m2 = 0.f;
   for (size_t i = 0; i < boxsz; i++) {
@@ -477,7 +479,7 @@ extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, fl
   const int nt = std::min(c->tile_batch, g.ntiles);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-  const int64_t bcs = (int64_t)g.ntiles * g.fb * g.fb * g.fb;
+  const int64_t bcs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2, bcs));  // warm-up
   HIP_TRY(hipEventRecord(e0, c->stream));
   for (int i = 0; i < reps; i++) P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2, bcs));

@@ -48,6 +48,7 @@ struct Geometry {
   int px;      // device complex row pitch of a fine array (fft plan), real pitch = 2*px
   int pxc;     // same for the coarse mesh
   int fb;      // force box edge: pt+3   (force_f(3, nb-1:nf-nb+1,...), cubep3m.fh:36)
+  int fbp;     // row pitch of the force box on the device: fb rounded up to 4 floats (16-byte row stores)
   int cart[3]; // z,y,x rank coordinates (mpi_initialization.f90:60-64)
   int nbr[6];  // -z,+z,-y,+y,-x,+x
   int64_t max_np;
@@ -76,7 +77,7 @@ struct p3m_ctx {
   int tile_batch = 0;          // tiles processed per sweep
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
   float *work = nullptr;       // [3][batch][nf][nf][2*px]  i*K_c*rho-hat -> force, all three components
-  float *fbox = nullptr;       // [3][ntiles][fb][fb][fb] extracted force (SoA planes)
+  float *fbox = nullptr;       // [3][ntiles][fb][fb][fbp] extracted force (SoA planes, pad columns zero)
   float *kern_f = nullptr;     // [3][nf][nf][px]  SoA planes of kern_f
   FftPlan plan_f;
   // ---- coarse mesh
