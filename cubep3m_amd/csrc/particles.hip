@@ -221,35 +221,48 @@ int particles_pass_and_sort(p3m_ctx *c) {
 // Records travel as 48-byte AoS {x,y,z,w, vx,vy,vz,w, pid(8 B), pad(8 B)}.
 // dir_plus: records with x_a >= Nn-nb go to the +a neighbour (particle_pass.f90:83), dir_minus: x_a < nb to the
 // -a neighbour (:185).  Only records that existed before this axis (i < n_cur) are offered.
+constexpr int PACK_RPT = 8;  // records per thread: one pair of atomics per 2048 records
 __global__ __launch_bounds__(PT) void k_pass_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
                                                   int n_cur, int axis, float Nn, float nb, float4 *__restrict__ sbuf_plus,
                                                   float4 *__restrict__ sbuf_minus, int cap_buf, int *__restrict__ counts) {
   // one atomic per block and direction (a per-record atomic on one address serialises the whole chip)
-  __shared__ int wsum[2][PT / 64];
+  __shared__ int wsum[2][PACK_RPT][PT / 64];
   __shared__ int base_sh[2];
-  const int i = blockIdx.x * PT + threadIdx.x;
-  bool hi = false, lo = false;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n_cur) {
-    p = pos[i];
-    if (in_hoc_range(p, -nb, Nn + nb)) { const float x = comp(p, axis); hi = x >= Nn - nb; lo = x < nb; }
-  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned long long mh = __ballot(hi), ml = __ballot(lo);
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int ph = __popcll(mh & below), pl = __popcll(ml & below);
-  if (lane == 0) { wsum[0][w] = __popcll(mh); wsum[1][w] = __popcll(ml); }
-  __syncthreads();
-  int offh = 0, offl = 0, toth = 0, totl = 0;
+  const int i0 = blockIdx.x * (PT * PACK_RPT) + threadIdx.x;
+  float4 p[PACK_RPT];
+  int slot[PACK_RPT];  // bit 30: goes +, bit 29: goes -, low bits: rank inside the wave for either direction
 #pragma unroll
-  for (int k = 0; k < PT / 64; k++) { if (k < w) { offh += wsum[0][k]; offl += wsum[1][k]; } toth += wsum[0][k]; totl += wsum[1][k]; }
-  if (threadIdx.x == 0) { base_sh[0] = toth ? atomicAdd(&counts[0], toth) : 0; base_sh[1] = totl ? atomicAdd(&counts[1], totl) : 0; }
+  for (int r = 0; r < PACK_RPT; r++) {
+    const int i = i0 + r * PT;
+    bool hi = false, lo = false;
+    p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n_cur) {
+      p[r] = pos[i];
+      if (in_hoc_range(p[r], -nb, Nn + nb)) { const float x = comp(p[r], axis); hi = x >= Nn - nb; lo = x < nb; }
+    }
+    const unsigned long long mh = __ballot(hi), ml = __ballot(lo);
+    slot[r] = (hi ? (1 << 30) : 0) | (lo ? (1 << 29) : 0) | (__popcll(mh & below) << 8) | __popcll(ml & below);
+    if (lane == 0) { wsum[0][r][w] = __popcll(mh); wsum[1][r][w] = __popcll(ml); }
+  }
   __syncthreads();
-  if (!(hi || lo)) return;
-  const float4 v = vel[i]; const int64_t id = pid[i];
-  float4 idv; idv.x = __int_as_float((int)(id & 0xffffffffLL)); idv.y = __int_as_float((int)(id >> 32)); idv.z = 0.f; idv.w = 0.f;
-  if (hi) { const int s = base_sh[0] + offh + ph; if (s < cap_buf) { sbuf_plus[3 * s] = p; sbuf_plus[3 * s + 1] = v; sbuf_plus[3 * s + 2] = idv; } }
-  if (lo) { const int s = base_sh[1] + offl + pl; if (s < cap_buf) { sbuf_minus[3 * s] = p; sbuf_minus[3 * s + 1] = v; sbuf_minus[3 * s + 2] = idv; } }
+  if (threadIdx.x < 2) {  // exclusive scan of the 32 (round, wave) counts of one direction, then one atomic
+    int run = 0;
+    for (int r = 0; r < PACK_RPT; r++)
+      for (int k = 0; k < PT / 64; k++) { const int v = wsum[threadIdx.x][r][k]; wsum[threadIdx.x][r][k] = run; run += v; }
+    base_sh[threadIdx.x] = run ? atomicAdd(&counts[threadIdx.x], run) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PACK_RPT; r++) {
+    if (!(slot[r] >> 29)) continue;
+    const int i = i0 + r * PT;
+    const float4 v = vel[i]; const int64_t id = pid[i];
+    float4 idv; idv.x = __int_as_float((int)(id & 0xffffffffLL)); idv.y = __int_as_float((int)(id >> 32)); idv.z = 0.f; idv.w = 0.f;
+    if (slot[r] & (1 << 30)) { const int s = base_sh[0] + wsum[0][r][w] + ((slot[r] >> 8) & 0x7f); if (s < cap_buf) { sbuf_plus[3 * s] = p[r]; sbuf_plus[3 * s + 1] = v; sbuf_plus[3 * s + 2] = idv; } }
+    if (slot[r] & (1 << 29)) { const int s = base_sh[1] + wsum[1][r][w] + (slot[r] & 0x7f); if (s < cap_buf) { sbuf_minus[3 * s] = p[r]; sbuf_minus[3 * s + 1] = v; sbuf_minus[3 * s + 2] = idv; } }
+  }
 }
 // from_plus_dir: the buffer was sent towards +a by the -a neighbour: x_a <- max(x_a - Nn, -nb) (:162);
 // otherwise it came from the +a neighbour: eps guard, x_a <- min(x_a + Nn, Nn+nb-eps) (:257-265).
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(PT) void k_pass_unpack(const float4 *__restrict__ r
 }
 int particles_pass_pack(p3m_ctx *c, int n_cur, int axis, float4 *sp, float4 *sm, int cap_buf, int *d_counts) {
   if (n_cur == 0) return P3M_OK;
-  hipLaunchKernelGGL(k_pass_pack, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
+  hipLaunchKernelGGL(k_pass_pack, dim3(cdiv(n_cur, PT * PACK_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
                      n_cur, axis, (float)c->g.Nn, (float)c->g.nb, sp, sm, cap_buf, d_counts);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
