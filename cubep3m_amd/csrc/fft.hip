@@ -40,55 +40,69 @@ __device__ __forceinline__ int64_t bundle_off2(int64_t b, int planes, int line, 
 }
 
 // ------------------------------------------------------------------ x pass, forward (r2c): ROWS -> LY
-// RB consecutive rows per workgroup; LDS holds element m of row r at m*RBP + r with RBP odd
-// (conflict-free both along rows and along the transform).
+// RB consecutive rows per batch; LDS holds element m of row r at m*RBP + r with RBP odd
+// (conflict-free both along rows and along the transform).  Persistent workgroups walk a grid-stride
+// list of batches, software-pipelined like k_fft_lines: the next batch's rows are in flight (XLU 16-byte
+// loads per lane, whose (row, quad) split is loop-invariant) while the butterflies of this one run.
+constexpr int XTB = 256, XLU = 6;
 template <int RSET>
-__global__ __launch_bounds__(256) void k_fft_x_fwd(const float *__restrict__ src, float2 *__restrict__ dst, int n, int px, int rows_total, int RB,
+__global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src, float2 *__restrict__ dst, int n, int px, int rows_total, int RB,
                                                    int RBP, Factors fac, const float2 *__restrict__ tw_g) {
   extern __shared__ float2 lds[];
   const int h = n >> 1, q4 = n >> 2, nchunk = px / BXC;
   float2 *A = lds, *B = A + h * RBP, *tw = B + h * RBP;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
-  const int64_t row0 = (int64_t)blockIdx.x * RB;
-  const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
-  {
-    constexpr int LU = 6;
-    const int T = blockDim.x, ne = nrows * q4;
-    for (int e0 = threadIdx.x; e0 < ne; e0 += LU * T) {
-      float4 v[LU];
+  for (int i = threadIdx.x; i < n; i += XTB) tw[i] = tw_g[i];
+  const int nbatch = (rows_total + RB - 1) / RB, ne = RB * q4;
+  __shared__ int64_t drow[64];
+  const fdiv_t dRB = mk_fdiv(RB);
+  int rq[XLU];   // row | quad << 8, or -1
 #pragma unroll
-      for (int u = 0; u < LU; u++) {
-        const int e = min(e0 + u * T, ne - 1);
-        const int r = e / q4, m = e - r * q4;
-        v[u] = reinterpret_cast<const float4 *>(src + (row0 + r) * (int64_t)(2 * px))[m];
-      }
+  for (int u = 0; u < XLU; u++) { const int e = (int)threadIdx.x + u * XTB; const int r = e / q4; rq[u] = e < ne ? (r | ((e - r * q4) << 8)) : -1; }
+  float4 v[XLU];
+  auto fetch = [&](int w) {
+    const int64_t row0 = (int64_t)w * RB;
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
 #pragma unroll
-      for (int u = 0; u < LU; u++) {
-        const int e = e0 + u * T;
-        if (e < ne) { const int r = e / q4, m = e - r * q4; A[(2 * m) * RBP + r] = make_float2(v[u].x, v[u].y); A[(2 * m + 1) * RBP + r] = make_float2(v[u].z, v[u].w); }
+    for (int u = 0; u < XLU; u++) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int r = rq[u] & 255, m = rq[u] >> 8;
+      if (rq[u] >= 0 && r < nrows) v[u] = reinterpret_cast<const float4 *>(src + (row0 + r) * (int64_t)(2 * px))[m];
+    }
+  };
+  int w = blockIdx.x;
+  if (w < nbatch) fetch(w);
+  for (; w < nbatch; w += gridDim.x) {
+    const int64_t row0 = (int64_t)w * RB;
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
+#pragma unroll
+    for (int u = 0; u < XLU; u++)
+      if (rq[u] >= 0) { const int r = rq[u] & 255, m = rq[u] >> 8; A[(2 * m) * RBP + r] = make_float2(v[u].x, v[u].y); A[(2 * m + 1) * RBP + r] = make_float2(v[u].z, v[u].w); }
+    __syncthreads();
+    { const int wn = w + gridDim.x; if (wn < nbatch) fetch(wn); }
+    if ((int)threadIdx.x < nrows) {   // LY offset of (row, chunk 0, column 0); read after the barriers of fft_lds
+      const unsigned row = (unsigned)row0 + threadIdx.x, bz = row / (unsigned)n;   // bz = b*n + z; rows_total is an int
+      drow[threadIdx.x] = (((int64_t)bz * nchunk) * n + (row - bz * n)) * BXC;
+    }
+    const float2 *Z = fft_lds<false, RSET>(A, B, h, nrows, RBP, 1, fac, tw, 2);
+    // X[k] = E + W_n^k O,  E = (Z[k]+conj Z[h-k])/2,  O = (Z[k]-conj Z[h-k])/(2i); lanes run over the 16
+    // columns of a chunk, then over rows: consecutive rows of one chunk are contiguous in LY
+    const int tot = nrows * px;
+    const fdiv_t dR = nrows == RB ? dRB : mk_fdiv(nrows);
+    for (int e = threadIdx.x; e < tot; e += XTB) {
+      const int l = e & (BXC - 1), chunk = fdiv(e >> 4, dR), r = (e >> 4) - chunk * nrows;
+      const int k = chunk * BXC + l;
+      float2 X = make_float2(0.f, 0.f);
+      if (k <= h) {
+        const float2 zk = Z[(k == h ? 0 : k) * RBP + r];
+        const float2 zc = cconj(Z[(k == 0 ? 0 : h - k) * RBP + r]);
+        const float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+        const float2 O = make_float2(0.5f * (zk.y - zc.y), -0.5f * (zk.x - zc.x));
+        const float2 wk = (k == h) ? make_float2(-1.f, 0.f) : tw[k];
+        X = cadd(E, cmul(O, wk));
       }
+      dst[drow[r] + ((int64_t)chunk * n) * BXC + l] = X;
     }
-  }
-  __syncthreads();
-  const float2 *Z = fft_lds<false, RSET>(A, B, h, nrows, RBP, 1, fac, tw, 2);
-  // X[k] = E + W_n^k O,  E = (Z[k]+conj Z[h-k])/2,  O = (Z[k]-conj Z[h-k])/(2i); lanes run over the 16
-  // columns of a chunk, then over rows: consecutive rows of one chunk are contiguous in LY
-  const int tot = nrows * px;
-  for (int e = threadIdx.x; e < tot; e += blockDim.x) {
-    const int l = e & (BXC - 1), r = (e >> 4) % nrows, chunk = (e >> 4) / nrows;
-    const int k = chunk * BXC + l;
-    float2 X = make_float2(0.f, 0.f);
-    if (k <= h) {
-      const float2 zk = Z[(k == h ? 0 : k) * RBP + r];
-      const float2 zc = cconj(Z[(k == 0 ? 0 : h - k) * RBP + r]);
-      const float2 E = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
-      const float2 O = make_float2(0.5f * (zk.y - zc.y), -0.5f * (zk.x - zc.x));
-      const float2 w = (k == h) ? make_float2(-1.f, 0.f) : tw[k];
-      X = cadd(E, cmul(O, w));
-    }
-    const int64_t row = row0 + r;
-    const int y = (int)(row % n); const int64_t bz = row / n;   // bz = b*n + z
-    dst[((bz * nchunk + chunk) * n + y) * BXC + l] = X;
+    __syncthreads();
   }
 }
 
@@ -96,89 +110,106 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd(const float *__restrict__ src
 // mode 0: all rows, real rows written to out (ROWS layout).  mode 1: rows enumerate (b, kk, jj) over the
 // force box force_f(c, nb-1:nf-nb+1,...) (particle_mesh_threaded.f90:202), b = comp*ntile + tile; only
 // the box columns are written, to box + comp*box_comp_stride + tile*fb^3; lo = nb-2 (first box cell).
+// Same persistent, pipelined structure as the forward pass; the per-row source/destination tables are
+// double-buffered because the prefetch needs the next batch's.
 template <int RSET>
-__global__ __launch_bounds__(256) void k_fft_x_inv(const float2 *__restrict__ src, float *__restrict__ out, int n, int px, int rows_total, int RB,
+__global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ src, float *__restrict__ out, int n, int px, int rows_total, int RB,
                                                    int RBP, Factors fac, const float2 *__restrict__ tw_g, float inv_scale, int mode,
                                                    float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
   extern __shared__ float2 lds[];
   const int h = n >> 1, nchunk = px / BXC, fbp = (fb + 3) & ~3;
   float2 *A = lds, *B = A + (h + 1) * RBP, *tw = B + (h + 1) * RBP;
-  __shared__ int64_t src_bz[64], dst_off[64];
-  __shared__ int src_y[64];
-  for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
-  const int64_t row0 = (int64_t)blockIdx.x * RB;
-  const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
-  if (threadIdx.x < nrows) {
-    const int64_t srow = row0 + threadIdx.x;
-    if (mode == 1) {
-      const int jj = (int)(srow % fb); const int64_t t2 = srow / fb; const int kk = (int)(t2 % fb); const int64_t b = t2 / fb;
-      const int comp = (int)(b / ntile), tl = (int)(b % ntile);
-      src_bz[threadIdx.x] = b * n + (kk + lo); src_y[threadIdx.x] = jj + lo;
-      dst_off[threadIdx.x] = comp * box_comp_stride + (((int64_t)tl * fb + kk) * fb + jj) * fbp;
+  __shared__ int64_t src_row[2][64], dst_off[2][64];   // element offset of (row, chunk 0, column 0) in LY; chunks are n*16 apart
+  for (int i = threadIdx.x; i < n; i += XTB) tw[i] = tw_g[i];
+  const int nbatch = (rows_total + RB - 1) / RB;
+  const int ncol = (h + BXC) & ~(BXC - 1);   // columns 0..h rounded up to whole chunks
+  const int ne = RB * (ncol >> 1);
+  auto tables = [&](int w, int buf) {
+    const int64_t srow = (int64_t)w * RB + threadIdx.x;
+    if ((int)threadIdx.x < RB && srow < rows_total) {
+      if (mode == 1) {
+        // rows_total is an int: 32-bit unsigned divisions
+        const unsigned s32 = (unsigned)srow, t2 = s32 / (unsigned)fb, bb = t2 / (unsigned)fb;
+        const int jj = (int)(s32 - t2 * fb), kk = (int)(t2 - bb * fb);
+        const int comp = (int)(bb / (unsigned)ntile), tl = (int)(bb - comp * ntile);
+        const int64_t b = bb;
+        src_row[buf][threadIdx.x] = (((b * n + (kk + lo)) * nchunk) * n + (jj + lo)) * BXC;
+        dst_off[buf][threadIdx.x] = comp * box_comp_stride + (((int64_t)tl * fb + kk) * fb + jj) * fbp;
+      } else {
+        const unsigned bz = (unsigned)srow / (unsigned)n;
+        src_row[buf][threadIdx.x] = (((int64_t)bz * nchunk) * n + ((unsigned)srow - bz * n)) * BXC;
+        dst_off[buf][threadIdx.x] = srow * (int64_t)(2 * px);
+      }
+    }
+  };
+  const fdiv_t dRB = mk_fdiv(RB), dPx = mk_fdiv(px), dNq = mk_fdiv(fbp >> 2 ? fbp >> 2 : 1);
+  int lrc[XLU];   // l4 | row << 3 | chunk << 9, or -1
+#pragma unroll
+  for (int u = 0; u < XLU; u++) { const int e = (int)threadIdx.x + u * XTB; lrc[u] = e < ne ? ((e & 7) | (((e >> 3) % RB) << 3) | (((e >> 3) / RB) << 9)) : -1; }
+  float4 v[XLU];
+  auto fetch = [&](int w, int buf) {
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - (int64_t)w * RB);
+#pragma unroll
+    for (int u = 0; u < XLU; u++) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int l4 = lrc[u] & 7, r = (lrc[u] >> 3) & 63, chunk = lrc[u] >> 9;
+      if (lrc[u] >= 0 && r < nrows) v[u] = reinterpret_cast<const float4 *>(src + src_row[buf][r] + (int64_t)chunk * n * BXC)[l4];
+    }
+  };
+  int w = blockIdx.x, buf = 0;
+  if (w < nbatch) tables(w, 0);
+  __syncthreads();
+  if (w < nbatch) fetch(w, 0);
+  for (; w < nbatch; w += gridDim.x, buf ^= 1) {
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - (int64_t)w * RB);
+    const int wn = w + gridDim.x;
+    // the gathered rows (columns 0..h) go to B[k*RBP + r]
+#pragma unroll
+    for (int u = 0; u < XLU; u++)
+      if (lrc[u] >= 0) {
+        const int l4 = lrc[u] & 7, r = (lrc[u] >> 3) & 63, chunk = lrc[u] >> 9;
+        const int k = chunk * BXC + 2 * l4;
+        if (k <= h) B[k * RBP + r] = make_float2(v[u].x, v[u].y);
+        if (k + 1 <= h) B[(k + 1) * RBP + r] = make_float2(v[u].z, v[u].w);
+      }
+    if (wn < nbatch) tables(wn, buf ^ 1);
+    __syncthreads();
+    if (wn < nbatch) fetch(wn, buf ^ 1);
+    // Z'[m] = (X[m] + conj X[h-m]) + i (X[m] - conj X[h-m]) W_n^{-m}; conj() on the way in: the
+    // forward machinery then yields conj(IFFT), undone on the way out.
+    const fdiv_t dR = nrows == RB ? dRB : mk_fdiv(nrows);
+    for (int e = threadIdx.x; e < nrows * h; e += XTB) {
+      const int m = fdiv(e, dR), r = e - m * nrows;
+      const float2 xk = B[m * RBP + r], xc = cconj(B[(h - m) * RBP + r]);
+      const float2 e2 = cadd(xk, xc), d = csub(xk, xc);
+      const float2 o = cmul(d, cconj(tw[m]));
+      A[m * RBP + r] = make_float2(e2.x - o.y, -(e2.y + o.x));  // conj(e + i o)
+    }
+    __syncthreads();
+    const float2 *Z = fft_lds<false, RSET>(A, B, h, nrows, RBP, 1, fac, tw, 2);
+    if (mode == 0) {
+      for (int e = threadIdx.x; e < nrows * px; e += XTB) {
+        const int r = fdiv(e, dPx), m = e - r * px;
+        float2 z = make_float2(0.f, 0.f);
+        if (m < h) { z = Z[m * RBP + r]; z = make_float2(z.x / inv_scale, -z.y / inv_scale); }
+        reinterpret_cast<float2 *>(out + dst_off[buf][r])[m] = z;
+      }
     } else {
-      src_bz[threadIdx.x] = srow / n; src_y[threadIdx.x] = (int)(srow % n);
-      dst_off[threadIdx.x] = srow * (int64_t)(2 * px);
-    }
-  }
-  __syncthreads();
-  // gather the rows (columns 0..h) out of LY into B[k*RBP + r]
-  {
-    const int ncol = (h + BXC) & ~(BXC - 1);   // columns 0..h rounded up to whole chunks
-    constexpr int LU = 6;
-    const int T = blockDim.x, ne = nrows * (ncol >> 1);
-    for (int e0 = threadIdx.x; e0 < ne; e0 += LU * T) {
-      float4 v[LU];
-#pragma unroll
-      for (int u = 0; u < LU; u++) {
-        const int e = min(e0 + u * T, ne - 1);
-        const int l4 = e & 7, r = (e >> 3) % nrows, chunk = (e >> 3) / nrows;
-        v[u] = reinterpret_cast<const float4 *>(src + ((src_bz[r] * nchunk + chunk) * n + src_y[r]) * BXC)[l4];
-      }
-#pragma unroll
-      for (int u = 0; u < LU; u++) {
-        const int e = e0 + u * T;
-        if (e < ne) {
-          const int l4 = e & 7, r = (e >> 3) % nrows, chunk = (e >> 3) / nrows;
-          const int k = chunk * BXC + 2 * l4;
-          if (k <= h) B[k * RBP + r] = make_float2(v[u].x, v[u].y);
-          if (k + 1 <= h) B[(k + 1) * RBP + r] = make_float2(v[u].z, v[u].w);
-        }
+      // 4 consecutive box cells = 2 complex values per lane, one 16-byte store (lo is even, fbp % 4 == 0)
+      const int nq = fbp >> 2;
+      for (int e = threadIdx.x; e < nrows * nq; e += XTB) {
+        const int r = fdiv(e, dNq), q = e - r * nq;
+        const int cx = (4 * q + lo) >> 1;
+        const float2 z0 = Z[cx * RBP + r], z1 = Z[(cx + 1) * RBP + r];
+        float4 o = make_float4(z0.x / inv_scale, -z0.y / inv_scale, z1.x / inv_scale, -z1.y / inv_scale);
+        if (4 * q + 0 >= fb) o.x = 0.f;
+        if (4 * q + 1 >= fb) o.y = 0.f;
+        if (4 * q + 2 >= fb) o.z = 0.f;
+        if (4 * q + 3 >= fb) o.w = 0.f;
+        *reinterpret_cast<float4 *>(box + dst_off[buf][r] + 4 * q) = o;
       }
     }
-  }
-  __syncthreads();
-  // Z'[m] = (X[m] + conj X[h-m]) + i (X[m] - conj X[h-m]) W_n^{-m}; conj() on the way in: the
-  // forward machinery then yields conj(IFFT), undone on the way out.
-  for (int e = threadIdx.x; e < nrows * h; e += blockDim.x) {
-    const int r = e % nrows, m = e / nrows;
-    const float2 xk = B[m * RBP + r], xc = cconj(B[(h - m) * RBP + r]);
-    const float2 e2 = cadd(xk, xc), d = csub(xk, xc);
-    const float2 o = cmul(d, cconj(tw[m]));
-    A[m * RBP + r] = make_float2(e2.x - o.y, -(e2.y + o.x));  // conj(e + i o)
-  }
-  __syncthreads();
-  const float2 *Z = fft_lds<false, RSET>(A, B, h, nrows, RBP, 1, fac, tw, 2);
-  if (mode == 0) {
-    for (int e = threadIdx.x; e < nrows * px; e += blockDim.x) {
-      const int r = e / px, m = e - r * px;
-      float2 z = make_float2(0.f, 0.f);
-      if (m < h) { z = Z[m * RBP + r]; z = make_float2(z.x / inv_scale, -z.y / inv_scale); }
-      reinterpret_cast<float2 *>(out + dst_off[r])[m] = z;
-    }
-  } else {
-    // 4 consecutive box cells = 2 complex values per lane, one 16-byte store (lo is even, fbp % 4 == 0)
-    const int nq = fbp >> 2;
-    for (int e = threadIdx.x; e < nrows * nq; e += blockDim.x) {
-      const int r = e / nq, q = e - r * nq;
-      const int cx = (4 * q + lo) >> 1;
-      const float2 z0 = Z[cx * RBP + r], z1 = Z[(cx + 1) * RBP + r];
-      float4 o = make_float4(z0.x / inv_scale, -z0.y / inv_scale, z1.x / inv_scale, -z1.y / inv_scale);
-      if (4 * q + 0 >= fb) o.x = 0.f;
-      if (4 * q + 1 >= fb) o.y = 0.f;
-      if (4 * q + 2 >= fb) o.z = 0.f;
-      if (4 * q + 3 >= fb) o.w = 0.f;
-      *reinterpret_cast<float4 *>(box + dst_off[r] + 4 * q) = o;
-    }
+    __syncthreads();
   }
 }
 
@@ -324,7 +355,13 @@ int fft_plan_create(FftPlan *pl, int n) {
 }
 void fft_plan_destroy(FftPlan *pl) { if (pl->d_tw) (void)hipFree(pl->d_tw); pl->d_tw = nullptr; }
 
-static Factors mkfac(int nfac, const int *f) { Factors F; F.nfac = nfac; for (int i = 0; i < nfac; i++) F.f[i] = f[i]; return F; }
+static Factors mkfac(int nfac, const int *f) {
+  Factors F{}; F.nfac = nfac;
+  int n = 1; for (int i = 0; i < nfac; i++) n *= f[i];
+  int Ns = 1;
+  for (int i = 0; i < nfac; i++) { F.f[i] = f[i]; F.mNs[i] = fdiv_magic(Ns); F.mNb[i] = fdiv_magic(n / f[i]); Ns *= f[i]; }
+  return F;
+}
 
 template <typename K> static int set_lds(K kern, size_t bytes) {
   if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -333,7 +370,17 @@ template <typename K> static int set_lds(K kern, size_t bytes) {
 static void x_rows(int n, int *RB, int *RBP) {
   int rb = (2816 / (n / 2)) / 8 * 8;
   rb = rb < 8 ? 8 : (rb > 64 ? 64 : rb);
+  // one batch must fit the XLU prefetch registers of both x kernels
+  const int h = n / 2, ncol = (h + BXC) & ~(BXC - 1);
+  while (rb > 8 && (rb * (ncol / 2) > XLU * XTB || rb * (n / 4) > XLU * XTB)) rb -= 8;
   *RB = rb; *RBP = rb | 1;
+}
+// persistent grid of the x kernels: what is resident at once, never more than there are batches
+template <typename K> static int x_grid(K kern, size_t lds, int64_t nbatch) {
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), XTB, lds) != hipSuccess || occ < 1) occ = 1;
+  const int64_t g = (int64_t)256 * occ;
+  return (int)(g < nbatch ? g : (nbatch < 1 ? 1 : nbatch));
 }
 
 static int rset_of(int nfac, const int *fac) {
@@ -345,7 +392,7 @@ template <int RSET> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const f
   const int n = pl.n; int RB, RBP; x_rows(n, &RB, &RBP);
   const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2) * RBP + n);
   P3M_TRY(set_lds(k_fft_x_fwd<RSET>, lds));
-  hipLaunchKernelGGL(k_fft_x_fwd<RSET>, dim3(cdiv(rows, RB)), dim3(256), lds, c->stream, src, reinterpret_cast<float2 *>(dst), n, pl.px, (int)rows, RB,
+  hipLaunchKernelGGL(k_fft_x_fwd<RSET>, dim3(x_grid(k_fft_x_fwd<RSET>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream, src, reinterpret_cast<float2 *>(dst), n, pl.px, (int)rows, RB,
                      RBP, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
@@ -368,7 +415,7 @@ static int x_inv_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *ou
   const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2 + 1) * RBP + n);
   const float scale = (float)n * (float)n * (float)n;  // real(nf_tile)**3, fftw2.f90:22
   P3M_TRY(set_lds(k_fft_x_inv<RSET>, lds));
-  hipLaunchKernelGGL(k_fft_x_inv<RSET>, dim3(cdiv(rows, RB)), dim3(256), lds, c->stream, reinterpret_cast<const float2 *>(src), out, n, pl.px, (int)rows,
+  hipLaunchKernelGGL(k_fft_x_inv<RSET>, dim3(x_grid(k_fft_x_inv<RSET>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream, reinterpret_cast<const float2 *>(src), out, n, pl.px, (int)rows,
                      RB, RBP, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw, scale, mode, box, fb, lo, ntile, bcs);
   HIP_TRY(hipGetLastError());
   return P3M_OK;

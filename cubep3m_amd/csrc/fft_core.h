@@ -1,6 +1,14 @@
 // fft_core.h -- in-LDS mixed-radix Stockham machinery shared by the FFT kernels (see fft.hip).
 #pragma once
-struct Factors { int nfac; int f[12]; };
+// mNs[s] / mNb[s]: division magics (see fdiv) of stage s's Ns = f[0]*...*f[s-1] and nb = n/f[s], filled by the host
+struct Factors { int nfac; int f[12]; unsigned mNs[12], mNb[12]; };
+
+// Exact x / d for x*d < 2^32 as one mulhi (the integer divisions of the index arithmetic otherwise cost more
+// issue slots than the butterflies): m = floor((2^32-1)/d) + 1; d == 1 wraps to m == 0 and is special-cased.
+struct fdiv_t { unsigned m; int d; };
+__host__ __device__ __forceinline__ unsigned fdiv_magic(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }
+__device__ __forceinline__ fdiv_t mk_fdiv(int d) { fdiv_t f; f.m = fdiv_magic(d); f.d = d; return f; }
+__device__ __forceinline__ int fdiv(int x, fdiv_t f) { return f.d == 1 ? x : (int)__umulhi((unsigned)x, f.m); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -114,15 +122,17 @@ template <> __device__ __forceinline__ void dft<19>(float2 (&v)[19]) { dft_odd<1
 // k = 0) nor in the last (Ns = n/R > j, k = j); NL > 0 makes the line count a compile-time constant.
 template <int R, bool ROWS, int NL>
 __device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 *__restrict__ out, int n, int Ns, int nl_rt,
-                                          int sI, int sL, const float2 *__restrict__ tw, int twm) {
+                                          int sI, int sL, const float2 *__restrict__ tw, int twm, fdiv_t dNs, fdiv_t dNb, fdiv_t dNl) {
   const int nl = NL > 0 ? NL : nl_rt;
   const int nb = n / R, ntask = nb * nl;
   const int tstep = (n / (Ns * R)) * twm;
   const bool last = (Ns == nb);
   for (int task = threadIdx.x; task < ntask; task += blockDim.x) {
     int j, line;
-    if (ROWS) { line = task / nb; j = task - line * nb; } else { j = task / nl; line = task - j * nl; }
-    const int k = (Ns == 1) ? 0 : (last ? j : j % Ns);
+    if (ROWS) { line = fdiv(task, dNb); j = task - line * nb; }
+    else if (NL > 0) { j = task / NL; line = task - j * NL; }
+    else { j = fdiv(task, dNl); line = task - j * nl; }
+    const int k = (Ns == 1) ? 0 : (last ? j : j - fdiv(j, dNs) * Ns);
     const float2 *pin = in + line * sL;
     float2 v[R];
 #pragma unroll
@@ -150,24 +160,26 @@ __device__ __forceinline__ float2 *fft_lds(float2 *A, float2 *B, int n, int nl, 
 #ifdef P3M_ABLATE_NOFFT   // timing-only build: global<->LDS traffic without the butterflies (outputs are wrong)
   return in;
 #endif
+  const fdiv_t dNl = mk_fdiv(NL > 0 ? NL : nl);
   for (int s = 0; s < fac.nfac; s++) {
     const int R = fac.f[s];
+    fdiv_t dNs, dNb; dNs.m = fac.mNs[s]; dNs.d = Ns; dNb.m = fac.mNb[s]; dNb.d = n / R;
     switch (R) {
-      case 2: fft_stage<2, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 3: fft_stage<3, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 4: fft_stage<4, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 5: fft_stage<5, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 7: fft_stage<7, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 8: fft_stage<8, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
-      case 16: fft_stage<16, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm); break;
+      case 2: fft_stage<2, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl); break;
+      case 3: fft_stage<3, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl); break;
+      case 4: fft_stage<4, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl); break;
+      case 5: fft_stage<5, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl); break;
+      case 7: fft_stage<7, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl); break;
+      case 8: fft_stage<8, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl); break;
+      case 16: fft_stage<16, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl); break;
       default:
         if constexpr (RSET >= 1) {
-          if (R == 11) fft_stage<11, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
-          else if (R == 13) fft_stage<13, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          if (R == 11) fft_stage<11, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl);
+          else if (R == 13) fft_stage<13, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl);
         }
         if constexpr (RSET >= 2) {
-          if (R == 17) fft_stage<17, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
-          else if (R == 19) fft_stage<19, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm);
+          if (R == 17) fft_stage<17, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl);
+          else if (R == 19) fft_stage<19, ROWS, NL>(in, out, n, Ns, nl, sI, sL, tw, twm, dNs, dNb, dNl);
         }
         break;
     }
