@@ -40,21 +40,22 @@ __device__ __forceinline__ int64_t bundle_off2(int64_t b, int planes, int line, 
 }
 
 // ------------------------------------------------------------------ x pass, forward (r2c): ROWS -> LY
-// RB consecutive rows per batch; LDS holds element m of row r at m*RBP + r with RBP odd
-// (conflict-free both along rows and along the transform).  Persistent workgroups walk a grid-stride
-// list of batches, software-pipelined like k_fft_lines: the next batch's rows are in flight (XLU 16-byte
-// loads per lane, whose (row, quad) split is loop-invariant) while the butterflies of this one run.
+// RB consecutive rows per batch (a power of two, compile-time, so that all LDS index arithmetic is shifts
+// and adds); LDS holds element m of row r at m*(RB+1) + r (odd pitch: conflict-free both along rows and
+// along the transform).  Persistent workgroups walk a grid-stride list of batches, software-pipelined
+// like k_fft_lines: the next batch's rows are in flight (XLU 16-byte loads per lane, whose (row, quad)
+// split is loop-invariant) while the butterflies of this one run.  A short last batch is padded with zero rows.
 constexpr int XTB = 256, XLU = 6;
-template <int RSET>
-__global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src, float2 *__restrict__ dst, int n, int px, int rows_total, int RB,
-                                                   int RBP, Factors fac, const float2 *__restrict__ tw_g) {
+template <int RSET, int RB>
+__global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src, float2 *__restrict__ dst, int n, int px, int rows_total,
+                                                   Factors fac, const float2 *__restrict__ tw_g) {
   extern __shared__ float2 lds[];
+  constexpr int RBP = RB + 1, LRB = __builtin_ctz(RB);
   const int h = n >> 1, q4 = n >> 2, nchunk = px / BXC;
   float2 *A = lds, *B = A + h * RBP, *tw = B + h * RBP;
   for (int i = threadIdx.x; i < n; i += XTB) tw[i] = tw_g[i];
   const int nbatch = (rows_total + RB - 1) / RB, ne = RB * q4;
-  __shared__ int64_t drow[64];
-  const fdiv_t dRB = mk_fdiv(RB);
+  __shared__ int64_t drow[RB];
   int rq[XLU];   // row | quad << 8, or -1
 #pragma unroll
   for (int u = 0; u < XLU; u++) { const int e = (int)threadIdx.x + u * XTB; const int r = e / q4; rq[u] = e < ne ? (r | ((e - r * q4) << 8)) : -1; }
@@ -76,20 +77,19 @@ __global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src
     const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
 #pragma unroll
     for (int u = 0; u < XLU; u++)
-      if (rq[u] >= 0) { const int r = rq[u] & 255, m = rq[u] >> 8; A[(2 * m) * RBP + r] = make_float2(v[u].x, v[u].y); A[(2 * m + 1) * RBP + r] = make_float2(v[u].z, v[u].w); }
+      if (rq[u] >= 0) { const int r = rq[u] & 255, m = rq[u] >> 8; float2 *pa = A + (2 * m) * RBP + r; pa[0] = make_float2(v[u].x, v[u].y); pa[RBP] = make_float2(v[u].z, v[u].w); }
     __syncthreads();
     { const int wn = w + gridDim.x; if (wn < nbatch) fetch(wn); }
     if ((int)threadIdx.x < nrows) {   // LY offset of (row, chunk 0, column 0); read after the barriers of fft_lds
       const unsigned row = (unsigned)row0 + threadIdx.x, bz = row / (unsigned)n;   // bz = b*n + z; rows_total is an int
       drow[threadIdx.x] = (((int64_t)bz * nchunk) * n + (row - bz * n)) * BXC;
     }
-    const float2 *Z = fft_lds<false, RSET>(A, B, h, nrows, RBP, 1, fac, tw, 2);
+    const float2 *Z = fft_lds<false, RSET, RB>(A, B, h, RB, RBP, 1, fac, tw, 2);
     // X[k] = E + W_n^k O,  E = (Z[k]+conj Z[h-k])/2,  O = (Z[k]-conj Z[h-k])/(2i); lanes run over the 16
     // columns of a chunk, then over rows: consecutive rows of one chunk are contiguous in LY
-    const int tot = nrows * px;
-    const fdiv_t dR = nrows == RB ? dRB : mk_fdiv(nrows);
+    const int tot = RB * px;
     for (int e = threadIdx.x; e < tot; e += XTB) {
-      const int l = e & (BXC - 1), chunk = fdiv(e >> 4, dR), r = (e >> 4) - chunk * nrows;
+      const int l = e & (BXC - 1), r = (e >> 4) & (RB - 1), chunk = e >> (4 + LRB);
       const int k = chunk * BXC + l;
       float2 X = make_float2(0.f, 0.f);
       if (k <= h) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src
         const float2 wk = (k == h) ? make_float2(-1.f, 0.f) : tw[k];
         X = cadd(E, cmul(O, wk));
       }
-      dst[drow[r] + ((int64_t)chunk * n) * BXC + l] = X;
+      if (r < nrows) dst[drow[r] + ((int64_t)chunk * n) * BXC + l] = X;
     }
     __syncthreads();
   }
@@ -112,14 +112,15 @@ __global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src
 // the box columns are written, to box + comp*box_comp_stride + tile*fb^3; lo = nb-2 (first box cell).
 // Same persistent, pipelined structure as the forward pass; the per-row source/destination tables are
 // double-buffered because the prefetch needs the next batch's.
-template <int RSET>
-__global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ src, float *__restrict__ out, int n, int px, int rows_total, int RB,
-                                                   int RBP, Factors fac, const float2 *__restrict__ tw_g, float inv_scale, int mode,
+template <int RSET, int RB>
+__global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ src, float *__restrict__ out, int n, int px, int rows_total,
+                                                   Factors fac, const float2 *__restrict__ tw_g, float inv_scale, int mode,
                                                    float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
   extern __shared__ float2 lds[];
+  constexpr int RBP = RB + 1, LRB = __builtin_ctz(RB);
   const int h = n >> 1, nchunk = px / BXC, fbp = (fb + 3) & ~3;
   float2 *A = lds, *B = A + (h + 1) * RBP, *tw = B + (h + 1) * RBP;
-  __shared__ int64_t src_row[2][64], dst_off[2][64];   // element offset of (row, chunk 0, column 0) in LY; chunks are n*16 apart
+  __shared__ int64_t src_row[2][RB], dst_off[2][RB];   // element offset of (row, chunk 0, column 0) in LY; chunks are n*16 apart
   for (int i = threadIdx.x; i < n; i += XTB) tw[i] = tw_g[i];
   const int nbatch = (rows_total + RB - 1) / RB;
   const int ncol = (h + BXC) & ~(BXC - 1);   // columns 0..h rounded up to whole chunks
@@ -142,18 +143,17 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
       }
     }
   };
-  const fdiv_t dRB = mk_fdiv(RB), dPx = mk_fdiv(px), dNq = mk_fdiv(fbp >> 2 ? fbp >> 2 : 1);
-  int lrc[XLU];   // l4 | row << 3 | chunk << 9, or -1
-#pragma unroll
-  for (int u = 0; u < XLU; u++) { const int e = (int)threadIdx.x + u * XTB; lrc[u] = e < ne ? ((e & 7) | (((e >> 3) % RB) << 3) | (((e >> 3) / RB) << 9)) : -1; }
+  const fdiv_t dPx = mk_fdiv(px), dNq = mk_fdiv(fbp >> 2 ? fbp >> 2 : 1);
   float4 v[XLU];
+  // load e = tid + u*XTB: l4 = e & 7, row = (e >> 3) & (RB-1), chunk = e >> (3 + LRB)
   auto fetch = [&](int w, int buf) {
     const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - (int64_t)w * RB);
 #pragma unroll
     for (int u = 0; u < XLU; u++) {
+      const int e = (int)threadIdx.x + u * XTB;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int l4 = lrc[u] & 7, r = (lrc[u] >> 3) & 63, chunk = lrc[u] >> 9;
-      if (lrc[u] >= 0 && r < nrows) v[u] = reinterpret_cast<const float4 *>(src + src_row[buf][r] + (int64_t)chunk * n * BXC)[l4];
+      const int l4 = e & 7, r = (e >> 3) & (RB - 1), chunk = e >> (3 + LRB);
+      if (e < ne && r < nrows) v[u] = reinterpret_cast<const float4 *>(src + src_row[buf][r] + (int64_t)chunk * n * BXC)[l4];
     }
   };
   int w = blockIdx.x, buf = 0;
@@ -165,28 +165,30 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
     const int wn = w + gridDim.x;
     // the gathered rows (columns 0..h) go to B[k*RBP + r]
 #pragma unroll
-    for (int u = 0; u < XLU; u++)
-      if (lrc[u] >= 0) {
-        const int l4 = lrc[u] & 7, r = (lrc[u] >> 3) & 63, chunk = lrc[u] >> 9;
+    for (int u = 0; u < XLU; u++) {
+      const int e = (int)threadIdx.x + u * XTB;
+      if (e < ne) {
+        const int l4 = e & 7, r = (e >> 3) & (RB - 1), chunk = e >> (3 + LRB);
         const int k = chunk * BXC + 2 * l4;
-        if (k <= h) B[k * RBP + r] = make_float2(v[u].x, v[u].y);
-        if (k + 1 <= h) B[(k + 1) * RBP + r] = make_float2(v[u].z, v[u].w);
+        float2 *pb = B + k * RBP + r;
+        if (k <= h) pb[0] = make_float2(v[u].x, v[u].y);
+        if (k + 1 <= h) pb[RBP] = make_float2(v[u].z, v[u].w);
       }
+    }
     if (wn < nbatch) tables(wn, buf ^ 1);
     __syncthreads();
     if (wn < nbatch) fetch(wn, buf ^ 1);
     // Z'[m] = (X[m] + conj X[h-m]) + i (X[m] - conj X[h-m]) W_n^{-m}; conj() on the way in: the
     // forward machinery then yields conj(IFFT), undone on the way out.
-    const fdiv_t dR = nrows == RB ? dRB : mk_fdiv(nrows);
-    for (int e = threadIdx.x; e < nrows * h; e += XTB) {
-      const int m = fdiv(e, dR), r = e - m * nrows;
+    for (int e = threadIdx.x; e < RB * h; e += XTB) {
+      const int m = e >> LRB, r = e & (RB - 1);
       const float2 xk = B[m * RBP + r], xc = cconj(B[(h - m) * RBP + r]);
       const float2 e2 = cadd(xk, xc), d = csub(xk, xc);
       const float2 o = cmul(d, cconj(tw[m]));
       A[m * RBP + r] = make_float2(e2.x - o.y, -(e2.y + o.x));  // conj(e + i o)
     }
     __syncthreads();
-    const float2 *Z = fft_lds<false, RSET>(A, B, h, nrows, RBP, 1, fac, tw, 2);
+    const float2 *Z = fft_lds<false, RSET, RB>(A, B, h, RB, RBP, 1, fac, tw, 2);
     if (mode == 0) {
       for (int e = threadIdx.x; e < nrows * px; e += XTB) {
         const int r = fdiv(e, dPx), m = e - r * px;
@@ -367,13 +369,12 @@ template <typename K> static int set_lds(K kern, size_t bytes) {
   if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return P3M_OK;
 }
-static void x_rows(int n, int *RB, int *RBP) {
-  int rb = (2816 / (n / 2)) / 8 * 8;
-  rb = rb < 8 ? 8 : (rb > 64 ? 64 : rb);
-  // one batch must fit the XLU prefetch registers of both x kernels
+// rows per batch: the largest power of two <= 64 whose batch fits the XLU prefetch registers of both x kernels
+static int x_rows(int n) {
   const int h = n / 2, ncol = (h + BXC) & ~(BXC - 1);
-  while (rb > 8 && (rb * (ncol / 2) > XLU * XTB || rb * (n / 4) > XLU * XTB)) rb -= 8;
-  *RB = rb; *RBP = rb | 1;
+  int rb = 64;
+  while (rb > 8 && (rb * h > 2816 || rb * (ncol / 2) > XLU * XTB || rb * (n / 4) > XLU * XTB)) rb >>= 1;
+  return rb;
 }
 // persistent grid of the x kernels: what is resident at once, never more than there are batches
 template <typename K> static int x_grid(K kern, size_t lds, int64_t nbatch) {
@@ -388,44 +389,64 @@ static int rset_of(int nfac, const int *fac) {
   for (int i = 0; i < nfac; i++) { if (fac[i] >= 17) r = 2; else if (fac[i] >= 11 && r < 1) r = 1; }
   return r;
 }
-template <int RSET> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
-  const int n = pl.n; int RB, RBP; x_rows(n, &RB, &RBP);
-  const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2) * RBP + n);
-  P3M_TRY(set_lds(k_fft_x_fwd<RSET>, lds));
-  hipLaunchKernelGGL(k_fft_x_fwd<RSET>, dim3(x_grid(k_fft_x_fwd<RSET>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream, src, reinterpret_cast<float2 *>(dst), n, pl.px, (int)rows, RB,
-                     RBP, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw);
+template <int RSET, int RB> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+  const int n = pl.n;
+  if (n > 8 * XLU * XTB / 2 || rows > 0x7fffffffLL) { p3m_set_error("fft x pass: n=%d or %lld rows out of range", n, (long long)rows); return P3M_EINVAL; }
+  const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2) * (RB + 1) + n);
+  P3M_TRY((set_lds(k_fft_x_fwd<RSET, RB>, lds)));
+  hipLaunchKernelGGL((k_fft_x_fwd<RSET, RB>), dim3(x_grid(k_fft_x_fwd<RSET, RB>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream, src,
+                     reinterpret_cast<float2 *>(dst), n, pl.px, (int)rows, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
+template <int RSET> static int x_fwd_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+  switch (x_rows(pl.n)) {
+    case 8: return x_fwd_impl<RSET, 8>(c, pl, src, dst, rows);
+    case 16: return x_fwd_impl<RSET, 16>(c, pl, src, dst, rows);
+    case 32: return x_fwd_impl<RSET, 32>(c, pl, src, dst, rows);
+    default: return x_fwd_impl<RSET, 64>(c, pl, src, dst, rows);
+  }
+}
 int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
   switch (rset_of(pl.nfac_half, pl.fac_half)) {
-    case 0: return x_fwd_impl<0>(c, pl, src, dst, rows);
-    case 1: return x_fwd_impl<1>(c, pl, src, dst, rows);
-    default: return x_fwd_impl<2>(c, pl, src, dst, rows);
+    case 0: return x_fwd_rb<0>(c, pl, src, dst, rows);
+    case 1: return x_fwd_rb<1>(c, pl, src, dst, rows);
+    default: return x_fwd_rb<2>(c, pl, src, dst, rows);
   }
 }
 int fft_x_forward(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int batch) {
   return fft_x_forward_rows(c, pl, src, dst, (int64_t)batch * pl.n * pl.n);
 }
-template <int RSET>
+template <int RSET, int RB>
 static int x_inv_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
-  const int n = pl.n; int RB, RBP; x_rows(n, &RB, &RBP);
+  const int n = pl.n;
   // mode 0: `batch` counts ROWS when negative (distributed slabs), whole n^2 arrays otherwise
   const int64_t rows = mode == 0 ? (batch < 0 ? -(int64_t)batch : (int64_t)batch * n * n) : (int64_t)batch * fb * fb;
-  const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2 + 1) * RBP + n);
+  if (rows > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)rows); return P3M_EINVAL; }
+  const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2 + 1) * (RB + 1) + n);
   const float scale = (float)n * (float)n * (float)n;  // real(nf_tile)**3, fftw2.f90:22
-  P3M_TRY(set_lds(k_fft_x_inv<RSET>, lds));
-  hipLaunchKernelGGL(k_fft_x_inv<RSET>, dim3(x_grid(k_fft_x_inv<RSET>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream, reinterpret_cast<const float2 *>(src), out, n, pl.px, (int)rows,
-                     RB, RBP, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw, scale, mode, box, fb, lo, ntile, bcs);
+  P3M_TRY((set_lds(k_fft_x_inv<RSET, RB>, lds)));
+  hipLaunchKernelGGL((k_fft_x_inv<RSET, RB>), dim3(x_grid(k_fft_x_inv<RSET, RB>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream,
+                     reinterpret_cast<const float2 *>(src), out, n, pl.px, (int)rows, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw, scale, mode, box, fb, lo,
+                     ntile, bcs);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
+}
+template <int RSET>
+static int x_inv_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
+  switch (x_rows(pl.n)) {
+    case 8: return x_inv_impl<RSET, 8>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    case 16: return x_inv_impl<RSET, 16>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    case 32: return x_inv_impl<RSET, 32>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    default: return x_inv_impl<RSET, 64>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+  }
 }
 // src in LY; mode 0 writes real ROWS to out, mode 1 the force box
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
   switch (rset_of(pl.nfac_half, pl.fac_half)) {
-    case 0: return x_inv_impl<0>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
-    case 1: return x_inv_impl<1>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
-    default: return x_inv_impl<2>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    case 0: return x_inv_rb<0>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    case 1: return x_inv_rb<1>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    default: return x_inv_rb<2>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
   }
 }
 template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {

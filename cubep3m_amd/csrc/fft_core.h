@@ -127,26 +127,30 @@ __device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 
   const int nb = n / R, ntask = nb * nl;
   const int tstep = (n / (Ns * R)) * twm;
   const bool last = (Ns == nb);
+  // addresses are base + m*step with uniform steps (scalar multiplies); per-lane products go through the
+  // full-rate 24-bit multiplier (v_mul_lo_u32 is quarter rate and the indices are tiny)
+  const int step_in = nb * sI, step_out = Ns * sI;
   for (int task = threadIdx.x; task < ntask; task += blockDim.x) {
     int j, line;
-    if (ROWS) { line = fdiv(task, dNb); j = task - line * nb; }
+    if (ROWS) { line = fdiv(task, dNb); j = task - __mul24(line, nb); }
     else if (NL > 0) { j = task / NL; line = task - j * NL; }
-    else { j = fdiv(task, dNl); line = task - j * nl; }
-    const int k = (Ns == 1) ? 0 : (last ? j : j - fdiv(j, dNs) * Ns);
-    const float2 *pin = in + line * sL;
+    else { j = fdiv(task, dNl); line = task - __mul24(j, nl); }
+    const int k = (Ns == 1) ? 0 : (last ? j : j - __mul24(fdiv(j, dNs), Ns));
+    const float2 *pin = in + __mul24(line, sL) + __mul24(j, sI);
     float2 v[R];
 #pragma unroll
-    for (int m = 0; m < R; m++) v[m] = pin[(j + m * nb) * sI];
+    for (int m = 0; m < R; m++) v[m] = pin[m * step_in];
     if (Ns > 1) {
-      const int ts = tstep * k;
+      const int ts = __mul24(tstep, k);
+      int ti = ts;
 #pragma unroll
-      for (int m = 1; m < R; m++) v[m] = cmul(v[m], tw[m * ts]);
+      for (int m = 1; m < R; m++) { v[m] = cmul(v[m], tw[ti]); ti += ts; }
     }
     dft<R>(v);
-    const int j0 = (j - k) * R + k;
-    float2 *pout = out + line * sL;
+    const int j0 = __mul24(j - k, R) + k;
+    float2 *pout = out + __mul24(line, sL) + __mul24(j0, sI);
 #pragma unroll
-    for (int m = 0; m < R; m++) pout[(j0 + m * Ns) * sI] = v[m];
+    for (int m = 0; m < R; m++) pout[m * step_out] = v[m];
   }
 }
 
