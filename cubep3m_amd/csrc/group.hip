@@ -54,6 +54,8 @@ struct p3m_group {
   std::vector<p3m_ctx *> ctx; std::vector<int> lrank, owner, lidx;
   std::vector<CoarseDist> cd;
   ncclComm_t comm = nullptr; bool force_nccl = false;
+  p3m_transport tr{}; bool have_tr = false;
+  char *h_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};   // pinned send / receive staging of the host transport
   FftPlan plan_c; int s = 0, nchunk = 0, cap_buf = 0;
   int *h_cnt = nullptr;        // pinned [nlocal*4]
   float *d_red4 = nullptr; double *d_sum3 = nullptr; float *h_red4 = nullptr; double *h_sum3 = nullptr;
@@ -62,6 +64,52 @@ struct p3m_group {
 };
 
 struct XMsg { int src, dst; const void *sptr; void *rptr; size_t bytes; };
+
+// Host-callback route: the messages to / from each peer process are concatenated (in list order, which is
+// the same on both sides) into pinned staging, handed to ONE exchange callback, and copied back up.
+static int host_exchange(p3m_group *G, const std::vector<XMsg> &msgs) {
+  const int np = G->nprocs;
+  std::vector<size_t> sb(np, 0), rb(np, 0), so(np, 0), ro(np, 0);
+  for (const XMsg &m : msgs) {
+    const int ps = G->owner[m.src], pd = G->owner[m.dst];
+    if (m.bytes == 0 || ps == pd) continue;
+    if (ps == G->proc) sb[pd] += m.bytes;
+    if (pd == G->proc) rb[ps] += m.bytes;
+  }
+  size_t tot[2] = {0, 0};
+  for (int q = 0; q < np; q++) { so[q] = tot[0]; ro[q] = tot[1]; tot[0] += sb[q]; tot[1] += rb[q]; }
+  for (int k = 0; k < 2; k++)
+    if (tot[k] > G->stage_cap[k]) {
+      if (G->h_stage[k]) (void)hipHostFree(G->h_stage[k]);
+      G->h_stage[k] = nullptr; G->stage_cap[k] = 0;
+      const size_t cap = tot[k] + tot[k] / 4 + 4096;
+      if (hipHostMalloc(reinterpret_cast<void **>(&G->h_stage[k]), cap) != hipSuccess) { p3m_set_error("pinned staging of %zu bytes failed", cap); return P3M_ENOMEM; }
+      G->stage_cap[k] = cap;
+    }
+  std::vector<size_t> cur = so;
+  for (const XMsg &m : msgs) {
+    const int ps = G->owner[m.src], pd = G->owner[m.dst];
+    if (m.bytes == 0 || ps == pd || ps != G->proc) continue;
+    HIP_TRY(hipMemcpyAsync(G->h_stage[0] + cur[pd], m.sptr, m.bytes, hipMemcpyDeviceToHost, G->stream));
+    cur[pd] += m.bytes;
+  }
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  std::vector<int32_t> peer; std::vector<const void *> sp; std::vector<void *> rp; std::vector<int64_t> sn, rn;
+  for (int q = 0; q < np; q++)
+    if (sb[q] || rb[q]) { peer.push_back(q); sp.push_back(G->h_stage[0] + so[q]); rp.push_back(G->h_stage[1] + ro[q]); sn.push_back((int64_t)sb[q]); rn.push_back((int64_t)rb[q]); }
+  if (!peer.empty()) {
+    const int rc = G->tr.exchange(G->tr.user, (int32_t)peer.size(), peer.data(), sp.data(), sn.data(), rp.data(), rn.data());
+    if (rc) { p3m_set_error("host transport: exchange callback returned %d", rc); return P3M_ECOMM; }
+  }
+  cur = ro;
+  for (const XMsg &m : msgs) {
+    const int ps = G->owner[m.src], pd = G->owner[m.dst];
+    if (m.bytes == 0 || ps == pd || pd != G->proc) continue;
+    HIP_TRY(hipMemcpyAsync(m.rptr, G->h_stage[1] + cur[ps], m.bytes, hipMemcpyHostToDevice, G->stream));
+    cur[ps] += m.bytes;
+  }
+  return P3M_OK;
+}
 
 // every process builds the SAME global message list (same order); pointers are only needed for local ends
 static int do_exchange(p3m_group *G, const std::vector<XMsg> &msgs) {
@@ -73,7 +121,8 @@ static int do_exchange(p3m_group *G, const std::vector<XMsg> &msgs) {
     else if (sl || dl) any_remote = true;
   }
   if (!any_remote) return P3M_OK;
-  if (!G->comm) { p3m_set_error("group exchange needs RCCL (p3m_hip_group_comm_init_rccl)"); return P3M_ECOMM; }
+  if (!G->comm && G->have_tr) return host_exchange(G, msgs);
+  if (!G->comm) { p3m_set_error("group exchange between processes needs RCCL (p3m_hip_group_comm_init_rccl) or a host transport (p3m_hip_group_set_transport)"); return P3M_ECOMM; }
   NCCL_TRY(ncclGroupStart());
   for (const XMsg &m : msgs) {
     if (m.bytes == 0) continue;
@@ -111,6 +160,7 @@ extern "C" void p3m_hip_group_destroy(p3m_group *G) {
   if (G->h_cnt) (void)hipHostFree(G->h_cnt);
   if (G->h_red4) (void)hipHostFree(G->h_red4);
   if (G->h_sum3) (void)hipHostFree(G->h_sum3);
+  for (int k = 0; k < 2; k++) if (G->h_stage[k]) (void)hipHostFree(G->h_stage[k]);
   fft_plan_destroy(&G->plan_c);
   if (G->stream) (void)hipStreamDestroy(G->stream);
   delete G;
@@ -189,6 +239,11 @@ extern "C" int p3m_hip_group_comm_init_rccl(p3m_group *G, const void *unique_id_
   ncclUniqueId id; memcpy(&id, unique_id_128, sizeof(id));
   NCCL_TRY(ncclCommInitRank(&G->comm, G->nprocs, id, G->proc));
   G->force_nccl = force_for_local_peers != 0;
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_set_transport(p3m_group *G, const p3m_transport *t) {
+  if (!G || !t || !t->exchange || !t->allreduce_max_f32 || !t->allreduce_sum_f64) return P3M_EINVAL;
+  G->tr = *t; G->have_tr = true;
   return P3M_OK;
 }
 extern "C" int p3m_hip_comm_init_rccl(p3m_ctx *ctx, const void *unique_id_128) {
@@ -585,7 +640,10 @@ static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out) {
     }
     sums[0] += c->h_sums[0]; sums[1] += c->h_sums[1]; sums[2] += (double)c->np_local; ng += c->np_ghost; ndel += c->np_deleted;
   }
-  if (G->nprocs > 1) {   // mpi_reduce + mpi_bcast pairs (:646-696, coarse_max_dt.f90:34-37) as two all-reduces
+  if (G->nprocs > 1 && !G->comm && G->have_tr) {   // host transport: the values are on the host already
+    if (G->tr.allreduce_max_f32(G->tr.user, v, 4) || G->tr.allreduce_sum_f64(G->tr.user, sums, 3)) { p3m_set_error("host transport: all-reduce callback failed"); return P3M_ECOMM; }
+  } else if (G->nprocs > 1) {   // mpi_reduce + mpi_bcast pairs (:646-696, coarse_max_dt.f90:34-37) as two all-reduces
+    if (!G->comm) { p3m_set_error("group reduction between processes needs RCCL or a host transport"); return P3M_ECOMM; }
     memcpy(G->h_red4, v, sizeof(v)); memcpy(G->h_sum3, sums, sizeof(sums));
     HIP_TRY(hipMemcpyAsync(G->d_red4, G->h_red4, 4 * sizeof(float), hipMemcpyHostToDevice, G->stream));
     HIP_TRY(hipMemcpyAsync(G->d_sum3, G->h_sum3, 3 * sizeof(double), hipMemcpyHostToDevice, G->stream));

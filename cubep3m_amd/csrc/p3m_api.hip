@@ -492,11 +492,11 @@ extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, fl
   return P3M_OK;
 }
 
-// ------------------------------------------------------------------ transport (multi-rank) -- see transport.hip
+// ------------------------------------------------------------------ transport (multi-rank) -- see group.hip
 extern "C" int p3m_hip_set_transport(p3m_ctx *c, const p3m_transport *t) {
-  if (!c || !t) return P3M_EINVAL;
-  c->transport = *t; c->have_transport = true;
-  return P3M_OK;
+  (void)c; (void)t;
+  p3m_set_error("multi-rank contexts are driven through p3m_hip_group_* (p3m_hip_group_set_transport)");
+  return P3M_ECOMM;
 }
 
 // ------------------------------------------------------------------ F77-ABI wrapper (style of pp_force_c_, nbody-ueli.cu:368)

@@ -96,7 +96,7 @@ struct p3m_ctx {
   p3m_step_out last{};
   int np_ghost = 0, np_deleted = 0;
   // ---- transport
-  p3m_transport transport{}; bool have_transport = false;
+  p3m_transport transport{}; bool have_transport = false;   // unused: exchanges belong to the group (group.hip)
   void *rccl_comm = nullptr;
 };
 

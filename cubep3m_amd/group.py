@@ -26,6 +26,60 @@ def rccl_unique_id() -> bytes:
     return bytes(buf)
 
 
+# ---- host transport (struct p3m_transport of include/p3m_hip.h) -----------------------------------
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+ALLREDUCE_F32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int32)
+ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+
+
+class P3MTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("exchange", EXCHANGE_FN), ("allreduce_max_f32", ALLREDUCE_F32_FN),
+                ("allreduce_sum_f64", ALLREDUCE_F64_FN)]
+
+
+def torch_transport(dist, group=None) -> P3MTransport:
+    """The three callbacks over a CPU-tensor torch.distributed backend (gloo): what an MPI host implements with
+    MPI_Irecv/MPI_Isend/MPI_Waitall and MPI_Allreduce.  Used where RCCL cannot connect the processes
+    (e.g. two processes sharing one GPU in the tests)."""
+    import traceback
+
+    import torch
+
+    def _view(ptr, nbytes):
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes),)))
+
+    def exchange(user, n, peer, sbuf, sbytes, rbuf, rbytes):
+        try:
+            works = []
+            for i in range(n):
+                if rbytes[i] > 0:
+                    works.append(dist.irecv(_view(rbuf[i], rbytes[i]), src=int(peer[i]), group=group))
+            for i in range(n):
+                if sbytes[i] > 0:
+                    works.append(dist.isend(_view(sbuf[i], sbytes[i]), dst=int(peer[i]), group=group))
+            for w in works:
+                w.wait()
+            return 0
+        except Exception:  # an exception must not unwind through the C frames
+            traceback.print_exc()
+            return 1
+
+    def _allreduce(ctype, op):
+        def fn(user, v, n):
+            try:
+                t = torch.from_numpy(np.ctypeslib.as_array(v, shape=(int(n),)))
+                dist.all_reduce(t, op=op, group=group)
+                return 0
+            except Exception:
+                traceback.print_exc()
+                return 1
+        return fn
+
+    return P3MTransport(None, EXCHANGE_FN(exchange), ALLREDUCE_F32_FN(_allreduce(C.c_float, dist.ReduceOp.MAX)),
+                        ALLREDUCE_F64_FN(_allreduce(C.c_double, dist.ReduceOp.SUM)))
+
+
 def rank_coords(rank, nd):
     return rank // (nd * nd), (rank // nd) % nd, rank % nd  # c1 (z), c2 (y), c3 (x)
 
@@ -58,7 +112,7 @@ def split_global(params: Params, xv, pid, ranks):
 
 class ParticleMeshGroup:
     def __init__(self, params: Params, proc=0, nprocs=1, fine_table=None, coarse_table=None, unique_id=None,
-                 force_rccl=False, set_kernels=True):
+                 force_rccl=False, set_kernels=True, transport: "P3MTransport | None" = None):
         self.params = params
         self.L = _lib.load()
         self._cp = params.to_c()
@@ -69,6 +123,9 @@ class ParticleMeshGroup:
         if unique_id is not None:
             buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id)[:128].ljust(128, b"\0"))
             _lib.check(self.L.p3m_hip_group_comm_init_rccl(self.h, C.cast(buf, C.c_void_p), 1 if force_rccl else 0))
+        if transport is not None:
+            self._transport = transport   # keeps the ctypes callbacks alive as long as the group
+            _lib.check(self.L.p3m_hip_group_set_transport(self.h, C.byref(transport)))
         self.nlocal = self.L.p3m_hip_group_nlocal(self.h)
         self.local_ranks = [self.L.p3m_hip_group_local_rank(self.h, i) for i in range(self.nlocal)]
         if set_kernels:

@@ -98,23 +98,22 @@ typedef struct p3m_step_out {
 } p3m_step_out;
 
 /*
- * Transport for multi-rank runs (replaces the MPI calls of particle_pass.f90,
- * fftw3ds.f90:24-39,84-99, coarse_force_buffer.f90:25-63 and the mpi_reduce/bcast pairs).
- * All buffers handed to the callbacks are HOST pointers (pinned staging owned by the
- * library) so that any transport can serve: MPI in a Fortran host, torch.distributed
- * (gloo or nccl) in the Python host.  With nodes_dim == 1 no transport is needed.
- * When the library is built with RCCL and p3m_hip_comm_init_rccl() has been called the
- * callbacks are bypassed and device buffers go straight over xGMI.
+ * Host transport for multi-process groups (replaces the MPI calls of particle_pass.f90,
+ * fftw3ds.f90:24-39,84-99, coarse_force_buffer.f90:25-63 and the mpi_reduce/bcast pairs) when the
+ * processes are NOT connected by RCCL: an MPI Fortran host, or torch.distributed/gloo in the Python
+ * host.  All buffers handed to the callbacks are HOST pointers (pinned staging owned by the
+ * library).  With RCCL (p3m_hip_group_comm_init_rccl) the callbacks are not used and device
+ * buffers go straight over xGMI.  Exchanges between logical ranks of one process never leave the GPU.
  */
 typedef struct p3m_transport {
   void *user;
-  /* exchange with two peers at once: send sbytes to dst, receive up to rcap bytes from src;
-     *rbytes returns what arrived.  (mpi_sendrecv_replace + isend/irecv pairs) */
-  int (*sendrecv)(void *user, const void *sbuf, int64_t sbytes, int32_t dst,
-                  void *rbuf, int64_t rcap, int64_t *rbytes, int32_t src, int32_t tag);
-  /* personalised all-to-all with equal block size (FFT transpose, pack_slab/unpack_slab) */
-  int (*alltoall)(void *user, const void *sbuf, void *rbuf, int64_t block_bytes);
-  /* in-place max / sum over all ranks (mpi_reduce + mpi_bcast pairs) */
+  /* One neighbourhood exchange: for i < npeers send sbytes[i] bytes from sbuf[i] to process peer[i] and
+     receive exactly rbytes[i] bytes from it into rbuf[i] (either may be 0).  Post every receive and send,
+     then wait for all (MPI_Irecv / MPI_Isend / MPI_Waitall).  All processes call this the same number of
+     times in the same order and the sizes agree by construction.  Return 0 on success. */
+  int (*exchange)(void *user, int32_t npeers, const int32_t *peer, const void *const *sbuf, const int64_t *sbytes,
+                  void *const *rbuf, const int64_t *rbytes);
+  /* in-place max / sum over all processes (the mpi_reduce + mpi_bcast pairs) */
   int (*allreduce_max_f32)(void *user, float *v, int32_t n);
   int (*allreduce_sum_f64)(void *user, double *v, int32_t n);
 } p3m_transport;
@@ -130,7 +129,7 @@ const char *p3m_hip_last_error(void);
    2 nc_node_dim, 3 nf_physical_node_dim, 4 nc_slab, 5 nf_physical_tile_dim */
 int64_t p3m_hip_derived(const p3m_ctx *ctx, int32_t what);
 
-int p3m_hip_set_transport(p3m_ctx *ctx, const p3m_transport *t);
+int p3m_hip_set_transport(p3m_ctx *ctx, const p3m_transport *t);   /* always P3M_ECOMM: use p3m_hip_group_set_transport */
 /* RCCL over xGMI: unique_id is the 128-byte ncclUniqueId the host broadcast from rank 0
    (p3m_hip_rccl_unique_id fills it on rank 0). */
 int p3m_hip_rccl_unique_id(void *unique_id_128);
@@ -206,6 +205,8 @@ void p3m_hip_group_destroy(p3m_group *g);
 /* nprocs > 1: every process calls this with the id rank 0 obtained from p3m_hip_rccl_unique_id and the
    host broadcast.  force_for_local_peers != 0 routes even same-GPU exchanges through RCCL (test mode). */
 int p3m_hip_group_comm_init_rccl(p3m_group *g, const void *unique_id_128, int32_t force_for_local_peers);
+/* host-callback transport instead of RCCL (the struct is copied; `user` must outlive the group) */
+int p3m_hip_group_set_transport(p3m_group *g, const p3m_transport *t);
 int32_t p3m_hip_group_nlocal(const p3m_group *g);                 /* logical ranks owned by this process */
 int32_t p3m_hip_group_local_rank(const p3m_group *g, int32_t i);  /* logical rank id of the i-th local one */
 p3m_ctx *p3m_hip_group_ctx(p3m_group *g, int32_t i);              /* its context (probes, derived sizes) */

@@ -88,3 +88,89 @@ def test_distributed_coarse_mesh_vs_oracle():
         ro, fo = o.rho_c(i), o.force_c(i)
         assert np.abs(rg - ro).max() <= 4e-6 * np.abs(ro).max(), i
         assert rel_rms(fg, fo) < 3e-6, i      # interior and the one-cell halo from the neighbours
+
+
+# ------------------------------------------------------------------ two PROCESSES (4 logical ranks each)
+def _two_proc_worker(rank, world, port, outdir, kw):
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cubep3m_amd.group import ParticleMeshGroup, torch_transport
+
+    p = cfg1(nodes_dim=2, **kw)
+    xv, pid = global_ic("clustered", 60000, float(p.nf_physical_dim), 99)
+    g = ParticleMeshGroup(p, rank, world, FINE_TABLE, COARSE_TABLE, transport=torch_transport(dist))
+    assert g.local_ranks == list(range(rank * 8 // world, (rank + 1) * 8 // world))
+    g.scatter_global(xv, pid)
+    out = g.particle_mesh(0.01, 0.3, 0.3, 8.0)
+    res = {"np_total": out.np_total, "np_ghost": out.np_ghost, "np_deleted": out.np_deleted, "dt_f_acc": out.dt_f_acc, "dt_c_acc": out.dt_c_acc,
+           "dt_pp_acc": out.dt_pp_acc, "dt_pp_ext_acc": out.dt_pp_ext_acc, "sum_rho_f": out.sum_rho_f, "sum_rho_c": out.sum_rho_c}
+    for i, r in enumerate(g.local_ranks):
+        x, q = g.download_particles(i)
+        res["xv%d" % r], res["pid%d" % r] = x, q
+    np.savez(os.path.join(outdir, "proc%d.npz" % rank), **res)
+    dist.barrier()
+    g.close()
+    dist.destroy_process_group()
+
+
+def test_two_processes_host_transport_match_oracle(tmp_path):
+    """The process-level split (4 logical ranks per process, remote peers, announced counts, the all-to-all and halo
+    message lists, the dt reductions) driven by two processes sharing this one GPU through the host-callback
+    transport over gloo -- RCCL refuses two ranks on one device, and an MPI host would take this same route."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    kw = dict(ngp=True, ppint=True, pp_ext=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_two_proc_worker, args=(r, 2, port, str(tmp_path), kw)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+        assert pr.exitcode == 0
+    p = cfg1(nodes_dim=2, **kw)
+    xv, pid = global_ic("clustered", 60000, float(p.nf_physical_dim), 99)
+    from cubep3m_amd.group import split_global
+
+    parts = split_global(p, xv, pid, range(8))
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    for r in range(8):
+        o.set_particles(r, *parts[r])
+    oo = o.particle_mesh(0.01, 0.3, 0.3, 8.0)
+    res = [np.load(tmp_path / ("proc%d.npz" % r)) for r in range(2)]
+    ghosts = 0
+    for d in res:   # the reductions reached both processes
+        assert int(d["np_total"]) == oo.np_total == len(xv)
+        for name in ("dt_f_acc", "dt_c_acc", "dt_pp_acc", "dt_pp_ext_acc"):
+            assert float(d[name]) == pytest.approx(getattr(oo, name), rel=1e-5), name
+        assert float(d["sum_rho_f"]) == pytest.approx(oo.sum_rho_f, rel=1e-6) and float(d["sum_rho_c"]) == pytest.approx(oo.sum_rho_c, rel=1e-6)
+        ghosts += int(d["np_ghost"])
+    assert ghosts == oo.np_ghost
+    v0 = dict(zip(pid.tolist(), xv[:, 3:]))
+    num = den = 0.0
+    for r in range(8):
+        d = res[r // 4]
+        xg, pg = by_pid(d["xv%d" % r], d["pid%d" % r])
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
+        assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 1e-4
+        vin = np.stack([v0[q] for q in pg.tolist()])
+        dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
+        num += ((dg - do) ** 2).sum()
+        den += (do ** 2).sum()
+    assert np.sqrt(num / den) <= 1e-5, np.sqrt(num / den)
