@@ -1,16 +1,15 @@
 // particles.hip -- particle bookkeeping of the gravity step on the device:
 //   update_position.f90:68-76   -> k_drift
 //   link_list.f90 + particle_pass.f90 (single rank: periodic self exchange) -> k_pass_axis
-//   link_list's chaining mesh hoc/ll (and llf, hoc_fine/ll_fine) -> counting sort by extended
-//     fine cell: k_cell_hist / exclusive scan / k_scatter
+//   link_list's chaining mesh hoc/ll (and llf, hoc_fine/ll_fine) -> sort by extended fine cell:
+//     k_row_hist / exclusive scan / k_row_scatter (by x-row), k_row_sort (inside each row)
 //   delete_particles.f90 + move_grid_back.f90 -> k_flag_physical / scan / k_compact
 // Records are SoA float4 pos, float4 vel, int64 pid.  Everything here is HBM-bound streaming
-// except the cell histogram/scatter (one int atomic per particle).
+// (the row histogram / scatter aggregate their atomics per block in LDS).
 #include "p3m_internal.h"
 #include <algorithm>
 
 #define PT 256
-#define RPT 4   // records per thread in the histogram / scatter kernels
 
 // ------------------------------------------------------------------ update_position.f90:68-76
 __global__ __launch_bounds__(PT) void k_drift(float4 *__restrict__ pos, const float4 *__restrict__ vel, int n, float dt, float dt_old,
@@ -95,67 +94,134 @@ __global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, fl
       }
 }
 
-// ------------------------------------------------------------------ counting sort by extended fine cell
+// ------------------------------------------------------------------ sort by extended fine cell
 // cell = ((cz*E + cy)*E + cx), c_d = floor(x_d) + nb in [0,E).  cs[c] = start(c), cs[c+1] = end(c).
-// Also flags the coarse (hoc) cells that hold a physical record whose TILE-LOCAL fine cell
+// Two levels, because a device-scope atomic costs a fabric transaction and the cell array (E^3 ints) is ten
+// times larger than the particle arrays at the reference's density of 1/8 per fine cell:
+//   1. counting sort by x-ROW (cz*E + cy): k_row_hist / exclusive scan of E^2 counters / k_row_scatter.
+//      Records arrive nearly sorted (the previous step's order, ghosts appended face by face), so a block of
+//      2048 records touches a few dozen rows: counts and cursor reservations are aggregated per block in an
+//      LDS table and hit global memory once per (block, row).  A full table (random order, first step)
+//      degrades to one global atomic per record, never to a wrong result.
+//   2. k_row_sort: one wavefront per row orders the row's records by x cell with an LDS histogram and writes
+//      the row of cs[] -- write-only, no memset, no scan, no atomics on the big array.
+// k_row_hist also flags the coarse (hoc) cells that hold a physical record whose TILE-LOCAL fine cell
 // floor(x + offset_tile) (particle_mesh_threaded.f90:248-249) differs from floor(x): the intra-cell PP
 // buckets of such a coarse cell (:276-284) are not the sorted fine cells and take the slow path.
-__global__ __launch_bounds__(PT) void k_cell_hist(const float4 *__restrict__ pos, int n, int np_orig, float Nn, float nb, int E,
-                                                  int *__restrict__ cell_of, int *__restrict__ cs, int *__restrict__ ndeleted,
-                                                  unsigned char *__restrict__ cflag, int ms, int pt) {
-  // RPT records per thread, a block stride apart: several independent atomics in flight per lane
-#pragma unroll
-  for (int u = 0; u < RPT; u++) {
-  const int i = (blockIdx.x * RPT + u) * PT + threadIdx.x;
-  if (i >= n) continue;
-  const float4 p = pos[i];
-  int cell = -1;
-  if (in_hoc_range(p, -nb, Nn + nb)) {
-    const int cx = (int)floorf(p.x) + (int)nb, cy = (int)floorf(p.y) + (int)nb, cz = (int)floorf(p.z) + (int)nb;
-    cell = (cz * E + cy) * E + cx;
-    atomicAdd(&cs[cell + 1], 1);
-    if (cflag && p.x >= 0.f && p.x < Nn && p.y >= 0.f && p.y < Nn && p.z >= 0.f && p.z < Nn) {
-      const int nct = pt / ms; const float xs[3] = {p.x, p.y, p.z}; bool displaced = false; int cc[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        cc[d] = (int)floorf(xs[d] / (float)ms);
-        const int t = cc[d] / nct;
-        const float xl = xs[d] + (nb - (float)(t * pt));
-        displaced = displaced || ((int)floorf(xl) != (int)floorf(xs[d]) + (int)nb - t * pt);
-      }
-      if (displaced) { const int Ec = E / ms, cb = (int)nb / ms; cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] = 1; }
-    }
-  } else if (i < np_orig) {
-    atomicAdd(ndeleted, 1);
+#define SORT_RPT 8
+#define SORT_HB 512   // entries of the per-block (row -> count/base) table, a power of two
+__device__ __forceinline__ int rowtab_slot(int *key, int row) {
+  const unsigned h = ((unsigned)row * 2654435761u) >> 23;
+#pragma unroll 1
+  for (int t = 0; t < 8; t++) {
+    const int e = (int)((h + t) & (SORT_HB - 1));
+    const int k = key[e];
+    if (k == row) return e;
+    if (k == -1) { const int old = atomicCAS(&key[e], -1, row); if (old == -1 || old == row) return e; }
   }
-  cell_of[i] = cell;
+  return -1;   // crowded: the caller goes to global memory directly
+}
+__global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos, int n, int np_orig, float Nn, float nb, int E,
+                                                 int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt) {
+  __shared__ int key[SORT_HB], val[SORT_HB];
+  for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    if (i >= n) continue;
+    const float4 p = pos[i];
+    if (in_hoc_range(p, -nb, Nn + nb)) {
+      const int cy = (int)floorf(p.y) + (int)nb, cz = (int)floorf(p.z) + (int)nb;
+      const int row = cz * E + cy;
+      const int e = rowtab_slot(key, row);
+      if (e >= 0) atomicAdd(&val[e], 1); else atomicAdd(&rs[row + 1], 1);
+      if (cflag && p.x >= 0.f && p.x < Nn && p.y >= 0.f && p.y < Nn && p.z >= 0.f && p.z < Nn) {
+        const int nct = pt / ms; const float xs[3] = {p.x, p.y, p.z}; bool displaced = false; int cc[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          cc[d] = (int)floorf(xs[d] / (float)ms);
+          const int t = cc[d] / nct;
+          const float xl = xs[d] + (nb - (float)(t * pt));
+          displaced = displaced || ((int)floorf(xl) != (int)floorf(xs[d]) + (int)nb - t * pt);
+        }
+        if (displaced) { const int Ec = E / ms, cb = (int)nb / ms; cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] = 1; }
+      }
+    } else if (i < np_orig) {
+      atomicAdd(ndeleted, 1);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < SORT_HB; e += PT) if (val[e] > 0) atomicAdd(&rs[key[e] + 1], val[e]);
+}
+
+// rs[r+1] holds start(r) on entry and end(r) = start(r+1) on exit
+__global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
+                                                    int n, float Nn, float nb, int E, int *__restrict__ rs, float4 *__restrict__ tpos,
+                                                    float4 *__restrict__ tvel, int64_t *__restrict__ tpid) {
+  __shared__ int key[SORT_HB], val[SORT_HB];
+  for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
+  __syncthreads();
+  float4 p[SORT_RPT]; int ent[SORT_RPT], rank[SORT_RPT];   // ent: table entry | -1 dropped | -2 rank is already the global slot
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    ent[u] = -1; rank[u] = 0; p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= n) continue;
+    p[u] = pos[i];
+    if (!in_hoc_range(p[u], -nb, Nn + nb)) continue;
+    const int cy = (int)floorf(p[u].y) + (int)nb, cz = (int)floorf(p[u].z) + (int)nb;
+    const int row = cz * E + cy;
+    const int e = rowtab_slot(key, row);
+    if (e >= 0) { ent[u] = e; rank[u] = atomicAdd(&val[e], 1); } else { ent[u] = -2; rank[u] = atomicAdd(&rs[row + 1], 1); }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < SORT_HB; e += PT) if (val[e] > 0) val[e] = atomicAdd(&rs[key[e] + 1], val[e]);   // count -> base
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {
+    if (ent[u] == -1) continue;
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    const int s = ent[u] >= 0 ? val[ent[u]] + rank[u] : rank[u];
+    tpos[s] = p[u]; tvel[s] = vel[i]; tpid[s] = pid[i];
   }
 }
 
-__global__ __launch_bounds__(PT) void k_scatter(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
-                                                const int *__restrict__ cell_of, int n, int *__restrict__ cs, float4 *__restrict__ spos,
-                                                float4 *__restrict__ svel, int64_t *__restrict__ spid, int *__restrict__ cand,
-                                                int *__restrict__ ncand, int cand_cap) {
-  int idx[RPT], slot[RPT];
+// one wavefront per row: bins[] = LDS histogram of the row's x cells -> exclusive prefix (the row of cs) -> cursors
+__global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos, const float4 *__restrict__ tvel, const int64_t *__restrict__ tpid,
+                                                 const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
+                                                 float4 *__restrict__ spos, float4 *__restrict__ svel, int64_t *__restrict__ spid,
+                                                 int *__restrict__ cand, int *__restrict__ ncand, int cand_cap) {
+  extern __shared__ int bins[];
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int r0 = rs[row], r1 = rs[row + 1];
+  for (int j = lane; j < E; j += 64) bins[j] = 0;
+  __syncthreads();
+  for (int i = r0 + lane; i < r1; i += 64) atomicAdd(&bins[(int)floorf(tpos[i].x) + (int)nb], 1);
+  __syncthreads();
+  const int chunk = (E + 63) / 64, j0 = min(lane * chunk, E), j1 = min(j0 + chunk, E);
+  int sum = 0;
+  for (int j = j0; j < j1; j++) sum += bins[j];
+  int inc = sum;
 #pragma unroll
-  for (int u = 0; u < RPT; u++) {                    // issue all the cursor atomics first
-    const int i = (blockIdx.x * RPT + u) * PT + threadIdx.x;
-    idx[u] = i; slot[u] = -1;
-    if (i < n) { const int cell = cell_of[i]; if (cell >= 0) slot[u] = atomicAdd(&cs[cell + 1], 1); }
-  }
-#pragma unroll
-  for (int u = 0; u < RPT; u++) {
-  const int i = idx[u], s = slot[u];
-  if (s < 0) continue;
-  const float4 p = pos[i];
-  spos[s] = p; svel[s] = vel[i]; spid[s] = pid[i];
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  int run = r0 + inc - sum;
+  for (int j = j0; j < j1; j++) { const int t = bins[j]; bins[j] = run; run += t; }
+  __syncthreads();
+  int *csr = cs + (int64_t)row * E;
+  for (int j = lane; j < E; j += 64) csr[j] = bins[j];
+  if (row == nrows - 1 && lane == 0) csr[E] = r1;
   // records with a coordinate within 2^-10 below a cell face: only these can be moved into the next
   // cell by the rounding of xv + offset_tile (fine_mesh.hip, count-based NGP deposit fix-up)
   const float thr = 1.0f - 0.0009765625f;
-  if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
-    const int k = atomicAdd(ncand, 1);
-    if (k < cand_cap) cand[k] = s;
-  }
+  for (int i = r0 + lane; i < r1; i += 64) {
+    const float4 p = tpos[i];
+    const int s = atomicAdd(&bins[(int)floorf(p.x) + (int)nb], 1);
+    spos[s] = p; svel[s] = tvel[i]; spid[s] = tpid[i];
+    if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
+      const int k = atomicAdd(ncand, 1);
+      if (k < cand_cap) cand[k] = s;
+    }
   }
 }
 
@@ -181,28 +247,33 @@ int particles_pass_self(p3m_ctx *c) {
   return P3M_OK;
 }
 
-// counting sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell
+// sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell
 int particles_sort(p3m_ctx *c) {
   const Geometry &g = c->g;
   int *cnt = c->d_counters;
   const int n_cur = c->np_all;
   c->np_ghost = n_cur - c->np_local;
   HIP_TRY(hipMemsetAsync(cnt + 4, 0, 2 * sizeof(int), c->stream));
-  const int64_t ncell = (int64_t)g.E * g.E * g.E;
-  HIP_TRY(hipMemsetAsync(c->cell_end - 3, 0, (size_t)(ncell + 8) * sizeof(int), c->stream));
+  const int nrows = g.E * g.E;
+  HIP_TRY(hipMemsetAsync(c->row_end - 3, 0, (size_t)(nrows + 8) * sizeof(int), c->stream));
   const bool want_cflag = (c->p.flags & P3M_FLAG_PPINT) != 0;
   if (want_cflag) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
+  const int nblk = cdiv(n_cur, PT * SORT_RPT);
   if (n_cur > 0) {
-    hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(n_cur, PT * RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, c->np_local, (float)g.Nn,
-                       (float)g.nb, g.E, c->cell_of, c->cell_end, cnt + 4, want_cflag ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
+    hipLaunchKernelGGL(k_row_hist, dim3(nblk), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, c->np_local, (float)g.Nn, (float)g.nb, g.E,
+                       c->row_end, cnt + 4, want_cflag ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
     HIP_TRY(hipGetLastError());
   }
-  P3M_TRY(exclusive_scan_i32(c, c->cell_end + 1, ncell));
+  P3M_TRY(exclusive_scan_i32(c, c->row_end + 1, nrows));
   if (n_cur > 0) {
-    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n_cur, PT * RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel,
-                       (const int64_t *)c->pid, (const int *)c->cell_of, n_cur, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5, (int)c->cap);
+    hipLaunchKernelGGL(k_row_scatter, dim3(nblk), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid, n_cur,
+                       (float)g.Nn, (float)g.nb, g.E, c->row_end, c->tpos, c->tvel, c->tpid);
     HIP_TRY(hipGetLastError());
   }
+  hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos, (const float4 *)c->tvel,
+                     (const int64_t *)c->tpid, (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5,
+                     (int)c->cap);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->np_deleted = c->h_counters[4];
