@@ -1,5 +1,5 @@
 // coarse_mesh.hip -- long-range force on the mesh_scale-times coarser global mesh (coarse_mesh.f90):
-//   coarse_mass.f90 + coarse_cic_mass(.f90|_buffer.f90) -> k_coarse_deposit (gather, no atomics to HBM)
+//   coarse_mass.f90 + coarse_cic_mass(.f90|_buffer.f90) -> k_coarse_moments + k_coarse_collect (no atomics)
 //   coarse_force.f90 + fftw3ds.f90 (single rank: cube == slab)      -> coarse_force
 //   coarse_force_buffer.f90 (periodic 1-cell halo)                   -> k_coarse_unpack
 //   coarse_max_dt.f90                                                -> k_coarse_max
@@ -10,71 +10,100 @@
 
 struct CGeo { int nb, E, Nn, ms, ncn, nc; };
 
-// One 256-thread workgroup per CT x CT block of coarse output rows (J0..J0+3, K0..K0+3).  A particle's CIC
-// footprint is the cells i1 = floor(x/ms - 0.5) + 1 and i1+1 per axis (coarse_cic_mass.f90:18-21), clipped
-// to 1..ncn (coarse_cic_mass_buffer.f90:59-113); the block is fed by the fine cell rows
-// [ms*J0 - ms/2, ms*(J0+CT) + ms/2) x same in z, each read once per block (re-read factor (1+1/CT)^2).
-#define CT 4
-__global__ __launch_bounds__(256) void k_coarse_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho_c, CGeo G,
-                                                       float mass_p, double *__restrict__ sum_out) {
-  extern __shared__ float rows[];   // [CT][CT][ncn]
-  const int nJ = (G.ncn + CT - 1) / CT;
-  const int J0 = (blockIdx.x % nJ) * CT, K0 = (blockIdx.x / nJ) * CT;
-  for (int i = threadIdx.x; i < CT * CT * G.ncn; i += 256) rows[i] = 0.f;
-  __syncthreads();
+// CIC deposit without atomics.  A particle's footprint is the cells i1 = floor(x/ms - 0.5) + 1 and i1+1 per
+// axis (coarse_cic_mass.f90:18-21), clipped to 1..ncn (coarse_cic_mass_buffer.f90:59-113).  All particles with
+// the same (i1,j1,k1) share their 8 target cells, and they are exactly the records of ms^3 fine cells = ms^2
+// contiguous record ranges of the sorted store.  Pass 1: one thread per (i1,j1,k1) in [0,ncn]^3 sums the 8
+// corner weights of its records in registers (every record is read once, in sorted order) and stores them
+// SoA in mom[corner][k1][j1][i1].  Pass 2: one thread per coarse cell adds the 8 moments that land on it.
+// (LDS float atomics cost ~2.5 clocks per lane on this part: a scatter into an LDS tile spent 80 % of its time
+// in ds_add_f32, and a gather per output cell re-reads cell_end 1.5 times.)
+// The chain window hoc(0:ncn+1) of coarse_mass.f90:85-87 is implied: i1 in [0,ncn] <=> x in [-ms/2, Nn+ms/2).
+#define CROWS 4   // fine rows whose range / first record loads are in flight together
+__global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ mom, CGeo G,
+                                                       float mass_p, float *__restrict__ rho_c) {
+  const int m1 = G.ncn + 1;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)m1 * m1 * m1;
+  if (t >= tot) return;
+  const int ci = (int)(t % m1), cj = (int)((t / m1) % m1), ck = (int)(t / ((int64_t)m1 * m1));   // i1, j1, k1
   const int h = G.ms / 2;
   const float inv = 1.0f / (float)G.ms;
-  const int xlo = G.nb - G.ms, xhi = G.nb + G.Nn + G.ms;  // chains hoc(0:ncn+1) only (coarse_mass.f90:85-87)
-  // The fine cell rows fy0..fy1 of one z-plane are ONE contiguous record range (whole rows incl. the few
-  // ghost-zone cells beyond the chain window, which the clipping below discards): two offset loads per
-  // plane instead of two per row, and all 256 lanes stream the range.
-  const int ny = G.ms * CT + G.ms;
-  const int fy0 = max(G.ms * J0 - h + G.nb, 0), fy1 = min(G.ms * J0 - h + ny + G.nb, G.E);   // extended-cell rows [fy0, fy1)
-  for (int zz = 0; zz < ny; zz++) {
-    const int cz0 = G.ms * K0 - h + zz + G.nb;
-    if (cz0 < 0 || cz0 >= G.E) continue;
-    const int p0 = cs[((int64_t)cz0 * G.E + fy0) * G.E], p1 = cs[((int64_t)cz0 * G.E + fy1) * G.E];
-    for (int s = p0 + (int)threadIdx.x; s < p1; s += 256) {
-      const float4 p = spos[s];
-      { const int cx = (int)floorf(p.x) + G.nb; if (cx < xlo || cx >= xhi) continue; }      // chain window hoc(0:ncn+1)
-      const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;     // coarse_cic_mass.f90:18
-      const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;  // 1-based
-      float dx1 = (float)i1 - x; const float dy1 = (float)j1 - y, dz1 = (float)k1 - z;
-      float dx2 = 1.0f - dx1; const float dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
-      dx1 = mass_p * dx1; dx2 = mass_p * dx2;                                             // :32-33
+  const int x0 = G.ms * ci - h + G.nb, y0 = G.ms * cj - h + G.nb, z0 = G.ms * ck - h + G.nb;      // first fine cell of the cube, extended index
+  float acc[8];
 #pragma unroll
-      for (int cz = 0; cz < 2; cz++) {
-        const int K = k1 - 1 + cz - K0;                       // 0-based output row, relative to the block
-        if (K < 0 || K >= CT || K + K0 >= G.ncn) continue;
-        const float wz = cz ? dz2 : dz1;
+  for (int c = 0; c < 8; c++) acc[c] = 0.f;
+  auto add = [&](const float4 &p) {
+    const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;     // coarse_cic_mass.f90:18
+    const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;  // 1-based
+    float dx1 = (float)i1 - x; const float dy1 = (float)j1 - y, dz1 = (float)k1 - z;
+    float dx2 = 1.0f - dx1; const float dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+    dx1 = mass_p * dx1; dx2 = mass_p * dx2;                                             // :32-33
+    if (i1 == ci && j1 == cj && k1 == ck) {
+      acc[0] += dx1 * dy1 * dz1; acc[1] += dx2 * dy1 * dz1; acc[2] += dx1 * dy2 * dz1; acc[3] += dx2 * dy2 * dz1;
+      acc[4] += dx1 * dy1 * dz2; acc[5] += dx2 * dy1 * dz2; acc[6] += dx1 * dy2 * dz2; acc[7] += dx2 * dy2 * dz2;
+    } else {
+      // the fp32 expression put the record into a neighbouring cube (possible when 1/ms is inexact): rare, exact, slow
 #pragma unroll
-        for (int cy = 0; cy < 2; cy++) {
-          const int J = j1 - 1 + cy - J0;
-          if (J < 0 || J >= CT || J + J0 >= G.ncn) continue;
-          const float wy = cy ? dy2 : dy1;
-          float *row = rows + (K * CT + J) * G.ncn;
-          if (i1 >= 1 && i1 <= G.ncn) atomicAdd(&row[i1 - 1], dx1 * wy * wz);
-          if (i1 + 1 >= 1 && i1 + 1 <= G.ncn) atomicAdd(&row[i1], dx2 * wy * wz);
-        }
+      for (int c = 0; c < 8; c++) {
+        const int I = i1 + (c & 1), J = j1 + ((c >> 1) & 1), K = k1 + (c >> 2);
+        if (I >= 1 && I <= G.ncn && J >= 1 && J <= G.ncn && K >= 1 && K <= G.ncn)
+          atomicAdd(&rho_c[((int64_t)(K - 1) * G.ncn + (J - 1)) * G.ncn + (I - 1)], ((c & 1) ? dx2 : dx1) * (((c >> 1) & 1) ? dy2 : dy1) * ((c >> 2) ? dz2 : dz1));
       }
     }
+  };
+  const int nrow = G.ms * G.ms;
+  for (int r0 = 0; r0 < nrow; r0 += CROWS) {
+    int p0[CROWS], p1[CROWS];
+#pragma unroll
+    for (int u = 0; u < CROWS; u++) {
+      const int r = r0 + u, zz = r / G.ms, yy = r - zz * G.ms;
+      p0[u] = 0; p1[u] = 0;
+      if (r < nrow) { const int *row = cs + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * G.E + x0; p0[u] = row[0]; p1[u] = row[G.ms]; }
+    }
+    float4 first[CROWS];
+#pragma unroll
+    for (int u = 0; u < CROWS; u++) { first[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (p1[u] > p0[u]) first[u] = spos[p0[u]]; }
+#pragma unroll
+    for (int u = 0; u < CROWS; u++) {
+      if (p1[u] > p0[u]) add(first[u]);
+      for (int s = p0[u] + 1; s < p1[u]; s++) add(spos[s]);
+    }
   }
-  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 8; c++) mom[c * tot + t] = acc[c];
+}
+// rho_c(I,J,K) (1-based) = sum over corners c = (cx,cy,cz) of mom[c](I-cx, J-cy, K-cz); added to what the rare
+// path of pass 1 left in rho_c (zeroed before pass 1)
+__global__ __launch_bounds__(256) void k_coarse_collect(const float *__restrict__ mom, float *__restrict__ rho_c, int ncn, double *__restrict__ sum_out) {
+  __shared__ float sh[4];
+  const int m1 = ncn + 1;
+  const int64_t n3 = (int64_t)ncn * ncn * ncn, tot = (int64_t)m1 * m1 * m1;
   float part = 0.f;
-  for (int e = threadIdx.x; e < CT * CT * G.ncn; e += 256) {
-    const int i = e % G.ncn, J = (e / G.ncn) % CT, K = e / (G.ncn * CT);
-    if (J0 + J < G.ncn && K0 + K < G.ncn) { const float v = rows[e]; rho_c[((int64_t)(K0 + K) * G.ncn + (J0 + J)) * G.ncn + i] = v; part += v; }
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n3; t += (int64_t)gridDim.x * 256) {
+    const int I = (int)(t % ncn) + 1, J = (int)((t / ncn) % ncn) + 1, K = (int)(t / ((int64_t)ncn * ncn)) + 1;
+    float v = rho_c[t];
+#pragma unroll
+    for (int c = 0; c < 8; c++) v += mom[c * tot + ((int64_t)(K - (c >> 2)) * m1 + (J - ((c >> 1) & 1))) * m1 + (I - (c & 1))];
+    rho_c[t] = v;
+    part += v;
   }
+  // one double atomic per workgroup (a per-wave atomic on one address serialises)
   for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-  if ((threadIdx.x & 63) == 0 && sum_out && part != 0.f) atomicAdd(sum_out, (double)part);  // coarse_mesh.f90:31-43
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0 && sum_out) { const float s4 = (sh[0] + sh[1]) + (sh[2] + sh[3]); if (s4 != 0.f) atomicAdd(sum_out, (double)s4); }  // coarse_mesh.f90:31-43
 }
 
 int coarse_deposit(p3m_ctx *c, float mass_p) {
   const Geometry &g = c->g;
   CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc};
-  const int nJ = (g.ncn + CT - 1) / CT;
-  hipLaunchKernelGGL(k_coarse_deposit, dim3(nJ * nJ), dim3(256), sizeof(float) * CT * CT * g.ncn, c->stream, (const float4 *)c->spos,
-                     (const int *)c->cell_end, c->rho_c, G, mass_p, c->d_sums + 1);
+  if (g.ms / 2 > g.nb) { p3m_set_error("coarse_deposit: mesh_scale/2 > nf_buf"); return P3M_EINVAL; }
+  const int64_t m1 = g.ncn + 1, tot = m1 * m1 * m1, n3 = (int64_t)g.ncn * g.ncn * g.ncn;
+  HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));
+  hipLaunchKernelGGL(k_coarse_moments, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G,
+                     mass_p, c->rho_c);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_coarse_collect, dim3((unsigned)std::min<int64_t>(1024, cdiv(n3, 256))), dim3(256), 0, c->stream, (const float *)c->cmom, c->rho_c, g.ncn, c->d_sums + 1 * P3M_SUM_SPAN);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(256) void k_coarse_max(const float *__restrict__ fc
     mx = fmaxf(mx, sqrtf(a * a + b * b + d * d));
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(mx));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out) + p3m_slot() * 16, __float_as_uint(mx));
 }
 
 int coarse_force(p3m_ctx *c) {
@@ -127,7 +156,7 @@ int coarse_force(p3m_ctx *c) {
     HIP_TRY(hipGetLastError());
   }
   hipLaunchKernelGGL(k_coarse_max, dim3(std::min<int64_t>(1024, cdiv((int64_t)n * n * n, 256))), dim3(256), 0, c->stream, (const float *)c->force_c,
-                     n, c->d_red + 2);
+                     n, c->d_red + 2 * P3M_RED_SPAN);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

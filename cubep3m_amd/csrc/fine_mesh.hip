@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
   }
   if (sum_interior) {
     for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-    if (threadIdx.x == 0 && interior_row && part != 0.f) atomicAdd(sum_interior, (double)part);
+    if (threadIdx.x == 0 && interior_row && part != 0.f) atomicAdd(sum_interior + p3m_slot() * 8, (double)part);
   }
 }
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, 
   }
   if (sum_interior) {
     const float s = block_sum_f(part, sh);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(sum_interior, (double)s);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(sum_interior + p3m_slot() * 8, (double)s);
   }
 }
 // candidates: sorted indices of records within 2^-10 below a cell face in some coordinate (k_scatter)
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_force_max(const float *__restrict__ fbo
     m = fmaxf(m, f);
   }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(m));    // m >= 0
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out) + p3m_slot() * 16, __float_as_uint(m));    // m >= 0
 }
 int fine_force_max(p3m_ctx *c) {
   const Geometry &g = c->g;

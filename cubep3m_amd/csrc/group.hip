@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_gmax_interior(const float *__restrict__
     mx = fmaxf(mx, sqrtf(a * a + b * b + d * d));                        // coarse_max_dt.f90:24-31
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(mx));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out) + p3m_slot() * 16, __float_as_uint(mx));
 }
 // real-space coarse kernel on this rank's cube, global coordinates (kernel_initialization.f90:293-336, :366-457)
 __global__ __launch_bounds__(256) void k_ck_cube(float *__restrict__ cube, const float *__restrict__ table, int ncn, int nc, int ox, int oy, int oz, int ms,
@@ -591,7 +591,7 @@ static int coarse_force_dist(p3m_group *G) {
   }
   for (int i = 0; i < nl; i++) {
     hipLaunchKernelGGL(k_gmax_interior, dim3(std::min<int64_t>(1024, cdiv((int64_t)ncn * ncn * ncn, 256))), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, ncn,
-                       G->ctx[i]->d_red + 2);
+                       G->ctx[i]->d_red + 2 * P3M_RED_SPAN);
     HIP_TRY(hipGetLastError());
   }
   return P3M_OK;
@@ -626,12 +626,12 @@ static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out) {
   const Geometry &g = G->ctx[0]->g;
   float v[4] = {0, 0, 0, 0}; double sums[3] = {0, 0, 0}; int ng = 0, ndel = 0;
   for (p3m_ctx *c : G->ctx) {
-    HIP_TRY(hipMemcpyAsync(c->h_red, c->d_red, 8 * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+    P3M_TRY(reductions_download(c));
     HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_sums, c->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, G->stream));
   }
   HIP_TRY(hipStreamSynchronize(G->stream));
   for (p3m_ctx *c : G->ctx) {
+    reductions_fold(c);
     v[0] = std::max(v[0], sqrtf(c->h_red[0])); v[1] = std::max(v[1], c->h_red[1]); v[3] = std::max(v[3], c->h_red[2]);
     if (c->p.flags & P3M_FLAG_PP_EXT) {   // per-thread "last tile" overwrite, particle_mesh_threaded.f90:617
       const int cores = std::max(1, c->p.cores), nt = std::min(cores, g.ntiles), base = g.ntiles / nt, rem = g.ntiles % nt;
@@ -694,7 +694,7 @@ extern "C" int p3m_hip_group_probe_coarse(p3m_group *G, float mass_p, int32_t i,
   HIP_TRY(hipSetDevice(G->device));
   const Geometry &g = G->ctx[0]->g;
   if (G->nodes == 1) return p3m_hip_probe_coarse(G->ctx[0], mass_p, rho_c, force_c);
-  for (p3m_ctx *c : G->ctx) { HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * sizeof(double), G->stream)); HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * sizeof(float), G->stream)); P3M_TRY(coarse_deposit(c, mass_p)); }
+  for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(coarse_deposit(c, mass_p)); }
   if (rho_c) HIP_TRY(hipMemcpyAsync(rho_c, G->ctx[i]->rho_c, sizeof(float) * (size_t)g.ncn * g.ncn * g.ncn, hipMemcpyDeviceToHost, G->stream));
   if (force_c) {
     P3M_TRY(coarse_force_dist(G));

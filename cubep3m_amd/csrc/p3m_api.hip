@@ -96,6 +96,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   A(fft_plan_create(&c->plan_f, g.nf));
   // coarse mesh
   A(dalloc(&c->rho_c, (size_t)g.ncn * g.ncn * g.ncn));
+  A(dalloc(&c->cmom, (size_t)8 * (g.ncn + 1) * (g.ncn + 1) * (g.ncn + 1)));
   A(dalloc(&c->force_c, (size_t)3 * (g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2)));
   if (g.nodes == 1) {
     const size_t Sc = (size_t)g.nc * g.nc * (2 * g.pxc);
@@ -105,10 +106,10 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
         hipMemset(c->kern_c, 0, (size_t)3 * g.nc * g.nc * g.pxc * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
     A(fft_plan_create(&c->plan_c, g.nc));
   }
-  A(dalloc(&c->d_red, 8)); A(dalloc(&c->d_tile_ext, g.ntiles)); A(dalloc(&c->d_sums, 4));
-  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_red), 8 * sizeof(float)) != hipSuccess) return fail(P3M_ENOMEM);
+  A(dalloc(&c->d_red, 8 * P3M_RED_SPAN)); A(dalloc(&c->d_tile_ext, g.ntiles)); A(dalloc(&c->d_sums, 4 * P3M_SUM_SPAN));
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_red_raw), 8 * P3M_RED_SPAN * sizeof(float)) != hipSuccess) return fail(P3M_ENOMEM);
   if (hipHostMalloc(reinterpret_cast<void **>(&c->h_tile_ext), g.ntiles * sizeof(float)) != hipSuccess) return fail(P3M_ENOMEM);
-  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sums), 4 * sizeof(double)) != hipSuccess) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sums_raw), 4 * P3M_SUM_SPAN * sizeof(double)) != hipSuccess) return fail(P3M_ENOMEM);
 #undef A
   // variable_initialization.f90:22-29
   c->last.dt_f_acc = c->last.dt_pp_acc = c->last.dt_pp_ext_acc = c->last.dt_c_acc = 1000.f;
@@ -125,12 +126,12 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->kern_f);
-  dfree(c->rho_c); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->slab_o); dfree(c->kern_c);
+  dfree(c->rho_c); dfree(c->cmom); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->slab_o); dfree(c->kern_c);
   dfree(c->d_red); dfree(c->d_tile_ext); dfree(c->d_sums);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
-  if (c->h_red) (void)hipHostFree(c->h_red);
+  if (c->h_red_raw) (void)hipHostFree(c->h_red_raw);
   if (c->h_tile_ext) (void)hipHostFree(c->h_tile_ext);
-  if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_sums_raw) (void)hipHostFree(c->h_sums_raw);
   fft_plan_destroy(&c->plan_f); fft_plan_destroy(&c->plan_c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -290,13 +291,27 @@ static int fine_sweep(p3m_ctx *c, float mass_p) {
   return P3M_OK;
 }
 
+int reductions_clear(p3m_ctx *c) {
+  HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * P3M_RED_SPAN * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * P3M_SUM_SPAN * sizeof(double), c->stream));
+  return P3M_OK;
+}
+int reductions_download(p3m_ctx *c) {
+  HIP_TRY(hipMemcpyAsync(c->h_red_raw, c->d_red, 8 * P3M_RED_SPAN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_sums_raw, c->d_sums, 4 * P3M_SUM_SPAN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return P3M_OK;
+}
+void reductions_fold(p3m_ctx *c) {
+  for (int k = 0; k < 8; k++) { float m = 0.f; for (int sl = 0; sl < P3M_NSLOT; sl++) m = std::max(m, c->h_red_raw[k * P3M_RED_SPAN + sl * 16]); c->h_red[k] = m; }
+  for (int k = 0; k < 4; k++) { double t = 0.0; for (int sl = 0; sl < P3M_NSLOT; sl++) t += c->h_sums_raw[k * P3M_SUM_SPAN + sl * 8]; c->h_sums[k] = t; }
+}
+
 extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (!c) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
-  HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * sizeof(float), c->stream));
+  P3M_TRY(reductions_clear(c));
   HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * sizeof(double), c->stream));
   P3M_TRY(fine_sweep(c, mass_p));
   P3M_TRY(fine_force_max(c));
   P3M_TRY(fine_kick(c, a_mid, dt));
@@ -325,10 +340,10 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
   if (!c || !out) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
   const Geometry &g = c->g;
-  HIP_TRY(hipMemcpyAsync(c->h_red, c->d_red, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  P3M_TRY(reductions_download(c));
   HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_sums, c->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  reductions_fold(c);
   p3m_step_out o; memset(&o, 0, sizeof(o));
   float fmax = sqrtf(c->h_red[0]);                         // :643
   float ppmax = c->h_red[1], cmax = c->h_red[2];
@@ -418,8 +433,7 @@ extern "C" int p3m_hip_probe_coarse(p3m_ctx *c, float mass_p, float *rho_c, floa
   if (!c) return P3M_EINVAL;
   const Geometry &g = c->g;
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * sizeof(double), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * sizeof(float), c->stream));
+  P3M_TRY(reductions_clear(c));
   P3M_TRY(coarse_deposit(c, mass_p));
   if (rho_c) HIP_TRY(hipMemcpyAsync(rho_c, c->rho_c, sizeof(float) * (size_t)g.ncn * g.ncn * g.ncn, hipMemcpyDeviceToHost, c->stream));
   if (force_c) {

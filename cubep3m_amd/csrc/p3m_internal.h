@@ -28,6 +28,13 @@ void p3m_set_error(const char *fmt, ...);
     if (_r != P3M_OK) return _r; \
   } while (0)
 
+#define P3M_NSLOT 64
+#define P3M_SUM_SPAN (P3M_NSLOT * 8)    // doubles per reduced sum
+#define P3M_RED_SPAN (P3M_NSLOT * 16)   // floats per reduced maximum
+#ifdef __HIPCC__
+__device__ __forceinline__ int p3m_slot() { return (int)((blockIdx.x + 13u * blockIdx.y + 31u * blockIdx.z) & (P3M_NSLOT - 1)); }
+#endif
+
 // ------------------------------------------------------------------ FFT plan (fft.hip)
 struct FftPlan {
   int n = 0;               // real transform length per axis
@@ -83,6 +90,7 @@ struct p3m_ctx {
   FftPlan plan_f;
   // ---- coarse mesh
   float *rho_c = nullptr;      // [ncn][ncn][ncn]
+  float *cmom = nullptr;       // [8][(ncn+1)^3] corner sums of the coarse CIC deposit (coarse_mesh.hip)
   float *slab = nullptr;       // [nc][nc][2*pxc] (single rank) density -> hat
   float *slab_w = nullptr, *slab_o = nullptr;  // scratch (LY) and real output of the inverse
   float *force_c = nullptr;    // [3][ncn+2][ncn+2][ncn+2] SoA planes incl. halo
@@ -90,10 +98,14 @@ struct p3m_ctx {
   FftPlan plan_c;
   bool have_kf = false, have_kc = false;
   // ---- per-step reductions (device) and results
-  float *d_red = nullptr;      // [0] f_force_max^2 [1] pp_force_max [2] c_force_max [3..] scratch
+  // Reduced scalars live in P3M_NSLOT slots of one 64-byte line each: a kernel's workgroups spread their
+  // atomics over the slots (tens of thousands of atomics on ONE address serialise at ~12 ns each), the host
+  // folds the slots after the download (reductions_fold).
+  float *d_red = nullptr;      // [8][P3M_RED_SPAN]: [0] f_force_max^2 [1] pp_force_max [2] c_force_max [3..] scratch
   float *d_tile_ext = nullptr; // [ntiles] per-tile pp_ext max
-  double *d_sums = nullptr;    // [0] sum rho_f (interior) [1] sum rho_c
-  float *h_red = nullptr; float *h_tile_ext = nullptr; double *h_sums = nullptr;  // pinned
+  double *d_sums = nullptr;    // [4][P3M_SUM_SPAN]: [0] sum rho_f (interior) [1] sum rho_c
+  float *h_red_raw = nullptr; double *h_sums_raw = nullptr; float *h_tile_ext = nullptr;  // pinned mirrors
+  float h_red[8] = {0}; double h_sums[4] = {0};   // folded values
   p3m_step_out last{};
   int np_ghost = 0, np_deleted = 0;
   // ---- transport
@@ -143,4 +155,7 @@ int coarse_kick(p3m_ctx *c, float a_mid, float dt);
 int build_coarse_kernel(p3m_ctx *c, const float *table4_host);
 
 // ---- scan.hip
+int reductions_clear(p3m_ctx *c);      // zero d_red / d_sums
+int reductions_download(p3m_ctx *c);   // enqueue the copies to the pinned mirrors
+void reductions_fold(p3m_ctx *c);      // after the stream sync: slots -> c->h_red[], c->h_sums[]
 int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n);  // in place; data[n] (one past) receives the total

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     }
   }
   for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_down(mag, o, 64));
-  if ((threadIdx.x & 63) == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out), __float_as_uint(mag));
+  if ((threadIdx.x & 63) == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out) + p3m_slot() * 16, __float_as_uint(mag));
 }
 
 int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
@@ -91,7 +91,7 @@ int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (c->np_all == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   hipLaunchKernelGGL(k_pp_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end,
-                     (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1);
+                     (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1 * P3M_RED_SPAN);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
