@@ -251,6 +251,55 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
   svel[s] = v;
 }
 
+// NGP: max |F|^2 (:208-223) and the kick (:244-270) in ONE pass over the force box.  One wavefront per box row
+// (tile, kk, jj): the three component rows go through LDS (coalesced 16-byte loads, each box byte is read once),
+// the row's maximum goes to the reduction slots, and the physical records of the same cell row -- one contiguous
+// range of the sorted store -- that this tile owns take their force from LDS.  A record whose reference cell
+// floor(xv + offset_tile) is in another row than its sorted cell (rounding at a face) reads global memory.
+__global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, TileGeo G,
+                                                      int Nn, int ms, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
+                                                      float *__restrict__ fmax_out) {
+  extern __shared__ float frow[];   // [3][fbp]
+  const int fb = G.fb, fbp = G.fbp, lo = G.nb - 2, lane = threadIdx.x;
+  const int jj = blockIdx.x % fb, kk = (blockIdx.x / fb) % fb, tile = blockIdx.x / (fb * fb);
+  int tx, ty, tz; tile_xyz(tile, G.T, tx, ty, tz);
+  const float *f0 = fbox + (int64_t)tile * fb * fb * fbp;
+  const int64_t ro = ((int64_t)kk * fb + jj) * fbp;
+  float m = 0.f;
+  for (int q = lane; q < (fbp >> 2); q += 64) {
+    const float4 a = *reinterpret_cast<const float4 *>(f0 + ro + 4 * q), b = *reinterpret_cast<const float4 *>(f0 + ro + comp_stride + 4 * q),
+                 d = *reinterpret_cast<const float4 *>(f0 + ro + 2 * comp_stride + 4 * q);
+    *reinterpret_cast<float4 *>(frow + 4 * q) = a; *reinterpret_cast<float4 *>(frow + fbp + 4 * q) = b; *reinterpret_cast<float4 *>(frow + 2 * fbp + 4 * q) = d;
+    m = fmaxf(m, fmaxf(fmaxf(a.x * a.x + b.x * b.x + d.x * d.x, a.y * a.y + b.y * b.y + d.y * d.y),                 // :217-218 (pad columns are zero)
+                       fmaxf(a.z * a.z + b.z * b.z + d.z * d.z, a.w * a.w + b.w * b.w + d.w * d.w)));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out) + p3m_slot() * 16, __float_as_uint(m));
+  __syncthreads();
+  // tile-local cell l <-> extended cell l + t*pt; the box row (jj,kk) is the local cell row (jj+lo, kk+lo)
+  const int64_t row = ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * G.E + tx * G.pt + lo;
+  const int p0 = cs[row], p1 = cs[row + fb];
+  const float fNn = (float)Nn;
+  const int nct = G.pt / ms;
+  const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
+  for (int s = p0 + lane; s < p1; s += 64) {
+    const float4 p = spos[s];
+    if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) continue;  // chains of hoc(1..ncn) only (:234-236)
+    // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
+    if (((int)floorf(p.x / (float)ms)) / nct != tx || ((int)floorf(p.y / (float)ms)) / nct != ty || ((int)floorf(p.z / (float)ms)) / nct != tz) continue;
+    const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
+    const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
+    float fx, fy, fz;
+    if (j1 == jj && k1 == kk) { fx = frow[i1]; fy = frow[fbp + i1]; fz = frow[2 * fbp + i1]; }
+    else { const int64_t o = ((int64_t)k1 * fb + j1) * fbp + i1; fx = f0[o]; fy = f0[o + comp_stride]; fz = f0[o + 2 * comp_stride]; }
+    float4 v = svel[s];
+    v.x = v.x + fx * a_mid * P3M_G_F * dt;                                                             // :265-266
+    v.y = v.y + fy * a_mid * P3M_G_F * dt;
+    v.z = v.z + fz * a_mid * P3M_G_F * dt;
+    svel[s] = v;
+  }
+}
+
 int fine_kick(p3m_ctx *c, float a_mid, float dt) {
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
@@ -262,6 +311,17 @@ int fine_kick(p3m_ctx *c, float a_mid, float dt) {
   else
     hipLaunchKernelGGL(k_fine_kick<false>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G, g.Nn,
                        g.ms, (const float *)c->fbox, cs, a_mid, dt);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+// :208-319 for every tile: maximum and kick; fused into one pass over the force box for NGP
+int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
+  const Geometry &g = c->g;
+  if (!(c->p.flags & P3M_FLAG_NGP)) { P3M_TRY(fine_force_max(c)); return fine_kick(c, a_mid, dt); }
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
+  const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
+  hipLaunchKernelGGL(k_fine_kick_rows, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
+                     (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

@@ -313,8 +313,7 @@ extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p
   P3M_TRY(reductions_clear(c));
   HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
   P3M_TRY(fine_sweep(c, mass_p));
-  P3M_TRY(fine_force_max(c));
-  P3M_TRY(fine_kick(c, a_mid, dt));
+  P3M_TRY(fine_max_and_kick(c, a_mid, dt));
   if ((c->p.flags & P3M_FLAG_PPINT) && (c->p.flags & P3M_FLAG_NGP)) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
   if (c->p.flags & P3M_FLAG_PP_EXT) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
   return P3M_OK;

@@ -140,6 +140,7 @@ int particles_finalize(p3m_ctx *c, const float *move_back);
 int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p);
 int fine_force(p3m_ctx *c, int tile0, int ntile);
 int fine_kick(p3m_ctx *c, float a_mid, float dt);
+int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt);
 int fine_force_max(p3m_ctx *c);
 int fine_sum_mass(p3m_ctx *c, int tile0, int ntile);
 int build_fine_kernel(p3m_ctx *c, const float *table16_host);
