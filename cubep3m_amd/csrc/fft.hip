@@ -454,7 +454,8 @@ template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines
   a.n = n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
   const size_t lds = sizeof(float2) * ((size_t)2 * n * BXC + n);
   P3M_TRY((set_lds(k_fft_lines<INV, TR, NC, RSET, TB, LUX>, lds)));
-  // persistent grid: as many workgroups as are resident at once, a multiple of 24 (XCD/component map)
+  // persistent grid: as many workgroups as are resident at once (256 CUs: the three components of one bundle,
+  // 8 item numbers apart, run on the same XCD at the same time)
   const int nwork = NC == 3 ? ((a.nbundles + 7) / 8) * 24 : a.nbundles;
   // never more than fit at once (a straggler wave of workgroups would double the time)
   static int occ_cache = 0, occ_lds = 0;
@@ -466,7 +467,6 @@ template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines
   hipDeviceProp_t prop; int ncu = 256;
   (void)prop;
   int grid = ncu * occ_cache;
-  if (NC == 3) grid = nwork;   // one (bundle, component) per workgroup: measured faster than the persistent form here
   if (grid > nwork) grid = nwork;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_fft_lines<INV, TR, NC, RSET, TB, LUX>), dim3((unsigned)grid), dim3(TB), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);

@@ -37,83 +37,91 @@ template <int R> struct TrigTab {
   }
 };
 
-// forward DFT (sign -1) of R values held in registers
-template <int R> __device__ __forceinline__ void dft(float2 (&v)[R]);
+// The butterflies work on a native 2-vector (re, im) so that every complex add is ONE v_pk_add_f32 and every
+// complex product TWO packed instructions (swizzles and sign flips ride on op_sel / neg modifiers); written with
+// HIP's float2 struct the compiler pairs up unrelated scalars and pays for it in v_mov shuffles.
+typedef float c32 __attribute__((ext_vector_type(2), may_alias));
+__device__ __forceinline__ c32 vmul(c32 a, c32 b) { return a.yx * (c32){-b.y, b.y} + a * b.xx; }
+__device__ __forceinline__ c32 vmi(c32 a) { return (c32){a.y, -a.x}; }   // * -i
 
-template <> __device__ __forceinline__ void dft<2>(float2 (&v)[2]) {
-  float2 a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b);
+// forward DFT (sign -1) of R values held in registers
+template <int R> __device__ __forceinline__ void dft(c32 (&v)[R]);
+
+template <> __device__ __forceinline__ void dft<2>(c32 (&v)[2]) {
+  const c32 a = v[0], b = v[1]; v[0] = a + b; v[1] = a - b;
 }
-template <> __device__ __forceinline__ void dft<4>(float2 (&v)[4]) {
-  float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
-  float2 jd = make_float2(d.y, -d.x);  // -i*d
-  v[0] = cadd(a, c); v[1] = cadd(b, jd); v[2] = csub(a, c); v[3] = csub(b, jd);
+template <> __device__ __forceinline__ void dft<4>(c32 (&v)[4]) {
+  const c32 a = v[0] + v[2], b = v[0] - v[2], c = v[1] + v[3], d = v[1] - v[3];
+  const c32 jd = vmi(d);
+  v[0] = a + c; v[1] = b + jd; v[2] = a - c; v[3] = b - jd;
 }
-template <> __device__ __forceinline__ void dft<8>(float2 (&v)[8]) {
+template <> __device__ __forceinline__ void dft<8>(c32 (&v)[8]) {
   const float r = 0.70710678118654752440f;
-  float2 a[4], b[4];
+  c32 a[4], b[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) { a[k] = cadd(v[k], v[k + 4]); b[k] = csub(v[k], v[k + 4]); }
-  b[1] = make_float2(r * (b[1].x + b[1].y), r * (b[1].y - b[1].x));    // * (1-i)/sqrt2
-  b[2] = make_float2(b[2].y, -b[2].x);                                 // * -i
-  b[3] = make_float2(r * (b[3].y - b[3].x), -r * (b[3].x + b[3].y));   // * (-1-i)/sqrt2
+  for (int k = 0; k < 4; k++) { a[k] = v[k] + v[k + 4]; b[k] = v[k] - v[k + 4]; }
+  b[1] = r * (b[1] + vmi(b[1]));    // * (1-i)/sqrt2
+  b[2] = vmi(b[2]);                 // * -i
+  b[3] = r * (vmi(b[3]) - b[3]);    // * (-1-i)/sqrt2
   dft<4>(a); dft<4>(b);
 #pragma unroll
   for (int q = 0; q < 4; q++) { v[2 * q] = a[q]; v[2 * q + 1] = b[q]; }
 }
 // radix 16 = 4 x 4: Y_{n1} = DFT4 over n2 of v[n1+4*n2]; twiddle W16^{n1*k2}; X[4*k1+k2] = DFT4 over n1
-template <> __device__ __forceinline__ void dft<16>(float2 (&v)[16]) {
+template <> __device__ __forceinline__ void dft<16>(c32 (&v)[16]) {
   const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r = 0.70710678118654752440f;
-  float2 y[4][4];
+  c32 y[4][4];
 #pragma unroll
   for (int n1 = 0; n1 < 4; n1++) {
-    float2 t[4] = {v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]};
+    c32 t[4] = {v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]};
     dft<4>(t);
 #pragma unroll
     for (int k2 = 0; k2 < 4; k2++) y[n1][k2] = t[k2];
   }
   // W16^m = exp(-2 pi i m/16): m = n1*k2
-  const float2 w1 = make_float2(c1, -s1), w2 = make_float2(r, -r), w3 = make_float2(s1, -c1);
-  const float2 w6 = make_float2(-r, -r), w9 = make_float2(-c1, s1);
-  y[1][1] = cmul(y[1][1], w1); y[1][2] = cmul(y[1][2], w2); y[1][3] = cmul(y[1][3], w3);
-  y[2][1] = cmul(y[2][1], w2); y[2][2] = make_float2(y[2][2].y, -y[2][2].x); y[2][3] = cmul(y[2][3], w6);
-  y[3][1] = cmul(y[3][1], w3); y[3][2] = cmul(y[3][2], w6); y[3][3] = cmul(y[3][3], w9);
+  const c32 w1 = {c1, -s1}, w3 = {s1, -c1}, w9 = {-c1, s1};
+  y[1][1] = vmul(y[1][1], w1); y[1][2] = r * (y[1][2] + vmi(y[1][2])); y[1][3] = vmul(y[1][3], w3);
+  y[2][1] = r * (y[2][1] + vmi(y[2][1])); y[2][2] = vmi(y[2][2]); y[2][3] = r * (vmi(y[2][3]) - y[2][3]);
+  y[3][1] = vmul(y[3][1], w3); y[3][2] = r * (vmi(y[3][2]) - y[3][2]); y[3][3] = vmul(y[3][3], w9);
 #pragma unroll
   for (int k2 = 0; k2 < 4; k2++) {
-    float2 t[4] = {y[0][k2], y[1][k2], y[2][k2], y[3][k2]};
+    c32 t[4] = {y[0][k2], y[1][k2], y[2][k2], y[3][k2]};
     dft<4>(t);
 #pragma unroll
     for (int k1 = 0; k1 < 4; k1++) v[4 * k1 + k2] = t[k1];
   }
 }
-template <int R> __device__ __forceinline__ void dft_odd(float2 (&v)[R]) {
+template <int R> __device__ __forceinline__ void dft_odd(c32 (&v)[R]) {
   constexpr int H = (R - 1) / 2;
   constexpr TrigTab<R> tab{};
-  float2 t[H + 1], u[H + 1];
+  c32 t[H + 1], u[H + 1];
 #pragma unroll
-  for (int p = 1; p <= H; p++) { t[p] = cadd(v[p], v[R - p]); u[p] = csub(v[p], v[R - p]); }
-  float2 v0 = v[0], s0 = v[0];
+  for (int p = 1; p <= H; p++) { t[p] = v[p] + v[R - p]; u[p] = v[p] - v[R - p]; }
+  const c32 v0 = v[0];
+  c32 s0 = v[0];
 #pragma unroll
-  for (int p = 1; p <= H; p++) s0 = cadd(s0, t[p]);
+  for (int p = 1; p <= H; p++) s0 = s0 + t[p];
   v[0] = s0;
 #pragma unroll
   for (int a = 1; a <= H; a++) {
-    float2 A = v0, B = make_float2(0.f, 0.f);
+    c32 A = v0, B = {0.f, 0.f};
 #pragma unroll
     for (int p = 1; p <= H; p++) {
       const float cc = tab.c[(a * p) % R], ss = tab.s[(a * p) % R];
-      A.x += cc * t[p].x; A.y += cc * t[p].y; B.x += ss * u[p].x; B.y += ss * u[p].y;
+      A = A + cc * t[p]; B = B + ss * u[p];
     }
-    v[a] = make_float2(A.x + B.y, A.y - B.x);      // A - iB
-    v[R - a] = make_float2(A.x - B.y, A.y + B.x);  // A + iB
+    const c32 jB = vmi(B);
+    v[a] = A + jB;       // A - iB
+    v[R - a] = A - jB;   // A + iB
   }
 }
-template <> __device__ __forceinline__ void dft<3>(float2 (&v)[3]) { dft_odd<3>(v); }
-template <> __device__ __forceinline__ void dft<5>(float2 (&v)[5]) { dft_odd<5>(v); }
-template <> __device__ __forceinline__ void dft<7>(float2 (&v)[7]) { dft_odd<7>(v); }
-template <> __device__ __forceinline__ void dft<11>(float2 (&v)[11]) { dft_odd<11>(v); }
-template <> __device__ __forceinline__ void dft<13>(float2 (&v)[13]) { dft_odd<13>(v); }
-template <> __device__ __forceinline__ void dft<17>(float2 (&v)[17]) { dft_odd<17>(v); }
-template <> __device__ __forceinline__ void dft<19>(float2 (&v)[19]) { dft_odd<19>(v); }
+template <> __device__ __forceinline__ void dft<3>(c32 (&v)[3]) { dft_odd<3>(v); }
+template <> __device__ __forceinline__ void dft<5>(c32 (&v)[5]) { dft_odd<5>(v); }
+template <> __device__ __forceinline__ void dft<7>(c32 (&v)[7]) { dft_odd<7>(v); }
+template <> __device__ __forceinline__ void dft<11>(c32 (&v)[11]) { dft_odd<11>(v); }
+template <> __device__ __forceinline__ void dft<13>(c32 (&v)[13]) { dft_odd<13>(v); }
+template <> __device__ __forceinline__ void dft<17>(c32 (&v)[17]) { dft_odd<17>(v); }
+template <> __device__ __forceinline__ void dft<19>(c32 (&v)[19]) { dft_odd<19>(v); }
 
 // One radix-R Stockham stage on `nl` lines of length n held in LDS.
 // element (idx,line) lives at idx*sI + line*sL.  ROWS: lanes run along the line (x pass);
@@ -136,19 +144,19 @@ __device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 
     else if (NL > 0) { j = task / NL; line = task - j * NL; }
     else { j = fdiv(task, dNl); line = task - __mul24(j, nl); }
     const int k = (Ns == 1) ? 0 : (last ? j : j - __mul24(fdiv(j, dNs), Ns));
-    const float2 *pin = in + __mul24(line, sL) + __mul24(j, sI);
-    float2 v[R];
+    const c32 *pin = reinterpret_cast<const c32 *>(in) + __mul24(line, sL) + __mul24(j, sI);
+    c32 v[R];
 #pragma unroll
     for (int m = 0; m < R; m++) v[m] = pin[m * step_in];
     if (Ns > 1) {
+      const c32 *twv = reinterpret_cast<const c32 *>(tw);
       const int ts = __mul24(tstep, k);
-      int ti = ts;
 #pragma unroll
-      for (int m = 1; m < R; m++) { v[m] = cmul(v[m], tw[ti]); ti += ts; }
+      for (int m = 1; m < R; m++) v[m] = vmul(v[m], twv[__mul24(m, ts)]);   // 24-bit multiply: full rate
     }
     dft<R>(v);
     const int j0 = __mul24(j - k, R) + k;
-    float2 *pout = out + __mul24(line, sL) + __mul24(j0, sI);
+    c32 *pout = reinterpret_cast<c32 *>(out) + __mul24(line, sL) + __mul24(j0, sI);
 #pragma unroll
     for (int m = 0; m < R; m++) pout[m * step_out] = v[m];
   }
