@@ -43,7 +43,7 @@ struct CoarseDist {            // per local logical rank
   float *blocks_out = nullptr; // [nd^2][3][s][ncn][ncn]   slab -> cube departures
   float *blocks_back = nullptr;// [nd^2][3][s][ncn][ncn]   arrivals at the cube
   float *halo_s[2] = {nullptr, nullptr}, *halo_r[2] = {nullptr, nullptr};  // [3][(ncn+2)^2]
-  float4 *sb[2] = {nullptr, nullptr}, *rb[2] = {nullptr, nullptr};         // ghost records, 48 B each
+  float4 *sb[2] = {nullptr, nullptr}, *rb[2] = {nullptr, nullptr};         // ghost records, 32 B each
   int *d_cnt = nullptr;        // [0..1] own send counts, [2..3] counts announced by the neighbours
 };
 
@@ -111,15 +111,47 @@ static int host_exchange(p3m_group *G, const std::vector<XMsg> &msgs) {
   return P3M_OK;
 }
 
+// All device-to-device messages of one exchange in ONE launch (an exchange is dozens of small messages; as
+// separate copies each costs ~6 us of dependent-launch latency on the stream).  blockIdx.y = message.
+#define XCOPY_MAX 40
+struct XCopyBatch { const char *src[XCOPY_MAX]; char *dst[XCOPY_MAX]; unsigned long long bytes[XCOPY_MAX]; };
+__global__ __launch_bounds__(256) void k_multi_copy(XCopyBatch b) {
+  const char *src = b.src[blockIdx.y]; char *dst = b.dst[blockIdx.y];
+  const unsigned long long n = b.bytes[blockIdx.y];
+  const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x, stride = (unsigned long long)gridDim.x * 256;
+  if ((((unsigned long long)src | (unsigned long long)dst | n) & 15) == 0) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src); float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (unsigned long long i = t; i < (n >> 4); i += stride) d4[i] = s4[i];
+  } else if ((((unsigned long long)src | (unsigned long long)dst | n) & 3) == 0) {
+    const int *s1 = reinterpret_cast<const int *>(src); int *d1 = reinterpret_cast<int *>(dst);
+    for (unsigned long long i = t; i < (n >> 2); i += stride) d1[i] = s1[i];
+  } else {
+    for (unsigned long long i = t; i < n; i += stride) dst[i] = src[i];
+  }
+}
+static int flush_copies(p3m_group *G, XCopyBatch &b, int &nb, size_t &maxb) {
+  if (nb == 0) return P3M_OK;
+  const unsigned gx = (unsigned)std::min<size_t>(256, std::max<size_t>(1, (maxb + 16 * 256 * 8 - 1) / (16 * 256 * 8)));
+  hipLaunchKernelGGL(k_multi_copy, dim3(gx, nb), dim3(256), 0, G->stream, b);
+  HIP_TRY(hipGetLastError());
+  nb = 0; maxb = 0;
+  return P3M_OK;
+}
+
 // every process builds the SAME global message list (same order); pointers are only needed for local ends
 static int do_exchange(p3m_group *G, const std::vector<XMsg> &msgs) {
   bool any_remote = false;
+  XCopyBatch batch; int nb = 0; size_t maxb = 0;
   for (const XMsg &m : msgs) {
     const bool sl = G->owner[m.src] == G->proc, dl = G->owner[m.dst] == G->proc;
     if (m.bytes == 0) continue;
-    if (sl && dl && !G->force_nccl) HIP_TRY(hipMemcpyAsync(m.rptr, m.sptr, m.bytes, hipMemcpyDeviceToDevice, G->stream));
-    else if (sl || dl) any_remote = true;
+    if (sl && dl && !G->force_nccl) {
+      batch.src[nb] = static_cast<const char *>(m.sptr); batch.dst[nb] = static_cast<char *>(m.rptr); batch.bytes[nb] = m.bytes;
+      maxb = std::max(maxb, m.bytes);
+      if (++nb == XCOPY_MAX) P3M_TRY(flush_copies(G, batch, nb, maxb));
+    } else if (sl || dl) any_remote = true;
   }
+  P3M_TRY(flush_copies(G, batch, nb, maxb));
   if (!any_remote) return P3M_OK;
   if (!G->comm && G->have_tr) return host_exchange(G, msgs);
   if (!G->comm) { p3m_set_error("group exchange between processes needs RCCL (p3m_hip_group_comm_init_rccl) or a host transport (p3m_hip_group_set_transport)"); return P3M_ECOMM; }
@@ -208,7 +240,7 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
       A(galloc(&d.blocks_out, (size_t)nd * nd * 3 * blk)); A(galloc(&d.blocks_back, (size_t)nd * nd * 3 * blk));
       for (int i = 0; i < 2; i++) {
         A(galloc(&d.halo_s[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2))); A(galloc(&d.halo_r[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2)));
-        A(galloc(&d.sb[i], (size_t)3 * G->cap_buf)); A(galloc(&d.rb[i], (size_t)3 * G->cap_buf));
+        A(galloc(&d.sb[i], (size_t)2 * G->cap_buf)); A(galloc(&d.rb[i], (size_t)2 * G->cap_buf));
       }
       A(galloc(&d.d_cnt, 8));
 #undef A
@@ -306,9 +338,9 @@ static int ghost_pass(p3m_group *G) {
       const int li = G->lidx[r], lp = G->lidx[rp], lm = G->lidx[rm];
       // bytes: take whichever end is local (both agree)
       size_t bp = 0, bm = 0;
-      if (li >= 0) { bp = (size_t)G->h_cnt[4 * li + 0] * 48; bm = (size_t)G->h_cnt[4 * li + 1] * 48; }
-      if (lp >= 0) bp = (size_t)G->h_cnt[4 * lp + 2] * 48;
-      if (lm >= 0) bm = (size_t)G->h_cnt[4 * lm + 3] * 48;
+      if (li >= 0) { bp = (size_t)G->h_cnt[4 * li + 0] * 32; bm = (size_t)G->h_cnt[4 * li + 1] * 32; }
+      if (lp >= 0) bp = (size_t)G->h_cnt[4 * lp + 2] * 32;
+      if (lm >= 0) bm = (size_t)G->h_cnt[4 * lm + 3] * 32;
       pm.push_back({r, rp, li >= 0 ? (const void *)G->cd[li].sb[0] : nullptr, lp >= 0 ? (void *)G->cd[lp].rb[0] : nullptr, bp});
       pm.push_back({r, rm, li >= 0 ? (const void *)G->cd[li].sb[1] : nullptr, lm >= 0 ? (void *)G->cd[lm].rb[1] : nullptr, bm});
     }
