@@ -162,7 +162,9 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   const Geometry &g = c->g;
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   if (c->p.flags & P3M_FLAG_NGP) {
-    hipLaunchKernelGGL(k_ngp_counts, dim3(cdiv(g.nf, 8), g.nf, ntile), dim3(256), 0, c->stream, (const int *)c->cell_end,
+    const bool have = c->rho_from_sort && tile0 == 0 && ntile == g.ntiles;   // written by k_row_sort of this step
+    c->rho_from_sort = false;
+    if (!have) hipLaunchKernelGGL(k_ngp_counts, dim3(cdiv(g.nf, 8), g.nf, ntile), dim3(256), 0, c->stream, (const int *)c->cell_end,
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
     HIP_TRY(hipGetLastError());
     if (c->ncand > 0) {

@@ -708,7 +708,7 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   for (p3m_ctx *c : G->ctx) if (!c->have_kf || !c->have_kc) { p3m_set_error("particle_mesh before the Green's functions were set"); return P3M_ESTATE; }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
   P3M_TRY(ghost_pass(G));                                                                           // :61-63
-  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort(c));
+  for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort(c, mass_p)); }
   for (p3m_ctx *c : G->ctx) P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));                       // :72-628
   for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                     // coarse_mass
   P3M_TRY(coarse_force_dist(G));                                                                    // coarse_force, _buffer, max

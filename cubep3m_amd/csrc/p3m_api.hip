@@ -310,7 +310,7 @@ extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p
   if (!c) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
-  P3M_TRY(reductions_clear(c));
+  if (!c->rho_from_sort) P3M_TRY(reductions_clear(c));   // else cleared before the sort, which already added the NGP mass sum
   HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
   P3M_TRY(fine_sweep(c, mass_p));
   P3M_TRY(fine_max_and_kick(c, a_mid, dt));
@@ -380,7 +380,11 @@ extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt
   if (!c) return P3M_EINVAL;
   P3M_TRY(need_kernels(c));
   P3M_TRY(p3m_hip_update_position(c, dt, dt_old, offset));   // :56
-  P3M_TRY(p3m_hip_link_list_and_pass(c));                    // :61-63
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }
+  P3M_TRY(reductions_clear(c));
+  P3M_TRY(particles_pass_self(c));                           // :61-63
+  P3M_TRY(particles_sort(c, mass_p));
   P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));          // :72-628
   P3M_TRY(p3m_hip_coarse_mesh(c, a_mid, dt, mass_p));        // :712
   P3M_TRY(p3m_hip_delete_particles(c, move_back));           // :716-720

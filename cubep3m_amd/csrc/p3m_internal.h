@@ -83,6 +83,7 @@ struct p3m_ctx {
   int *h_counters = nullptr;   // pinned mirror
   // ---- fine mesh, all tiles batched
   int tile_batch = 0;          // tiles processed per sweep
+  bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
   float *work = nullptr;       // [3][batch][nf][nf][2*px]  i*K_c*rho-hat -> force, all three components
   float *fbox = nullptr;       // [3][ntiles][fb][fb][fbp] extracted force (SoA planes, pad columns zero)
@@ -131,7 +132,7 @@ int fft_lz_to_rows(p3m_ctx *c, const FftPlan &pl, const float *lz, float *rows);
 int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset);
 int particles_pass_and_sort(p3m_ctx *c);
 int particles_pass_self(p3m_ctx *c);
-int particles_sort(p3m_ctx *c);
+int particles_sort(p3m_ctx *c, float deposit_mass);
 int particles_pass_pack(p3m_ctx *c, int n_cur, int axis, float4 *sbuf_plus, float4 *sbuf_minus, int cap_buf, int *d_counts);
 int particles_pass_unpack(p3m_ctx *c, const float4 *rbuf, int nrecv, int axis, int from_plus_dir, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);

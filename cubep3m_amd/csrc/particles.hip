@@ -188,10 +188,11 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
 }
 
 // one wavefront per row: bins[] = LDS histogram of the row's x cells -> exclusive prefix (the row of cs) -> cursors
+struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, rp; };   // fused NGP deposit (rho == nullptr: off)
 __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos, const float4 *__restrict__ tvel, const int64_t *__restrict__ tpid,
                                                  const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
                                                  float4 *__restrict__ spos, float4 *__restrict__ svel, int64_t *__restrict__ spid,
-                                                 int *__restrict__ cand, int *__restrict__ ncand, int cand_cap) {
+                                                 int *__restrict__ cand, int *__restrict__ ncand, int cand_cap, RowDep dep) {
   extern __shared__ int bins[];
   const int row = blockIdx.x, lane = threadIdx.x;
   const int r0 = rs[row], r1 = rs[row + 1];
@@ -211,6 +212,38 @@ __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos
   int *csr = cs + (int64_t)row * E;
   for (int j = lane; j < E; j += 64) csr[j] = bins[j];
   if (row == nrows - 1 && lane == 0) csr[E] = r1;
+  // NGP deposit straight from the row histogram (particle_mesh_threaded.f90:131-151): rho(cell) = mass_p added
+  // count(cell) times, cells outside the chain window [4, nf-4) zero (:120-121).  Every row of every tile is
+  // the image of exactly one extended row, so each rho row is written once, here, while its counts are in
+  // LDS; records whose xv + offset_tile rounds into the next cell are moved afterwards by k_ngp_fixup.
+  if (dep.rho) {
+    const int cz = row / E, cy = row - cz * E, nbi = (int)nb;
+    float part = 0.f;
+    for (int tz = max(0, (cz - dep.nf + dep.pt) / dep.pt); tz < dep.T && tz * dep.pt <= cz; tz++)
+      for (int ty = max(0, (cy - dep.nf + dep.pt) / dep.pt); ty < dep.T && ty * dep.pt <= cy; ty++) {
+        const int k = cz - tz * dep.pt, j = cy - ty * dep.pt;
+        if (k >= dep.nf || j >= dep.nf) continue;
+        const bool row_in = (j >= 4 && j < dep.nf - 4 && k >= 4 && k < dep.nf - 4);
+        const bool row_int = (j >= nbi && j < dep.nf - nbi && k >= nbi && k < dep.nf - nbi);
+        for (int tx = 0; tx < dep.T; tx++) {
+          float *out = dep.rho + ((((int64_t)(tz * dep.T + ty) * dep.T + tx) * dep.nf + k) * dep.nf + j) * dep.rp;
+          for (int i = lane; i < dep.rp; i += 64) {
+            float r = 0.f;
+            if (row_in && i >= 4 && i < dep.nf - 4) {
+              const int c = tx * dep.pt + i;
+              const int cnt = (c + 1 < E ? bins[c + 1] : r1) - bins[c];
+              for (int q = 0; q < cnt; q++) r = r + dep.mass_p;                      // :148, same partial sums
+              if (row_int && i >= nbi && i < dep.nf - nbi) part += r;                // :167-173
+            }
+            out[i] = r;
+          }
+        }
+      }
+    if (dep.sum_interior) {
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+      if (lane == 0 && part != 0.f) atomicAdd(dep.sum_interior + p3m_slot() * 8, (double)part);
+    }
+  }
   // records with a coordinate within 2^-10 below a cell face: only these can be moved into the next
   // cell by the rounding of xv + offset_tile (fine_mesh.hip, count-based NGP deposit fix-up)
   const float thr = 1.0f - 0.0009765625f;
@@ -247,8 +280,9 @@ int particles_pass_self(p3m_ctx *c) {
   return P3M_OK;
 }
 
-// sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell
-int particles_sort(p3m_ctx *c) {
+// sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell; deposit_mass >= 0 (whole-step
+// entry points, where mass_p is known here) also writes the NGP density of every tile (c->rho_from_sort)
+int particles_sort(p3m_ctx *c, float deposit_mass) {
   const Geometry &g = c->g;
   int *cnt = c->d_counters;
   const int n_cur = c->np_all;
@@ -270,9 +304,14 @@ int particles_sort(p3m_ctx *c) {
                        (float)g.Nn, (float)g.nb, g.E, c->row_end, c->tpos, c->tvel, c->tpid);
     HIP_TRY(hipGetLastError());
   }
+  RowDep dep{nullptr, nullptr, 0.f, g.T, g.nf, g.pt, 2 * g.px};
+  c->rho_from_sort = false;
+  if (deposit_mass >= 0.f && (c->p.flags & P3M_FLAG_NGP) && c->tile_batch == g.ntiles) {
+    dep.rho = c->rho; dep.sum_interior = c->d_sums; dep.mass_p = deposit_mass; c->rho_from_sort = true;
+  }
   hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos, (const float4 *)c->tvel,
                      (const int64_t *)c->tpid, (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5,
-                     (int)c->cap);
+                     (int)c->cap, dep);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -285,7 +324,7 @@ int particles_sort(p3m_ctx *c) {
 int particles_pass_and_sort(p3m_ctx *c) {
   if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }
   P3M_TRY(particles_pass_self(c));
-  return particles_sort(c);
+  return particles_sort(c, -1.f);
 }
 
 // ------------------------------------------------------------------ multi-rank ghost pass: pack / unpack one axis
