@@ -43,8 +43,8 @@ struct CoarseDist {            // per local logical rank
   float *blocks_out = nullptr; // [nd^2][3][s][ncn][ncn]   slab -> cube departures
   float *blocks_back = nullptr;// [nd^2][3][s][ncn][ncn]   arrivals at the cube
   float *halo_s[2] = {nullptr, nullptr}, *halo_r[2] = {nullptr, nullptr};  // [3][(ncn+2)^2]
-  float4 *sb[2] = {nullptr, nullptr}, *rb[2] = {nullptr, nullptr};         // ghost records, 32 B each
-  int *d_cnt = nullptr;        // [0..1] own send counts, [2..3] counts announced by the neighbours
+  float4 *sb = nullptr, *rb = nullptr;   // ghost records, 32 B each, 26 segments (one per shift, G->seg_off)
+  int *d_cnt = nullptr;        // [0..26] own send counts per shift, [32..58] counts announced by the neighbours
 };
 
 struct p3m_group {
@@ -56,7 +56,8 @@ struct p3m_group {
   ncclComm_t comm = nullptr; bool force_nccl = false;
   p3m_transport tr{}; bool have_tr = false;
   char *h_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};   // pinned send / receive staging of the host transport
-  FftPlan plan_c; int s = 0, nchunk = 0, cap_buf = 0;
+  FftPlan plan_c; int s = 0, nchunk = 0;
+  int seg_off[27] = {0}, seg_cap[27] = {0}; int64_t seg_total = 0;   // ghost segments by shift: faces, edges, corners
   int *h_cnt = nullptr;        // pinned [nlocal*4]
   float *d_red4 = nullptr; double *d_sum3 = nullptr; float *h_red4 = nullptr; double *h_sum3 = nullptr;
   bool have_k = false;
@@ -183,8 +184,8 @@ extern "C" void p3m_hip_group_destroy(p3m_group *G) {
   for (CoarseDist &d : G->cd) {
     gfree(d.blocks_in); gfree(d.rows); gfree(d.ly); gfree(d.send); gfree(d.recv); gfree(d.lz); gfree(d.kern);
     gfree(d.blocks_out); gfree(d.blocks_back);
-    for (int i = 0; i < 2; i++) { gfree(d.halo_s[i]); gfree(d.halo_r[i]); gfree(d.sb[i]); gfree(d.rb[i]); }
-    gfree(d.d_cnt);
+    for (int i = 0; i < 2; i++) { gfree(d.halo_s[i]); gfree(d.halo_r[i]); }
+    gfree(d.sb); gfree(d.rb); gfree(d.d_cnt);
   }
   for (p3m_ctx *c : G->ctx) { if (c) { c->stream = nullptr; p3m_hip_destroy(c); } }
   if (G->comm) (void)ncclCommDestroy(G->comm);
@@ -223,13 +224,28 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     G->lidx[r] = (int)G->ctx.size(); G->ctx.push_back(c); G->lrank.push_back(r);
   }
   const Geometry &g = G->ctx[0]->g;
+  if (nodes > 1 && g.Nn < 2 * g.nb) {   // one ghost shift per axis (k_ghost_pack)
+    p3m_set_error("multi-rank groups need nf_physical_node_dim >= 2*nf_buf (%d < %d)", g.Nn, 2 * g.nb);
+    return fail(P3M_EINVAL);
+  }
   if (nodes > 1) {
     G->s = g.nc_slab;
     int rc = fft_plan_create(&G->plan_c, g.nc);
     if (rc) return fail(rc);
     G->nchunk = G->plan_c.px / 16;
-    // ghost buffers: the largest single-axis face shell, sized from the rank's capacity
-    G->cap_buf = (int)std::min<int64_t>(g.max_np, (int64_t)(g.max_np / 2) + 1024);
+    // ghost segments, sized from the rank's capacity: a face shell holds nb/Nn of the particles, an edge (nb/Nn)^2, ...
+    {
+      const double f = std::min(1.0, 2.5 * (double)g.nb / (double)g.Nn);   // 2.5x the uniform-density share
+      int64_t run = 0;
+      for (int m = 0; m < 27; m++) {
+        const int nz = (m % 3 != 0) + ((m / 3) % 3 != 0) + (m / 9 != 0);
+        int64_t cap = nz == 0 ? 0 : (int64_t)((double)g.max_np * (nz == 1 ? f : (nz == 2 ? f * f : f * f * f))) + 4096;
+        cap = std::min<int64_t>(cap, g.max_np);
+        G->seg_off[m] = (int)run; G->seg_cap[m] = (int)cap; run += cap;
+      }
+      if (run > 0x3fffffff) return fail(P3M_ECAPACITY);
+      G->seg_total = run;
+    }
     const size_t NB = (size_t)G->s * G->nchunk * g.nc * 16 * 2;          // floats of one component's complex slab
     const size_t blk = (size_t)G->s * g.ncn * g.ncn;
     G->cd.resize(G->ctx.size());
@@ -240,15 +256,15 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
       A(galloc(&d.blocks_out, (size_t)nd * nd * 3 * blk)); A(galloc(&d.blocks_back, (size_t)nd * nd * 3 * blk));
       for (int i = 0; i < 2; i++) {
         A(galloc(&d.halo_s[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2))); A(galloc(&d.halo_r[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2)));
-        A(galloc(&d.sb[i], (size_t)2 * G->cap_buf)); A(galloc(&d.rb[i], (size_t)2 * G->cap_buf));
       }
-      A(galloc(&d.d_cnt, 8));
+      A(galloc(&d.sb, (size_t)2 * G->seg_total)); A(galloc(&d.rb, (size_t)2 * G->seg_total));
+      A(galloc(&d.d_cnt, 64));
 #undef A
       if (hipMemset(d.rows, 0, sizeof(float) * 3 * G->s * g.nc * 2 * G->plan_c.px) != hipSuccess) return fail(P3M_EDEVICE);
     }
   }
   if (galloc(&G->d_red4, 8) || galloc(&G->d_sum3, 4)) return fail(P3M_ENOMEM);
-  if (hipHostMalloc(reinterpret_cast<void **>(&G->h_cnt), sizeof(int) * 8 * G->ctx.size()) != hipSuccess) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&G->h_cnt), sizeof(int) * 64 * G->ctx.size()) != hipSuccess) return fail(P3M_ENOMEM);
   if (hipHostMalloc(reinterpret_cast<void **>(&G->h_red4), sizeof(float) * 8) != hipSuccess) return fail(P3M_ENOMEM);
   if (hipHostMalloc(reinterpret_cast<void **>(&G->h_sum3), sizeof(double) * 4) != hipSuccess) return fail(P3M_ENOMEM);
   G->last.dt_f_acc = G->last.dt_pp_acc = G->last.dt_pp_ext_acc = G->last.dt_c_acc = 1000.f;
@@ -288,72 +304,66 @@ extern "C" int32_t p3m_hip_group_local_rank(const p3m_group *G, int32_t i) { ret
 extern "C" p3m_ctx *p3m_hip_group_ctx(p3m_group *G, int32_t i) { return (G && i >= 0 && i < (int)G->ctx.size()) ? G->ctx[i] : nullptr; }
 
 // ================================================================== ghost pass (particle_pass.f90)
+// One round for all 26 directions (particles.hip, k_ghost_pack): counts first, then the records.
+static int shift_neighbour(const p3m_group *G, int r, int m) {
+  const int nd = G->nd, c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
+  const int a = m % 3, b = (m / 3) % 3, c = m / 9;                  // x <-> c3, y <-> c2, z <-> c1; 1: + neighbour, 2: - neighbour
+  auto mv = [&](int v, int s) { return s == 1 ? (v + 1) % nd : (s == 2 ? (v - 1 + nd) % nd : v); };
+  return mv(c1, c) * nd * nd + mv(c2, b) * nd + mv(c3, a);
+}
 static int ghost_pass(p3m_group *G) {
   const int nl = (int)G->ctx.size();
   if (G->nodes == 1) return particles_pass_self(G->ctx[0]);
-  std::vector<int> n_cur(nl);
-  for (int i = 0; i < nl; i++) n_cur[i] = G->ctx[i]->np_local;
-  for (int axis = 0; axis < 3; axis++) {
-    // 1. pack both directions, fetch the counts
-    for (int i = 0; i < nl; i++) {
-      CoarseDist &d = G->cd[i];
-      HIP_TRY(hipMemsetAsync(d.d_cnt, 0, 8 * sizeof(int), G->stream));
-      P3M_TRY(particles_pass_pack(G->ctx[i], n_cur[i], axis, d.sb[0], d.sb[1], G->cap_buf, d.d_cnt));
+  // 1. pack every image into the segment of its shift
+  for (int i = 0; i < nl; i++) {
+    CoarseDist &d = G->cd[i];
+    HIP_TRY(hipMemsetAsync(d.d_cnt, 0, 64 * sizeof(int), G->stream));
+    P3M_TRY(particles_ghost_pack(G->ctx[i], d.sb, G->seg_off, G->seg_cap, d.d_cnt));
+  }
+  // 2. announce the counts: shift m of rank r lands in slot m of the rank at r + shift (one source per slot)
+  std::vector<XMsg> cm;
+  for (int r = 0; r < G->nodes; r++)
+    for (int m = 1; m < 27; m++) {
+      const int dst = shift_neighbour(G, r, m), li = G->lidx[r], ld = G->lidx[dst];
+      cm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].d_cnt + m) : nullptr, ld >= 0 ? (void *)(G->cd[ld].d_cnt + 32 + m) : nullptr, sizeof(int)});
     }
-    // 2. announce counts: +dir buffer goes to the +axis neighbour, which receives it as "from its -axis side"
-    //    nbr[] = {-z,+z,-y,+y,-x,+x}; axis 0 = x
-    std::vector<XMsg> cm;
-    for (int r = 0; r < G->nodes; r++) {
-      const int nd = G->nd, c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
-      int cp[3] = {c1, c2, c3}, cmn[3] = {c1, c2, c3};
-      const int dim = 2 - axis;  // x <-> cart dim 3 (index 2), y <-> 1, z <-> 0
-      cp[dim] = (cp[dim] + 1) % nd; cmn[dim] = (cmn[dim] - 1 + nd) % nd;
-      const int rp = cp[0] * nd * nd + cp[1] * nd + cp[2], rm = cmn[0] * nd * nd + cmn[1] * nd + cmn[2];
-      const int li = G->lidx[r], lp = G->lidx[rp], lm = G->lidx[rm];
-      cm.push_back({r, rp, li >= 0 ? (const void *)(G->cd[li].d_cnt + 0) : nullptr, lp >= 0 ? (void *)(G->cd[lp].d_cnt + 2) : nullptr, sizeof(int)});
-      cm.push_back({r, rm, li >= 0 ? (const void *)(G->cd[li].d_cnt + 1) : nullptr, lm >= 0 ? (void *)(G->cd[lm].d_cnt + 3) : nullptr, sizeof(int)});
-    }
-    P3M_TRY(do_exchange(G, cm));
-    for (int i = 0; i < nl; i++) HIP_TRY(hipMemcpyAsync(G->h_cnt + 4 * i, G->cd[i].d_cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, G->stream));
-    HIP_TRY(hipStreamSynchronize(G->stream));
-    for (int i = 0; i < nl; i++) {
-      const int *h = G->h_cnt + 4 * i;
-      if (h[0] > G->cap_buf || h[1] > G->cap_buf || h[2] > G->cap_buf || h[3] > G->cap_buf) {
-        p3m_set_error("rank %d: not enough buffer space in pass (%d,%d,%d,%d > %d) (particle_pass.f90:96-99)", G->lrank[i], h[0], h[1], h[2], h[3], G->cap_buf);
+  P3M_TRY(do_exchange(G, cm));
+  for (int i = 0; i < nl; i++) HIP_TRY(hipMemcpyAsync(G->h_cnt + 64 * i, G->cd[i].d_cnt, 64 * sizeof(int), hipMemcpyDeviceToHost, G->stream));
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  for (int i = 0; i < nl; i++) {
+    const int *h = G->h_cnt + 64 * i;
+    int64_t in = 0;
+    for (int m = 1; m < 27; m++) {
+      if (h[m] > G->seg_cap[m] || h[32 + m] > G->seg_cap[m]) {
+        p3m_set_error("rank %d: not enough buffer space in pass (shift %d: %d out, %d in > %d) (particle_pass.f90:96-99)", G->lrank[i], m, h[m], h[32 + m], G->seg_cap[m]);
         return P3M_ECAPACITY;
       }
-      if ((int64_t)n_cur[i] + h[2] + h[3] > G->ctx[i]->cap) {
-        p3m_set_error("rank %d: exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139)", G->lrank[i], (long long)n_cur[i] + h[2] + h[3], (long long)G->ctx[i]->cap);
-        return P3M_ECAPACITY;
-      }
+      in += h[32 + m];
     }
-    // 3. payloads.  Sizes: the sender knows its own counts, the receiver the announced ones.
-    std::vector<XMsg> pm;
-    for (int r = 0; r < G->nodes; r++) {
-      const int nd = G->nd, c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
-      int cp[3] = {c1, c2, c3}, cmn[3] = {c1, c2, c3};
-      const int dim = 2 - axis;
-      cp[dim] = (cp[dim] + 1) % nd; cmn[dim] = (cmn[dim] - 1 + nd) % nd;
-      const int rp = cp[0] * nd * nd + cp[1] * nd + cp[2], rm = cmn[0] * nd * nd + cmn[1] * nd + cmn[2];
-      const int li = G->lidx[r], lp = G->lidx[rp], lm = G->lidx[rm];
-      // bytes: take whichever end is local (both agree)
-      size_t bp = 0, bm = 0;
-      if (li >= 0) { bp = (size_t)G->h_cnt[4 * li + 0] * 32; bm = (size_t)G->h_cnt[4 * li + 1] * 32; }
-      if (lp >= 0) bp = (size_t)G->h_cnt[4 * lp + 2] * 32;
-      if (lm >= 0) bm = (size_t)G->h_cnt[4 * lm + 3] * 32;
-      pm.push_back({r, rp, li >= 0 ? (const void *)G->cd[li].sb[0] : nullptr, lp >= 0 ? (void *)G->cd[lp].rb[0] : nullptr, bp});
-      pm.push_back({r, rm, li >= 0 ? (const void *)G->cd[li].sb[1] : nullptr, lm >= 0 ? (void *)G->cd[lm].rb[1] : nullptr, bm});
-    }
-    P3M_TRY(do_exchange(G, pm));
-    // 4. append: arrivals from the -axis neighbour's +buffer first (as the reference: +x then -x, :160-168,:252-268)
-    for (int i = 0; i < nl; i++) {
-      const int *h = G->h_cnt + 4 * i;
-      P3M_TRY(particles_pass_unpack(G->ctx[i], G->cd[i].rb[0], h[2], axis, 1, n_cur[i]));
-      P3M_TRY(particles_pass_unpack(G->ctx[i], G->cd[i].rb[1], h[3], axis, 0, n_cur[i] + h[2]));
-      n_cur[i] += h[2] + h[3];
+    if ((int64_t)G->ctx[i]->np_local + in > G->ctx[i]->cap) {
+      p3m_set_error("rank %d: exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139)", G->lrank[i], (long long)G->ctx[i]->np_local + in, (long long)G->ctx[i]->cap);
+      return P3M_ECAPACITY;
     }
   }
-  for (int i = 0; i < nl; i++) G->ctx[i]->np_all = n_cur[i];
+  // 3. payloads.  Sizes: the sender knows its own counts, the receiver the announced ones (they agree).
+  std::vector<XMsg> pm;
+  for (int r = 0; r < G->nodes; r++)
+    for (int m = 1; m < 27; m++) {
+      const int dst = shift_neighbour(G, r, m), li = G->lidx[r], ld = G->lidx[dst];
+      size_t bytes = 0;
+      if (li >= 0) bytes = (size_t)G->h_cnt[64 * li + m] * 32;
+      if (ld >= 0) bytes = (size_t)G->h_cnt[64 * ld + 32 + m] * 32;
+      pm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].sb + 2 * (size_t)G->seg_off[m]) : nullptr,
+                    ld >= 0 ? (void *)(G->cd[ld].rb + 2 * (size_t)G->seg_off[m]) : nullptr, bytes});
+    }
+  P3M_TRY(do_exchange(G, pm));
+  // 4. append
+  for (int i = 0; i < nl; i++) {
+    const int *h = G->h_cnt + 64 * i;
+    P3M_TRY(particles_ghost_unpack(G->ctx[i], G->cd[i].rb, G->seg_off, h + 32, G->ctx[i]->np_local));
+    int in = 0; for (int m = 1; m < 27; m++) in += h[32 + m];
+    G->ctx[i]->np_all = G->ctx[i]->np_local + in;
+  }
   return P3M_OK;
 }
 

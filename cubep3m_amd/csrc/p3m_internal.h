@@ -133,8 +133,8 @@ int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset);
 int particles_pass_and_sort(p3m_ctx *c);
 int particles_pass_self(p3m_ctx *c);
 int particles_sort(p3m_ctx *c, float deposit_mass);
-int particles_pass_pack(p3m_ctx *c, int n_cur, int axis, float4 *sbuf_plus, float4 *sbuf_minus, int cap_buf, int *d_counts);
-int particles_pass_unpack(p3m_ctx *c, const float4 *rbuf, int nrecv, int axis, int from_plus_dir, int base);
+int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts);
+int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);
 
 // ---- fine_mesh.hip

@@ -327,81 +327,99 @@ int particles_pass_and_sort(p3m_ctx *c) {
   return particles_sort(c, -1.f);
 }
 
-// ------------------------------------------------------------------ multi-rank ghost pass: pack / unpack one axis
-// Records travel as 32-byte AoS {x,y,z,vx | vy,vz,pid(8 B)}: the w lanes of pos/vel are padding (zero) and
-// are not sent -- a third less over xGMI than the device-side SoA record.
-// dir_plus: records with x_a >= Nn-nb go to the +a neighbour (particle_pass.f90:83), dir_minus: x_a < nb to the
-// -a neighbour (:185).  Only records that existed before this axis (i < n_cur) are offered.
-constexpr int PACK_RPT = 8;  // records per thread: one pair of atomics per 2048 records
-__global__ __launch_bounds__(PT) void k_pass_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
-                                                  int n_cur, int axis, float Nn, float nb, float4 *__restrict__ sbuf_plus,
-                                                  float4 *__restrict__ sbuf_minus, int cap_buf, int *__restrict__ counts) {
-  // one atomic per block and direction (a per-record atomic on one address serialises the whole chip)
-  __shared__ int wsum[2][PACK_RPT][PT / 64];
-  __shared__ int base_sh[2];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int i0 = blockIdx.x * (PT * PACK_RPT) + threadIdx.x;
-  float4 p[PACK_RPT];
-  int slot[PACK_RPT];  // bit 30: goes +, bit 29: goes -, low bits: rank inside the wave for either direction
+// ------------------------------------------------------------------ multi-rank ghost pass: all 26 directions in one round
+// particle_pass.f90 exchanges +x,-x | -y,+y | +z,-z in sequence, each axis seeing the arrivals of the earlier
+// ones, so that a record's ghosts are the Cartesian product of its per-axis image sets (see k_make_images).
+// Here every image is sent straight to the rank that owns it: shift m = a + 3b + 9c, a/b/c in {0 none,
+// 1 to the + neighbour (x_a >= Nn-nb, image max(x_a-Nn,-nb), :83,:162), 2 to the - neighbour (x_a < nb, image
+// min(guard(x_a)+Nn, Nn+nb-eps), :185,:257-265)} for x/y/z.  One pack, one count exchange, one payload exchange
+// over up to 7 different peers (all xGMI links at once instead of one link three times), one unpack.
+// Records travel as 32-byte AoS {x,y,z,vx | vy,vz,pid(8 B)} with FINAL coordinates: the w lanes of pos/vel
+// are padding (zero) and are not sent.
+struct GhostSegs { int off[27]; int cap[27]; };   // record offset / capacity of each shift's segment in the send and receive buffers
+// the (at most one, since Nn >= 2 nb) shift of a coordinate: 0 none, 1 image at the + neighbour, 2 at the - neighbour
+__device__ __forceinline__ int axis_shift(float x, float Nn, float nb, float *img) {
+  if (x >= Nn - nb) { *img = fmaxf(x - Nn, -nb); return 1; }
+  if (x < nb) {
+    float xg = x; if (fabsf(xg) < P3M_EPS_F) xg = (xg < 0.0f) ? -P3M_EPS_F : P3M_EPS_F;
+    *img = fminf(xg + Nn, Nn + nb - P3M_EPS_F); return 2;
+  }
+  *img = x; return 0;
+}
+constexpr int GP_RPT = 8;   // records per thread: <= 26 reservation atomics per 2048 records
+__global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
+                                                   int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts) {
+  __shared__ int lc[27], base[27];
+  if (threadIdx.x < 27) lc[threadIdx.x] = 0;
+  __syncthreads();
+  // the images of a record are the non-empty subsets t = 1..7 of its shifted axes (bit 0: x, 1: y, 2: z)
+  float4 p[GP_RPT]; int rk[GP_RPT][7]; int sh[GP_RPT];   // sh: sx | sy << 2 | sz << 4, 0: nothing to send
 #pragma unroll
-  for (int r = 0; r < PACK_RPT; r++) {
-    const int i = i0 + r * PT;
-    bool hi = false, lo = false;
-    p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n_cur) {
-      p[r] = pos[i];
-      if (in_hoc_range(p[r], -nb, Nn + nb)) { const float x = comp(p[r], axis); hi = x >= Nn - nb; lo = x < nb; }
+  for (int r = 0; r < GP_RPT; r++) {
+    const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
+    p[r] = make_float4(0.f, 0.f, 0.f, 0.f); sh[r] = 0;
+    if (i < n) p[r] = pos[i];
+    if (i >= n || !in_hoc_range(p[r], -nb, Nn + nb)) continue;   // dropped by link_list ("PARTICLE DELETED")
+    float dummy;
+    const int sx = axis_shift(p[r].x, Nn, nb, &dummy), sy = axis_shift(p[r].y, Nn, nb, &dummy), sz = axis_shift(p[r].z, Nn, nb, &dummy);
+    sh[r] = sx | (sy << 2) | (sz << 4);
+#pragma unroll
+    for (int t = 1; t < 8; t++) {
+      const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
+      if (ok) rk[r][t - 1] = atomicAdd(&lc[((t & 1) ? sx : 0) + 3 * ((t & 2) ? sy : 0) + 9 * ((t & 4) ? sz : 0)], 1);
     }
-    const unsigned long long mh = __ballot(hi), ml = __ballot(lo);
-    slot[r] = (hi ? (1 << 30) : 0) | (lo ? (1 << 29) : 0) | (__popcll(mh & below) << 8) | __popcll(ml & below);
-    if (lane == 0) { wsum[0][r][w] = __popcll(mh); wsum[1][r][w] = __popcll(ml); }
   }
   __syncthreads();
-  if (threadIdx.x < 2) {  // exclusive scan of the 32 (round, wave) counts of one direction, then one atomic
-    int run = 0;
-    for (int r = 0; r < PACK_RPT; r++)
-      for (int k = 0; k < PT / 64; k++) { const int v = wsum[threadIdx.x][r][k]; wsum[threadIdx.x][r][k] = run; run += v; }
-    base_sh[threadIdx.x] = run ? atomicAdd(&counts[threadIdx.x], run) : 0;
-  }
+  if (threadIdx.x < 27) base[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]) : 0;
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < PACK_RPT; r++) {
-    if (!(slot[r] >> 29)) continue;
-    const int i = i0 + r * PT;
+  for (int r = 0; r < GP_RPT; r++) {
+    if (sh[r] == 0) continue;
+    const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
+    const int sx = sh[r] & 3, sy = (sh[r] >> 2) & 3, sz = sh[r] >> 4;
+    float ix, iy, iz;
+    (void)axis_shift(p[r].x, Nn, nb, &ix); (void)axis_shift(p[r].y, Nn, nb, &iy); (void)axis_shift(p[r].z, Nn, nb, &iz);
     const float4 v = vel[i]; const int64_t id = pid[i];
-    const float4 r0 = make_float4(p[r].x, p[r].y, p[r].z, v.x);
     const float4 r1 = make_float4(v.y, v.z, __int_as_float((int)(id & 0xffffffffLL)), __int_as_float((int)(id >> 32)));
-    if (slot[r] & (1 << 30)) { const int s = base_sh[0] + wsum[0][r][w] + ((slot[r] >> 8) & 0x7f); if (s < cap_buf) { sbuf_plus[2 * s] = r0; sbuf_plus[2 * s + 1] = r1; } }
-    if (slot[r] & (1 << 29)) { const int s = base_sh[1] + wsum[1][r][w] + (slot[r] & 0x7f); if (s < cap_buf) { sbuf_minus[2 * s] = r0; sbuf_minus[2 * s + 1] = r1; } }
+#pragma unroll
+    for (int t = 1; t < 8; t++) {
+      const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
+      if (!ok) continue;
+      const int m = ((t & 1) ? sx : 0) + 3 * ((t & 2) ? sy : 0) + 9 * ((t & 4) ? sz : 0);
+      const int s = base[m] + rk[r][t - 1];
+      if (s < S.cap[m]) {
+        float4 *o = sbuf + 2 * ((int64_t)S.off[m] + s);
+        o[0] = make_float4((t & 1) ? ix : p[r].x, (t & 2) ? iy : p[r].y, (t & 4) ? iz : p[r].z, v.x); o[1] = r1;
+      }
+    }
   }
 }
-// from_plus_dir: the buffer was sent towards +a by the -a neighbour: x_a <- max(x_a - Nn, -nb) (:162);
-// otherwise it came from the +a neighbour: eps guard, x_a <- min(x_a + Nn, Nn+nb-eps) (:257-265).
-__global__ __launch_bounds__(PT) void k_pass_unpack(const float4 *__restrict__ rbuf, int nrecv, int axis, int from_plus_dir, float Nn, float nb,
-                                                    float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid, int base) {
-  const int i = blockIdx.x * PT + threadIdx.x;
-  if (i >= nrecv) return;
-  const float4 r0 = rbuf[2 * i], r1 = rbuf[2 * i + 1];
-  float4 p = make_float4(r0.x, r0.y, r0.z, 0.f);
-  float x = comp(p, axis);
-  if (from_plus_dir) x = fmaxf(x - Nn, -nb);
-  else { if (fabsf(x) < P3M_EPS_F) x = (x < 0.0f) ? -P3M_EPS_F : P3M_EPS_F; x = fminf(x + Nn, Nn + nb - P3M_EPS_F); }
-  setcomp(p, axis, x);
-  pos[base + i] = p; vel[base + i] = make_float4(r0.w, r1.x, r1.y, 0.f);
-  pid[base + i] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
+// appends the received segments: blockIdx.y = shift; dst[m] = first record index of that segment in pos/vel/pid
+struct GhostIn { int off[27]; int cnt[27]; int dst[27]; };
+__global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ rbuf, GhostIn T, float4 *__restrict__ pos, float4 *__restrict__ vel,
+                                                     int64_t *__restrict__ pid) {
+  const int m = blockIdx.y + 1, n = T.cnt[m];
+  for (int i = blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) {
+    const float4 *r = rbuf + 2 * ((int64_t)T.off[m] + i);
+    const float4 r0 = r[0], r1 = r[1];
+    const int o = T.dst[m] + i;
+    pos[o] = make_float4(r0.x, r0.y, r0.z, 0.f); vel[o] = make_float4(r0.w, r1.x, r1.y, 0.f);
+    pid[o] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
+  }
 }
-int particles_pass_pack(p3m_ctx *c, int n_cur, int axis, float4 *sp, float4 *sm, int cap_buf, int *d_counts) {
-  if (n_cur == 0) return P3M_OK;
-  hipLaunchKernelGGL(k_pass_pack, dim3(cdiv(n_cur, PT * PACK_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
-                     n_cur, axis, (float)c->g.Nn, (float)c->g.nb, sp, sm, cap_buf, d_counts);
+int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts) {
+  if (c->np_local == 0) return P3M_OK;
+  GhostSegs S; for (int m = 0; m < 27; m++) { S.off[m] = seg_off[m]; S.cap[m] = seg_cap[m]; }
+  hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, PT * GP_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
+                     c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-int particles_pass_unpack(p3m_ctx *c, const float4 *rbuf, int nrecv, int axis, int from_plus_dir, int base) {
-  if (nrecv == 0) return P3M_OK;
-  hipLaunchKernelGGL(k_pass_unpack, dim3(cdiv(nrecv, PT)), dim3(PT), 0, c->stream, rbuf, nrecv, axis, from_plus_dir, (float)c->g.Nn, (float)c->g.nb,
-                     c->pos, c->vel, c->pid, base);
+int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base) {
+  GhostIn T; int mx = 0, run = base;
+  for (int m = 0; m < 27; m++) { T.off[m] = seg_off[m]; T.cnt[m] = m ? cnt[m] : 0; T.dst[m] = run; run += T.cnt[m]; mx = std::max(mx, T.cnt[m]); }
+  if (mx == 0) return P3M_OK;
+  hipLaunchKernelGGL(k_ghost_unpack, dim3(std::min(1024, cdiv(mx, PT)), 26), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
