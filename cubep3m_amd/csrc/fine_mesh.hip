@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, 
     if (threadIdx.x == 0 && s != 0.f) atomicAdd(sum_interior + p3m_slot() * 8, (double)s);
   }
 }
-// candidates: sorted indices of records within 2^-10 below a cell face in some coordinate (k_scatter)
+// candidates: sorted indices of records within 2^-10 below a cell face in some coordinate (k_row_sort)
 __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, const int *__restrict__ cand, int ncand, float *__restrict__ rho,
                                                    int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
