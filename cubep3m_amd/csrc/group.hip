@@ -1,9 +1,10 @@
 // group.hip -- multi-rank gravity step: the reference's nodes_dim^3 cubic sub-volumes ("logical
 // ranks", mpi_initialization.f90:42-76) distributed over the GPUs of one node.  One process drives
 // one GPU and owns a contiguous block of logical ranks (1, 2, 4 or 8 of the 8 when nodes_dim = 2);
-// exchanges between ranks of the same process are device-to-device copies, exchanges between
-// processes are RCCL send/recv over xGMI.  Replaces the MPI traffic of
-//   particle_pass.f90            -> ghost_pass()        3 axes x 2 directions, counts first
+// exchanges between ranks of the same process are device-to-device copies (one launch per exchange),
+// exchanges between processes are RCCL send/recv over xGMI or the host-callback transport.  Replaces
+// the MPI traffic of
+//   particle_pass.f90            -> ghost_pass()        all 26 shifts in one round, counts first
 //   fftw3ds.f90 pack/unpack_slab -> cube_to_slab() / slab_to_cube()  (all-to-all inside a z-layer)
 //   rfftwnd_f77_mpi (FFTW-MPI)   -> slab FFT: local x,y passes, ONE global all-to-all transpose per
 //                                   transform written directly by the y/z pass kernels, local z pass
