@@ -144,6 +144,7 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
     }
   };
   const fdiv_t dPx = mk_fdiv(px), dNq = mk_fdiv(fbp >> 2 ? fbp >> 2 : 1);
+  const float rscale = 1.0f / inv_scale;   // the division by n^3 (fftw2.f90:22) as a multiplication: one ulp, inside the FFT's own rounding
   float4 v[XLU];
   // load e = tid + u*XTB: l4 = e & 7, row = (e >> 3) & (RB-1), chunk = e >> (3 + LRB)
   auto fetch = [&](int w, int buf) {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
       for (int e = threadIdx.x; e < nrows * px; e += XTB) {
         const int r = fdiv(e, dPx), m = e - r * px;
         float2 z = make_float2(0.f, 0.f);
-        if (m < h) { z = Z[m * RBP + r]; z = make_float2(z.x / inv_scale, -z.y / inv_scale); }
+        if (m < h) { z = Z[m * RBP + r]; z = make_float2(z.x * rscale, -z.y * rscale); }
         reinterpret_cast<float2 *>(out + dst_off[buf][r])[m] = z;
       }
     } else {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
         const int r = fdiv(e, dNq), q = e - r * nq;
         const int cx = (4 * q + lo) >> 1;
         const float2 z0 = Z[cx * RBP + r], z1 = Z[(cx + 1) * RBP + r];
-        float4 o = make_float4(z0.x / inv_scale, -z0.y / inv_scale, z1.x / inv_scale, -z1.y / inv_scale);
+        float4 o = make_float4(z0.x * rscale, -z0.y * rscale, z1.x * rscale, -z1.y * rscale);
         if (4 * q + 0 >= fb) o.x = 0.f;
         if (4 * q + 1 >= fb) o.y = 0.f;
         if (4 * q + 2 >= fb) o.z = 0.f;
