@@ -5,6 +5,8 @@
 // llf / hoc_fine / ll_fine: a cell's partners are index ranges.  FP32-ALU bound (about 20 flop per
 // pair incl. the reciprocal square root); reported as pairs/s, not against the HBM roofline.
 #include "p3m_internal.h"
+#include <algorithm>
+#include <cmath>
 
 struct PPGeo { int T, nb, pt, E, Nn, ms, ppr; float rsoft, pp_bias, ncut; };
 
@@ -156,11 +158,187 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
   if (threadIdx.x == 0 && mymax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(mymax));
 }
 
+// The same sums from LDS: one 256-thread workgroup per block of PB_X x PB_Y x PB_Z home cells of a tile's extended
+// region.  The records of the block's halo (home rows +- pp_range, x range +- pp_range) and the cell offsets of
+// those row segments are staged in LDS with coalesced loads; every home record then walks its partners -- same
+// rows and cells as k_pp_ext -- without touching global memory.  A block whose
+// halo does not fit the staging area (strong clustering) falls back to global loads for what was not staged.
+#define PB_Y 4
+#define PB_Z 4
+#define PPT_CAP 2048    // staged records per block
+#define PP_LPH 2        // lanes per home record
+__global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G,
+                                                      float mass_p, float a_mid, float dt, float *__restrict__ tile_max, int bx_cells, int nbx, int nby) {
+  extern __shared__ int lds_i[];
+  const int ppr = G.ppr, e = G.pt + 2 * ppr;
+  const int HR = (PB_Y + 2 * ppr) * (PB_Z + 2 * ppr);        // halo rows
+  const int wseg = bx_cells + 2 * ppr + 1;                     // cell offsets per staged row segment
+  int *rp0 = lds_i;                 // [HR] first record of the staged segment (global sorted index)
+  int *rcnt = rp0 + HR;             // [HR] records staged of it
+  int *roff = rcnt + HR;            // [HR] their offset in lp
+  int *rtot = roff + HR;            // [HR] records in the segment
+  int *hpre = rtot + HR;            // [PB_Y*PB_Z + 1] prefix of home record counts
+  int *cseg = hpre + PB_Y * PB_Z + 1;   // [HR][wseg] cell offsets relative to rp0
+  float4 *lp = reinterpret_cast<float4 *>(cseg + ((HR * wseg + 3) & ~3));
+  __shared__ float wmax[4];
+  int b = blockIdx.x;
+  const int ibx = b % nbx; b /= nbx;
+  const int iby = b % nby; b /= nby;
+  const int nbz = nby, ibz = b % nbz, tile = b / nbz;
+  const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+  const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;   // extended region [lo, lo+e)
+  const int hx0 = lox + ibx * bx_cells, hx1 = min(hx0 + bx_cells, lox + e);      // home cells in x
+  const int hy0 = loy + iby * PB_Y, hz0 = loz + ibz * PB_Z;
+  const int sx0 = max(hx0 - ppr, lox), sx1 = min(hx1 + ppr, lox + e);           // staged cells in x
+  const int ny = PB_Y + 2 * ppr;
+  // ---- stage: segment ranges and cell offsets
+  for (int r = threadIdx.x; r < HR; r += 256) {
+    const int yy = hy0 - ppr + r % ny, zz = hz0 - ppr + r / ny;
+    int p0 = 0, p1 = 0;
+    if (yy >= loy && yy < loy + e && zz >= loz && zz < loz + e) { const int64_t rb = ((int64_t)zz * G.E + yy) * G.E; p0 = cs[rb + sx0]; p1 = cs[rb + sx1]; }
+    rp0[r] = p0; rtot[r] = p1 - p0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int r = 0; r < HR; r++) { roff[r] = run; const int c = min(rtot[r], PPT_CAP - run); rcnt[r] = c; run += c; }
+    hpre[PB_Y * PB_Z] = run;   // borrowed until the home prefix is built: number of staged records
+  }
+  for (int r = threadIdx.x >> 6; r < HR; r += 4) {   // one wavefront per row segment: no per-element index divisions
+    const int ry_ = r % ny, yy = hy0 - ppr + ry_, zz = hz0 - ppr + r / ny;
+    const bool inside = yy >= loy && yy < loy + e && zz >= loz && zz < loz + e;
+    const int *src = cs + ((int64_t)zz * G.E + yy) * G.E + sx0;
+    const int base = rp0[r];
+    for (int k = threadIdx.x & 63; k < wseg; k += 64) cseg[r * wseg + k] = (inside && sx0 + k <= sx1) ? src[k] - base : 0;
+  }
+  __syncthreads();
+  {
+    const int nst = hpre[PB_Y * PB_Z];
+    for (int t = threadIdx.x; t < nst; t += 256) {   // staged record t belongs to the last row r with roff[r] <= t
+      int lo_r = 0, hi_r = HR - 1;
+      while (lo_r < hi_r) { const int mid = (lo_r + hi_r + 1) >> 1; if (roff[mid] <= t) lo_r = mid; else hi_r = mid - 1; }
+      lp[t] = spos[rp0[lo_r] + (t - roff[lo_r])];
+    }
+  }
+  __syncthreads();
+  // home records: rows (jy, jz) of the block, cells [hx0, hx1)
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int hr = 0; hr < PB_Y * PB_Z; hr++) {
+      hpre[hr] = run;
+      const int r = (hr / PB_Y + ppr) * ny + (hr % PB_Y + ppr);
+      const int yy = hy0 + hr % PB_Y, zz = hz0 + hr / PB_Y;
+      if (yy < loy + e && zz < loz + e && hx1 > hx0) run += cseg[r * wseg + (hx1 - sx0)] - cseg[r * wseg + (hx0 - sx0)];
+    }
+    hpre[PB_Y * PB_Z] = run;
+  }
+  __syncthreads();
+  const int nhome = hpre[PB_Y * PB_Z];
+  const float tmax = G.ncut + sqrtf(3.0f);
+  float mymax = 0.f;
+  auto partner = [&](int r, int q) -> float4 { const int k = q - rp0[r]; return k < rcnt[r] ? lp[roff[r] + k] : spos[q]; };
+  // PP_LPH lanes share one home record: lane u takes the partner rows u, u+PP_LPH, ... of the (zz,yy) sweep and walks
+  // them with a flat cursor (a wavefront pays for its busiest lane, not for the busiest lane of every row); the
+  // partial sums are added across the lanes at the end.
+  const float incut = 1.0f / G.ncut;
+  const int nround = (nhome * PP_LPH + 255) / 256;
+  for (int rd = 0; rd < nround; rd++) {
+    const int t = rd * 256 + (int)threadIdx.x, hidx = t / PP_LPH, u = t - hidx * PP_LPH;
+    const bool live = hidx < nhome;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0, cx = 0, cy = 0, cz = 0;
+    if (live) {
+      int hr = 0;
+#pragma unroll
+      for (int k = 1; k < PB_Y * PB_Z; k++) hr += (hidx >= hpre[k]) ? 1 : 0;
+      const int jy = hr % PB_Y, jz = hr / PB_Y;
+      const int r_own = (jz + ppr) * ny + (jy + ppr);
+      s = rp0[r_own] + cseg[r_own * wseg + (hx0 - sx0)] + (hidx - hpre[hr]);
+      p = partner(r_own, s);
+      cy = hy0 + jy; cz = hz0 + jz;
+      cx = (int)floorf(p.x) + G.nb;                                // :412 (floor(xv)+1, global)
+      const int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);
+      const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1);
+      const int x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
+      const int nyr = y1 - y0 + 1, nrow = (z1 - z0 + 1) * nyr;
+      int zi = 0, yi = u - PP_LPH, q = 0, q1 = 0, s0 = 0, s1 = 0, r = 0;   // (zi, yi): the row ordinal u, u+PP_LPH, ... as a mixed-radix counter
+      const int nzr = z1 - z0 + 1;
+      (void)nrow;
+      for (;;) {
+        if (q >= q1) {
+          yi += PP_LPH;
+          while (yi >= nyr) { yi -= nyr; zi++; }
+          if (zi >= nzr) break;
+          const int zz = z0 + zi, yy = y0 + yi;
+          r = (zz - hz0 + ppr) * ny + (yy - hy0 + ppr);
+          const int *cr = cseg + r * wseg - sx0;
+          q = rp0[r] + cr[x0]; q1 = rp0[r] + cr[x1 + 1];
+          const bool own = (zz == cz && yy == cy);
+          s0 = own ? rp0[r] + cr[cx] : 0; s1 = own ? rp0[r] + cr[cx + 1] : 0;   // own cell is excluded (:515-516)
+          continue;
+        }
+        if (q >= s0 && q < s1) { q = s1; continue; }
+        const float4 o = partner(r, q);
+        q++;
+        const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;            // :551
+        const float rmag = sqrtf(sx * sx + sy * sy + sz * sz);
+        if (rmag > G.rsoft) {                                                   // :558
+          // one division per pair: sep/rb^3 as sep * (1/rb^3) and rb/ncut as rb * (1/ncut), one ulp each
+          const float rb1 = rmag * G.pp_bias, irb3 = 1.0f / (rb1 * rb1 * rb1);
+          float fx = mass_p * (sx * irb3), fy = mass_p * (sy * irb3), fz = mass_p * (sz * irb3);
+          if (!(rmag > tmax)) {                                                 // :559-564
+            const float qq = rb1 * incut;
+            const float taper = 1.f - (7.0f / 4.0f) * (qq * qq * qq) + (3.0f / 4.0f) * (qq * qq * qq * qq * qq);
+            fx *= taper; fy *= taper; fz *= taper;
+          }
+          ax -= fx; ay -= fy; az -= fz;                                         // :571
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < PP_LPH; o <<= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
+    if (live && u == 0) {
+      const int ry = cy - loy, rz = cz - loz;
+      const bool phys = (cx >= lox + ppr && cx < lox + ppr + G.pt && ry >= ppr && ry < ppr + G.pt && rz >= ppr && rz < ppr + G.pt);
+      if (phys) {                                                                   // :576-582
+        float4 v = svel[s];
+        v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
+        svel[s] = v;
+      }
+      mymax = fmaxf(mymax, sqrtf(ax * ax + ay * ay + az * az));                     // :617
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mymax = fmaxf(mymax, __shfl_down(mymax, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mymax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (m4 > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(m4));
+  }
+}
+
 int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   const Geometry &g = c->g;
   if (g.pp_range == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   const int e = g.pt + 2 * g.pp_range;
+  if (g.pp_range <= 4) {
+    // x extent of a block: about 200 busy lanes (home records x PP_LPH) at the mean density, at most 128 cells
+    const double rho = (double)c->np_all / ((double)g.E * g.E * g.E);
+    int nbx = (int)std::ceil((double)e * PB_Y * PB_Z * rho * PP_LPH / 200.0);
+    nbx = std::max(nbx, (e + 127) / 128); nbx = std::min(nbx, std::max(1, e / 8));
+    const int bx_cells = (e + nbx - 1) / nbx, nby = (e + PB_Y - 1) / PB_Y;
+    nbx = (e + bx_cells - 1) / bx_cells;
+    const int HR = (PB_Y + 2 * g.pp_range) * (PB_Z + 2 * g.pp_range), wseg = bx_cells + 2 * g.pp_range + 1;
+    const size_t lds = sizeof(int) * (4 * HR + PB_Y * PB_Z + 1 + ((HR * wseg + 3) & ~3) + 4) + sizeof(float4) * PPT_CAP;
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pp_ext_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned blocks = (unsigned)((int64_t)g.ntiles * nbx * nby * nby);
+    hipLaunchKernelGGL(k_pp_ext_tiled, dim3(blocks), dim3(256), lds, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, mass_p, a_mid,
+                       dt, c->d_tile_ext, bx_cells, nbx, nby);
+    HIP_TRY(hipGetLastError());
+    return P3M_OK;
+  }
   const unsigned blocks = (unsigned)((int64_t)g.ntiles * e * e);
   hipLaunchKernelGGL(k_pp_ext, dim3(blocks), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, mass_p, a_mid,
                      dt, c->d_tile_ext);
