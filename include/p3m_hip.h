@@ -193,6 +193,35 @@ int p3m_hip_time_fft_pass(p3m_ctx *ctx, int32_t which, int32_t reps, float *ms_p
 /* HIP stream the kernels are launched on (for hipEvent timing by the host). */
 void *p3m_hip_stream(p3m_ctx *ctx);
 
+/* -- host time loop: timestep.f90 ---------------------------------
+ * Pure host arithmetic (no device work): the step-size choice and the scale-factor integration the
+ * reference does between two particle_mesh calls, so that a host without cubep3m's Fortran can run
+ * multi-step simulations.  A Fortran host keeps its own timestep.f90 and never calls these. */
+#define P3M_MAX_INPUT 100   /* cubepm.par:183 max_input */
+typedef struct p3m_time_params {
+  int32_t cosmo;        /* cubepm.par:15                                                   */
+  int32_t restrict_da;  /* -DRESTRICT_DA (timestep.f90:75-88)                              */
+  float omega_m, omega_l, wde;              /* parameters file; cubepm.par:19              */
+  float dt_scale, dt_max, ra_max, da_max;   /* cubepm.par:27-30                            */
+  int32_t num_checkpoints, num_projections, num_halofinds;
+  /* scale factors of the output steps; timestep.f90 reads entry cur_* even past num_* (the
+     reference leaves zeros there): callers pad with a value > 1                                    */
+  float a_checkpoint[P3M_MAX_INPUT], a_projection[P3M_MAX_INPUT], a_halofind[P3M_MAX_INPUT];
+} p3m_time_params;
+typedef struct p3m_time_state {   /* the COMMON variables timestep.f90 reads and writes (cubepm.fh:19-29) */
+  int32_t nts;
+  float a, a_mid, da, dt, dt_old, dt_gas, tau, t;
+  int32_t cur_checkpoint, cur_projection, cur_halofind;   /* 1-based; advanced by the HOST after an output step,
+                                                             as checkpoint.f90 / projection.f90 / halofind.f90 do */
+  int32_t checkpoint_step, projection_step, halofind_step, final_step;
+} p3m_time_state;
+/* subroutine expansion (timestep.f90:218-293): third-order integration of the Friedmann equation over two half steps */
+void p3m_hip_expansion(const p3m_time_params *par, float a0, float dt0, float *da1, float *da2);
+/* subroutine timestep (timestep.f90:2-216) on rank 0's values; flags: P3M_FLAG_PPINT / P3M_FLAG_PP_EXT select the limits
+   that enter the minimum (:93-115).  The four dt_*_acc are what p3m_step_out returned for the previous step. */
+int p3m_hip_timestep(const p3m_time_params *par, uint32_t flags, p3m_time_state *st, float dt_f_acc, float dt_pp_acc,
+                     float dt_pp_ext_acc, float dt_c_acc);
+
 /* -- multi-rank: a group of logical ranks (the reference's nodes_dim^3 MPI ranks) ---------
  * One process drives one GPU and owns nodes_dim^3 / nprocs consecutive logical ranks; ranks on the
  * same GPU exchange by device copies, ranks on different GPUs by RCCL send/recv over xGMI

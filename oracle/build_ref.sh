@@ -18,7 +18,7 @@ MPI_LIB=/opt/conda/lib
 
 SRCS="update_position link_list particle_pass delete_particles move_grid_back mpi_initialization \
       fine_ngp_mass fine_cic_mass fine_cic_mass_buffer coarse_mass coarse_cic_mass \
-      coarse_cic_mass_buffer coarse_force_buffer coarse_max_dt coarse_velocity"
+      coarse_cic_mass_buffer coarse_force_buffer coarse_max_dt coarse_velocity timestep"
 
 build_cfg () {  # name nodes_dim tiles nf_tile cores density_buffer "cpp flags"
   local name=$1 nd=$2 T=$3 nf=$4 cores=$5 dens=$6 flags=$7
@@ -65,3 +65,5 @@ PAR
 # The CI makefile (Makefile_gnu_sfftw2:6) leaves PID_FLAG off.
 build_cfg  cfg1_1rank  1  2 80  2     2.0  "-DNGP -DPID_FLAG"
 build_cfg  cfg1_8rank  2  2 80  2     2.0  "-DNGP"
+# the PP switches change which limits timestep.f90 takes the minimum of (:93-115)
+build_cfg  cfg1_pp     1  2 80  2     2.0  "-DNGP -DPPINT -DPP_EXT -DPID_FLAG"

@@ -1038,3 +1038,111 @@ int orc_particle_mesh(orc_ctx *c, float a_mid, float dt, float dt_old, float mas
   if (out) orc_step_out(c, a_mid, out);
   return 0;
 }
+
+/* ===================================================================== host time loop (timestep.f90)
+ * TEST INFRASTRUCTURE like everything in this file.  Pinned bit for bit against the reference's own
+ * timestep.o (oracle/_ref, tests/golden/ref_timestep.npz). */
+static float orc_half_expansion(const p3m_time_params *P, double ax, float dtx) {
+  /* timestep.f90:237-253 (and :255-271 with a_x = a0 + da1); real(8) a_x, adot, addot, atdot, arkm, a3rlm, omHsq */
+  double omHsq = (double)(4.0f / 9.0f);
+  double a3rlm = pow(ax, (double)(-(3 * P->wde)));
+  a3rlm = a3rlm * P->omega_l;
+  a3rlm = a3rlm / P->omega_m;
+  double arkm = ax * ((1.0f - P->omega_m) - P->omega_l);
+  arkm = arkm / P->omega_m;
+  double adot = sqrt((omHsq * (ax * ax * ax)) * ((1.0 + arkm) + a3rlm));
+  float c2 = 1.5f * (1.0f - P->wde);
+  float c3 = (1.5f * (2.0f - 3.0f * P->wde)) * (1.0f - P->wde);
+  double addot = ((ax * ax) * omHsq) * ((1.5 + 2.0 * arkm) + c2 * a3rlm);
+  double atdot = ((ax * adot) * omHsq) * ((3.0 + 6.0 * arkm) + c3 * a3rlm);
+  float d2 = dtx * dtx;
+  float d3 = d2 * dtx;
+  double s = adot * dtx;
+  s = s + (addot * d2) / 2.0;
+  s = s + (atdot * d3) / 6.0;
+  return (float)s;
+}
+void orc_expansion(const p3m_time_params *P, float a0, float dt0, float *da1, float *da2) {
+  float dtx = dt0 / 2;
+  *da1 = orc_half_expansion(P, a0, dtx);
+  float a1 = a0 + *da1;
+  *da2 = orc_half_expansion(P, a1, dtx);
+}
+void orc_timestep(const p3m_time_params *P, unsigned flags, p3m_time_state *S, float dt_f_acc, float dt_pp_acc, float dt_pp_ext_acc,
+                  float dt_c_acc) {
+  float da_1 = 0.f, da_2 = 0.f, ra, dt_e, am, dt;
+  int n;
+  S->nts += 1;                                                     /* :20 */
+  if (S->nts != 1) S->dt_old = S->dt;                              /* :21 */
+  if (!P->cosmo) {                                                 /* :197-216 */
+    S->a = 1.0f; S->a_mid = S->a; S->da = 0.0f;
+    dt = 1.0f;
+    if (dt_f_acc < dt) dt = dt_f_acc;
+    if ((flags & P3M_FLAG_PPINT) && dt_pp_acc < dt) dt = dt_pp_acc;
+    if ((flags & P3M_FLAG_PPINT) && (flags & P3M_FLAG_PP_EXT) && dt_pp_ext_acc < dt) dt = dt_pp_ext_acc;
+    if (dt_c_acc < dt) dt = dt_c_acc;
+    S->dt = dt; S->t += dt;
+    return;
+  }
+  dt_e = P->dt_max;                                                /* :59 */
+  n = 0;
+  for (;;) {                                                       /* :63-74 */
+    n = n + 1;
+    orc_expansion(P, S->a, dt_e, &da_1, &da_2);
+    S->da = da_1 + da_2;
+    ra = S->da / (S->a + S->da);
+    if (ra > P->ra_max) dt_e = dt_e * (P->ra_max / ra); else break;
+    if (n > 10) break;
+  }
+  if (P->restrict_da) {                                            /* :76-88 */
+    n = 0;
+    for (;;) {
+      orc_expansion(P, S->a, dt_e, &da_1, &da_2);
+      S->da = da_1 + da_2;
+      if (S->da > P->da_max) dt_e = dt_e * (P->da_max / S->da); else break;
+      n = n + 1;
+      if (n > 10) break;
+    }
+  }
+  dt = dt_e;                                                       /* :93-115 */
+  if (dt_f_acc < dt) dt = dt_f_acc;
+  if ((flags & P3M_FLAG_PPINT) && dt_pp_acc < dt) dt = dt_pp_acc;
+  if ((flags & P3M_FLAG_PPINT) && (flags & P3M_FLAG_PP_EXT) && dt_pp_ext_acc < dt) dt = dt_pp_ext_acc;
+  if (dt_c_acc < dt) dt = dt_c_acc;
+  dt = dt * P->dt_scale;                                           /* :117 */
+  orc_expansion(P, S->a, dt, &da_1, &da_2);                        /* :119 */
+  S->da = da_1 + da_2;
+  S->checkpoint_step = 0; S->projection_step = 0; S->halofind_step = 0;
+  {
+    float ac = P->a_checkpoint[S->cur_checkpoint - 1], ap = P->a_projection[S->cur_projection - 1], ah = P->a_halofind[S->cur_halofind - 1];
+    am = ac; if (ap < am) am = ap; if (ah < am) am = ah;             /* :130 */
+    if (ac == am) {                                                /* :135 */
+      if (S->a + S->da > ac) {
+        S->checkpoint_step = 1;
+        dt = dt * (ac - S->a) / S->da;
+        orc_expansion(P, S->a, dt, &da_1, &da_2);
+        if (S->cur_checkpoint == P->num_checkpoints) S->final_step = 1;
+        if (ap == am && S->cur_projection <= P->num_projections) S->projection_step = 1;
+        if (ah == am && S->cur_halofind <= P->num_halofinds) S->halofind_step = 1;
+      }
+    } else if (ap == am && S->cur_projection <= P->num_projections) {   /* :144 */
+      if (S->a + S->da > ap) {
+        S->projection_step = 1;
+        dt = dt * (ap - S->a) / S->da;
+        orc_expansion(P, S->a, dt, &da_1, &da_2);
+        if (ah == am && S->cur_halofind <= P->num_halofinds) S->halofind_step = 1;
+      }
+    } else if (ah == am && S->cur_halofind <= P->num_halofinds) {       /* :153 */
+      if (S->a + S->da > ah) {
+        S->halofind_step = 1;
+        dt = dt * (ah - S->a) / S->da;
+        orc_expansion(P, S->a, dt, &da_1, &da_2);
+      }
+    }
+  }
+  S->dt = dt;
+  S->dt_gas = dt / 4;                                              /* :165 */
+  S->da = da_1 + da_2;
+  S->a_mid = S->a + (S->da / 2);                                   /* :168 */
+  S->tau = S->tau + dt; S->t = S->t + dt; S->a = S->a + S->da;     /* :193-195 */
+}

@@ -75,6 +75,11 @@ void orc_coarse_max_dt_and_velocity(orc_ctx *c, float a_mid, float dt); /* coars
 void orc_fft3d(float *data, int n, int dir);                 /* fftw2.f90 semantics       */
 void orc_fft3d_rect(float *data, int nx, int ny, int nz, int dir);
 
+/* host time loop (timestep.f90) */
+void orc_expansion(const p3m_time_params *P, float a0, float dt0, float *da1, float *da2);
+void orc_timestep(const p3m_time_params *P, unsigned flags, p3m_time_state *S, float dt_f_acc, float dt_pp_acc, float dt_pp_ext_acc,
+                  float dt_c_acc);
+
 #ifdef __cplusplus
 }
 #endif

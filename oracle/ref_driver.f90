@@ -198,3 +198,59 @@ subroutine ref_finalize() bind(C, name="ref_finalize")
   call mpi_barrier(mpi_comm_world, ierr2)
   call mpi_finalize(ierr2)
 end subroutine ref_finalize
+
+! --- timestep.f90 (host time loop, SURVEY section 8f rank 1) --------------------------------
+! rv_in : a, tau, t, dt, dt_old, dt_f_acc, dt_pp_acc, dt_pp_ext_acc, dt_c_acc ; iv_in : nts, cur_checkpoint, cur_projection, cur_halofind
+subroutine ref_time_set(rv_in, iv_in, a_chk, n_chk, a_prj, n_prj, a_hf, n_hf) bind(C, name="ref_time_set")
+  use iso_c_binding
+  implicit none
+  include 'cubepm.fh'
+  real(c_float) :: rv_in(9)
+  integer(c_int) :: iv_in(4)
+  integer(c_int), value :: n_chk, n_prj, n_hf
+  real(c_float) :: a_chk(n_chk), a_prj(n_prj), a_hf(n_hf)
+  a = rv_in(1); tau = rv_in(2); t = rv_in(3); dt = rv_in(4); dt_old = rv_in(5)
+  dt_f_acc = rv_in(6); dt_pp_acc = rv_in(7); dt_pp_ext_acc = rv_in(8); dt_c_acc = rv_in(9)
+  nts = iv_in(1); cur_checkpoint = iv_in(2); cur_projection = iv_in(3); cur_halofind = iv_in(4)
+  a_checkpoint = 100.0; a_projection = 100.0; a_halofind = 100.0
+  num_checkpoints = n_chk; num_projections = n_prj; num_halofinds = n_hf
+  a_checkpoint(1:n_chk) = a_chk(1:n_chk); a_projection(1:n_prj) = a_prj(1:n_prj); a_halofind(1:n_hf) = a_hf(1:n_hf)
+  final_step = .false.
+end subroutine ref_time_set
+
+subroutine ref_timestep() bind(C, name="ref_timestep")
+  call timestep
+end subroutine
+
+! rv_out : a, a_mid, da, dt, dt_old, dt_gas, tau, t ; iv_out : nts, checkpoint_step, projection_step, halofind_step, final_step
+subroutine ref_time_get(rv_out, iv_out) bind(C, name="ref_time_get")
+  use iso_c_binding
+  implicit none
+  include 'cubepm.fh'
+  real(c_float) :: rv_out(8)
+  integer(c_int) :: iv_out(5)
+  rv_out(1) = a; rv_out(2) = a_mid; rv_out(3) = da; rv_out(4) = dt; rv_out(5) = dt_old; rv_out(6) = dt_gas; rv_out(7) = tau; rv_out(8) = t
+  iv_out(1) = nts
+  iv_out(2) = merge(1, 0, checkpoint_step); iv_out(3) = merge(1, 0, projection_step)
+  iv_out(4) = merge(1, 0, halofind_step); iv_out(5) = merge(1, 0, final_step)
+end subroutine ref_time_get
+
+subroutine ref_expansion(a0, dt0, da1, da2) bind(C, name="ref_expansion")
+  use iso_c_binding
+  implicit none
+  real(c_float), value :: a0, dt0
+  real(c_float) :: da1, da2
+  real(4) :: a0_, dt0_
+  a0_ = a0; dt0_ = dt0
+  call expansion(a0_, dt0_, da1, da2)
+end subroutine ref_expansion
+
+! cosmo, dt_scale, dt_max, ra_max, da_max, wde, omega_m, omega_l of this build (cubepm.par, parameters)
+subroutine ref_time_params(out) bind(C, name="ref_time_params")
+  use iso_c_binding
+  implicit none
+  include 'cubepm.fh'
+  real(c_float) :: out(8)
+  out(1) = merge(1.0, 0.0, cosmo); out(2) = dt_scale; out(3) = dt_max; out(4) = ra_max; out(5) = da_max
+  out(6) = wde; out(7) = omega_m; out(8) = omega_l
+end subroutine ref_time_params

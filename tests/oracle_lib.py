@@ -198,3 +198,15 @@ def fft3d(a, n, direction):
     a = np.ascontiguousarray(a, np.float32)
     lib().orc_fft3d(a, n, direction)
     return a
+
+
+# ---- host time loop (timestep.f90): oracle side, same structs as the C ABI -------------------------------
+def oracle_time_api():
+    from cubep3m_amd.timestep import P3MTimeParams, P3MTimeState
+
+    L = lib()
+    L.orc_expansion.argtypes = [C.POINTER(P3MTimeParams), C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_expansion.restype = None
+    L.orc_timestep.argtypes = [C.POINTER(P3MTimeParams), C.c_uint, C.POINTER(P3MTimeState)] + [C.c_float] * 4
+    L.orc_timestep.restype = None
+    return L

@@ -295,3 +295,53 @@ def test_config2_mass_conservation_and_momentum(PM):
     dv = xo[:, 3:].astype(np.float64)
     # total momentum change ~ 0 (antisymmetric kernels, pairwise PP): compare with the rms kick
     assert np.abs(dv.mean(0)).max() < 2e-3 * rms(dv)
+
+
+def test_multi_step_simulation_with_the_host_time_loop(PM):
+    """cubepm.f90's main loop (timestep -> particle_mesh -> output-step half drift) on the GPU against the same loop on
+    the oracle: the step sizes are chosen from the dt limits each side computed itself, over a checkpoint step."""
+    import ctypes as C
+
+    from cubep3m_amd.timestep import Simulation, TimeParams, new_state
+    from cubep3m_amd.params import FLAG_PP_EXT, FLAG_PPINT
+
+    p = cfg1(ngp=True, ppint=True, pp_ext=True)
+    xv = clustered_particles(20000, float(p.nf_physical_node_dim), seed=31, frac=0.3, nblobs=12, sigma=0.8, vel_sigma=0.3)
+    pid = np.arange(1, len(xv) + 1, dtype=np.int64)
+    tp = TimeParams(omega_m=0.24, omega_l=0.76, ra_max=0.05, a_checkpoint=[0.0213, 0.05], a_projection=[0.0213], a_halofind=[])
+    a0 = 0.02
+    pm = PM(p, FINE_TABLE, COARSE_TABLE)
+    pm.upload_particles(xv, pid)
+    sim = Simulation(pm, tp, new_state(a0), mass_p=8.0)
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    o.set_particles(0, xv, pid)
+    L = ol.oracle_time_api()
+    tpc, so = tp.to_c(), new_state(a0)
+    lim = [1000.0] * 4
+    flags = FLAG_PPINT | FLAG_PP_EXT
+    saw_output = False
+    for step in range(6):
+        go_on = sim.step()
+        L.orc_timestep(C.byref(tpc), flags, C.byref(so), *[C.c_float(v) for v in lim])
+        oo = o.particle_mesh(so.a_mid, so.dt, so.dt_old, 8.0)
+        lim = [oo.dt_f_acc, oo.dt_pp_acc, oo.dt_pp_ext_acc, oo.dt_c_acc]
+        if so.checkpoint_step or so.projection_step or so.halofind_step:      # cubepm.f90:196-231
+            saw_output = True
+            o.update_position(so.dt, 0.0)
+            so.dt_old = 0.0
+            so.cur_checkpoint += so.checkpoint_step
+            so.cur_projection += so.projection_step
+            so.cur_halofind += so.halofind_step
+            so.dt = 0.0
+        st = sim.st
+        assert (st.nts, st.checkpoint_step, st.projection_step, st.cur_checkpoint, st.cur_projection) == \
+               (so.nts, so.checkpoint_step, so.projection_step, so.cur_checkpoint, so.cur_projection), step
+        assert st.dt == pytest.approx(so.dt, rel=2e-5, abs=1e-12) and st.a == pytest.approx(so.a, rel=1e-6) and st.a_mid == pytest.approx(so.a_mid, rel=1e-6), step
+        assert go_on
+    assert saw_output
+    xg, pg = by_pid(*pm.download_particles())
+    xo, po = by_pid(*o.get_particles(0))
+    assert np.array_equal(pg, po)
+    assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 2e-3
+    assert rel_rms(xg[:, 3:], xo[:, 3:]) <= 1e-4
