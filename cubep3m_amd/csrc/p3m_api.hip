@@ -75,7 +75,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
 #define A(x) do { int _r = (x); if (_r) return fail(_r); } while (0)
   A(dalloc(&c->pos, c->cap)); A(dalloc(&c->vel, c->cap)); A(dalloc(&c->pid, c->cap));
   A(dalloc(&c->spos, c->cap)); A(dalloc(&c->svel, c->cap)); A(dalloc(&c->spid, c->cap));
-  A(dalloc(&c->tpos, c->cap)); A(dalloc(&c->tvel, c->cap)); A(dalloc(&c->tpid, c->cap));
+  A(dalloc(&c->tpos, c->cap)); A(dalloc(&c->tidx, c->cap));
   A(dalloc(&c->flags, c->cap + 8)); A(dalloc(&c->cand, c->cap));
   const int64_t ncell = (int64_t)g.E * g.E * g.E;
   int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // every entry of [0, ncell] is rewritten by each sort; the pads stay zero
@@ -122,7 +122,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->pid); dfree(c->spos); dfree(c->svel); dfree(c->spid);
-  dfree(c->tpos); dfree(c->tvel); dfree(c->tpid); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters);
+  dfree(c->tpos); dfree(c->tidx); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->kern_f);

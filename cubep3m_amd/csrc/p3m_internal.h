@@ -74,7 +74,7 @@ struct p3m_ctx {
   float4 *spos = nullptr, *svel = nullptr; int64_t *spid = nullptr;    // sorted by extended fine cell
   int *cell_end = nullptr;     // [E^3+1] inclusive prefix of per-cell counts, shifted by one: start(c)=cell_end[c], end(c)=cell_end[c+1]
   int *row_end = nullptr;      // [E^2+1] the same for whole x-rows of cells (first level of the sort)
-  float4 *tpos = nullptr, *tvel = nullptr; int64_t *tpid = nullptr;    // row-bucketed intermediate of the sort
+  float4 *tpos = nullptr; int *tidx = nullptr;    // row-bucketed intermediate of the sort: position and arrival index
   int *scan_tmp = nullptr; size_t scan_tmp_n = 0;
   int *flags = nullptr;        // [cap] compaction flags / offsets
   unsigned char *cflag = nullptr; // [(E/ms)^3] coarse cells holding a record whose tile-local cell differs from floor(x)

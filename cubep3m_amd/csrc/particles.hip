@@ -156,9 +156,8 @@ __global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos,
 }
 
 // rs[r+1] holds start(r) on entry and end(r) = start(r+1) on exit
-__global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
-                                                    int n, float Nn, float nb, int E, int *__restrict__ rs, float4 *__restrict__ tpos,
-                                                    float4 *__restrict__ tvel, int64_t *__restrict__ tpid) {
+__global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ pos, int n, float Nn, float nb, int E, int *__restrict__ rs,
+                                                    float4 *__restrict__ tpos, int *__restrict__ tidx) {
   __shared__ int key[SORT_HB], val[SORT_HB];
   for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
   __syncthreads();
@@ -183,14 +182,14 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
     if (ent[u] == -1) continue;
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
     const int s = ent[u] >= 0 ? val[ent[u]] + rank[u] : rank[u];
-    tpos[s] = p[u]; tvel[s] = vel[i]; tpid[s] = pid[i];
+    tpos[s] = p[u]; tidx[s] = i;   // velocity and PID stay where they are: k_row_sort fetches them by index
   }
 }
 
 // one wavefront per row: bins[] = LDS histogram of the row's x cells -> exclusive prefix (the row of cs) -> cursors
 struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, rp; };   // fused NGP deposit (rho == nullptr: off)
-__global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos, const float4 *__restrict__ tvel, const int64_t *__restrict__ tpid,
-                                                 const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
+__global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ tidx, const float4 *__restrict__ vel,
+                                                 const int64_t *__restrict__ pid, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
                                                  float4 *__restrict__ spos, float4 *__restrict__ svel, int64_t *__restrict__ spid,
                                                  int *__restrict__ cand, int *__restrict__ ncand, int cand_cap, RowDep dep) {
   extern __shared__ int bins[];
@@ -250,7 +249,8 @@ __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos
   for (int i = r0 + lane; i < r1; i += 64) {
     const float4 p = tpos[i];
     const int s = atomicAdd(&bins[(int)floorf(p.x) + (int)nb], 1);
-    spos[s] = p; svel[s] = tvel[i]; spid[s] = tpid[i];
+    const int src = tidx[i];
+    spos[s] = p; svel[s] = vel[src]; spid[s] = pid[src];
     if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
       const int k = atomicAdd(ncand, 1);
       if (k < cand_cap) cand[k] = s;
@@ -300,8 +300,8 @@ int particles_sort(p3m_ctx *c, float deposit_mass) {
   }
   P3M_TRY(exclusive_scan_i32(c, c->row_end + 1, nrows));
   if (n_cur > 0) {
-    hipLaunchKernelGGL(k_row_scatter, dim3(nblk), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid, n_cur,
-                       (float)g.Nn, (float)g.nb, g.E, c->row_end, c->tpos, c->tvel, c->tpid);
+    hipLaunchKernelGGL(k_row_scatter, dim3(nblk), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, (float)g.Nn, (float)g.nb, g.E, c->row_end,
+                       c->tpos, c->tidx);
     HIP_TRY(hipGetLastError());
   }
   RowDep dep{nullptr, nullptr, 0.f, g.T, g.nf, g.pt, 2 * g.px};
@@ -309,8 +309,8 @@ int particles_sort(p3m_ctx *c, float deposit_mass) {
   if (deposit_mass >= 0.f && (c->p.flags & P3M_FLAG_NGP) && c->tile_batch == g.ntiles) {
     dep.rho = c->rho; dep.sum_interior = c->d_sums; dep.mass_p = deposit_mass; c->rho_from_sort = true;
   }
-  hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos, (const float4 *)c->tvel,
-                     (const int64_t *)c->tpid, (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5,
+  hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos, (const int *)c->tidx,
+                     (const float4 *)c->vel, (const int64_t *)c->pid, (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5,
                      (int)c->cap, dep);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
