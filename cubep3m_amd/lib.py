@@ -26,7 +26,8 @@ EXPORTS = [
     "p3m_hip_update_position", "p3m_hip_link_list_and_pass", "p3m_hip_fine_mesh", "p3m_hip_coarse_mesh",
     "p3m_hip_delete_particles", "p3m_hip_get_step_out", "p3m_hip_probe_tile_density", "p3m_hip_probe_tile_force",
     "p3m_hip_probe_coarse", "p3m_hip_fft3d", "p3m_hip_time_fine_sweep", "p3m_hip_time_fft_pass", "p3m_hip_stream", "particle_mesh_hip_",
-    "p3m_hip_group_create", "p3m_hip_group_destroy", "p3m_hip_group_comm_init_rccl", "p3m_hip_group_set_transport", "p3m_hip_expansion", "p3m_hip_timestep", "p3m_hip_group_nlocal", "p3m_hip_group_local_rank",
+    "p3m_hip_group_create", "p3m_hip_group_destroy", "p3m_hip_group_comm_init_rccl", "p3m_hip_group_set_transport", "p3m_hip_expansion", "p3m_hip_timestep", "p3m_hip_write_checkpoint", "p3m_hip_read_checkpoint", "p3m_hip_write_pid_checkpoint",
+    "p3m_hip_read_pid_checkpoint", "p3m_hip_write_ic", "p3m_hip_read_ic", "p3m_hip_group_nlocal", "p3m_hip_group_local_rank",
     "p3m_hip_group_ctx", "p3m_hip_group_set_kernel_tables", "p3m_hip_group_upload_particles", "p3m_hip_group_download_particles",
     "p3m_hip_group_particle_mesh", "p3m_hip_group_probe_coarse",
 ]
@@ -85,6 +86,12 @@ def load():
     L.p3m_hip_expansion.argtypes = [vp, f32, f32, C.POINTER(f32), C.POINTER(f32)]
     L.p3m_hip_expansion.restype = None
     L.p3m_hip_timestep.argtypes = [vp, C.c_uint32, vp, f32, f32, f32, f32]
+    L.p3m_hip_write_checkpoint.argtypes = [C.c_char_p, vp, vp, vp, i32, i32]
+    L.p3m_hip_read_checkpoint.argtypes = [C.c_char_p, vp, vp, C.c_int64, i32, i32]
+    L.p3m_hip_write_pid_checkpoint.argtypes = [C.c_char_p, vp, vp, i32, i32]
+    L.p3m_hip_read_pid_checkpoint.argtypes = [C.c_char_p, vp, vp, C.c_int64, i32, i32]
+    L.p3m_hip_write_ic.argtypes = [C.c_char_p, vp, i32, i32]
+    L.p3m_hip_read_ic.argtypes = [C.c_char_p, vp, C.c_int64, C.POINTER(i32), i32]
     L.p3m_hip_group_nlocal.argtypes = [vp]
     L.p3m_hip_group_local_rank.argtypes = [vp, i32]
     L.p3m_hip_group_ctx.argtypes = [vp, i32]

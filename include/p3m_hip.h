@@ -222,6 +222,25 @@ void p3m_hip_expansion(const p3m_time_params *par, float a0, float dt0, float *d
 int p3m_hip_timestep(const p3m_time_params *par, uint32_t flags, p3m_time_state *st, float dt_f_acc, float dt_pp_acc,
                      float dt_pp_ext_acc, float dt_c_acc);
 
+/* -- particle files: checkpoint.f90, particle_initialization.f90 ------
+ * Host code.  `binary` != 0: form='binary' (-DBINARY: a byte stream); 0: form='unformatted' (every Fortran
+ * WRITE is a record framed by two 4-byte length markers -- one record PER PARTICLE in the checkpoint and in
+ * the unformatted IC file).  `ppint` != 0: the header carries dt_pp_acc (-DPPINT, checkpoint.f90:55-61). */
+typedef struct p3m_ckpt_header {   /* checkpoint.f90:55-61 */
+  int32_t np_local; float a, t, tau; int32_t nts; float dt_f_acc, dt_pp_acc, dt_c_acc;
+  int32_t cur_checkpoint, cur_projection, cur_halofind; float mass_p;
+} p3m_ckpt_header;
+/* <z>xv<rank>.dat: header, then xv(1:3,j) - shake_offset, xv(4:6,j) per particle (checkpoint.f90:63-83) */
+int p3m_hip_write_checkpoint(const char *path, const p3m_ckpt_header *h, const float *xv6, const float *shake_offset3, int32_t binary, int32_t ppint);
+/* header only (xv6 == NULL) or header + particles (particle_initialization.f90:114-145); cap = room in xv6 (particles) */
+int p3m_hip_read_checkpoint(const char *path, p3m_ckpt_header *h, float *xv6, int64_t cap, int32_t binary, int32_t ppint);
+/* <z>PID<rank>.dat: the same header, then PID(j) per particle (checkpoint.f90:86-124) */
+int p3m_hip_write_pid_checkpoint(const char *path, const p3m_ckpt_header *h, const int64_t *pid, int32_t binary, int32_t ppint);
+int p3m_hip_read_pid_checkpoint(const char *path, p3m_ckpt_header *h, int64_t *pid, int64_t cap, int32_t binary, int32_t ppint);
+/* xv<rank>.ic: np_local, then xv(:,i) per particle (unformatted) or as one block (binary) (particle_initialization.f90:296-332) */
+int p3m_hip_write_ic(const char *path, const float *xv6, int32_t np_local, int32_t binary);
+int p3m_hip_read_ic(const char *path, float *xv6, int64_t cap, int32_t *np_local, int32_t binary);
+
 /* -- multi-rank: a group of logical ranks (the reference's nodes_dim^3 MPI ranks) ---------
  * One process drives one GPU and owns nodes_dim^3 / nprocs consecutive logical ranks; ranks on the
  * same GPU exchange by device copies, ranks on different GPUs by RCCL send/recv over xGMI

@@ -254,3 +254,22 @@ subroutine ref_time_params(out) bind(C, name="ref_time_params")
   out(1) = merge(1.0, 0.0, cosmo); out(2) = dt_scale; out(3) = dt_max; out(4) = ra_max; out(5) = da_max
   out(6) = wde; out(7) = omega_m; out(8) = omega_l
 end subroutine ref_time_params
+
+! --- checkpoint.f90 / particle_initialization.f90 (particle files, SURVEY section 8f rank 2) ------
+! rv_in : a, t, tau, dt_f_acc, dt_pp_acc, dt_c_acc, mass_p, z_write, shake_offset(3) ; iv_in : nts, cur_checkpoint, cur_projection, cur_halofind
+subroutine ref_checkpoint(rv_in, iv_in) bind(C, name="ref_checkpoint")
+  use iso_c_binding
+  implicit none
+  include 'cubepm.fh'
+  real(c_float) :: rv_in(11)
+  integer(c_int) :: iv_in(4)
+  a = rv_in(1); t = rv_in(2); tau = rv_in(3); dt_f_acc = rv_in(4); dt_pp_acc = rv_in(5); dt_c_acc = rv_in(6); mass_p = rv_in(7)
+  shake_offset = rv_in(9:11)
+  nts = iv_in(1); cur_checkpoint = iv_in(2); cur_projection = iv_in(3); cur_halofind = iv_in(4)
+  z_checkpoint(cur_checkpoint) = rv_in(8)
+  call checkpoint
+end subroutine ref_checkpoint
+
+subroutine ref_particle_initialize() bind(C, name="ref_particle_initialize")
+  call particle_initialize
+end subroutine
