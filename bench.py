@@ -49,6 +49,9 @@ CONFIGS = {
     # configs[2]: 256^3 / 128^3, PM+PP+extended PP
     "cfg3": dict(params=dict(tiles_node_dim=2, nf_tile=176, ngp=True, ppint=True, pp_ext=True, density_buffer=1.5), nside_rank=128,
                  workload="256^3 fine mesh / 128^3 particles, PM+PP+PP_EXT, nf_tile=176, 2^3 tiles"),
+    # configs[1] with the CIC mass assignment / interpolation (the reference built without -DNGP)
+    "cfg2_cic": dict(params=dict(tiles_node_dim=2, nf_tile=176, ngp=False, density_buffer=1.5), nside_rank=128,
+                     workload="256^3 fine mesh / 128^3 particles, PM-only (CIC), nf_tile=176, 2^3 tiles, 64^3 coarse"),
     # one rank's share of configs[3] on its own
     "big512": dict(params=dict(tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3), nside_rank=256,
                    workload="512^3 fine mesh / 256^3 particles (one rank's share of 1024^3/512^3), PM-only, nf_tile=560, 1 tile"),
