@@ -101,7 +101,8 @@ int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
 // ------------------------------------------------------------------ extended PP
 // One 64-lane workgroup per (tile, z, y) row of the tile's region extended by pp_range cells
 // (:397-402); one lane per record of the row.  Partner cells: Chebyshev distance 1..pp_range,
-// clipped to the extended region exactly as the reference's half-shell sweep is (:503-523), so the
+// clipped to the extended region exactly as the reference's half-shell sweep is (:496-523, incl. its
+// omission of the pairs inside the top pp_range planes), so the
 // per-tile maxval(|pp_ext_force_accum|) (:617) is reproduced including the partial sums of records
 // in the rim.  Only records whose cell is in the physical tile are kicked (:576-590).
 __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G,
@@ -120,7 +121,10 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
     const float4 p = spos[s];
     const int cx = (int)floorf(p.x) + G.nb;                                // :412 (floor(xv)+1, global)
     float ax = 0.f, ay = 0.f, az = 0.f;
-    const int z0 = max(cz - G.ppr, loz), z1 = min(cz + G.ppr, loz + e - 1);
+    int z0 = max(cz - G.ppr, loz), z1 = min(cz + G.ppr, loz + e - 1);
+    // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496 "we never loop towards
+    // smaller z"): a pair whose two cells both lie in the top pp_range planes of the region is never formed
+    if (cz - loz >= G.pt + G.ppr) z1 = min(z1, loz + G.pt + G.ppr - 1);
     const int y0 = max(cy - G.ppr, loy), y1 = min(cy + G.ppr, loy + e - 1);
     const int x0 = max(cx - G.ppr, lox), x1 = min(cx + G.ppr, lox + e - 1);
     for (int zz = z0; zz <= z1; zz++)
@@ -258,7 +262,10 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
       p = partner(r_own, s);
       cy = hy0 + jy; cz = hz0 + jz;
       cx = (int)floorf(p.x) + G.nb;                                // :412 (floor(xv)+1, global)
-      const int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);
+      int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);
+      // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): a pair whose two cells
+      // both lie in the top pp_range planes of the region is never formed
+      if (cz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
       const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1);
       const int x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
       const int nyr = y1 - y0 + 1, nrow = (z1 - z0 + 1) * nyr;

@@ -345,3 +345,17 @@ def test_multi_step_simulation_with_the_host_time_loop(PM):
     assert np.array_equal(pg, po)
     assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 2e-3
     assert rel_rms(xg[:, 3:], xo[:, 3:]) <= 1e-4
+
+
+def test_extended_pp_dense_blob_overflows_the_lds_staging(PM):
+    """One blob of 6000 particles within ~1.5 cells: the blocks of the tiled extended-PP kernel around it hold more
+    records than their LDS staging area (PPT_CAP = 2048), so partners come partly from LDS and partly from global
+    memory; the oracle's O(n^2) sums over the same cells are the check."""
+    p = cfg1(ngp=True, ppint=True, pp_ext=True, density_buffer=3.0)
+    rng = np.random.default_rng(77)
+    xv = uniform_particles(12000, 64.0, seed=9)
+    blob = np.float32(31.3) + rng.normal(0, 0.75, (6000, 3)).astype(np.float32)
+    xv[:6000, :3] = np.clip(blob, 0.01, 63.99)
+    xg, pg, xo, po, outs = run_step(PM, p, xv, (0.005, 0.2, 0.0, 8.0))
+    check_step(xv, xg, pg, xo, po, outs, "pp ext")
+    assert rel_rms(xg[:, 3:], xo[:, 3:]) <= KICK_TOL
