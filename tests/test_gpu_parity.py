@@ -359,3 +359,33 @@ def test_extended_pp_dense_blob_overflows_the_lds_staging(PM):
     xg, pg, xo, po, outs = run_step(PM, p, xv, (0.005, 0.2, 0.0, 8.0))
     check_step(xv, xg, pg, xo, po, outs, "pp ext")
     assert rel_rms(xg[:, 3:], xo[:, 3:]) <= KICK_TOL
+
+
+@pytest.mark.parametrize("move_back", [False, True])
+def test_disp_mesh_offsets_and_move_grid_back(PM, move_back):
+    """-DDISP_MESH: update_position adds a random mesh offset (update_position.f90:56-76, the host keeps the RNG and the
+    running shake_offset); -DMOVE_GRID_BACK subtracts shake_offset again before delete_particles
+    (particle_mesh_threaded.f90:716-720, move_grid_back.f90:17-24).  Three steps with the reference's offset recipe."""
+    p = cfg1(ngp=True, ppint=True, pp_ext=True, move_grid_back=move_back)
+    xv = clustered_particles(24000, 64.0, seed=4, frac=0.3, nblobs=30, sigma=0.7, vel_sigma=0.6)
+    pid = np.arange(1, len(xv) + 1, dtype=np.int64) * 7
+    g, o = both(PM, p)
+    g.upload_particles(xv, pid)
+    o.set_particles(0, xv, pid)
+    rng = np.random.default_rng(123)
+    shake = np.zeros(3, np.float32)
+    for step in range(3):
+        off = ((rng.random(3, dtype=np.float32) - np.float32(0.5)) * np.float32(p.mesh_scale) * np.float32(4.0) - shake).astype(np.float32)   # :57
+        shake = (shake + off).astype(np.float32)                                                                                            # :58
+        og = g.particle_mesh(0.3, 0.04, 0.03, 8.0, offset=off, move_back=shake if move_back else None)
+        oo = o.particle_mesh(0.3, 0.04, 0.03, 8.0, offset=off, move_back=shake if move_back else None)
+        if move_back:
+            shake[:] = 0.0                                                                                                                  # move_grid_back.f90:24
+        assert og.np_total == oo.np_total == len(xv) and og.np_ghost == oo.np_ghost and og.np_deleted == oo.np_deleted, step
+        assert og.dt_f_acc == pytest.approx(oo.dt_f_acc, rel=DT_TOL) and og.dt_pp_ext_acc == pytest.approx(oo.dt_pp_ext_acc, rel=DT_TOL), step
+    xg, pg = by_pid(*g.download_particles())
+    xo, po = by_pid(*o.get_particles(0))
+    assert np.array_equal(pg, po)
+    assert np.abs(xg[:, :3] - xo[:, :3]).max() <= POS_TOL
+    v0 = xv[np.argsort(pid), 3:]
+    assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 3 * KICK_TOL
