@@ -208,3 +208,25 @@ def test_eight_logical_ranks_with_mesh_offsets_and_move_grid_back():
         num += ((dg - do) ** 2).sum()
         den += (do ** 2).sum()
     assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)
+
+
+def test_eight_logical_ranks_one_tile_each_like_the_bench_workload():
+    """The shape of the default bench workload (nodes_dim = 2, ONE tile per rank) at test size."""
+    p = cfg1(nodes_dim=2, tiles_node_dim=1, nf_tile=112, ngp=True)
+    xv, pid = global_ic("uniform", 100000, float(p.nf_physical_dim), 3)
+    xv[:, 3:] = np.random.default_rng(8).normal(0, 0.4, (len(xv), 3)).astype(np.float32)
+    g, o, og, oo = run_both(p, xv, pid, (0.3, 0.1, 0.1, 8.0), steps=2)
+    assert og.np_total == oo.np_total == len(xv) and og.np_ghost == oo.np_ghost
+    assert og.dt_f_acc == pytest.approx(oo.dt_f_acc, rel=1e-5) and og.dt_c_acc == pytest.approx(oo.dt_c_acc, rel=1e-5)
+    v0 = dict(zip(pid.tolist(), xv[:, 3:]))
+    num = den = 0.0
+    for i, r in enumerate(g.local_ranks):
+        xg, pg = by_pid(*g.download_particles(i))
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
+        assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 1e-4
+        vin = np.stack([v0[q] for q in pg.tolist()])
+        dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
+        num += ((dg - do) ** 2).sum()
+        den += (do ** 2).sum()
+    assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)

@@ -389,3 +389,21 @@ def test_disp_mesh_offsets_and_move_grid_back(PM, move_back):
     assert np.abs(xg[:, :3] - xo[:, :3]).max() <= POS_TOL
     v0 = xv[np.argsort(pid), 3:]
     assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 3 * KICK_TOL
+
+
+@pytest.mark.parametrize("T,nf,cores,kw", [
+    (3, 64, 2, dict(ngp=True, ppint=True, pp_ext=True)),      # odd tile count, 16-cell physical tiles (fewer than the 24-cell buffer)
+    (4, 64, 3, dict(ngp=True, ppint=True, pp_ext=True)),      # 64 tiles on 3 "threads": the per-thread last-tile rule with a remainder
+    (3, 64, 2, dict(ngp=False)),                              # CIC deposit and interpolation across many tile seams
+    (1, 112, 2, dict(ngp=True, ppint=True, pp_ext=True)),     # one tile per rank
+])
+def test_other_tilings_whole_step_parity(PM, T, nf, cores, kw):
+    p = cfg1(tiles_node_dim=T, nf_tile=nf, cores=cores, **kw)
+    box = float(p.nf_physical_node_dim)
+    n = int(box ** 3 / 8)
+    xv = clustered_particles(n, box, seed=100 + T, frac=0.3, nblobs=20, sigma=1.0, vel_sigma=0.5)
+    pid = np.arange(1, n + 1, dtype=np.int64)
+    xg, pg, xo, po, outs = run_step(PM, p, xv, (0.2, 0.05, 0.04, 8.0), pid=pid, steps=2)
+    check_step(xv, xg, pg, xo, po, outs, "pp ext" if kw.get("pp_ext") else "")
+    v0 = xv[np.argsort(pid), 3:]
+    assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
