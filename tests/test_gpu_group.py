@@ -122,10 +122,12 @@ def _two_proc_worker(rank, world, port, outdir, kw):
     dist.destroy_process_group()
 
 
-def test_two_processes_host_transport_match_oracle(tmp_path):
-    """The process-level split (4 logical ranks per process, remote peers, announced counts, the all-to-all and halo
-    message lists, the dt reductions) driven by two processes sharing this one GPU through the host-callback
-    transport over gloo -- RCCL refuses two ranks on one device, and an MPI host would take this same route."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_several_processes_host_transport_match_oracle(tmp_path, world):
+    """The process-level split (8/world logical ranks per process, remote peers, announced counts, the all-to-all and
+    halo message lists, the dt reductions) driven by `world` processes sharing this one GPU through the host-callback
+    transport over gloo -- RCCL refuses two ranks on one device, and an MPI host would take this same route.
+    world = 8 is the shape of an 8-GPU run: one logical rank per process, every exchange leaves the process."""
     import socket
 
     import torch.multiprocessing as mp
@@ -136,7 +138,7 @@ def test_two_processes_host_transport_match_oracle(tmp_path):
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_two_proc_worker, args=(r, 2, port, str(tmp_path), kw)) for r in range(2)]
+    procs = [ctx.Process(target=_two_proc_worker, args=(r, world, port, str(tmp_path), kw)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:
@@ -152,7 +154,7 @@ def test_two_processes_host_transport_match_oracle(tmp_path):
     for r in range(8):
         o.set_particles(r, *parts[r])
     oo = o.particle_mesh(0.01, 0.3, 0.3, 8.0)
-    res = [np.load(tmp_path / ("proc%d.npz" % r)) for r in range(2)]
+    res = [np.load(tmp_path / ("proc%d.npz" % r)) for r in range(world)]
     ghosts = 0
     for d in res:   # the reductions reached both processes
         assert int(d["np_total"]) == oo.np_total == len(xv)
@@ -164,7 +166,7 @@ def test_two_processes_host_transport_match_oracle(tmp_path):
     v0 = dict(zip(pid.tolist(), xv[:, 3:]))
     num = den = 0.0
     for r in range(8):
-        d = res[r // 4]
+        d = res[r // (8 // world)]
         xg, pg = by_pid(d["xv%d" % r], d["pid%d" % r])
         xo, po = by_pid(*o.get_particles(r))
         assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
