@@ -44,8 +44,8 @@ struct CoarseDist {            // per local logical rank
   float *blocks_out = nullptr; // [nd^2][3][s][ncn][ncn]   slab -> cube departures
   float *blocks_back = nullptr;// [nd^2][3][s][ncn][ncn]   arrivals at the cube
   float *halo_s[2] = {nullptr, nullptr}, *halo_r[2] = {nullptr, nullptr};  // [3][(ncn+2)^2]
-  float4 *sb = nullptr, *rb = nullptr;   // ghost records, 32 B each, 26 segments (one per shift, G->seg_off)
-  int *d_cnt = nullptr;        // [0..26] own send counts per shift, [32..58] counts announced by the neighbours
+  float4 *sb = nullptr, *rb = nullptr;   // ghost (16 B) and migrant (32 B) records, 52 segments (G->seg_off, in float4 units)
+  int *d_cnt = nullptr;        // [0..53] own send counts per slot, [64..117] counts announced by the neighbours
 };
 
 struct p3m_group {
@@ -58,7 +58,7 @@ struct p3m_group {
   p3m_transport tr{}; bool have_tr = false;
   char *h_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};   // pinned send / receive staging of the host transport
   FftPlan plan_c; int s = 0, nchunk = 0;
-  int seg_off[27] = {0}, seg_cap[27] = {0}; int64_t seg_total = 0;   // ghost segments by shift: faces, edges, corners
+  int seg_off[54] = {0}, seg_cap[54] = {0}; int64_t seg_total = 0;   // segments by slot (2m ghosts, 2m+1 migrants), offsets in float4 units
   int *h_cnt = nullptr;        // pinned [nlocal*4]
   float *d_red4 = nullptr; double *d_sum3 = nullptr; float *h_red4 = nullptr; double *h_sum3 = nullptr;
   bool have_k = false;
@@ -242,7 +242,11 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
         const int nz = (m % 3 != 0) + ((m / 3) % 3 != 0) + (m / 9 != 0);
         int64_t cap = nz == 0 ? 0 : (int64_t)((double)g.max_np * (nz == 1 ? f : (nz == 2 ? f * f : f * f * f))) + 4096;
         cap = std::min<int64_t>(cap, g.max_np);
-        G->seg_off[m] = (int)run; G->seg_cap[m] = (int)cap; run += cap;
+        // migrants: records that left the rank through this face / edge / corner in one step -- or, with -DMOVE_GRID_BACK
+        // (ghosts can turn physical when the grid moves back), every image
+        const int64_t capm = nz == 0 ? 0 : ((base->flags & P3M_FLAG_MOVE_GRID_BACK) ? cap : cap / 4 + 4096);
+        G->seg_off[2 * m] = (int)run; G->seg_cap[2 * m] = (int)cap; run += cap;                 // ghosts: one float4 each
+        G->seg_off[2 * m + 1] = (int)run; G->seg_cap[2 * m + 1] = (int)capm; run += 2 * capm;   // migrants: two
       }
       if (run > 0x3fffffff) return fail(P3M_ECAPACITY);
       G->seg_total = run;
@@ -258,14 +262,14 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
       for (int i = 0; i < 2; i++) {
         A(galloc(&d.halo_s[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2))); A(galloc(&d.halo_r[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2)));
       }
-      A(galloc(&d.sb, (size_t)2 * G->seg_total)); A(galloc(&d.rb, (size_t)2 * G->seg_total));
-      A(galloc(&d.d_cnt, 64));
+      A(galloc(&d.sb, (size_t)G->seg_total)); A(galloc(&d.rb, (size_t)G->seg_total));
+      A(galloc(&d.d_cnt, 128));
 #undef A
       if (hipMemset(d.rows, 0, sizeof(float) * 3 * G->s * g.nc * 2 * G->plan_c.px) != hipSuccess) return fail(P3M_EDEVICE);
     }
   }
   if (galloc(&G->d_red4, 8) || galloc(&G->d_sum3, 4)) return fail(P3M_ENOMEM);
-  if (hipHostMalloc(reinterpret_cast<void **>(&G->h_cnt), sizeof(int) * 64 * G->ctx.size()) != hipSuccess) return fail(P3M_ENOMEM);
+  if (hipHostMalloc(reinterpret_cast<void **>(&G->h_cnt), sizeof(int) * 128 * G->ctx.size()) != hipSuccess) return fail(P3M_ENOMEM);
   if (hipHostMalloc(reinterpret_cast<void **>(&G->h_red4), sizeof(float) * 8) != hipSuccess) return fail(P3M_ENOMEM);
   if (hipHostMalloc(reinterpret_cast<void **>(&G->h_sum3), sizeof(double) * 4) != hipSuccess) return fail(P3M_ENOMEM);
   G->last.dt_f_acc = G->last.dt_pp_acc = G->last.dt_pp_ext_acc = G->last.dt_c_acc = 1000.f;
@@ -315,31 +319,33 @@ static int shift_neighbour(const p3m_group *G, int r, int m) {
 static int ghost_pass(p3m_group *G) {
   const int nl = (int)G->ctx.size();
   if (G->nodes == 1) return particles_pass_self(G->ctx[0]);
-  // 1. pack every image into the segment of its shift
+  // slot k = 2m (ghosts of shift m, 16 B each) or 2m+1 (migrants, 32 B each); d_cnt: [0..53] own counts, [64..117] announced
+  // 1. pack every image into the segment of its slot
   for (int i = 0; i < nl; i++) {
     CoarseDist &d = G->cd[i];
-    HIP_TRY(hipMemsetAsync(d.d_cnt, 0, 64 * sizeof(int), G->stream));
+    HIP_TRY(hipMemsetAsync(d.d_cnt, 0, 128 * sizeof(int), G->stream));
     P3M_TRY(particles_ghost_pack(G->ctx[i], d.sb, G->seg_off, G->seg_cap, d.d_cnt));
   }
-  // 2. announce the counts: shift m of rank r lands in slot m of the rank at r + shift (one source per slot)
+  // 2. announce the counts: shift m of rank r lands in the slots of m at the rank at r + shift (one source per slot)
   std::vector<XMsg> cm;
   for (int r = 0; r < G->nodes; r++)
     for (int m = 1; m < 27; m++) {
       const int dst = shift_neighbour(G, r, m), li = G->lidx[r], ld = G->lidx[dst];
-      cm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].d_cnt + m) : nullptr, ld >= 0 ? (void *)(G->cd[ld].d_cnt + 32 + m) : nullptr, sizeof(int)});
+      cm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].d_cnt + 2 * m) : nullptr, ld >= 0 ? (void *)(G->cd[ld].d_cnt + 64 + 2 * m) : nullptr, 2 * sizeof(int)});
     }
   P3M_TRY(do_exchange(G, cm));
-  for (int i = 0; i < nl; i++) HIP_TRY(hipMemcpyAsync(G->h_cnt + 64 * i, G->cd[i].d_cnt, 64 * sizeof(int), hipMemcpyDeviceToHost, G->stream));
+  for (int i = 0; i < nl; i++) HIP_TRY(hipMemcpyAsync(G->h_cnt + 128 * i, G->cd[i].d_cnt, 128 * sizeof(int), hipMemcpyDeviceToHost, G->stream));
   HIP_TRY(hipStreamSynchronize(G->stream));
   for (int i = 0; i < nl; i++) {
-    const int *h = G->h_cnt + 64 * i;
+    const int *h = G->h_cnt + 128 * i;
     int64_t in = 0;
-    for (int m = 1; m < 27; m++) {
-      if (h[m] > G->seg_cap[m] || h[32 + m] > G->seg_cap[m]) {
-        p3m_set_error("rank %d: not enough buffer space in pass (shift %d: %d out, %d in > %d) (particle_pass.f90:96-99)", G->lrank[i], m, h[m], h[32 + m], G->seg_cap[m]);
+    for (int k = 2; k < 54; k++) {
+      if (h[k] > G->seg_cap[k] || h[64 + k] > G->seg_cap[k]) {
+        p3m_set_error("rank %d: not enough buffer space in pass (shift %d, %s: %d out, %d in > %d) (particle_pass.f90:96-99)", G->lrank[i], k / 2,
+                      (k & 1) ? "migrants" : "ghosts", h[k], h[64 + k], G->seg_cap[k]);
         return P3M_ECAPACITY;
       }
-      in += h[32 + m];
+      in += h[64 + k];
     }
     if ((int64_t)G->ctx[i]->np_local + in > G->ctx[i]->cap) {
       p3m_set_error("rank %d: exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139)", G->lrank[i], (long long)G->ctx[i]->np_local + in, (long long)G->ctx[i]->cap);
@@ -349,20 +355,21 @@ static int ghost_pass(p3m_group *G) {
   // 3. payloads.  Sizes: the sender knows its own counts, the receiver the announced ones (they agree).
   std::vector<XMsg> pm;
   for (int r = 0; r < G->nodes; r++)
-    for (int m = 1; m < 27; m++) {
-      const int dst = shift_neighbour(G, r, m), li = G->lidx[r], ld = G->lidx[dst];
+    for (int k = 2; k < 54; k++) {
+      const int dst = shift_neighbour(G, r, k / 2), li = G->lidx[r], ld = G->lidx[dst];
+      const size_t rec = (k & 1) ? 32 : 16;
       size_t bytes = 0;
-      if (li >= 0) bytes = (size_t)G->h_cnt[64 * li + m] * 32;
-      if (ld >= 0) bytes = (size_t)G->h_cnt[64 * ld + 32 + m] * 32;
-      pm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].sb + 2 * (size_t)G->seg_off[m]) : nullptr,
-                    ld >= 0 ? (void *)(G->cd[ld].rb + 2 * (size_t)G->seg_off[m]) : nullptr, bytes});
+      if (li >= 0) bytes = (size_t)G->h_cnt[128 * li + k] * rec;
+      if (ld >= 0) bytes = (size_t)G->h_cnt[128 * ld + 64 + k] * rec;
+      pm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].sb + (size_t)G->seg_off[k]) : nullptr,
+                    ld >= 0 ? (void *)(G->cd[ld].rb + (size_t)G->seg_off[k]) : nullptr, bytes});
     }
   P3M_TRY(do_exchange(G, pm));
   // 4. append
   for (int i = 0; i < nl; i++) {
-    const int *h = G->h_cnt + 64 * i;
-    P3M_TRY(particles_ghost_unpack(G->ctx[i], G->cd[i].rb, G->seg_off, h + 32, G->ctx[i]->np_local));
-    int in = 0; for (int m = 1; m < 27; m++) in += h[32 + m];
+    const int *h = G->h_cnt + 128 * i;
+    P3M_TRY(particles_ghost_unpack(G->ctx[i], G->cd[i].rb, G->seg_off, h + 64, G->ctx[i]->np_local));
+    int in = 0; for (int k = 2; k < 54; k++) in += h[64 + k];
     G->ctx[i]->np_all = G->ctx[i]->np_local + in;
   }
   return P3M_OK;

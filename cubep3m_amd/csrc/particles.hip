@@ -334,9 +334,14 @@ int particles_pass_and_sort(p3m_ctx *c) {
 // 1 to the + neighbour (x_a >= Nn-nb, image max(x_a-Nn,-nb), :83,:162), 2 to the - neighbour (x_a < nb, image
 // min(guard(x_a)+Nn, Nn+nb-eps), :185,:257-265)} for x/y/z.  One pack, one count exchange, one payload exchange
 // over up to 7 different peers (all xGMI links at once instead of one link three times), one unpack.
-// Records travel as 32-byte AoS {x,y,z,vx | vy,vz,pid(8 B)} with FINAL coordinates: the w lanes of pos/vel
-// are padding (zero) and are not sent.
-struct GhostSegs { int off[27]; int cap[27]; };   // record offset / capacity of each shift's segment in the send and receive buffers
+// Two classes per shift m (slot 2m: ghosts, slot 2m+1: migrants).  A GHOST (its image lies in the destination's buffer
+// zone) travels as ONE float4 {x,y,z,0}: ghosts only contribute mass and PP partners, are never kicked, and
+// delete_particles drops them before the step returns, so the velocity and PID the reference ships along
+// (particle_pass.f90 sends xv(1:6) and PID) would be dead weight on xGMI.  A MIGRANT (a record that drifted out of this
+// rank's volume: its image is PHYSICAL at the destination and survives there) travels with everything:
+// {x,y,z,vx | vy,vz,pid}.  Coordinates are final in both.
+#define GSLOTS 54
+struct GhostSegs { int off[GSLOTS]; int cap[GSLOTS]; };   // float4 offset / record capacity of each slot's segment in the send and receive buffers
 // the (at most one, since Nn >= 2 nb) shift of a coordinate: 0 none, 1 image at the + neighbour, 2 at the - neighbour
 __device__ __forceinline__ int axis_shift(float x, float Nn, float nb, float *img) {
   if (x >= Nn - nb) { *img = fmaxf(x - Nn, -nb); return 1; }
@@ -346,31 +351,41 @@ __device__ __forceinline__ int axis_shift(float x, float Nn, float nb, float *im
   }
   *img = x; return 0;
 }
-constexpr int GP_RPT = 8;   // records per thread: <= 26 reservation atomics per 2048 records
+constexpr int GP_RPT = 8;   // records per thread: <= 52 reservation atomics per 2048 records
 __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
-                                                   int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts) {
-  __shared__ int lc[27], base[27];
-  if (threadIdx.x < 27) lc[threadIdx.x] = 0;
+                                                   int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts, int all_full) {
+  __shared__ int lc[GSLOTS], base[GSLOTS];
+  if (threadIdx.x < GSLOTS) lc[threadIdx.x] = 0;
   __syncthreads();
   // the images of a record are the non-empty subsets t = 1..7 of its shifted axes (bit 0: x, 1: y, 2: z)
   float4 p[GP_RPT]; int rk[GP_RPT][7]; int sh[GP_RPT];   // sh: sx | sy << 2 | sz << 4, 0: nothing to send
+  auto slot_of = [&](const float4 &q, int t, int sx, int sy, int sz, float ix, float iy, float iz, float4 *img) {
+    const float x = (t & 1) ? ix : q.x, y = (t & 2) ? iy : q.y, z = (t & 4) ? iz : q.z;
+    *img = make_float4(x, y, z, 0.f);
+    const int m = ((t & 1) ? sx : 0) + 3 * ((t & 2) ? sy : 0) + 9 * ((t & 4) ? sz : 0);
+    // survives delete_particles over there; with -DMOVE_GRID_BACK the shift by shake_offset before the deletion can make
+    // any ghost physical: then every image travels as a full record
+    const bool phys = all_full || (x >= 0.f && x < Nn && y >= 0.f && y < Nn && z >= 0.f && z < Nn);
+    return 2 * m + (phys ? 1 : 0);
+  };
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
     const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
     p[r] = make_float4(0.f, 0.f, 0.f, 0.f); sh[r] = 0;
     if (i < n) p[r] = pos[i];
     if (i >= n || !in_hoc_range(p[r], -nb, Nn + nb)) continue;   // dropped by link_list ("PARTICLE DELETED")
-    float dummy;
-    const int sx = axis_shift(p[r].x, Nn, nb, &dummy), sy = axis_shift(p[r].y, Nn, nb, &dummy), sz = axis_shift(p[r].z, Nn, nb, &dummy);
+    float ix, iy, iz;
+    const int sx = axis_shift(p[r].x, Nn, nb, &ix), sy = axis_shift(p[r].y, Nn, nb, &iy), sz = axis_shift(p[r].z, Nn, nb, &iz);
     sh[r] = sx | (sy << 2) | (sz << 4);
 #pragma unroll
     for (int t = 1; t < 8; t++) {
       const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
-      if (ok) rk[r][t - 1] = atomicAdd(&lc[((t & 1) ? sx : 0) + 3 * ((t & 2) ? sy : 0) + 9 * ((t & 4) ? sz : 0)], 1);
+      float4 img;
+      if (ok) rk[r][t - 1] = atomicAdd(&lc[slot_of(p[r], t, sx, sy, sz, ix, iy, iz, &img)], 1);
     }
   }
   __syncthreads();
-  if (threadIdx.x < 27) base[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]) : 0;
+  if (threadIdx.x < GSLOTS) base[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]) : 0;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
@@ -379,47 +394,54 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
     const int sx = sh[r] & 3, sy = (sh[r] >> 2) & 3, sz = sh[r] >> 4;
     float ix, iy, iz;
     (void)axis_shift(p[r].x, Nn, nb, &ix); (void)axis_shift(p[r].y, Nn, nb, &iy); (void)axis_shift(p[r].z, Nn, nb, &iz);
-    const float4 v = vel[i]; const int64_t id = pid[i];
-    const float4 r1 = make_float4(v.y, v.z, __int_as_float((int)(id & 0xffffffffLL)), __int_as_float((int)(id >> 32)));
 #pragma unroll
     for (int t = 1; t < 8; t++) {
       const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
       if (!ok) continue;
-      const int m = ((t & 1) ? sx : 0) + 3 * ((t & 2) ? sy : 0) + 9 * ((t & 4) ? sz : 0);
-      const int s = base[m] + rk[r][t - 1];
-      if (s < S.cap[m]) {
-        float4 *o = sbuf + 2 * ((int64_t)S.off[m] + s);
-        o[0] = make_float4((t & 1) ? ix : p[r].x, (t & 2) ? iy : p[r].y, (t & 4) ? iz : p[r].z, v.x); o[1] = r1;
-      }
+      float4 img;
+      const int k = slot_of(p[r], t, sx, sy, sz, ix, iy, iz, &img);
+      const int s = base[k] + rk[r][t - 1];
+      if (s >= S.cap[k]) continue;
+      if (k & 1) {   // migrant: the whole record
+        const float4 v = vel[i]; const int64_t id = pid[i];
+        float4 *o = sbuf + (int64_t)S.off[k] + 2 * (int64_t)s;
+        img.w = v.x;
+        o[0] = img; o[1] = make_float4(v.y, v.z, __int_as_float((int)(id & 0xffffffffLL)), __int_as_float((int)(id >> 32)));
+      } else sbuf[(int64_t)S.off[k] + s] = img;
     }
   }
 }
-// appends the received segments: blockIdx.y = shift; dst[m] = first record index of that segment in pos/vel/pid
-struct GhostIn { int off[27]; int cnt[27]; int dst[27]; };
+// appends the received segments: blockIdx.y = slot - 2; dst[k] = first record index of that segment in pos/vel/pid
+struct GhostIn { int off[GSLOTS]; int cnt[GSLOTS]; int dst[GSLOTS]; };
 __global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ rbuf, GhostIn T, float4 *__restrict__ pos, float4 *__restrict__ vel,
                                                      int64_t *__restrict__ pid) {
-  const int m = blockIdx.y + 1, n = T.cnt[m];
-  for (int i = blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) {
-    const float4 *r = rbuf + 2 * ((int64_t)T.off[m] + i);
-    const float4 r0 = r[0], r1 = r[1];
-    const int o = T.dst[m] + i;
-    pos[o] = make_float4(r0.x, r0.y, r0.z, 0.f); vel[o] = make_float4(r0.w, r1.x, r1.y, 0.f);
-    pid[o] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
+  const int k = blockIdx.y + 2, n = T.cnt[k];
+  if (k & 1) {
+    for (int i = blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) {
+      const float4 *r = rbuf + (int64_t)T.off[k] + 2 * (int64_t)i;
+      const float4 r0 = r[0], r1 = r[1];
+      const int o = T.dst[k] + i;
+      pos[o] = make_float4(r0.x, r0.y, r0.z, 0.f); vel[o] = make_float4(r0.w, r1.x, r1.y, 0.f);
+      pid[o] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
+    }
+  } else {
+    // ghosts: the velocity / PID slots stay unwritten -- nothing reads them before delete_particles drops the record
+    for (int i = blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) pos[T.dst[k] + i] = rbuf[(int64_t)T.off[k] + i];
   }
 }
 int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts) {
   if (c->np_local == 0) return P3M_OK;
-  GhostSegs S; for (int m = 0; m < 27; m++) { S.off[m] = seg_off[m]; S.cap[m] = seg_cap[m]; }
+  GhostSegs S; for (int k = 0; k < GSLOTS; k++) { S.off[k] = seg_off[k]; S.cap[k] = seg_cap[k]; }
   hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, PT * GP_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
-                     c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts);
+                     c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
 int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base) {
   GhostIn T; int mx = 0, run = base;
-  for (int m = 0; m < 27; m++) { T.off[m] = seg_off[m]; T.cnt[m] = m ? cnt[m] : 0; T.dst[m] = run; run += T.cnt[m]; mx = std::max(mx, T.cnt[m]); }
+  for (int k = 0; k < GSLOTS; k++) { T.off[k] = seg_off[k]; T.cnt[k] = k >= 2 ? cnt[k] : 0; T.dst[k] = run; run += T.cnt[k]; mx = std::max(mx, T.cnt[k]); }
   if (mx == 0) return P3M_OK;
-  hipLaunchKernelGGL(k_ghost_unpack, dim3(std::min(1024, cdiv(mx, PT)), 26), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid);
+  hipLaunchKernelGGL(k_ghost_unpack, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
