@@ -83,6 +83,7 @@ struct p3m_ctx {
   int *h_counters = nullptr;   // pinned mirror
   // ---- fine mesh, all tiles batched
   int tile_batch = 0;          // tiles processed per sweep
+  bool pending_compact = false; int pend_n = 0; float pend_mb[3] = {0, 0, 0};   // deferred ghost removal (particles.hip)
   bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
   float *work = nullptr;       // [3][batch][nf][nf][2*px]  i*K_c*rho-hat -> force, all three components
@@ -136,6 +137,8 @@ int particles_sort(p3m_ctx *c, float deposit_mass);
 int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts);
 int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);
+int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset);
+int particles_resolve(p3m_ctx *c);   // finish a deferred ghost removal before the arrival arrays are read
 
 // ---- fine_mesh.hip
 int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p);

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(PT) void k_drift(float4 *__restrict__ pos, const fl
 }
 
 int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset) {
+  if (c->pending_compact) return particles_compact(c, true, dt, dt_old, offset);   // ghost removal of the last step + this drift in one pass
   if (c->np_local == 0) return P3M_OK;
   hipLaunchKernelGGL(k_drift, dim3(cdiv(c->np_local, PT)), dim3(PT), 0, c->stream, c->pos, (const float4 *)c->vel, c->np_local, dt, dt_old,
                      offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0);
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos
 
 // single rank: all ghost images in one kernel; leaves c->np_all = records incl. ghosts (unsorted)
 int particles_pass_self(p3m_ctx *c) {
+  P3M_TRY(particles_resolve(c));
   const Geometry &g = c->g;
   int *cnt = c->d_counters;  // [0] image count, [3] overflow, [4] deleted, [5] candidates
   HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
@@ -283,6 +285,7 @@ int particles_pass_self(p3m_ctx *c) {
 // sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell; deposit_mass >= 0 (whole-step
 // entry points, where mass_p is known here) also writes the NGP density of every tile (c->rho_from_sort)
 int particles_sort(p3m_ctx *c, float deposit_mass) {
+  P3M_TRY(particles_resolve(c));
   const Geometry &g = c->g;
   int *cnt = c->d_counters;
   const int n_cur = c->np_all;
@@ -430,6 +433,7 @@ __global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ 
   }
 }
 int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts) {
+  P3M_TRY(particles_resolve(c));
   if (c->np_local == 0) return P3M_OK;
   GhostSegs S; for (int k = 0; k < GSLOTS; k++) { S.off[k] = seg_off[k]; S.cap[k] = seg_cap[k]; }
   hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, PT * GP_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
@@ -457,31 +461,57 @@ __global__ __launch_bounds__(PT) void k_flag_physical(const float4 *__restrict__
   p.x -= mx; p.y -= my; p.z -= mz;
   flags[i] = (p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn) ? 1 : 0;
 }
+// DRIFT: the next step's update_position (update_position.f90:68-76) rides on the copy, applied to the very value
+// k_compact alone would have stored
+template <bool DRIFT>
 __global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos, const float4 *__restrict__ svel, const int64_t *__restrict__ spid,
                                                 const int *__restrict__ offs, int n, float Nn, float4 *__restrict__ pos, float4 *__restrict__ vel,
-                                                int64_t *__restrict__ pid, float mx, float my, float mz) {
+                                                int64_t *__restrict__ pid, float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off) {
   const int i = blockIdx.x * PT + threadIdx.x;
   if (i >= n) return;
   float4 p = spos[i];
   p.x -= mx; p.y -= my; p.z -= mz;
   if (!(p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn)) return;
   const int o = offs[i];
-  pos[o] = p; vel[o] = svel[i]; pid[o] = spid[i];
+  const float4 v = svel[i];
+  if (DRIFT) {
+    if (use_off) { p.x = p.x + v.x * hs + ox; p.y = p.y + v.y * hs + oy; p.z = p.z + v.z * hs + oz; }  // :71
+    else { p.x = p.x + v.x * hs; p.y = p.y + v.y * hs; p.z = p.z + v.z * hs; }                           // :73
+  }
+  pos[o] = p; vel[o] = v; pid[o] = spid[i];
 }
 
+// delete_particles: the survivors are counted now (the step's np_local), but the copy back to the arrival arrays is
+// deferred: the next step's drift does it in the same pass (particles_drift), anything else that reads the arrival
+// arrays first calls particles_resolve.
 int particles_finalize(p3m_ctx *c, const float *move_back) {
   const int n = c->np_all;
+  c->pending_compact = false;
   if (n == 0) { c->np_local = 0; return P3M_OK; }
   float mx = 0, my = 0, mz = 0;
   if (move_back) { mx = move_back[0]; my = move_back[1]; mz = move_back[2]; }
   hipLaunchKernelGGL(k_flag_physical, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, n, (float)c->g.Nn, c->flags, mx, my, mz);
   HIP_TRY(hipGetLastError());
   P3M_TRY(exclusive_scan_i32(c, c->flags, n));
-  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel,
-                     (const int64_t *)c->spid, (const int *)c->flags, n, (float)c->g.Nn, c->pos, c->vel, c->pid, mx, my, mz);
-  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_counters, c->flags + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->np_local = c->h_counters[0];
+  c->pending_compact = true; c->pend_n = n; c->pend_mb[0] = mx; c->pend_mb[1] = my; c->pend_mb[2] = mz;
   return P3M_OK;
 }
+int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset) {
+  if (!c->pending_compact) return P3M_OK;
+  c->pending_compact = false;
+  const int n = c->pend_n;
+  const float hs = 0.5f * (dt + dt_old);
+  if (drift)
+    hipLaunchKernelGGL(k_compact<true>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel, (const int64_t *)c->spid,
+                       (const int *)c->flags, n, (float)c->g.Nn, c->pos, c->vel, c->pid, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
+                       offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_compact<false>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel, (const int64_t *)c->spid,
+                       (const int *)c->flags, n, (float)c->g.Nn, c->pos, c->vel, c->pid, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], 0.f, 0.f, 0.f, 0.f, 0);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+int particles_resolve(p3m_ctx *c) { return particles_compact(c, false, 0.f, 0.f, nullptr); }
