@@ -57,6 +57,8 @@ static int fill_geometry(const p3m_params *p, Geometry *g) {
   return P3M_OK;
 }
 
+extern "C" int32_t p3m_hip_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
 extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   if (!params || !out) return P3M_EINVAL;
   *out = nullptr;

@@ -125,6 +125,7 @@ typedef struct p3m_ctx p3m_ctx;
 int p3m_hip_create(const p3m_params *params, p3m_ctx **out);
 void p3m_hip_destroy(p3m_ctx *ctx);
 const char *p3m_hip_last_error(void);
+int32_t p3m_hip_device_count(void);   /* GPUs visible to this process (an MPI host maps its local rank onto them) */
 /* Derived sizes exactly as cubepm.par:170-208 computes them. what: 0 max_np, 1 nc_dim,
    2 nc_node_dim, 3 nf_physical_node_dim, 4 nc_slab, 5 nf_physical_tile_dim */
 int64_t p3m_hip_derived(const p3m_ctx *ctx, int32_t what);

@@ -56,6 +56,15 @@ PAR
   $FC $FFLAGS -c "$HERE/ref_driver.f90" -o "$D/ref_driver.o"
   $FC -shared -fopenmp -o "$D/libref.so" $OBJS "$D/ref_driver.o" -L$MPI_LIB -Wl,-rpath,$MPI_LIB -lmpifort -lmpi
   echo "built $D/libref.so"
+  # an MPI host in the reference's language around the HIP library: the drop-in adapter + the reference's own
+  # mpi_initialization.o + COMMON blocks (multi-rank builds only; needs libp3m_hip.so at run time)
+  if [ "$nd" -gt 1 ] && [ -f "$HERE/../cubep3m_amd/libp3m_hip.so" ]; then
+    $FC $FFLAGS -DPID_FLAG -J "$D" -c "$HERE/../cubep3m_amd/fortran/particle_mesh_hip_mpi.f90" -o "$D/particle_mesh_hip_mpi.o" 2> "$D/adapter.log" || { cat "$D/adapter.log"; exit 1; }
+    $FC $FFLAGS -c "$HERE/hip_mpi_driver.f90" -o "$D/hip_mpi_driver.o"
+    $FC -fopenmp -o "$D/hip_mpi_driver" "$D/hip_mpi_driver.o" "$D/particle_mesh_hip_mpi.o" "$D/mpi_initialization.o" \
+        -L"$HERE/../cubep3m_amd" -lp3m_hip -Wl,-rpath,'$ORIGIN/../../../cubep3m_amd' -L$MPI_LIB -Wl,-rpath,$MPI_LIB -lmpifort -lmpi
+    echo "built $D/hip_mpi_driver"
+  fi
 }
 
 #          name        nd T nf  cores dens flags
@@ -67,3 +76,5 @@ build_cfg  cfg1_1rank  1  2 80  2     2.0  "-DNGP -DPID_FLAG"
 build_cfg  cfg1_8rank  2  2 80  2     2.0  "-DNGP"
 # the PP switches change which limits timestep.f90 takes the minimum of (:93-115)
 build_cfg  cfg1_pp     1  2 80  2     2.0  "-DNGP -DPPINT -DPP_EXT -DPID_FLAG"
+# the MPI host of tests/test_gpu_group.py (hip_mpi_driver): 8 ranks, PP switches on, DISP_MESH off
+build_cfg  cfg1_8rank_pp 2 2 80 2     2.0  "-DNGP -DPPINT -DPP_EXT"

@@ -232,3 +232,79 @@ def test_eight_logical_ranks_one_tile_each_like_the_bench_workload():
         num += ((dg - do) ** 2).sum()
         den += (do ** 2).sum()
     assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)
+
+
+# ------------------------------------------------------------------ the drop-in itself: a Fortran MPI host
+def _write_kernel_ascii(path, table):
+    """kernels/wfxyz*.ascii as fine_kernel / coarse_kernel read them: '(3i4,3e16.8)' per (i,j,k), i fastest
+    (kernel_initialization.f90:15-30,344-358); `table` is (n,n,n,3) indexed [k][j][i]."""
+    n = table.shape[0]
+    with open(path, "w") as f:
+        for k in range(n):
+            for j in range(n):
+                for i in range(n):
+                    f.write("%4d%4d%4d%16.8E%16.8E%16.8E\n" % ((i + 1, j + 1, k + 1) + tuple(float(v) for v in table[k, j, i])))
+
+
+@pytest.mark.parametrize("cfg,kw", [("cfg1_8rank_pp", dict(ngp=True, ppint=True, pp_ext=True)), ("cfg1_8rank", dict(ngp=True))])
+def test_fortran_mpi_host_calls_particle_mesh_through_the_adapter(tmp_path, cfg, kw):
+    """`mpiexec -n 8 hip_mpi_driver`: the reference's COMMON blocks and its own mpi_initialize, `call particle_mesh`
+    resolved by cubep3m_amd/fortran/particle_mesh_hip_mpi.f90 (ISO_C_BINDING + the three MPI transport callbacks),
+    eight MPI ranks sharing this GPU -- against the oracle's eight simulated ranks.  The binary is built in the dev
+    container from the reference's headers (oracle/build_ref.sh) and travels with the snapshot."""
+    import os
+    import shutil
+    import subprocess
+
+    from cubep3m_amd.group import split_global
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "oracle", "_ref", cfg)
+    exe = os.path.join(d, "hip_mpi_driver")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("oracle/_ref/%s/hip_mpi_driver not built (dev container: bash oracle/build_ref.sh)" % cfg)
+    os.makedirs(os.path.join(d, "kernels"), exist_ok=True)       # kernel_path = cubepm_root//'kernels/' (cubepm.par:10)
+    _write_kernel_ascii(os.path.join(d, "kernels", "wfxyzf.3.ascii"), FINE_TABLE)
+    _write_kernel_ascii(os.path.join(d, "kernels", "wfxyzc.2.ascii"), COARSE_TABLE)
+    p = cfg1(nodes_dim=2, **kw)
+    xv, pid = global_ic("clustered", 60000, float(p.nf_physical_dim), 314)
+    parts = split_global(p, xv, pid, range(8))
+    scal = np.asarray((0.01, 0.3, 0.3, 8.0), np.float32)
+    nsteps = 2
+    for r in range(8):
+        x, q = parts[r]
+        with open(tmp_path / ("in%d.bin" % r), "wb") as f:
+            np.asarray([len(x), nsteps], np.int32).tofile(f)
+            scal.tofile(f)
+            np.ascontiguousarray(x, np.float32).tofile(f)
+            np.ascontiguousarray(q, np.int64).tofile(f)
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([mpiexec, "-n", "8", exe, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    for r in range(8):
+        o.set_particles(r, *parts[r])
+    for s in range(nsteps):
+        oo = o.particle_mesh(float(scal[0]), float(scal[1]), float(scal[2]) if s == 0 else float(scal[1]), float(scal[3]))
+    v0 = dict(zip(pid.tolist(), xv[:, 3:]))
+    num = den = 0.0
+    for r in range(8):
+        raw = np.fromfile(tmp_path / ("out%d.bin" % r), np.uint8)
+        n = int(raw[:4].view(np.int32)[0])
+        dts = raw[4:20].view(np.float32)
+        xg = raw[20:20 + 24 * n].view(np.float32).reshape(n, 6)
+        pg = raw[20 + 24 * n:20 + 32 * n].view(np.int64)
+        assert dts[0] == pytest.approx(oo.dt_f_acc, rel=1e-5) and dts[3] == pytest.approx(oo.dt_c_acc, rel=1e-5), r     # reduced over ranks
+        if kw.get("pp_ext"):
+            assert dts[1] == pytest.approx(oo.dt_pp_acc, rel=1e-5) and dts[2] == pytest.approx(oo.dt_pp_ext_acc, rel=1e-5), r
+        xg, pg = by_pid(xg, pg)
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
+        assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 1e-4
+        vin = np.stack([v0[q] for q in pg.tolist()])
+        dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
+        num += ((dg - do) ** 2).sum()
+        den += (do ** 2).sum()
+    assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)
