@@ -65,6 +65,14 @@ PAR
         -L"$HERE/../cubep3m_amd" -lp3m_hip -Wl,-rpath,'$ORIGIN/../../../cubep3m_amd' -L$MPI_LIB -Wl,-rpath,$MPI_LIB -lmpifort -lmpi
     echo "built $D/hip_mpi_driver"
   fi
+  # the same host around the single-rank adapter (cubep3m_amd/fortran/particle_mesh_hip.f90)
+  if [ "$nd" -eq 1 ] && [ -f "$HERE/../cubep3m_amd/libp3m_hip.so" ]; then
+    $FC $FFLAGS -c "$HERE/../cubep3m_amd/fortran/particle_mesh_hip.f90" -o "$D/particle_mesh_hip.o" 2> "$D/adapter.log" || { cat "$D/adapter.log"; exit 1; }
+    $FC $FFLAGS -c "$HERE/hip_mpi_driver.f90" -o "$D/hip_mpi_driver.o"
+    $FC -fopenmp -o "$D/hip_mpi_driver" "$D/hip_mpi_driver.o" "$D/particle_mesh_hip.o" "$D/mpi_initialization.o" \
+        -L"$HERE/../cubep3m_amd" -lp3m_hip -Wl,-rpath,'$ORIGIN/../../../cubep3m_amd' -L$MPI_LIB -Wl,-rpath,$MPI_LIB -lmpifort -lmpi
+    echo "built $D/hip_mpi_driver (single-rank adapter)"
+  fi
 }
 
 #          name        nd T nf  cores dens flags

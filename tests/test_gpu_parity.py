@@ -407,3 +407,53 @@ def test_other_tilings_whole_step_parity(PM, T, nf, cores, kw):
     check_step(xv, xg, pg, xo, po, outs, "pp ext" if kw.get("pp_ext") else "")
     v0 = xv[np.argsort(pid), 3:]
     assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
+
+
+def test_fortran_host_calls_particle_mesh_through_the_single_rank_adapter(tmp_path):
+    """The single-rank drop-in cubep3m_amd/fortran/particle_mesh_hip.f90 linked into a Fortran host with the reference's
+    COMMON blocks (oracle/hip_mpi_driver.f90, built by oracle/build_ref.sh against the reference's headers with
+    -DNGP -DPPINT -DPP_EXT -DPID_FLAG): `call particle_mesh` twice, against the oracle."""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "oracle", "_ref", "cfg1_pp")
+    exe = os.path.join(d, "hip_mpi_driver")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("oracle/_ref/cfg1_pp/hip_mpi_driver not built (dev container: bash oracle/build_ref.sh)")
+    os.makedirs(os.path.join(d, "kernels"), exist_ok=True)
+    for name, tab in (("wfxyzf.3.ascii", FINE_TABLE), ("wfxyzc.2.ascii", COARSE_TABLE)):
+        n = tab.shape[0]
+        with open(os.path.join(d, "kernels", name), "w") as f:      # '(3i4,3e16.8)', i fastest (kernel_initialization.f90:15-30)
+            for k in range(n):
+                for j in range(n):
+                    for i in range(n):
+                        f.write("%4d%4d%4d%16.8E%16.8E%16.8E\n" % ((i + 1, j + 1, k + 1) + tuple(float(v) for v in tab[k, j, i])))
+    p = cfg1(ngp=True, ppint=True, pp_ext=True)
+    xv = clustered_particles(30000, 64.0, seed=271, frac=0.3, nblobs=40, sigma=0.7, vel_sigma=0.6)
+    pid = np.arange(1, len(xv) + 1, dtype=np.int64) * 5
+    scal = np.asarray((0.05, 0.2, 0.15, 8.0), np.float32)
+    with open(tmp_path / "in0.bin", "wb") as f:
+        np.asarray([len(xv), 2], np.int32).tofile(f)
+        scal.tofile(f)
+        xv.tofile(f)
+        pid.tofile(f)
+    res = subprocess.run([mpiexec, "-n", "1", exe, str(tmp_path)], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    o.set_particles(0, xv, pid)
+    o.particle_mesh(float(scal[0]), float(scal[1]), float(scal[2]), float(scal[3]))
+    oo = o.particle_mesh(float(scal[0]), float(scal[1]), float(scal[1]), float(scal[3]))
+    raw = np.fromfile(tmp_path / "out0.bin", np.uint8)
+    n = int(raw[:4].view(np.int32)[0])
+    dts = raw[4:20].view(np.float32)
+    xg, pg = by_pid(raw[20:20 + 24 * n].view(np.float32).reshape(n, 6), raw[20 + 24 * n:20 + 32 * n].view(np.int64))
+    xo, po = by_pid(*o.get_particles(0))
+    assert np.array_equal(pg, po) and np.abs(xg[:, :3] - xo[:, :3]).max() <= POS_TOL
+    for got, name in zip(dts, ("dt_f_acc", "dt_pp_acc", "dt_pp_ext_acc", "dt_c_acc")):
+        assert got == pytest.approx(getattr(oo, name), rel=DT_TOL), name
+    v0 = xv[np.argsort(pid), 3:]
+    assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
