@@ -172,7 +172,8 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
 #define PPT_CAP 2048    // staged records per block
 #define PP_LPH 2        // lanes per home record
 __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G,
-                                                      float mass_p, float a_mid, float dt, float *__restrict__ tile_max, int bx_cells, int nbx, int nby) {
+                                                      float mass_p, float a_mid, float dt, float *__restrict__ tile_max, int bx_cells, int nbx, int nby,
+                                                      float r2_soft, float r2_taper) {
   extern __shared__ int lds_i[];
   const int ppr = G.ppr, e = G.pt + 2 * ppr;
   const int HR = (PB_Y + 2 * ppr) * (PB_Z + 2 * ppr);        // halo rows
@@ -238,13 +239,12 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
   }
   __syncthreads();
   const int nhome = hpre[PB_Y * PB_Z];
-  const float tmax = G.ncut + sqrtf(3.0f);
   float mymax = 0.f;
   auto partner = [&](int r, int q) -> float4 { const int k = q - rp0[r]; return k < rcnt[r] ? lp[roff[r] + k] : spos[q]; };
   // PP_LPH lanes share one home record: lane u takes the partner rows u, u+PP_LPH, ... of the (zz,yy) sweep and walks
   // them with a flat cursor (a wavefront pays for its busiest lane, not for the busiest lane of every row); the
   // partial sums are added across the lanes at the end.
-  const float incut = 1.0f / G.ncut;
+  const float incut = 1.0f / G.ncut, ibias = 1.0f / G.pp_bias;
   const int nround = (nhome * PP_LPH + 255) / 256;
   for (int rd = 0; rd < nround; rd++) {
     const int t = rd * 256 + (int)threadIdx.x, hidx = t / PP_LPH, u = t - hidx * PP_LPH;
@@ -289,12 +289,14 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
         const float4 o = partner(r, q);
         q++;
         const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;            // :551
-        const float rmag = sqrtf(sx * sx + sy * sy + sz * sz);
-        if (rmag > G.rsoft) {                                                   // :558
-          // one division per pair: sep/rb^3 as sep * (1/rb^3) and rb/ncut as rb * (1/ncut), one ulp each
-          const float rb1 = rmag * G.pp_bias, irb3 = 1.0f / (rb1 * rb1 * rb1);
+        const float r2 = sx * sx + sy * sy + sz * sz;
+        // rmag = sqrt(r2) > rsoft decided EXACTLY on r2 (r2_soft = the smallest float whose correctly rounded root exceeds
+        // rsoft, found on the host), the magnitudes from the hardware reciprocal square root: no IEEE sqrt or division in
+        // the pair loop (about a third of its instructions); the force differs from sep/(rmag*pp_bias)^3 by a few ulp
+        if (r2 >= r2_soft) {                                                    // :558
+          const float ir = __builtin_amdgcn_rsqf(r2), rb1 = (r2 * ir) * G.pp_bias, ib = ir * ibias, irb3 = ib * ib * ib;
           float fx = mass_p * (sx * irb3), fy = mass_p * (sy * irb3), fz = mass_p * (sz * irb3);
-          if (!(rmag > tmax)) {                                                 // :559-564
+          if (r2 < r2_taper) {                                                  // :559-564, not (rmag > ncut + sqrt(3))
             const float qq = rb1 * incut;
             const float taper = 1.f - (7.0f / 4.0f) * (qq * qq * qq) + (3.0f / 4.0f) * (qq * qq * qq * qq * qq);
             fx *= taper; fy *= taper; fz *= taper;
@@ -325,6 +327,14 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
   }
 }
 
+// the smallest float r2 with sqrtf(r2) > t (sqrtf is correctly rounded and monotone): "rmag > t" becomes "r2 >= this"
+static float first_r2_with_root_above(float t) {
+  float r2 = t * t;
+  while (sqrtf(r2) > t) r2 = nextafterf(r2, 0.0f);
+  while (!(sqrtf(r2) > t)) r2 = nextafterf(r2, INFINITY);
+  return r2;
+}
+
 int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   const Geometry &g = c->g;
   if (g.pp_range == 0) return P3M_OK;
@@ -342,7 +352,7 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pp_ext_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned blocks = (unsigned)((int64_t)g.ntiles * nbx * nby * nby);
     hipLaunchKernelGGL(k_pp_ext_tiled, dim3(blocks), dim3(256), lds, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, mass_p, a_mid,
-                       dt, c->d_tile_ext, bx_cells, nbx, nby);
+                       dt, c->d_tile_ext, bx_cells, nbx, nby, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f)));
     HIP_TRY(hipGetLastError());
     return P3M_OK;
   }
