@@ -717,6 +717,13 @@ static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out) {
   return P3M_OK;
 }
 
+extern "C" int p3m_hip_group_update_position(p3m_group *G, float dt, float dt_old, const float *offset) {
+  if (!G) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));
+  return P3M_OK;
+}
+
 // subroutine particle_mesh on every local rank (particle_mesh_threaded.f90:2-726)
 extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, float dt_old, float mass_p, const float *offset,
                                            const float *move_back, p3m_step_out *out) {

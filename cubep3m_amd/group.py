@@ -182,6 +182,10 @@ class ParticleMeshGroup:
                                                       None if pm is None else pm.ctypes.data_as(C.c_void_p), C.byref(o)))
         return o
 
+    def update_position(self, dt, dt_old, offset=None):
+        po = None if offset is None else np.ascontiguousarray(offset, np.float32)
+        _lib.check(self.L.p3m_hip_group_update_position(self.h, dt, dt_old, None if po is None else po.ctypes.data_as(C.c_void_p)))
+
     def rank_context(self, i):
         """The i-th local rank's context as a ParticleMesh (probes, kernel timers)."""
         from .particle_mesh import ParticleMesh

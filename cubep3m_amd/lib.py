@@ -29,7 +29,7 @@ EXPORTS = [
     "p3m_hip_group_create", "p3m_hip_group_destroy", "p3m_hip_group_comm_init_rccl", "p3m_hip_group_set_transport", "p3m_hip_expansion", "p3m_hip_timestep", "p3m_hip_write_checkpoint", "p3m_hip_read_checkpoint", "p3m_hip_write_pid_checkpoint",
     "p3m_hip_read_pid_checkpoint", "p3m_hip_write_ic", "p3m_hip_read_ic", "p3m_hip_group_nlocal", "p3m_hip_group_local_rank",
     "p3m_hip_group_ctx", "p3m_hip_group_set_kernel_tables", "p3m_hip_group_upload_particles", "p3m_hip_group_download_particles",
-    "p3m_hip_group_particle_mesh", "p3m_hip_group_probe_coarse",
+    "p3m_hip_group_particle_mesh", "p3m_hip_group_update_position", "p3m_hip_group_probe_coarse",
 ]
 
 
@@ -100,6 +100,7 @@ def load():
     L.p3m_hip_group_upload_particles.argtypes = [vp, i32, vp, vp, i32]
     L.p3m_hip_group_download_particles.argtypes = [vp, i32, vp, vp, C.POINTER(i32)]
     L.p3m_hip_group_particle_mesh.argtypes = [vp, f32, f32, f32, f32, vp, vp, C.POINTER(P3MStepOut)]
+    L.p3m_hip_group_update_position.argtypes = [vp, f32, f32, vp]
     L.p3m_hip_group_probe_coarse.argtypes = [vp, f32, i32, vp, vp]
     L.p3m_hip_stream.argtypes = [vp]
     L.p3m_hip_stream.restype = vp

@@ -263,6 +263,8 @@ int p3m_hip_group_set_kernel_tables(p3m_group *g, const float *fine_table, const
 int p3m_hip_group_upload_particles(p3m_group *g, int32_t i, const float *xv6, const int64_t *pid, int32_t np_local);
 int p3m_hip_group_download_particles(p3m_group *g, int32_t i, float *xv6, int64_t *pid, int32_t *np_local);
 /* `particle_mesh` on all ranks; `out` holds the global dt limits and DIAG sums (identical on every process) */
+/* update_position.f90 on every local rank (the output-step half drift of cubepm.f90:196-198 uses it with dt_old = 0) */
+int p3m_hip_group_update_position(p3m_group *g, float dt, float dt_old, const float *offset);
 int p3m_hip_group_particle_mesh(p3m_group *g, float a_mid, float dt, float dt_old, float mass_p,
                                 const float *offset, const float *move_back, p3m_step_out *out);
 int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho_c, float *force_c);

@@ -308,3 +308,36 @@ def test_fortran_mpi_host_calls_particle_mesh_through_the_adapter(tmp_path, cfg,
         num += ((dg - do) ** 2).sum()
         den += (do ** 2).sum()
     assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)
+
+
+def test_standalone_run_reads_ic_and_writes_reference_checkpoints(tmp_path):
+    """python -m cubep3m_amd.run: IC files in, the time loop, checkpoint files in the reference's format out; the
+    checkpoint is read back and holds every particle once, inside the box, with the scale factor of the list."""
+    from cubep3m_amd import io_formats as iof
+    from cubep3m_amd import run as runmod
+    from cubep3m_amd.group import split_global
+
+    p = cfg1(nodes_dim=2, ngp=True)
+    xv, pid = global_ic("uniform", 40000, float(p.nf_physical_dim), 17)
+    xv[:, 3:] = np.random.default_rng(2).normal(0, 0.05, (len(xv), 3)).astype(np.float32)
+    parts = split_global(p, xv, pid, range(8))
+    ic, out = tmp_path / "ic", tmp_path / "out"
+    ic.mkdir()
+    for r in range(8):
+        iof.write_ic(ic / ("xv%d.ic" % r), parts[r][0])
+    rc = runmod.main(["--ic-dir", str(ic), "--out-dir", str(out), "--nodes-dim", "2", "--tiles", "2", "--nf-tile", "80", "--z-i", "49",
+                      "--checkpoints", "48.0,47.5", "--max-nts", "60"])
+    assert rc == 0
+    total = 0
+    for z in (48.0, 47.5):
+        n_z = 0
+        for r in range(8):
+            nx, npid = iof.checkpoint_names(z, r)
+            h, x = iof.read_checkpoint(out / nx)
+            hp, q = iof.read_pid_checkpoint(out / npid)
+            assert h.np_local == len(x) == len(q) and h.a == pytest.approx(1.0 / (1.0 + z), rel=1e-5)
+            assert np.all((x[:, :3] >= 0) & (x[:, :3] < p.nf_physical_node_dim))
+            n_z += len(x)
+        assert n_z == len(xv)
+        total += n_z
+    assert total == 2 * len(xv)
