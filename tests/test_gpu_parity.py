@@ -457,3 +457,27 @@ def test_fortran_host_calls_particle_mesh_through_the_single_rank_adapter(tmp_pa
         assert got == pytest.approx(getattr(oo, name), rel=DT_TOL), name
     v0 = xv[np.argsort(pid), 3:]
     assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
+
+
+def test_bench_sized_tile_properties(PM):
+    """BASELINE's full tile size (one rank's share of the 1024^3 / 512^3 workload: nf_tile = 560, 256^3 particles)
+    through size-independent properties: every particle back exactly once, mass on both meshes, momentum, and a second
+    step from the sorted state giving the same limits as a fresh context fed the same particles in their original order."""
+    p = Params(tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3)
+    n = 256 ** 3
+    xv = uniform_particles(n, 512.0, seed=99)
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    g.upload_particles(xv)
+    out = g.particle_mesh(0.5, 0.0, 0.0, 8.0)                # dt = 0: no kick, no drift: the state only gets sorted
+    assert out.np_total == n and out.np_deleted == 0
+    assert out.sum_rho_f == pytest.approx(8.0 * n, rel=1e-9) and out.sum_rho_c == pytest.approx(8.0 * n, rel=1e-6)
+    out2 = g.particle_mesh(0.5, 0.05, 0.0, 8.0)              # a real kick from the (now cell-sorted) arrival order
+    xo, pid = g.download_particles()
+    assert len(pid) == n and np.array_equal(np.sort(pid), np.arange(1, n + 1))
+    o = np.argsort(pid)
+    assert np.array_equal(xo[o, :3], xv[:, :3])              # dt_old = 0: positions untouched, bit for bit
+    dv = xo[:, 3:].astype(np.float64)
+    assert np.abs(dv.mean(0)).max() < 2e-3 * rms(dv)
+    # order independence: the limits depend on the particle SET only
+    assert out2.dt_f_acc == pytest.approx(out.dt_f_acc, rel=1e-6) and out2.dt_c_acc == pytest.approx(out.dt_c_acc, rel=1e-6)
+    assert out2.np_ghost == out.np_ghost
