@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the host side (gloo: debugging on fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -117,31 +119,59 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    local_dev = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
+    ddev = "cuda" if args.dist_backend == "nccl" else "cpu"      # where the host side's small collectives live
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from cubep3m_amd.group import ParticleMeshGroup, rccl_unique_id
 
     cfg = CONFIGS[args.config]
     p = Params(**cfg["params"])
-    p.device = local_rank
+    p.device = local_dev
     if p.nodes % world:
         raise SystemExit("%d logical ranks cannot be split over %d GPUs" % (p.nodes, world))
     uid = None
     if world > 1:   # rank 0 creates the RCCL id, torch.distributed (RCCL) broadcasts it
-        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(128, dtype=torch.uint8, device=ddev)
         if rank == 0:
             t.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
         dist.broadcast(t, 0)
         uid = bytes(t.cpu().numpy().tobytes())
 
     fine, coarse = default_tables()
-    grp = ParticleMeshGroup(p, rank, world, fine, coarse, unique_id=uid)
+    transport = "rccl" if world > 1 else "none"
+    if world > 1:
+        # RCCL inside the library; if its communicator cannot be set up on this node (agreed on by all ranks), the same
+        # exchanges go through the host-callback transport over a gloo group instead of failing the run
+        from cubep3m_amd.group import torch_transport
+        from cubep3m_amd.lib import P3MError
+
+        ok, grp = 1, None
+        try:
+            grp = ParticleMeshGroup(p, rank, world, unique_id=uid, set_kernels=False)
+        except P3MError as e:
+            ok = 0
+            print("rank %d: RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], device=ddev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if grp is not None:
+                grp.close()
+            gloo = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else None
+            grp = ParticleMeshGroup(p, rank, world, set_kernels=False, transport=torch_transport(dist, gloo))
+            transport = "host callbacks over gloo (RCCL unavailable)"
+        grp.set_kernel_tables(fine, coarse)
+    else:
+        grp = ParticleMeshGroup(p, rank, world, fine, coarse)
     box = float(p.nf_physical_node_dim)
     nside = cfg["nside_rank"]
     mass_p = float((p.nf_physical_node_dim / nside) ** 3)  # fine cells per particle = 8
@@ -170,7 +200,7 @@ def main():
     sync()
     el = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el], dtype=torch.float64, device=ddev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     assert out.np_total == n_total, (out.np_total, n_total)
@@ -212,7 +242,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config, "particles": n_total, "logical_ranks": p.nodes,
-                       "ranks_per_gpu": p.nodes // world, "tiles_per_rank": ntile, "nf_tile": p.nf_tile,
+                       "ranks_per_gpu": p.nodes // world, "tiles_per_rank": ntile, "nf_tile": p.nf_tile, "transport": transport,
                        "flags": {"ngp": p.ngp, "ppint": p.ppint, "pp_ext": p.pp_ext}},
             "roofline": roofline,
         }

@@ -129,10 +129,14 @@ class ParticleMeshGroup:
         self.nlocal = self.L.p3m_hip_group_nlocal(self.h)
         self.local_ranks = [self.L.p3m_hip_group_local_rank(self.h, i) for i in range(self.nlocal)]
         if set_kernels:
-            if fine_table is None or coarse_table is None:
-                fine_table, coarse_table = default_tables()
-            _lib.check(self.L.p3m_hip_group_set_kernel_tables(self.h, np.ascontiguousarray(fine_table, np.float32),
-                                                              np.ascontiguousarray(coarse_table, np.float32)))
+            self.set_kernel_tables(fine_table, coarse_table)
+
+    def set_kernel_tables(self, fine_table=None, coarse_table=None):
+        """fine_kernel / coarse_kernel from the two ascii tables (collective over the processes of the group)."""
+        if fine_table is None or coarse_table is None:
+            fine_table, coarse_table = default_tables()
+        _lib.check(self.L.p3m_hip_group_set_kernel_tables(self.h, np.ascontiguousarray(fine_table, np.float32),
+                                                          np.ascontiguousarray(coarse_table, np.float32)))
 
     def close(self):
         if getattr(self, "h", None):
