@@ -341,3 +341,29 @@ def test_standalone_run_reads_ic_and_writes_reference_checkpoints(tmp_path):
         assert n_z == len(xv)
         total += n_z
     assert total == 2 * len(xv)
+
+
+def test_bench_multi_process_launch_on_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two processes
+    on this one GPU: the host side on gloo, RCCL's refusal of two ranks per device answered by the collective fall-back
+    to the host transport.  Checks the launch contract (env, id broadcast, max-over-ranks timing, ONE JSON line)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--config", "cfg4_small", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["ranks_per_gpu"] == 4 and "roofline" in d and "cpu_baseline" not in d      # cpu_baseline: rank 0 at N = 1 only
