@@ -396,6 +396,9 @@ def test_disp_mesh_offsets_and_move_grid_back(PM, move_back):
     (4, 64, 3, dict(ngp=True, ppint=True, pp_ext=True)),      # 64 tiles on 3 "threads": the per-thread last-tile rule with a remainder
     (3, 64, 2, dict(ngp=False)),                              # CIC deposit and interpolation across many tile seams
     (1, 112, 2, dict(ngp=True, ppint=True, pp_ext=True)),     # one tile per rank
+    (2, 80, 2, dict(ngp=True, ppint=True, pp_ext=True, pp_range=1)),   # other extended-PP ranges (kernel corner, halo widths)
+    (2, 80, 2, dict(ngp=True, ppint=True, pp_ext=True, pp_range=3)),
+    (2, 80, 2, dict(ngp=True, ppint=True, pp_ext=True, pp_range=4)),
 ])
 def test_other_tilings_whole_step_parity(PM, T, nf, cores, kw):
     p = cfg1(tiles_node_dim=T, nf_tile=nf, cores=cores, **kw)
