@@ -234,6 +234,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_fft_lines (%s pass, %d tile(s)/launch, nf_tile=%d)" % (dom, nb, p.nf_tile), "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "ms_per_launch": passes[dom], "pass_ms": passes,
+                    # the same launch against the bytes it really moved (PMC): what the memory system sees
+                    "traffic_GBs": (traffic / (passes[dom] * 1e-3) / 1e9) if traffic else None,
+                    "traffic_frac": (traffic / (passes[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     "fine_sweep": {"ms": sweep_ms, "algorithmic_bytes": 10.5 * S * ntile,
                                    "achieved_GBs": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9,
                                    "frac": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
