@@ -127,11 +127,18 @@ __global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos,
   __shared__ int key[SORT_HB], val[SORT_HB];
   for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
   __syncthreads();
+  float4 pl[SORT_RPT];
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {   // all loads first: eight independent requests in flight per lane
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    pl[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) pl[u] = pos[i];
+  }
 #pragma unroll
   for (int u = 0; u < SORT_RPT; u++) {
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
     if (i >= n) continue;
-    const float4 p = pos[i];
+    const float4 p = pl[u];
     if (in_hoc_range(p, -nb, Nn + nb)) {
       const int cy = (int)floorf(p.y) + (int)nb, cz = (int)floorf(p.z) + (int)nb;
       const int row = cz * E + cy;
@@ -164,11 +171,16 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
   __syncthreads();
   float4 p[SORT_RPT]; int ent[SORT_RPT], rank[SORT_RPT];   // ent: table entry | -1 dropped | -2 rank is already the global slot
 #pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {   // all loads first
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) p[u] = pos[i];
+  }
+#pragma unroll
   for (int u = 0; u < SORT_RPT; u++) {
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
-    ent[u] = -1; rank[u] = 0; p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ent[u] = -1; rank[u] = 0;
     if (i >= n) continue;
-    p[u] = pos[i];
     if (!in_hoc_range(p[u], -nb, Nn + nb)) continue;
     const int cy = (int)floorf(p[u].y) + (int)nb, cz = (int)floorf(p[u].z) + (int)nb;
     const int row = cz * E + cy;
@@ -372,10 +384,15 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
     return 2 * m + (phys ? 1 : 0);
   };
 #pragma unroll
+  for (int r = 0; r < GP_RPT; r++) {   // all loads first: eight independent requests in flight per lane
+    const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
+    p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) p[r] = pos[i];
+  }
+#pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
     const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
-    p[r] = make_float4(0.f, 0.f, 0.f, 0.f); sh[r] = 0;
-    if (i < n) p[r] = pos[i];
+    sh[r] = 0;
     if (i >= n || !in_hoc_range(p[r], -nb, Nn + nb)) continue;   // dropped by link_list ("PARTICLE DELETED")
     float ix, iy, iz;
     const int sx = axis_shift(p[r].x, Nn, nb, &ix), sy = axis_shift(p[r].y, Nn, nb, &iy), sz = axis_shift(p[r].z, Nn, nb, &iz);
