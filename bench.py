@@ -231,7 +231,8 @@ def main():
                 traffic = json.load(open(tf)).get(args.config, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_fft_lines (%s pass, %d tile(s)/launch, nf_tile=%d)" % (dom, nb, p.nf_tile), "achieved": achieved,
+        kname = "k_fft_lines3" if dom == "z_inv_fused" else "k_fft_lines"
+        roofline = {"bound": "hbm", "kernel": "%s (%s pass, %d tile(s)/launch, nf_tile=%d)" % (kname, dom, nb, p.nf_tile), "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "ms_per_launch": passes[dom], "pass_ms": passes,
                     # the same launch against the bytes it really moved (PMC): what the memory system sees

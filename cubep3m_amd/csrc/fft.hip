@@ -221,7 +221,7 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
 // (LY for a y pass, LZ for a z pass).  The result goes either to the same bundle (TR = false:
 // z forward, y inverse) or, element idx of bundle (o,chunk), to element o of bundle (idx,chunk) of
 // the other bundle layout (TR = true: y forward LY->LZ, z inverse LZ->LY).
-// NC = 0: plain.  NC = 1|3: fused k-space multiply (particle_mesh_threaded.f90:183-192); the kernels
+// NC = 0: plain.  NC = 1: fused k-space multiply (particle_mesh_threaded.f90:183-192; all three components: k_fft_lines3); the kernels
 // K_c are stored in LZ like rho-hat; component c goes to dst + c*dst_comp_stride.
 // Pruning: bundles o in [olo, olo+ocount) only; line elements [slo, slo+scount) are stored.
 // Distributed (slab) transforms use src_planes / dst_planes / dst_line != n: a rank then holds only
@@ -234,10 +234,7 @@ struct LinesArgs {
 };
 // Each workgroup walks a grid-stride list of work items and is software-pipelined: the next
 // item's global loads are issued into registers (LUX 16-byte loads per lane) before the butterflies
-// of the current one run, so HBM latency hides under the LDS stages.  With NC = 3 a work item is
-// (bundle, component); the three components of one bundle are 8 item numbers apart, i.e. on the
-// same XCD under round-robin placement, so rho-hat comes from HBM once and from that XCD's L2
-// twice (a speed hint only, never correctness).
+// of the current one run, so HBM latency hides under the LDS stages.  (Three components: k_fft_lines3.)
 template <bool INV, bool TR, int NC, int RSET, int TB, int LUX>
 __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, const float2 *__restrict__ tw_g) {
   extern __shared__ float2 lds[];
@@ -246,11 +243,10 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
   float2 *A = lds, *B = A + n * BXC, *tw = B + n * BXC;
   for (int i = threadIdx.x; i < n; i += T) tw[i] = tw_g[i];
   const int ne = n * (BXC / 2);
-  const int nwork = (NC == 3) ? ((a.nbundles + 7) / 8) * 24 : a.nbundles;
+  static_assert(NC == 0 || NC == 1, "three components: k_fft_lines3");
+  const int nwork = a.nbundles;
   float4 v[LUX]; float2 K[LUX];
-  auto decode = [&](int w, int &comp, int &bid) {
-    if (NC == 3) { const int g = w / 24, s = w - g * 24; comp = s >> 3; bid = g * 8 + (s & 7); } else { comp = 0; bid = w; }
-  };
+  auto decode = [&](int w, int &comp, int &bid) { comp = 0; bid = w; };
   auto locate = [&](int bid, int &o, int &chunk, int64_t &b) {
     chunk = bid % a.nchunk; const int rest = bid / a.nchunk; o = a.olo + rest % a.ocount; b = rest / a.ocount;
   };
@@ -308,6 +304,64 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
       }
     }
     __syncthreads();
+  }
+}
+
+// The inverse z pass with the fused multiply, bundle-major: a work item is ONE bundle of rho-hat, loaded once and held
+// in registers while the three force components i*K_c*rho-hat are formed, transformed and stored one after the other;
+// K_{c+1} (and, behind the last component, the next bundle's rho-hat and K_0) is in flight during the butterflies of c.
+template <int RSET, int TB, int LUX>
+__global__ __launch_bounds__(TB) void k_fft_lines3(LinesArgs a, Factors fac, const float2 *__restrict__ tw_g) {
+  extern __shared__ float2 lds[];
+  const int n = a.n;
+  constexpr int T = TB;
+  float2 *A = lds, *B = A + n * BXC, *tw = B + n * BXC;
+  for (int i = threadIdx.x; i < n; i += T) tw[i] = tw_g[i];
+  const int ne = n * (BXC / 2), nwork = a.nbundles;
+  float4 v[LUX]; float2 K[LUX];
+  auto locate = [&](int bid, int &o, int &chunk, int64_t &b) {
+    chunk = bid % a.nchunk; const int rest = bid / a.nchunk; o = a.olo + rest % a.ocount; b = rest / a.ocount;
+  };
+  auto fetch_rho = [&](int bid) {
+    int o, chunk; int64_t b; locate(bid, o, chunk, b);
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.src + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk));
+#pragma unroll
+    for (int u = 0; u < LUX; u++) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if ((int)threadIdx.x + u * T < ne) v[u] = src4[(int)threadIdx.x + u * T]; }
+  };
+  auto fetch_k = [&](int bid, int comp) {
+    int o, chunk; int64_t b; locate(bid, o, chunk, b);
+    const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk));
+#pragma unroll
+    for (int u = 0; u < LUX; u++) { K[u] = make_float2(0.f, 0.f); if ((int)threadIdx.x + u * T < ne) K[u] = k2[(int)threadIdx.x + u * T]; }
+  };
+  int w = blockIdx.x;
+  if (w < nwork) { fetch_rho(w); fetch_k(w, 0); }
+  for (; w < nwork; w += gridDim.x) {
+    int o, chunk; int64_t b; locate(w, o, chunk, b);
+#pragma unroll 1
+    for (int comp = 0; comp < 3; comp++) {
+#pragma unroll
+      for (int u = 0; u < LUX; u++) {
+        const int e = (int)threadIdx.x + u * T;
+        if (e < ne) {
+          const float4 r = v[u];
+          reinterpret_cast<float4 *>(A)[e] = make_float4(-r.y * K[u].x, -(r.x * K[u].x), -r.w * K[u].y, -(r.z * K[u].y));  // (re,im)*i*K, then conj
+        }
+      }
+      __syncthreads();
+      if (comp < 2) fetch_k(w, comp + 1);
+      else { const int wn = w + gridDim.x; if (wn < nwork) { fetch_rho(wn); fetch_k(wn, 0); } }
+      const float2 *Z = fft_lds<false, RSET, BXC>(A, B, n, BXC, BXC, 1, fac, tw, 1);
+      float2 *dbase = a.dst + comp * a.dst_comp_stride;
+      const int e0 = a.slo * (BXC / 2), e1 = (a.slo + a.scount) * (BXC / 2);
+      for (int e = e0 + threadIdx.x; e < e1; e += T) {
+        const int idx = e >> 3, l4 = e & 7;
+        float4 r = reinterpret_cast<const float4 *>(Z)[e];
+        r.y = -r.y; r.w = -r.w;
+        reinterpret_cast<float4 *>(dbase + bundle_off2(b, a.dst_planes, a.dst_line, a.nchunk, idx, chunk) + (int64_t)o * BXC)[l4] = r;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -455,9 +509,8 @@ template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines
   a.n = n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
   const size_t lds = sizeof(float2) * ((size_t)2 * n * BXC + n);
   P3M_TRY((set_lds(k_fft_lines<INV, TR, NC, RSET, TB, LUX>, lds)));
-  // persistent grid: as many workgroups as are resident at once (256 CUs: the three components of one bundle,
-  // 8 item numbers apart, run on the same XCD at the same time)
-  const int nwork = NC == 3 ? ((a.nbundles + 7) / 8) * 24 : a.nbundles;
+  // persistent grid: as many workgroups as are resident at once
+  const int nwork = a.nbundles;
   // never more than fit at once (a straggler wave of workgroups would double the time)
   static int occ_cache = 0, occ_lds = 0;
   if (occ_cache == 0 || occ_lds != (int)lds) {
@@ -473,6 +526,29 @@ template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines
   hipLaunchKernelGGL((k_fft_lines<INV, TR, NC, RSET, TB, LUX>), dim3((unsigned)grid), dim3(TB), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
+}
+template <int RSET, int TB, int LUX> static int lines3_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
+  const int n = pl.n;
+  a.n = n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
+  const size_t lds = sizeof(float2) * ((size_t)2 * n * BXC + n);
+  P3M_TRY((set_lds(k_fft_lines3<RSET, TB, LUX>, lds)));
+  int occ = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines3<RSET, TB, LUX>), TB, lds));
+  int grid = 256 * (occ < 1 ? 1 : occ);
+  if (grid > a.nbundles) grid = a.nbundles;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_fft_lines3<RSET, TB, LUX>), dim3((unsigned)grid), dim3(TB), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+static int launch_lines3(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
+  const int rs = rset_of(pl.nfac_full, pl.fac_full);
+#define L3(TBv, LUXv) (rs == 0 ? lines3_impl<0, TBv, LUXv>(c, pl, a, batch) : rs == 1 ? lines3_impl<1, TBv, LUXv>(c, pl, a, batch) : lines3_impl<2, TBv, LUXv>(c, pl, a, batch))
+  if (pl.n <= 128) return L3(256, 4);
+  if (pl.n <= 192) return L3(256, 6);
+  if (pl.n <= 320) return L3(512, 5);
+  return L3(1024, 5);
+#undef L3
 }
 template <bool INV, bool TR, int NC> static int launch_lines(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
   const int rs = rset_of(pl.nfac_full, pl.fac_full);
@@ -527,7 +603,7 @@ int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, floa
   z.kern = kern3; z.kern_comp_stride = (int64_t)pl.n * pl.n * pl.px;      // one float per complex element, LZ order
   z.dst_comp_stride = (int64_t)batch * pl.n * pl.n * pl.px;
   z.slo = lo; z.scount = fb;                                              // only box planes are stored
-  return launch_lines<true, true, 3>(c, pl, z, batch);
+  return launch_lines3(c, pl, z, batch);
 }
 int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, int fb, int lo) {
   LinesArgs y = full_args(pl, work, work);
@@ -587,7 +663,7 @@ int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3
   LinesArgs a = full_args(pl, send3, lz);
   a.ocount = planes; a.src_planes = planes; a.dst_planes = pl.n; a.dst_line = planes;
   a.kern = kern3; a.kern_comp_stride = kern_comp_stride; a.dst_comp_stride = send_comp_stride;
-  return launch_lines<true, true, 3>(c, pl, a, 1);
+  return launch_lines3(c, pl, a, 1);
 }
 int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, float *ly3, int planes, int batch) {
   LinesArgs a = full_args(pl, ly3, ly3);
