@@ -216,13 +216,15 @@ def main():
             ms, nb = pm.time_fft_pass(i, reps=10)
             passes[name] = ms
         # per sweep over the batch, one launch each: x_fwd, y_fwd, z_fwd, z_inv_fused (3 components), y_inv (3), x_inv_extract (3)
-        dom = max(("y_fwd", "z_fwd", "z_inv_fused", "y_inv"), key=lambda k: passes[k])
+        # on the step's path: x_fwd, y_fwd, z_inv_fused (forward z pass + multiply + inverse z pass of all three components in
+        # one kernel), y_inv, x_inv_extract; the stand-alone z_fwd is only used when the Green's functions are built
+        dom = max(("y_fwd", "z_inv_fused", "y_inv"), key=lambda k: passes[k])
         sweep_ms = pm.time_fine_sweep(mass_p, reps=3)
         ntile = p.tiles_node_dim ** 3
         # the forward 3-D transform of one tile is 2*S algorithmic bytes (one read + one write), one force
         # component is 2.5*S (read rho-hat, read half-size kernel, write).  Three axis passes per transform: a forward pass
         # launch over `nb` tiles carries (2/3)*S*nb, an inverse pass launch (all three components) 3*(2.5/3)*S*nb.
-        alg_bytes = ((2.0 / 3.0) if dom.endswith("fwd") else 2.5) * S * nb
+        alg_bytes = {"y_fwd": 2.0 / 3.0, "y_inv": 2.5, "z_inv_fused": 2.5 + 2.0 / 3.0}[dom] * S * nb   # the fused kernel carries the forward z pass too
         achieved = alg_bytes / (passes[dom] * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")

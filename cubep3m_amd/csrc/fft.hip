@@ -310,7 +310,9 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
 // The inverse z pass with the fused multiply, bundle-major: a work item is ONE bundle of rho-hat, loaded once and held
 // in registers while the three force components i*K_c*rho-hat are formed, transformed and stored one after the other;
 // K_{c+1} (and, behind the last component, the next bundle's rho-hat and K_0) is in flight during the butterflies of c.
-template <int RSET, int TB, int LUX>
+// FWD: the bundle arrives BEFORE its forward z transform (the output of the forward y pass): the forward z pass runs
+// here first, in LDS, and rho-hat goes from LDS straight into the registers -- it is never written to or read from HBM.
+template <int RSET, int TB, int LUX, bool FWD>
 __global__ __launch_bounds__(TB) void k_fft_lines3(LinesArgs a, Factors fac, const float2 *__restrict__ tw_g) {
   extern __shared__ float2 lds[];
   const int n = a.n;
@@ -338,6 +340,15 @@ __global__ __launch_bounds__(TB) void k_fft_lines3(LinesArgs a, Factors fac, con
   if (w < nwork) { fetch_rho(w); fetch_k(w, 0); }
   for (; w < nwork; w += gridDim.x) {
     int o, chunk; int64_t b; locate(w, o, chunk, b);
+    if (FWD) {
+#pragma unroll
+      for (int u = 0; u < LUX; u++) { const int e = (int)threadIdx.x + u * T; if (e < ne) reinterpret_cast<float4 *>(A)[e] = v[u]; }
+      __syncthreads();
+      const float2 *Zf = fft_lds<false, RSET, BXC>(A, B, n, BXC, BXC, 1, fac, tw, 1);
+#pragma unroll
+      for (int u = 0; u < LUX; u++) { const int e = (int)threadIdx.x + u * T; if (e < ne) v[u] = reinterpret_cast<const float4 *>(Zf)[e]; }
+      __syncthreads();
+    }
 #pragma unroll 1
     for (int comp = 0; comp < 3; comp++) {
 #pragma unroll
@@ -527,28 +538,31 @@ template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-template <int RSET, int TB, int LUX> static int lines3_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
+template <int RSET, int TB, int LUX, bool FWD> static int lines3_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
   const int n = pl.n;
   a.n = n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
   const size_t lds = sizeof(float2) * ((size_t)2 * n * BXC + n);
-  P3M_TRY((set_lds(k_fft_lines3<RSET, TB, LUX>, lds)));
+  P3M_TRY((set_lds(k_fft_lines3<RSET, TB, LUX, FWD>, lds)));
   int occ = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines3<RSET, TB, LUX>), TB, lds));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines3<RSET, TB, LUX, FWD>), TB, lds));
   int grid = 256 * (occ < 1 ? 1 : occ);
   if (grid > a.nbundles) grid = a.nbundles;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_fft_lines3<RSET, TB, LUX>), dim3((unsigned)grid), dim3(TB), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
+  hipLaunchKernelGGL((k_fft_lines3<RSET, TB, LUX, FWD>), dim3((unsigned)grid), dim3(TB), lds, c->stream, a, mkfac(pl.nfac_full, pl.fac_full), pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-static int launch_lines3(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
+template <bool FWD> static int launch_lines3_t(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
   const int rs = rset_of(pl.nfac_full, pl.fac_full);
-#define L3(TBv, LUXv) (rs == 0 ? lines3_impl<0, TBv, LUXv>(c, pl, a, batch) : rs == 1 ? lines3_impl<1, TBv, LUXv>(c, pl, a, batch) : lines3_impl<2, TBv, LUXv>(c, pl, a, batch))
+#define L3(TBv, LUXv) (rs == 0 ? lines3_impl<0, TBv, LUXv, FWD>(c, pl, a, batch) : rs == 1 ? lines3_impl<1, TBv, LUXv, FWD>(c, pl, a, batch) : lines3_impl<2, TBv, LUXv, FWD>(c, pl, a, batch))
   if (pl.n <= 128) return L3(256, 4);
   if (pl.n <= 192) return L3(256, 6);
   if (pl.n <= 320) return L3(512, 5);
   return L3(1024, 5);
 #undef L3
+}
+static int launch_lines3(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch, bool fwd = false) {
+  return fwd ? launch_lines3_t<true>(c, pl, a, batch) : launch_lines3_t<false>(c, pl, a, batch);
 }
 template <bool INV, bool TR, int NC> static int launch_lines(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
   const int rs = rset_of(pl.nfac_full, pl.fac_full);
@@ -598,12 +612,18 @@ int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, const float *hat, float *tmp, f
 
 // fine mesh: the three force components of `batch` tiles from rho-hat (LZ), pruned to the force box.
 // work holds 3*batch arrays ([comp][tile]); box points at tile0 of component 0, bcs = component stride.
-int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, int fb, int lo) {
+// data: real ROWS in; out: after the forward x and y passes only (LZ layout, z still in real space) -- input of the
+// fused z pass of fft_inverse3_box_z(..., zfwd = true)
+int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch) {
+  P3M_TRY(fft_x_forward(c, pl, data, scratch, batch));                                        // ROWS -> LY
+  return launch_lines<false, true, 0>(c, pl, full_args(pl, data, scratch), batch);            // LY -> LZ
+}
+int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, int fb, int lo, bool zfwd) {
   LinesArgs z = full_args(pl, work, rho_hat);
   z.kern = kern3; z.kern_comp_stride = (int64_t)pl.n * pl.n * pl.px;      // one float per complex element, LZ order
   z.dst_comp_stride = (int64_t)batch * pl.n * pl.n * pl.px;
   z.slo = lo; z.scount = fb;                                              // only box planes are stored
-  return launch_lines3(c, pl, z, batch);
+  return launch_lines3(c, pl, z, batch, zfwd);
 }
 int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, int fb, int lo) {
   LinesArgs y = full_args(pl, work, work);
@@ -611,8 +631,8 @@ int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, in
   return launch_lines<true, false, 0>(c, pl, y, 3 * batch);
 }
 int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, float *box, int fb, int lo,
-                     int64_t bcs) {
-  P3M_TRY(fft_inverse3_box_z(c, pl, rho_hat, work, kern3, batch, fb, lo));
+                     int64_t bcs, bool zfwd) {
+  P3M_TRY(fft_inverse3_box_z(c, pl, rho_hat, work, kern3, batch, fb, lo, zfwd));
   P3M_TRY(fft_inverse3_box_y(c, pl, work, batch, fb, lo));
   return fft_x_inverse(c, pl, work, nullptr, 3 * batch, 1, box, fb, lo, batch, bcs);
 }
@@ -637,7 +657,7 @@ int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float
     case 0: return fft_x_forward(c, pl, data, work, batch);
     case 1: return launch_lines<false, true, 0>(c, pl, full_args(pl, data, work), batch);
     case 2: return launch_lines<false, false, 0>(c, pl, full_args(pl, data, data), batch);
-    case 3: return fft_inverse3_box_z(c, pl, data, work, kern, batch, fb, lo);
+    case 3: return fft_inverse3_box_z(c, pl, data, work, kern, batch, fb, lo, true);   // as the step runs it: forward z pass fused in (data: rho after x,y)
     case 4: return fft_inverse3_box_y(c, pl, work, batch, fb, lo);
     case 5: return fft_x_inverse(c, pl, work, nullptr, 3 * batch, 1, box, fb, lo, batch, bcs);
   }

@@ -15,7 +15,8 @@
 #include <algorithm>
 
 int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, float *box, int fb, int lo,
-                     int64_t bcs);
+                     int64_t bcs, bool zfwd);
+int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch);
 
 struct TileGeo { int T, nf, nb, pt, E, fb, rp, fbp; };  // rp: real row pitch of a fine array (2*px); fbp: force box row pitch
 
@@ -186,11 +187,12 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
 // ------------------------------------------------------------------ :176-204 forward FFT, 3 x (i K_c multiply, inverse FFT, box extract)
 int fine_force(p3m_ctx *c, int tile0, int ntile) {
   const Geometry &g = c->g;
-  P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, c->work, ntile));
+  // forward x and y passes; the forward z pass is the prologue of the inverse z pass (rho-hat never touches HBM)
+  P3M_TRY(fft3d_forward_xy(c, c->plan_f, c->rho, c->work, ntile));
   const size_t boxsz = (size_t)g.fb * g.fb * g.fbp;
-  // one fused launch per axis for all three components (rho-hat is read once)
+  // one fused launch per axis for all three components
   return fft_inverse3_box(c, c->plan_f, c->rho, c->work, c->kern_f, ntile, c->fbox + (size_t)tile0 * boxsz, g.fb, g.nb - 2,
-                          (int64_t)g.ntiles * boxsz);
+                          (int64_t)g.ntiles * boxsz, true);
 }
 
 // ------------------------------------------------------------------ :208-223 max |F|^2 over every tile's force box
