@@ -16,6 +16,7 @@
 // produce the planes/rows of the force box.  Bound: HBM (no MFMA: nothing here is a dense contraction).
 #include "p3m_internal.h"
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "fft_core.h"
 
@@ -30,6 +31,8 @@
 // inverse : z (LZ * iK -> LY, 3 components) ; y (LY in place) ; x (LY -> force box / ROWS)
 // Pad columns (kx > n/2) are written as zeros by the x pass and stay zero.
 #define BXC 16
+// line lengths n = R1*R2 with a two-register-stage y/z kernel (k_fft_lines2, k_fft_lines3r); anything else runs the LDS Stockham kernels
+#define P3M_LINES2_SIZES(X) X(80, 10, 8) X(112, 14, 8) X(176, 16, 11) X(256, 16, 16) X(560, 28, 20)
 
 __device__ __forceinline__ int64_t bundle_off(int64_t b, int n, int nchunk, int o, int chunk) {
   return (((b * n + o) * nchunk + chunk) * (int64_t)n) * BXC;
@@ -376,6 +379,188 @@ __global__ __launch_bounds__(TB) void k_fft_lines3(LinesArgs a, Factors fac, con
   }
 }
 
+// ------------------------------------------------------------------ y / z passes, two register stages (n = R1*R2)
+// For line lengths that split into two radices <= 32 a line never makes more than ONE trip through LDS: thread (b, col)
+// loads the R1 elements R2*a + b of column col straight from global memory into registers, transforms them (dft<R1>),
+// applies the twiddle W_n^{b*k1} and writes Y_b[k1] to LDS; after the barrier thread (k1, col) reads Y_0..R2-1[k1],
+// transforms (dft<R2>) and stores X[k1 + R1*k2] straight to global memory.  LDS traffic per element: 16 bytes instead of
+// 16 per Stockham stage plus the staging copy; one exchange buffer of n*16 complex, so two workgroups share a CU.
+// LDS element (k1, b, col) sits at ((k1*R2P + b)*16 + col), R2P = R2|1: the four line groups of a wave then fall in
+// different bank halves on the stage-2 read, and the stage-1 write is contiguous.
+template <int R1, int R2> struct L2Cfg {
+  static constexpr int n = R1 * R2, R2P = R2 | 1, S1 = R2 * BXC, S2 = R1 * BXC, TB = ((S1 > S2 ? S1 : S2) + 63) / 64 * 64;
+  static constexpr size_t lds = sizeof(float2) * ((size_t)R1 * R2P * BXC + n);
+};
+template <int R1, int R2, bool INV, bool TR>
+__global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) void k_fft_lines2(LinesArgs a, const float2 *__restrict__ tw_g) {
+  using C = L2Cfg<R1, R2>;
+  constexpr int n = C::n, R2P = C::R2P;
+  extern __shared__ float2 lds[];
+  c32 *X = reinterpret_cast<c32 *>(lds), *tw = X + R1 * R2P * BXC;
+  for (int i = threadIdx.x; i < n; i += C::TB) tw[i] = reinterpret_cast<const c32 *>(tw_g)[i];
+  const int col = threadIdx.x & (BXC - 1), g = threadIdx.x >> 4;
+  const bool s1 = (C::S1 == C::TB) || g < R2, s2 = (C::S2 == C::TB) || g < R1;
+  const int nwork = a.nbundles;
+  auto locate = [&](int bid, int &o, int &chunk, int64_t &b) {
+    chunk = bid % a.nchunk; const int rest = bid / a.nchunk; o = a.olo + rest % a.ocount; b = rest / a.ocount;
+  };
+  c32 v[R1];
+  auto fetch = [&](int w, bool on) {   // defines v on every path: a stale v would stay live through the whole loop body
+#pragma unroll
+    for (int m = 0; m < R1; m++) v[m] = (c32){0.f, 0.f};
+    if (!on) return;
+    int o, chunk; int64_t b; locate(w, o, chunk, b);
+    const c32 *src = reinterpret_cast<const c32 *>(a.src + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk)) + g * BXC + col;
+#pragma unroll
+    for (int m = 0; m < R1; m++) v[m] = src[m * (R2 * BXC)];
+  };
+  int w = blockIdx.x;
+  fetch(w, w < nwork && s1);
+  __syncthreads();
+  for (; w < nwork; w += gridDim.x) {
+    if (s1) {
+      if (INV) {
+#pragma unroll
+        for (int m = 0; m < R1; m++) v[m].y = -v[m].y;
+      }
+      dft<R1>(v);
+      c32 *px = X + g * BXC + col;
+      int gq = g; asm volatile("" : "+v"(gq));   // opaque: keeps the R1 twiddle offsets from being hoisted out of the loop into live registers
+#pragma unroll
+      for (int k1 = 0; k1 < R1; k1++) px[k1 * (R2P * BXC)] = k1 ? vmul(v[k1], tw[__mul24(gq, k1)]) : v[0];
+    }
+    __syncthreads();
+    { const int wn = w + gridDim.x; fetch(wn, wn < nwork && s1); }   // in flight during stage 2
+    if (s2) {
+      c32 u[R2];
+      const c32 *px = X + (g * R2P) * BXC + col;
+#pragma unroll
+      for (int m = 0; m < R2; m++) u[m] = px[m * BXC];
+      dft<R2>(u);
+      int o, chunk; int64_t b; locate(w, o, chunk, b);
+      c32 *d0; int64_t rstride;
+      if (!TR) { d0 = reinterpret_cast<c32 *>(a.dst + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk)) + col; rstride = BXC; }
+      else { d0 = reinterpret_cast<c32 *>(a.dst + bundle_off2(b, a.dst_planes, a.dst_line, a.nchunk, 0, chunk)) + o * BXC + col; rstride = (int64_t)a.nchunk * a.dst_line * BXC; }
+      d0 += g * rstride;
+      int r0 = g - a.slo; asm volatile("" : "+v"(r0));        // likewise the R2 row-range predicates
+      asm volatile("" : "+s"(rstride));                        // and row offsets
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) {
+        c32 r = u[k2];
+        if (INV) r.y = -r.y;
+        if ((unsigned)(r0 + R1 * k2) < (unsigned)a.scount) d0[(int64_t)(R1 * k2) * rstride] = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The fused z pass (forward z, multiply, three inverse z transforms; see k_fft_lines3) on two register stages.  The forward
+// transform runs as n = R1*R2 and leaves rho-hat element k1 + R1*k2 in thread (k1, col); the inverse transforms run as
+// n = R2*R1 (the roles of the radices swapped), whose first stage wants exactly those elements in that thread: rho-hat
+// stays in registers from the forward transform to the last component.  Two exchange buffers alternate, so that the
+// second stage of component c (role A: R2 line groups) and the first stage of component c+1 (role B: R1 line groups)
+// overlap across the waves of the workgroup and a bundle costs four barriers.
+template <int R1, int R2> struct L3Cfg {
+  static constexpr int n = R1 * R2, R2P = R2 | 1, R1P = R1 | 1, SA = R2 * BXC, SB = R1 * BXC, TB = ((SA > SB ? SA : SB) + 63) / 64 * 64;
+  static constexpr int bufe = (R1 * R2P > R2 * R1P ? R1 * R2P : R2 * R1P) * BXC;
+  static constexpr size_t lds = sizeof(float2) * ((size_t)2 * bufe + n);
+};
+template <int R1, int R2>
+__global__ __launch_bounds__((L3Cfg<R1, R2>::TB)) void k_fft_lines3r(LinesArgs a, const float2 *__restrict__ tw_g) {
+  using C = L3Cfg<R1, R2>;
+  constexpr int n = C::n, R2P = C::R2P, R1P = C::R1P;
+  extern __shared__ float2 lds[];
+  c32 *X0 = reinterpret_cast<c32 *>(lds), *X1 = X0 + C::bufe, *tw = X1 + C::bufe;
+  for (int i = threadIdx.x; i < n; i += C::TB) tw[i] = reinterpret_cast<const c32 *>(tw_g)[i];
+  const int col = threadIdx.x & (BXC - 1), g = threadIdx.x >> 4;
+  const bool rA = (C::SA == C::TB) || g < R2, rB = (C::SB == C::TB) || g < R1;
+  const int nwork = a.nbundles;
+  auto locate = [&](int bid, int &o, int &chunk, int64_t &b) {
+    chunk = bid % a.nchunk; const int rest = bid / a.nchunk; o = a.olo + rest % a.ocount; b = rest / a.ocount;
+  };
+  c32 v[R1];      // role A: the line elements R2*m + g on the way in
+  c32 rh[R2];     // role B: rho-hat elements g + R1*m
+  float K[R2];    // role B: K_c at those elements
+  auto fetch_rho = [&](int w, bool on) {
+#pragma unroll
+    for (int m = 0; m < R1; m++) v[m] = (c32){0.f, 0.f};
+    if (!on) return;
+    int o, chunk; int64_t b; locate(w, o, chunk, b);
+    const c32 *src = reinterpret_cast<const c32 *>(a.src + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk)) + g * BXC + col;
+#pragma unroll
+    for (int m = 0; m < R1; m++) v[m] = src[m * (R2 * BXC)];
+  };
+  auto fetch_k = [&](int w, int comp, bool on) {
+#pragma unroll
+    for (int m = 0; m < R2; m++) K[m] = 0.f;
+    if (!on) return;
+    int o, chunk; int64_t b; locate(w, o, chunk, b);
+    const float *k = a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk) + g * BXC + col;
+#pragma unroll
+    for (int m = 0; m < R2; m++) K[m] = k[m * (R1 * BXC)];
+  };
+  int w = blockIdx.x;
+  fetch_rho(w, w < nwork && rA); fetch_k(w, 0, w < nwork && rB);
+  __syncthreads();
+  for (; w < nwork; w += gridDim.x) {
+    int o, chunk; int64_t b; locate(w, o, chunk, b);
+    // forward, stage 1 (role A) -> X0 as (k1, b = g)
+    if (rA) {
+      dft<R1>(v);
+      c32 *px = X0 + g * BXC + col;
+      int gq = g; asm volatile("" : "+v"(gq));   // opaque: keeps the R1 twiddle offsets from being hoisted out of the loop into live registers
+#pragma unroll
+      for (int k1 = 0; k1 < R1; k1++) px[k1 * (R2P * BXC)] = k1 ? vmul(v[k1], tw[__mul24(gq, k1)]) : v[0];
+    }
+    __syncthreads();
+    // forward, stage 2 (role B): rho-hat g + R1*k2 into registers
+    if (rB) {
+      const c32 *px = X0 + (g * R2P) * BXC + col;
+#pragma unroll
+      for (int m = 0; m < R2; m++) rh[m] = px[m * BXC];
+      dft<R2>(rh);
+    }
+    const int64_t rstride = (int64_t)a.nchunk * a.dst_line * BXC;
+    c32 *d0 = reinterpret_cast<c32 *>(a.dst + bundle_off2(b, a.dst_planes, a.dst_line, a.nchunk, 0, chunk)) + o * BXC + col + g * rstride;
+    const int r0 = g - a.slo;
+#pragma unroll 1
+    for (int comp = 0; comp < 3; comp++) {
+      c32 *Xw = (comp & 1) ? X0 : X1;   // comp 0 -> X1, 1 -> X0, 2 -> X1
+      // inverse, stage 1 (role B): elements g + R1*m = R1*m + b', b' = g; n = R2 * R1, first radix R2
+      if (rB) {
+        c32 t[R2];
+#pragma unroll
+        for (int m = 0; m < R2; m++) t[m] = (c32){-rh[m].y * K[m], -(rh[m].x * K[m])};   // conj(i K rho-hat)
+        dft<R2>(t);
+        c32 *px = Xw + g * BXC + col;
+        int gq = g; asm volatile("" : "+v"(gq));
+#pragma unroll
+        for (int k1 = 0; k1 < R2; k1++) px[k1 * (R1P * BXC)] = k1 ? vmul(t[k1], tw[__mul24(gq, k1)]) : t[0];
+      }
+      __syncthreads();
+      if (comp < 2) fetch_k(w, comp + 1, rB);
+      else { const int wn = w + gridDim.x; fetch_k(wn, 0, wn < nwork && rB); }
+      // inverse, stage 2 (role A, k1' = g): elements g + R2*k2'
+      if (rA) {
+        c32 u[R1];
+        const c32 *px = Xw + (g * R1P) * BXC + col;
+#pragma unroll
+        for (int m = 0; m < R1; m++) u[m] = px[m * BXC];
+        dft<R1>(u);
+        c32 *dc = d0 + comp * a.dst_comp_stride;
+        int rq = r0; asm volatile("" : "+v"(rq));   // likewise the R1 row-range predicates
+        int64_t rs = rstride; asm volatile("" : "+s"(rs));   // and the R1 row offsets
+#pragma unroll
+        for (int k2 = 0; k2 < R1; k2++)
+          if ((unsigned)(rq + R2 * k2) < (unsigned)a.scount) dc[(int64_t)(R2 * k2) * rs] = (c32){u[k2].x, -u[k2].y};
+      }
+    }
+    { const int wn = w + gridDim.x; fetch_rho(wn, wn < nwork && rA); }
+    // X0 is rewritten by the next bundle's forward stage 1: the component-1 reads of X0 finished before the last barrier
+  }
+}
+
 // layout converters for the probes / raw kernel upload (not on the hot path)
 __global__ __launch_bounds__(256) void k_rows_to_lz(const float2 *__restrict__ rows, float2 *__restrict__ lz, int n, int px) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -561,11 +746,62 @@ template <bool FWD> static int launch_lines3_t(p3m_ctx *c, const FftPlan &pl, co
   return L3(1024, 5);
 #undef L3
 }
+// P3M_FFT_STOCKHAM=1 in the environment forces the LDS Stockham kernels for every size (A/B measurements)
+static bool lines2_off() { static const bool off = getenv("P3M_FFT_STOCKHAM") && getenv("P3M_FFT_STOCKHAM")[0] == '1'; return off; }
+static bool lines2_has(int n) {
+  if (lines2_off()) return false;
+#define X(N, A, B) if (n == N) return true;
+  P3M_LINES2_SIZES(X)
+#undef X
+  return false;
+}
+template <int R1, int R2> static int lines3r_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
+  using C = L3Cfg<R1, R2>;
+  a.n = pl.n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
+  P3M_TRY((set_lds(k_fft_lines3r<R1, R2>, C::lds)));
+  static int occ = 0;
+  if (occ == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines3r<R1, R2>), C::TB, C::lds));
+    if (occ < 1) occ = 1;
+  }
+  int grid = 256 * occ;
+  if (grid > a.nbundles) grid = a.nbundles;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_fft_lines3r<R1, R2>), dim3((unsigned)grid), dim3(C::TB), C::lds, c->stream, a, pl.d_tw);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
 static int launch_lines3(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch, bool fwd = false) {
+  if (fwd && lines2_has(pl.n)) {
+#define X(N, A, B) if (pl.n == N) return lines3r_impl<A, B>(c, pl, a, batch);
+    P3M_LINES2_SIZES(X)
+#undef X
+  }
   return fwd ? launch_lines3_t<true>(c, pl, a, batch) : launch_lines3_t<false>(c, pl, a, batch);
+}
+template <int R1, int R2, bool INV, bool TR> static int lines2_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
+  using C = L2Cfg<R1, R2>;
+  a.n = pl.n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
+  P3M_TRY((set_lds(k_fft_lines2<R1, R2, INV, TR>, C::lds)));
+  static int occ = 0;
+  if (occ == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines2<R1, R2, INV, TR>), C::TB, C::lds));
+    if (occ < 1) occ = 1;
+  }
+  int grid = 256 * occ;
+  if (grid > a.nbundles) grid = a.nbundles;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_fft_lines2<R1, R2, INV, TR>), dim3((unsigned)grid), dim3(C::TB), C::lds, c->stream, a, pl.d_tw);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
 }
 template <bool INV, bool TR, int NC> static int launch_lines(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
   const int rs = rset_of(pl.nfac_full, pl.fac_full);
+  if constexpr (NC == 0) if (lines2_has(pl.n)) {
+#define X(N, A, B) if (pl.n == N) return lines2_impl<A, B, INV, TR>(c, pl, a, batch);
+    P3M_LINES2_SIZES(X)
+#undef X
+  }
   if (pl.n <= 128) {   // 256 threads hold a bundle in 4 float4 per lane
     if (rs == 0) return lines_impl<INV, TR, NC, 0, 256, 4>(c, pl, a, batch);
     if (rs == 1) return lines_impl<INV, TR, NC, 1, 256, 4>(c, pl, a, batch);

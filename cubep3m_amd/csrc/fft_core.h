@@ -42,6 +42,9 @@ template <int R> struct TrigTab {
 // HIP's float2 struct the compiler pairs up unrelated scalars and pays for it in v_mov shuffles.
 typedef float c32 __attribute__((ext_vector_type(2), may_alias));
 __device__ __forceinline__ c32 vmul(c32 a, c32 b) { return a.yx * (c32){-b.y, b.y} + a * b.xx; }
+// a * (c - i s) with compile-time c, s: four scalar VOP2 operations carrying the constants as literals (the packed form
+// needs them in registers, 4 VGPRs per twiddle, hoisted out of every loop)
+__device__ __forceinline__ c32 vmulk(c32 a, float c, float s) { return (c32){a.x * c + a.y * s, a.y * c - a.x * s}; }
 __device__ __forceinline__ c32 vmi(c32 a) { return (c32){a.y, -a.x}; }   // * -i
 
 // forward DFT (sign -1) of R values held in registers
@@ -122,6 +125,40 @@ template <> __device__ __forceinline__ void dft<11>(c32 (&v)[11]) { dft_odd<11>(
 template <> __device__ __forceinline__ void dft<13>(c32 (&v)[13]) { dft_odd<13>(v); }
 template <> __device__ __forceinline__ void dft<17>(c32 (&v)[17]) { dft_odd<17>(v); }
 template <> __device__ __forceinline__ void dft<19>(c32 (&v)[19]) { dft_odd<19>(v); }
+
+// composite radix R = P*Q in registers: input j = Q*p + q, output k = kp + P*kq (one Cooley-Tukey step, all indices and
+// the inner twiddles W_R^{q*kp} compile-time)
+template <int P, int Q> __device__ __forceinline__ void dft_pq(c32 (&v)[P * Q]) {
+  constexpr int R = P * Q;
+  constexpr TrigTab<R> tab{};
+  c32 y[Q][P];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    c32 t[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) t[p] = v[Q * p + q];
+    dft<P>(t);
+#pragma unroll
+    for (int kp = 0; kp < P; kp++) {
+      const int m = (q * kp) % R;
+      y[q][kp] = (m == 0) ? t[kp] : vmulk(t[kp], tab.c[m], tab.s[m]);
+    }
+  }
+#pragma unroll
+  for (int kp = 0; kp < P; kp++) {
+    c32 u[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) u[q] = y[q][kp];
+    dft<Q>(u);
+#pragma unroll
+    for (int kq = 0; kq < Q; kq++) v[kp + P * kq] = u[kq];
+  }
+}
+template <> __device__ __forceinline__ void dft<10>(c32 (&v)[10]) { dft_pq<2, 5>(v); }
+template <> __device__ __forceinline__ void dft<14>(c32 (&v)[14]) { dft_pq<2, 7>(v); }
+template <> __device__ __forceinline__ void dft<20>(c32 (&v)[20]) { dft_pq<4, 5>(v); }
+template <> __device__ __forceinline__ void dft<28>(c32 (&v)[28]) { dft_pq<4, 7>(v); }
+template <> __device__ __forceinline__ void dft<32>(c32 (&v)[32]) { dft_pq<4, 8>(v); }
 
 // One radix-R Stockham stage on `nl` lines of length n held in LDS.
 // element (idx,line) lives at idx*sI + line*sL.  ROWS: lanes run along the line (x pass);
