@@ -42,6 +42,9 @@ __device__ __forceinline__ int64_t bundle_off2(int64_t b, int planes, int line, 
   return (((b * planes + o) * nchunk + chunk) * (int64_t)line) * BXC;
 }
 
+// P3M_FFT_STOCKHAM=1 in the environment forces the LDS Stockham kernels for every size (A/B measurements)
+static bool lines2_off() { static const bool off = getenv("P3M_FFT_STOCKHAM") && getenv("P3M_FFT_STOCKHAM")[0] == '1'; return off; }
+
 // ------------------------------------------------------------------ x pass, forward (r2c): ROWS -> LY
 // RB consecutive rows per batch (a power of two, compile-time, so that all LDS index arithmetic is shifts
 // and adds); LDS holds element m of row r at m*(RB+1) + r (odd pitch: conflict-free both along rows and
@@ -216,6 +219,129 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
       }
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ x pass, inverse, force box only: two register stages (h = n/2 = R1*R2)
+// Same idea as k_fft_lines2 below, along rows.  The rows of a batch are gathered from LY with 16-byte loads into LDS
+// (element m of row r at r*P + m, P = h+1) -- the only place a per-element global address is formed; everything after
+// that addresses LDS at a per-thread base plus compile-time offsets.  Thread (q, row) reads X[R2*a + q] and
+// X[h - R2*a - q], forms the packed c2r input, transforms (dft<R1>), twiddles (factors held in registers: q is fixed for
+// the life of the workgroup) and writes the exchange buffer once; thread (k1, row) finishes (dft<R2>) and stores the box
+// columns of real elements 2j, 2j+1, j = k1 + R1*k2, as 8-byte pairs at compile-time offsets.  A wave holds RPW whole
+// rows (Q = max(R1,R2) lanes each); exchange element (row, k1, b) sits at (row*R1 + k1)*R2P + b, R2P odd.  The next
+// batch's gather is in flight during both stages.
+template <int R1, int R2> struct X2Cfg {
+  static constexpr int h = R1 * R2, Q = R1 > R2 ? R1 : R2, RPW = 64 / Q, TB = 256, RB = RPW * (TB / 64), R2P = R2 | 1, P = h + 1;
+  static constexpr int NCH = h / BXC + 1, NLD = (RB * NCH * 8 + TB - 1) / TB;   // chunks holding columns 0..h; 16-byte loads per lane
+  static constexpr size_t lds = sizeof(float2) * ((size_t)RB * P + (size_t)RB * R1 * R2P + h);
+};
+template <int R1, int R2>
+__global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ src, int n, int px, int rows_total, const float2 *__restrict__ tw_g,
+                                                    float inv_scale, float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
+  using C = X2Cfg<R1, R2>;
+  constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P, NLD = C::NLD;
+  extern __shared__ float2 lds[];
+  c32 *B = reinterpret_cast<c32 *>(lds), *X = B + RB * P, *tw = X + RB * R1 * R2P;
+  __shared__ int64_t src_row[2][RB], dst_off[2][RB];
+  for (int i = threadIdx.x; i < h; i += C::TB) tw[i] = reinterpret_cast<const c32 *>(tw_g)[i];
+  const int nchunk = px / BXC, fbp = (fb + 3) & ~3;
+  const int lane = threadIdx.x & 63, rw = lane / Q, q = lane - rw * Q;
+  const int r = (threadIdx.x >> 6) * C::RPW + rw;
+  const bool act = rw < C::RPW, s1 = act && q < R2, s2 = act && q < R1;
+  const int nbatch = (rows_total + RB - 1) / RB;
+  const float rscale = 1.0f / inv_scale;
+  const int64_t cstride = (int64_t)n * BXC;
+  c32 twq[R1];   // W_h^{q*k1}
+#pragma unroll
+  for (int k1 = 0; k1 < R1; k1++) twq[k1] = reinterpret_cast<const c32 *>(tw_g)[s1 ? 2 * q * k1 : 0];
+  auto tables = [&](int w, int buf) {
+    const int64_t srow = (int64_t)w * RB + threadIdx.x;
+    if ((int)threadIdx.x < RB && srow < rows_total) {
+      const unsigned s32 = (unsigned)srow, t2 = s32 / (unsigned)fb, bb = t2 / (unsigned)fb;
+      const int jj = (int)(s32 - t2 * fb), kk = (int)(t2 - bb * fb);
+      const int comp = (int)(bb / (unsigned)ntile), tl = (int)(bb - comp * ntile);
+      src_row[buf][threadIdx.x] = ((((int64_t)bb * n + (kk + lo)) * nchunk) * n + (jj + lo)) * BXC;
+      dst_off[buf][threadIdx.x] = comp * box_comp_stride + (((int64_t)tl * fb + kk) * fb + jj) * fbp;
+    }
+  };
+  // gather item e = tid + u*TB: l4 = e & 7, row = (e >> 3) % RB, chunk = (e >> 3) / RB
+  int grc[NLD];   // row | chunk << 8 | l4 << 16, or -1
+#pragma unroll
+  for (int u = 0; u < NLD; u++) {
+    const int e = (int)threadIdx.x + u * C::TB, t = e >> 3, ch = t / RB;
+    grc[u] = ch < C::NCH ? ((t - ch * RB) | (ch << 8) | ((e & 7) << 16)) : -1;
+  }
+  float4 g4[NLD];
+  auto fetch = [&](int w, int buf) {
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - (int64_t)w * RB);
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+      g4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int rr = grc[u] & 255, ch = (grc[u] >> 8) & 255, l4 = grc[u] >> 16;
+      if (grc[u] >= 0 && rr < nrows) g4[u] = reinterpret_cast<const float4 *>(src + src_row[buf][rr] + ch * cstride)[l4];
+    }
+  };
+  int w = blockIdx.x, buf = 0;
+  if (w < nbatch) tables(w, 0);
+  __syncthreads();
+  if (w < nbatch) fetch(w, 0);
+  for (; w < nbatch; w += gridDim.x, buf ^= 1) {
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - (int64_t)w * RB);
+    const bool rowok = r < nrows;
+    const int wn = w + gridDim.x;
+#pragma unroll
+    for (int u = 0; u < NLD; u++)
+      if (grc[u] >= 0) {
+        const int rr = grc[u] & 255, k = ((grc[u] >> 8) & 255) * BXC + 2 * (grc[u] >> 16);
+        c32 *pb = B + rr * P + k;
+        if (k <= h) pb[0] = (c32){g4[u].x, g4[u].y};
+        if (k + 1 <= h) pb[1] = (c32){g4[u].z, g4[u].w};
+      }
+    if (wn < nbatch) tables(wn, buf ^ 1);
+    __syncthreads();
+    if (wn < nbatch) fetch(wn, buf ^ 1);
+    if (s1 && rowok) {
+      const c32 *pk = B + r * P + q, *pm = B + r * P + (h - R2 * (R1 - 1)) - q, *pt = tw + q;
+      c32 v[R1];
+#pragma unroll
+      for (int a = 0; a < R1; a++) {
+        const c32 xk = pk[R2 * a], xm = pm[R2 * (R1 - 1 - a)], t = pt[R2 * a];   // X[m], X[h-m], exp(-2 pi i m / n), m = R2*a + q
+        const c32 e2 = {xk.x + xm.x, xk.y - xm.y}, d = {xk.x - xm.x, xk.y + xm.y};
+        const c32 o = {d.x * t.x + d.y * t.y, d.y * t.x - d.x * t.y};   // d * conj(t)
+        v[a] = (c32){e2.x - o.y, -(e2.y + o.x)};                        // conj(e + i o): the forward machinery then yields conj(IFFT)
+      }
+      dft<R1>(v);
+      c32 *pxw = X + (r * R1) * R2P + q;
+#pragma unroll
+      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twq[k1]) : v[0];
+    }
+    __syncthreads();
+    if (s2 && rowok) {
+      c32 u[R2];
+      const c32 *pxr = X + (r * R1 + q) * R2P;
+#pragma unroll
+      for (int b = 0; b < R2; b++) u[b] = pxr[b];
+      dft<R2>(u);
+      const int x0 = 2 * q - lo;   // box column of real element 2j for k2 = 0; lo is even
+      float *pd = box + dst_off[buf][r] + x0;
+      if (fb == fbp) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++)
+          if ((unsigned)(x0 + 2 * R1 * k2) < (unsigned)fb) *reinterpret_cast<float2 *>(pd + 2 * R1 * k2) = make_float2(u[k2].x * rscale, -u[k2].y * rscale);
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) {
+          const int x = x0 + 2 * R1 * k2;
+          if ((unsigned)x < (unsigned)fbp) {
+            float2 o2 = make_float2(u[k2].x * rscale, -u[k2].y * rscale);
+            if (x >= fb) o2.x = 0.f;
+            if (x + 1 >= fb) o2.y = 0.f;
+            *reinterpret_cast<float2 *>(pd + 2 * R1 * k2) = o2;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -692,8 +818,34 @@ static int x_inv_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *out,
     default: return x_inv_impl<RSET, 64>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
   }
 }
+// half lengths h = R1*R2 with a two-register-stage x kernel (force-box mode)
+#define P3M_X2_SIZES(X) X(40, 8, 5) X(56, 8, 7) X(88, 11, 8) X(280, 20, 14)
+template <int R1, int R2> static int x_inv2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, int batch, float *box, int fb, int lo, int ntile, int64_t bcs) {
+  using C = X2Cfg<R1, R2>;
+  const int n = pl.n;
+  const int64_t rows = (int64_t)batch * fb * fb;
+  if (rows > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)rows); return P3M_EINVAL; }
+  const float scale = (float)n * (float)n * (float)n;
+  P3M_TRY((set_lds(k_fft_x_inv2<R1, R2>, C::lds)));
+  static int occ = 0;
+  if (occ == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_inv2<R1, R2>), C::TB, C::lds));
+    if (occ < 1) occ = 1;
+  }
+  const int64_t nbatch = cdiv(rows, C::RB);
+  const int64_t g = (int64_t)256 * occ;
+  hipLaunchKernelGGL((k_fft_x_inv2<R1, R2>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, reinterpret_cast<const float2 *>(src), n,
+                     pl.px, (int)rows, pl.d_tw, scale, box, fb, lo, ntile, bcs);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
 // src in LY; mode 0 writes real ROWS to out, mode 1 the force box
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
+  if (mode == 1 && (lo & 1) == 0 && !lines2_off()) {
+#define X(H, A, B) if (pl.n == 2 * H) return x_inv2_impl<A, B>(c, pl, src, batch, box, fb, lo, ntile, bcs);
+    P3M_X2_SIZES(X)
+#undef X
+  }
   switch (rset_of(pl.nfac_half, pl.fac_half)) {
     case 0: return x_inv_rb<0>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
     case 1: return x_inv_rb<1>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
@@ -746,8 +898,6 @@ template <bool FWD> static int launch_lines3_t(p3m_ctx *c, const FftPlan &pl, co
   return L3(1024, 5);
 #undef L3
 }
-// P3M_FFT_STOCKHAM=1 in the environment forces the LDS Stockham kernels for every size (A/B measurements)
-static bool lines2_off() { static const bool off = getenv("P3M_FFT_STOCKHAM") && getenv("P3M_FFT_STOCKHAM")[0] == '1'; return off; }
 static bool lines2_has(int n) {
   if (lines2_off()) return false;
 #define X(N, A, B) if (n == N) return true;
