@@ -31,6 +31,8 @@
 // inverse : z (LZ * iK -> LY, 3 components) ; y (LY in place) ; x (LY -> force box / ROWS)
 // Pad columns (kx > n/2) are written as zeros by the x pass and stay zero.
 #define BXC 16
+// half lengths h = n/2 = R1*R2 with two-register-stage x kernels (k_fft_x_fwd2, k_fft_x_inv2)
+#define P3M_X2_SIZES(X) X(40, 8, 5) X(56, 8, 7) X(88, 11, 8) X(280, 20, 14)
 // line lengths n = R1*R2 with a two-register-stage y/z kernel (k_fft_lines2, k_fft_lines3r); anything else runs the LDS Stockham kernels
 #define P3M_LINES2_SIZES(X) X(80, 10, 8) X(112, 14, 8) X(176, 16, 11) X(256, 16, 16) X(560, 28, 20)
 
@@ -222,6 +224,103 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
   }
 }
 
+// row geometry of the two-register-stage x kernels (see k_fft_x_inv2)
+template <int R1, int R2> struct X2Cfg {
+  static constexpr int h = R1 * R2, Q = R1 > R2 ? R1 : R2, RPW = 64 / Q, TB = 256, RB = RPW * (TB / 64), R2P = R2 | 1, P = h + 1;
+  static constexpr int NCH = h / BXC + 1, NLD = (RB * NCH * 8 + TB - 1) / TB;   // chunks holding columns 0..h; 16-byte loads per lane
+  static constexpr size_t lds = sizeof(float2) * ((size_t)RB * P + (size_t)RB * R1 * R2P + h);
+};
+
+// ------------------------------------------------------------------ x pass, forward: two register stages (h = n/2 = R1*R2)
+// Thread (q, row) loads the packed-real elements Z[R2*a + q] of its row straight into registers (8-byte loads at
+// compile-time offsets from one per-row address), transforms (dft<R1>), twiddles and writes the exchange buffer; thread
+// (k1, row) finishes (dft<R2>) and leaves Z^[k1 + R1*k2] in a second LDS array; the split X[k] = E + W^k O, X[h-k] =
+// conj(E - W^k O) then runs with lanes along the 16 columns of a chunk and stores both halves to LY.  Row geometry as
+// in k_fft_x_inv2; the next batch's rows are in flight during stage 2 and the split.
+template <int R1, int R2>
+__global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ src, float2 *__restrict__ dst_, int n, int px, int rows_total,
+                                                    const float2 *__restrict__ tw_g) {
+  using C = X2Cfg<R1, R2>;
+  constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P;
+  extern __shared__ float2 lds[];
+  c32 *Y = reinterpret_cast<c32 *>(lds), *X = Y + RB * P, *tw = X + RB * R1 * R2P;
+  __shared__ int64_t drow[2][RB];
+  for (int i = threadIdx.x; i < h; i += C::TB) tw[i] = reinterpret_cast<const c32 *>(tw_g)[i];
+  c32 *dst = reinterpret_cast<c32 *>(dst_);
+  const int nchunk = px / BXC;
+  const int lane = threadIdx.x & 63, rw = lane / Q, q = lane - rw * Q;
+  const int r = (threadIdx.x >> 6) * C::RPW + rw;
+  const bool act = rw < C::RPW, s1 = act && q < R2, s2 = act && q < R1;
+  const int nbatch = (rows_total + RB - 1) / RB;
+  const int64_t cstride = (int64_t)n * BXC;
+  c32 twq[R1];   // W_h^{q*k1}
+#pragma unroll
+  for (int k1 = 0; k1 < R1; k1++) twq[k1] = reinterpret_cast<const c32 *>(tw_g)[s1 ? 2 * q * k1 : 0];
+  c32 v[R1];
+  auto fetch = [&](int w) {
+    const int64_t row = (int64_t)w * RB + r;
+#pragma unroll
+    for (int a = 0; a < R1; a++) v[a] = (c32){0.f, 0.f};
+    if (s1 && row < rows_total) {
+      const c32 *ps = reinterpret_cast<const c32 *>(src + row * (int64_t)(2 * px)) + q;
+#pragma unroll
+      for (int a = 0; a < R1; a++) v[a] = ps[R2 * a];
+    }
+  };
+  // split item e = tid + u*TB: l = e & 15, row = (e >> 4) % RB, chunk = (e >> 4) / RB, k = 16*chunk + l <= h/2
+  constexpr int NCS = (h / 2) / BXC + 1, NSP = (RB * NCS * BXC + C::TB - 1) / C::TB;
+  int w = blockIdx.x, buf = 0;
+  if (w < nbatch) fetch(w);
+  __syncthreads();
+  for (; w < nbatch; w += gridDim.x, buf ^= 1) {
+    const int64_t row0 = (int64_t)w * RB;
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
+    if ((int)threadIdx.x < nrows) {   // LY offset of (row, chunk 0, column 0)
+      const unsigned row = (unsigned)row0 + threadIdx.x, bz = row / (unsigned)n;   // bz = b*n + z; rows_total is an int
+      drow[buf][threadIdx.x] = (((int64_t)bz * nchunk) * n + (row - bz * n)) * BXC;
+    }
+    if (s1) {
+      dft<R1>(v);
+      c32 *pxw = X + (r * R1) * R2P + q;
+#pragma unroll
+      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twq[k1]) : v[0];
+    }
+    __syncthreads();
+    fetch(w + gridDim.x);
+    if (s2) {
+      c32 u[R2];
+      const c32 *pxr = X + (r * R1 + q) * R2P;
+#pragma unroll
+      for (int b = 0; b < R2; b++) u[b] = pxr[b];
+      dft<R2>(u);
+      c32 *py = Y + r * P + q;
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) py[R1 * k2] = u[k2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NSP; u++) {
+      const int e = (int)threadIdx.x + u * C::TB, l = e & (BXC - 1), t = e >> 4, ch = t / RB, rr = t - ch * RB;
+      const int k = ch * BXC + l;
+      if (ch < NCS && k <= h / 2 && rr < nrows) {
+        const c32 zk = Y[rr * P + k], zm = Y[rr * P + (k == 0 ? 0 : h - k)];
+        const c32 E = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)}, O = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+        const c32 wk = tw[k];
+        const c32 T = {O.x * wk.x - O.y * wk.y, O.x * wk.y + O.y * wk.x};
+        c32 *pd = dst + drow[buf][rr];
+        const int km = h - k;   // k = 0: X[h] = E - T (real); k = h/2: the same element twice
+        pd[ch * cstride + l] = E + T;
+        pd[(km >> 4) * cstride + (km & 15)] = (c32){E.x - T.x, -(E.y - T.y)};
+      }
+    }
+    // pad columns h+1 .. px-1 hold zeros
+    for (int e = threadIdx.x; e < nrows * (px - h - 1); e += C::TB) {
+      const int rr = e / (px - h - 1), k = h + 1 + (e - rr * (px - h - 1));
+      dst[drow[buf][rr] + (k >> 4) * cstride + (k & 15)] = (c32){0.f, 0.f};
+    }
+  }
+}
+
 // ------------------------------------------------------------------ x pass, inverse, force box only: two register stages (h = n/2 = R1*R2)
 // Same idea as k_fft_lines2 below, along rows.  The rows of a batch are gathered from LY with 16-byte loads into LDS
 // (element m of row r at r*P + m, P = h+1) -- the only place a per-element global address is formed; everything after
@@ -231,11 +330,6 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
 // columns of real elements 2j, 2j+1, j = k1 + R1*k2, as 8-byte pairs at compile-time offsets.  A wave holds RPW whole
 // rows (Q = max(R1,R2) lanes each); exchange element (row, k1, b) sits at (row*R1 + k1)*R2P + b, R2P odd.  The next
 // batch's gather is in flight during both stages.
-template <int R1, int R2> struct X2Cfg {
-  static constexpr int h = R1 * R2, Q = R1 > R2 ? R1 : R2, RPW = 64 / Q, TB = 256, RB = RPW * (TB / 64), R2P = R2 | 1, P = h + 1;
-  static constexpr int NCH = h / BXC + 1, NLD = (RB * NCH * 8 + TB - 1) / TB;   // chunks holding columns 0..h; 16-byte loads per lane
-  static constexpr size_t lds = sizeof(float2) * ((size_t)RB * P + (size_t)RB * R1 * R2P + h);
-};
 template <int R1, int R2>
 __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ src, int n, int px, int rows_total, const float2 *__restrict__ tw_g,
                                                     float inv_scale, float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
@@ -784,7 +878,27 @@ template <int RSET> static int x_fwd_rb(p3m_ctx *c, const FftPlan &pl, const flo
     default: return x_fwd_impl<RSET, 64>(c, pl, src, dst, rows);
   }
 }
+template <int R1, int R2> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+  using C = X2Cfg<R1, R2>;
+  if (rows > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)rows); return P3M_EINVAL; }
+  P3M_TRY((set_lds(k_fft_x_fwd2<R1, R2>, C::lds)));
+  static int occ = 0;
+  if (occ == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_fwd2<R1, R2>), C::TB, C::lds));
+    if (occ < 1) occ = 1;
+  }
+  const int64_t nbatch = cdiv(rows, C::RB), g = (int64_t)256 * occ;
+  hipLaunchKernelGGL((k_fft_x_fwd2<R1, R2>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, src, reinterpret_cast<float2 *>(dst), pl.n,
+                     pl.px, (int)rows, pl.d_tw);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
 int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+  if (!lines2_off()) {
+#define X(H, A, B) if (pl.n == 2 * H) return x_fwd2_impl<A, B>(c, pl, src, dst, rows);
+    P3M_X2_SIZES(X)
+#undef X
+  }
   switch (rset_of(pl.nfac_half, pl.fac_half)) {
     case 0: return x_fwd_rb<0>(c, pl, src, dst, rows);
     case 1: return x_fwd_rb<1>(c, pl, src, dst, rows);
@@ -818,8 +932,6 @@ static int x_inv_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *out,
     default: return x_inv_impl<RSET, 64>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
   }
 }
-// half lengths h = R1*R2 with a two-register-stage x kernel (force-box mode)
-#define P3M_X2_SIZES(X) X(40, 8, 5) X(56, 8, 7) X(88, 11, 8) X(280, 20, 14)
 template <int R1, int R2> static int x_inv2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, int batch, float *box, int fb, int lo, int ntile, int64_t bcs) {
   using C = X2Cfg<R1, R2>;
   const int n = pl.n;
