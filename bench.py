@@ -218,22 +218,27 @@ def main():
         # per sweep over the batch, one launch each: x_fwd, y_fwd, z_fwd, z_inv_fused (3 components), y_inv (3), x_inv_extract (3)
         # on the step's path: x_fwd, y_fwd, z_inv_fused (forward z pass + multiply + inverse z pass of all three components in
         # one kernel), y_inv, x_inv_extract; the stand-alone z_fwd is only used when the Green's functions are built
-        dom = max(("y_fwd", "z_inv_fused", "y_inv"), key=lambda k: passes[k])
+        dom = max(("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_extract"), key=lambda k: passes[k])
         sweep_ms = pm.time_fine_sweep(mass_p, reps=3)
         ntile = p.tiles_node_dim ** 3
         # the forward 3-D transform of one tile is 2*S algorithmic bytes (one read + one write), one force
         # component is 2.5*S (read rho-hat, read half-size kernel, write).  Three axis passes per transform: a forward pass
         # launch over `nb` tiles carries (2/3)*S*nb, an inverse pass launch (all three components) 3*(2.5/3)*S*nb.
-        alg_bytes = {"y_fwd": 2.0 / 3.0, "y_inv": 2.5, "z_inv_fused": 2.5 + 2.0 / 3.0}[dom] * S * nb   # the fused kernel carries the forward z pass too
+        alg_bytes = {"x_fwd": 2.0 / 3.0, "y_fwd": 2.0 / 3.0, "y_inv": 2.5, "x_inv_extract": 2.5,
+                     "z_inv_fused": 2.5 + 2.0 / 3.0}[dom] * S * nb   # the fused kernel carries the forward z pass too
         achieved = alg_bytes / (passes[dom] * 1e-3) / 1e9
         traffic = None
+        kname = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(args.config, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tf)).get(args.config, {}).get("passes", {}).get(dom, {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                kname = rec.get("kernel")
             except Exception:
                 traffic = None
-        kname = "k_fft_lines3" if dom == "z_inv_fused" else "k_fft_lines"
+        if not kname:
+            kname = {"x_fwd": "k_fft_x_fwd*", "y_fwd": "k_fft_lines*", "z_inv_fused": "k_fft_lines3*", "y_inv": "k_fft_lines*", "x_inv_extract": "k_fft_x_inv*"}[dom]
         roofline = {"bound": "hbm", "kernel": "%s (%s pass, %d tile(s)/launch, nf_tile=%d)" % (kname, dom, nb, p.nf_tile), "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "ms_per_launch": passes[dom], "pass_ms": passes,

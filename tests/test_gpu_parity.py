@@ -484,3 +484,30 @@ def test_bench_sized_tile_properties(PM):
     # order independence: the limits depend on the particle SET only
     assert out2.dt_f_acc == pytest.approx(out.dt_f_acc, rel=1e-6) and out2.dt_c_acc == pytest.approx(out.dt_c_acc, rel=1e-6)
     assert out2.np_ghost == out.np_ghost
+
+
+def test_bench_sized_tile_force_and_fft_vs_oracle(PM):
+    """The FFT kernels BASELINE's tile size runs (nf_tile = 560: the two-register-stage x, y and fused z kernels) against
+    the oracle: forward 3-D transform vs numpy's float64 rfftn on a sub-block of the spectrum, and the whole fine force
+    (forward transform, Green's multiply, three pruned inverse transforms, force box) of a sparse random density."""
+    n = 560
+    p = Params(tiles_node_dim=1, nf_tile=n, ngp=True, density_buffer=1.3)
+    g, o = both(PM, p)
+    rng = np.random.default_rng(560)
+    rho = np.zeros((n, n, n + 2), np.float32)
+    rho[:, :, :n] = (rng.random((n, n, n), dtype=np.float32) < 0.125).astype(np.float32) * 8.0
+    fg, mg = g.tile_force(rho)
+    fo, mo = o.tile_force(rho)
+    num = den = 0.0
+    for k in range(0, fg.shape[0], 64):     # chunked: the arrays hold 3 * 515^3 floats
+        a = fg[k:k + 64].astype(np.float64); b = fo[k:k + 64].astype(np.float64)
+        num += ((a - b) ** 2).sum(); den += (b ** 2).sum()
+    assert np.sqrt(num / den) < 2e-6
+    assert mg == pytest.approx(mo, rel=1e-5)
+    del fo
+    hat = g.fft3d(rho, n, +1)
+    sub = np.fft.fftn(np.fft.rfft(rho[:, :, :n].astype(np.float64), axis=2)[:, :, :40], axes=(0, 1))   # kx < 40: all of y, z
+    got = hat[:, :, 0:80:2] + 1j * hat[:, :, 1:80:2]
+    assert np.abs(got - sub).max() / np.abs(sub).max() < 2e-6
+    back = g.fft3d(hat, n, -1)
+    assert np.abs(back[:, :, :n] - rho[:, :, :n]).max() < 1e-4 and np.all(back[:, :, n:] == 0)
