@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
       if (fb == fbp) {
 #pragma unroll
         for (int k2 = 0; k2 < R2; k2++)
-          if ((unsigned)(x0 + 2 * R1 * k2) < (unsigned)fb) *reinterpret_cast<float2 *>(pd + 2 * R1 * k2) = make_float2(u[k2].x * rscale, -u[k2].y * rscale);
+          if ((unsigned)(x0 + 2 * R1 * k2) < (unsigned)fb) __builtin_nontemporal_store((c32){u[k2].x * rscale, -u[k2].y * rscale}, reinterpret_cast<c32 *>(pd + 2 * R1 * k2));
       } else {
 #pragma unroll
         for (int k2 = 0; k2 < R2; k2++) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) void k_fft_lines2(LinesArgs a,
     int o, chunk; int64_t b; locate(w, o, chunk, b);
     const c32 *src = reinterpret_cast<const c32 *>(a.src + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk)) + g * BXC + col;
 #pragma unroll
-    for (int m = 0; m < R1; m++) v[m] = src[m * (R2 * BXC)];
+    for (int m = 0; m < R1; m++) v[m] = TR ? src[m * (R2 * BXC)] : __builtin_nontemporal_load(src + m * (R2 * BXC));   // in place, read once and written once: past the caches
   };
   int w = blockIdx.x;
   fetch(w, w < nwork && s1);
@@ -668,7 +668,7 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) void k_fft_lines2(LinesArgs a,
       for (int k2 = 0; k2 < R2; k2++) {
         c32 r = u[k2];
         if (INV) r.y = -r.y;
-        if ((unsigned)(r0 + R1 * k2) < (unsigned)a.scount) d0[(int64_t)(R1 * k2) * rstride] = r;
+        if ((unsigned)(r0 + R1 * k2) < (unsigned)a.scount) { if (TR) d0[(int64_t)(R1 * k2) * rstride] = r; else __builtin_nontemporal_store(r, d0 + (int64_t)(R1 * k2) * rstride); }
       }
     }
     __syncthreads();

@@ -260,9 +260,13 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 // the row's maximum goes to the reduction slots, and the physical records of the same cell row -- one contiguous
 // range of the sorted store -- that this tile owns take their force from LDS.  A record whose reference cell
 // floor(xv + offset_tile) is in another row than its sorted cell (rounding at a face) reads global memory.
+// COARSE: the coarse-mesh kick of coarse_velocity.f90:137-179 (k_coarse_kick, same arithmetic, same order of the eight
+// corner terms) follows the fine kick of a record in registers -- PM-only runs, where nothing else touches the
+// velocities between the two kicks, so the sums are the ones two separate passes would form.
+template <bool COARSE>
 __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, TileGeo G,
                                                       int Nn, int ms, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
-                                                      float *__restrict__ fmax_out) {
+                                                      float *__restrict__ fmax_out, const float *__restrict__ fc, int ncn) {
   extern __shared__ float frow[];   // [3][fbp]
   const int fb = G.fb, fbp = G.fbp, lo = G.nb - 2, lane = threadIdx.x;
   const int jj = blockIdx.x % fb, kk = (blockIdx.x / fb) % fb, tile = blockIdx.x / (fb * fb);
@@ -300,6 +304,24 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
     v.x = v.x + fx * a_mid * P3M_G_F * dt;                                                             // :265-266
     v.y = v.y + fy * a_mid * P3M_G_F * dt;
     v.z = v.z + fz * a_mid * P3M_G_F * dt;
+    if (COARSE) {
+      const float inv = 1.0f / (float)ms;
+      const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
+      const int ci = (int)floorf(cx_) + 1, cj = (int)floorf(cy_) + 1, ck = (int)floorf(cz_) + 1;
+      const float dx1 = (float)ci - cx_, dy1 = (float)cj - cy_, dz1 = (float)ck - cz_;
+      const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+      const int m = ncn + 2; const int64_t ccs = (int64_t)m * m * m;
+#pragma unroll
+      for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+        for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+          for (int cx = 0; cx < 2; cx++) {                                                              // :153-168
+            const float dV = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
+            const int64_t o = ((int64_t)(ck + cz) * m + (cj + cy)) * m + (ci + cx);
+            v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
+          }
+    }
     svel[s] = v;
   }
 }
@@ -324,8 +346,14 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
   if (!(c->p.flags & P3M_FLAG_NGP)) { P3M_TRY(fine_force_max(c)); return fine_kick(c, a_mid, dt); }
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
-  hipLaunchKernelGGL(k_fine_kick_rows, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
-                     (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red);
+  if (c->coarse_first)
+    hipLaunchKernelGGL(k_fine_kick_rows<true>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
+                       (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
+                       (const float *)c->force_c, g.ncn);
+  else
+    hipLaunchKernelGGL(k_fine_kick_rows<false>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
+                       (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
+                       (const float *)nullptr, g.ncn);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

@@ -734,10 +734,22 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
   P3M_TRY(ghost_pass(G));                                                                           // :61-63
   for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort(c, mass_p)); }
-  for (p3m_ctx *c : G->ctx) P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));                       // :72-628
-  for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                     // coarse_mass
-  P3M_TRY(coarse_force_dist(G));                                                                    // coarse_force, _buffer, max
-  for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt));                                     // coarse_velocity
+  if (!G->ctx.empty() && coarse_kick_rides_on_fine(G->ctx[0])) {
+    // PM-only NGP: coarse force first (it depends on positions only), its kick rides on the fine kick's pass (k_fine_kick_rows<true>)
+    for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                   // coarse_mass
+    P3M_TRY(coarse_force_dist(G));                                                                  // coarse_force, _buffer, max
+    for (p3m_ctx *c : G->ctx) {
+      c->coarse_first = true;
+      const int r = p3m_hip_fine_mesh(c, a_mid, dt, mass_p);                                        // :72-628 + coarse_velocity
+      c->coarse_first = false;
+      P3M_TRY(r);
+    }
+  } else {
+    for (p3m_ctx *c : G->ctx) P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));                     // :72-628
+    for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                   // coarse_mass
+    P3M_TRY(coarse_force_dist(G));                                                                  // coarse_force, _buffer, max
+    for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt));                                   // coarse_velocity
+  }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));  // :716-720
   p3m_step_out o;
   P3M_TRY(reduce_step_out(G, a_mid, &o));

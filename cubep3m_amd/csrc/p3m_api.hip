@@ -1,6 +1,7 @@
 // p3m_api.hip -- the C ABI of include/p3m_hip.h: context lifecycle, particle upload/download,
 // the `particle_mesh` sequence (particle_mesh_threaded.f90:2-726) and the probes/timers.
 #include "p3m_internal.h"
+#include <stdlib.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -309,6 +310,12 @@ void reductions_fold(p3m_ctx *c) {
   for (int k = 0; k < 4; k++) { double t = 0.0; for (int sl = 0; sl < P3M_NSLOT; sl++) t += c->h_sums_raw[k * P3M_SUM_SPAN + sl * 8]; c->h_sums[k] = t; }
 }
 
+// whole-step calls only: the fine kick can carry the coarse kick when no PP kick sits between them in the reference's order
+bool coarse_kick_rides_on_fine(const p3m_ctx *c) {
+  static const bool off = getenv("P3M_SEPARATE_COARSE_KICK") && getenv("P3M_SEPARATE_COARSE_KICK")[0] == '1';
+  return !off && (c->p.flags & P3M_FLAG_NGP) && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT));
+}
+
 extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (!c) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
@@ -388,8 +395,20 @@ extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt
   P3M_TRY(reductions_clear(c));
   P3M_TRY(particles_pass_self(c));                           // :61-63
   P3M_TRY(particles_sort(c, mass_p));
-  P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));          // :72-628
-  P3M_TRY(p3m_hip_coarse_mesh(c, a_mid, dt, mass_p));        // :712
+  if (coarse_kick_rides_on_fine(c)) {
+    // PM-only NGP: the coarse force does not depend on the fine kick (positions only), so it is formed first and its
+    // kick is applied by the fine kick's pass over the records (fine_mesh.hip, k_fine_kick_rows<true>)
+    P3M_TRY(need_kernels(c));
+    P3M_TRY(coarse_deposit(c, mass_p));
+    P3M_TRY(coarse_force(c));
+    c->coarse_first = true;
+    const int r = p3m_hip_fine_mesh(c, a_mid, dt, mass_p);
+    c->coarse_first = false;
+    P3M_TRY(r);
+  } else {
+    P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));          // :72-628
+    P3M_TRY(p3m_hip_coarse_mesh(c, a_mid, dt, mass_p));        // :712
+  }
   P3M_TRY(p3m_hip_delete_particles(c, move_back));           // :716-720
   p3m_step_out o;
   P3M_TRY(p3m_hip_get_step_out(c, a_mid, &o));               // :643-706

@@ -84,6 +84,7 @@ struct p3m_ctx {
   // ---- fine mesh, all tiles batched
   int tile_batch = 0;          // tiles processed per sweep
   bool pending_compact = false; int pend_n = 0; float pend_mb[3] = {0, 0, 0};   // deferred ghost removal (particles.hip)
+  bool coarse_first = false;   // whole-step PM-only NGP runs: the coarse force is ready before the fine kick, which then adds the coarse kick in the same pass
   bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
   float *work = nullptr;       // [3][batch][nf][nf][2*px]  i*K_c*rho-hat -> force, all three components
@@ -145,6 +146,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p);
 int fine_force(p3m_ctx *c, int tile0, int ntile);
 int fine_kick(p3m_ctx *c, float a_mid, float dt);
 int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt);
+bool coarse_kick_rides_on_fine(const p3m_ctx *c);   // p3m_api.hip
 int fine_force_max(p3m_ctx *c);
 int fine_sum_mass(p3m_ctx *c, int tile0, int ntile);
 int build_fine_kernel(p3m_ctx *c, const float *table16_host);
