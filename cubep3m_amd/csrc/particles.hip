@@ -122,6 +122,21 @@ __device__ __forceinline__ int rowtab_slot(int *key, int row) {
   }
   return -1;   // crowded: the caller goes to global memory directly
 }
+// Records arrive nearly sorted, so the lanes of a wavefront hold a few RUNS of equal rows: only the first lane of a run
+// (head) touches the row table, with the run length; the others take their rank from the head.  hl: lane of this
+// lane's head, cnt: run length (valid in the head).  An unsorted first step degrades to one-lane runs, i.e. to the
+// per-record table updates, plus a ballot.
+__device__ __forceinline__ bool row_run(int row, int &hl, int &cnt) {
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(row, 1, 64);
+  const bool head = lane == 0 || row != prev;
+  const unsigned long long hm = __ballot(head);
+  const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  hl = 63 - __clzll(hm & upto);
+  const unsigned long long above = hm & ~upto;
+  cnt = (above ? __ffsll((long long)above) - 1 : 64) - lane;
+  return head;
+}
 __global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos, int n, int np_orig, float Nn, float nb, int E,
                                                  int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt) {
   __shared__ int key[SORT_HB], val[SORT_HB];
@@ -137,13 +152,16 @@ __global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos,
 #pragma unroll
   for (int u = 0; u < SORT_RPT; u++) {
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
-    if (i >= n) continue;
     const float4 p = pl[u];
-    if (in_hoc_range(p, -nb, Nn + nb)) {
-      const int cy = (int)floorf(p.y) + (int)nb, cz = (int)floorf(p.z) + (int)nb;
-      const int row = cz * E + cy;
+    const bool inr = i < n && in_hoc_range(p, -nb, Nn + nb);
+    const int row = inr ? ((int)floorf(p.z) + (int)nb) * E + (int)floorf(p.y) + (int)nb : -1;
+    int hl, cnt;
+    if (row_run(row, hl, cnt) && row >= 0) {
       const int e = rowtab_slot(key, row);
-      if (e >= 0) atomicAdd(&val[e], 1); else atomicAdd(&rs[row + 1], 1);
+      if (e >= 0) atomicAdd(&val[e], cnt); else atomicAdd(&rs[row + 1], cnt);
+    }
+    if (i >= n) continue;
+    if (inr) {
       if (cflag && p.x >= 0.f && p.x < Nn && p.y >= 0.f && p.y < Nn && p.z >= 0.f && p.z < Nn) {
         const int nct = pt / ms; const float xs[3] = {p.x, p.y, p.z}; bool displaced = false; int cc[3];
 #pragma unroll
@@ -179,13 +197,14 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
 #pragma unroll
   for (int u = 0; u < SORT_RPT; u++) {
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
-    ent[u] = -1; rank[u] = 0;
-    if (i >= n) continue;
-    if (!in_hoc_range(p[u], -nb, Nn + nb)) continue;
-    const int cy = (int)floorf(p[u].y) + (int)nb, cz = (int)floorf(p[u].z) + (int)nb;
-    const int row = cz * E + cy;
-    const int e = rowtab_slot(key, row);
-    if (e >= 0) { ent[u] = e; rank[u] = atomicAdd(&val[e], 1); } else { ent[u] = -2; rank[u] = atomicAdd(&rs[row + 1], 1); }
+    const bool inr = i < n && in_hoc_range(p[u], -nb, Nn + nb);
+    const int row = inr ? ((int)floorf(p[u].z) + (int)nb) * E + (int)floorf(p[u].y) + (int)nb : -1;
+    int hl, cnt, eh = -1, base = 0;
+    if (row_run(row, hl, cnt) && row >= 0) {
+      const int e = rowtab_slot(key, row);
+      if (e >= 0) { eh = e; base = atomicAdd(&val[e], cnt); } else { eh = -2; base = atomicAdd(&rs[row + 1], cnt); }
+    }
+    ent[u] = __shfl(eh, hl, 64); rank[u] = __shfl(base, hl, 64) + ((int)(threadIdx.x & 63) - hl);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < SORT_HB; e += PT) if (val[e] > 0) val[e] = atomicAdd(&rs[key[e] + 1], val[e]);   // count -> base
@@ -208,9 +227,25 @@ __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos
   extern __shared__ int bins[];
   const int row = blockIdx.x, lane = threadIdx.x;
   const int r0 = rs[row], r1 = rs[row + 1];
-  for (int j = lane; j < E; j += 64) bins[j] = 0;
+  // the first 128 records of the row (a row holds ~70 at the reference's density) live in registers from here on: their
+  // positions feed both the histogram and the scatter, and their velocity / PID gathers are issued as soon as the
+  // arrival indices land, so that they complete under the histogram, the scan and the cell_end / density row stores
+  constexpr int RR = 2;
+  float4 rp[RR], rv[RR]; int64_t rid[RR]; bool rin[RR];
+#pragma unroll
+  for (int u = 0; u < RR; u++) { const int i = r0 + u * 64 + lane; rin[u] = i < r1; rp[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (rin[u]) rp[u] = tpos[i]; }
+  {
+    int rsrc[RR];
+#pragma unroll
+    for (int u = 0; u < RR; u++) { rsrc[u] = 0; if (rin[u]) rsrc[u] = tidx[r0 + u * 64 + lane]; }
+    for (int j = lane; j < E; j += 64) bins[j] = 0;
+#pragma unroll
+    for (int u = 0; u < RR; u++) { rv[u] = make_float4(0.f, 0.f, 0.f, 0.f); rid[u] = 0; if (rin[u]) { rv[u] = vel[rsrc[u]]; rid[u] = pid[rsrc[u]]; } }
+  }
   __syncthreads();
-  for (int i = r0 + lane; i < r1; i += 64) atomicAdd(&bins[(int)floorf(tpos[i].x) + (int)nb], 1);
+#pragma unroll
+  for (int u = 0; u < RR; u++) if (rin[u]) atomicAdd(&bins[(int)floorf(rp[u].x) + (int)nb], 1);
+  for (int i = r0 + RR * 64 + lane; i < r1; i += 64) atomicAdd(&bins[(int)floorf(tpos[i].x) + (int)nb], 1);
   __syncthreads();
   const int chunk = (E + 63) / 64, j0 = min(lane * chunk, E), j1 = min(j0 + chunk, E);
   int sum = 0;
@@ -259,16 +294,17 @@ __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos
   // records with a coordinate within 2^-10 below a cell face: only these can be moved into the next
   // cell by the rounding of xv + offset_tile (fine_mesh.hip, count-based NGP deposit fix-up)
   const float thr = 1.0f - 0.0009765625f;
-  for (int i = r0 + lane; i < r1; i += 64) {
-    const float4 p = tpos[i];
+  auto place = [&](const float4 &p, const float4 &v, int64_t id) {
     const int s = atomicAdd(&bins[(int)floorf(p.x) + (int)nb], 1);
-    const int src = tidx[i];
-    spos[s] = p; svel[s] = vel[src]; spid[s] = pid[src];
+    spos[s] = p; svel[s] = v; spid[s] = id;
     if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
       const int k = atomicAdd(ncand, 1);
       if (k < cand_cap) cand[k] = s;
     }
-  }
+  };
+#pragma unroll
+  for (int u = 0; u < RR; u++) if (rin[u]) place(rp[u], rv[u], rid[u]);
+  for (int i = r0 + RR * 64 + lane; i < r1; i += 64) { const int src = tidx[i]; place(tpos[i], vel[src], pid[src]); }
 }
 
 // single rank: all ghost images in one kernel; leaves c->np_all = records incl. ghosts (unsorted)
