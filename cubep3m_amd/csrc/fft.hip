@@ -32,9 +32,11 @@
 // Pad columns (kx > n/2) are written as zeros by the x pass and stay zero.
 #define BXC 16
 // half lengths h = n/2 = R1*R2 with two-register-stage x kernels (k_fft_x_fwd2, k_fft_x_inv2)
-#define P3M_X2_SIZES(X) X(40, 8, 5) X(56, 8, 7) X(88, 11, 8) X(280, 20, 14)
+#define P3M_X2_SIZES(X) X(32, 8, 4) X(40, 8, 5) X(48, 8, 6) X(56, 8, 7) X(64, 8, 8) X(80, 10, 8) X(88, 11, 8) X(96, 12, 8) X(104, 13, 8) X(112, 14, 8) \
+  X(128, 16, 8) X(152, 19, 8) X(160, 16, 10) X(176, 16, 11) X(192, 16, 12) X(224, 16, 14) X(256, 16, 16) X(280, 20, 14) X(304, 19, 16)
 // line lengths n = R1*R2 with a two-register-stage y/z kernel (k_fft_lines2, k_fft_lines3r); anything else runs the LDS Stockham kernels
-#define P3M_LINES2_SIZES(X) X(80, 10, 8) X(112, 14, 8) X(176, 16, 11) X(256, 16, 16) X(560, 28, 20)
+#define P3M_LINES2_SIZES(X) X(64, 8, 8) X(80, 10, 8) X(96, 12, 8) X(112, 14, 8) X(128, 16, 8) X(160, 16, 10) X(176, 16, 11) X(192, 16, 12) X(208, 16, 13) X(224, 16, 14) \
+  X(256, 16, 16) X(304, 19, 16) X(320, 20, 16) X(352, 22, 16) X(384, 24, 16) X(448, 28, 16) X(512, 32, 16) X(560, 28, 20) X(608, 32, 19)
 
 __device__ __forceinline__ int64_t bundle_off(int64_t b, int n, int nchunk, int o, int chunk) {
   return (((b * n + o) * nchunk + chunk) * (int64_t)n) * BXC;
@@ -1035,7 +1037,7 @@ template <int R1, int R2> static int lines3r_impl(p3m_ctx *c, const FftPlan &pl,
 }
 static int launch_lines3(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch, bool fwd = false) {
   if (fwd && lines2_has(pl.n)) {
-#define X(N, A, B) if (pl.n == N) return lines3r_impl<A, B>(c, pl, a, batch);
+#define X(N, A, B) if (pl.n == N) { if constexpr (L3Cfg<A, B>::lds <= 160 * 1024) return lines3r_impl<A, B>(c, pl, a, batch); }   // two exchange buffers must fit the LDS
     P3M_LINES2_SIZES(X)
 #undef X
   }

@@ -154,7 +154,12 @@ template <int P, int Q> __device__ __forceinline__ void dft_pq(c32 (&v)[P * Q]) 
     for (int kq = 0; kq < Q; kq++) v[kp + P * kq] = u[kq];
   }
 }
+template <> __device__ __forceinline__ void dft<6>(c32 (&v)[6]) { dft_pq<2, 3>(v); }
 template <> __device__ __forceinline__ void dft<10>(c32 (&v)[10]) { dft_pq<2, 5>(v); }
+template <> __device__ __forceinline__ void dft<12>(c32 (&v)[12]) { dft_pq<4, 3>(v); }
+template <> __device__ __forceinline__ void dft<22>(c32 (&v)[22]) { dft_pq<2, 11>(v); }
+template <> __device__ __forceinline__ void dft<24>(c32 (&v)[24]) { dft_pq<8, 3>(v); }
+template <> __device__ __forceinline__ void dft<26>(c32 (&v)[26]) { dft_pq<2, 13>(v); }
 template <> __device__ __forceinline__ void dft<14>(c32 (&v)[14]) { dft_pq<2, 7>(v); }
 template <> __device__ __forceinline__ void dft<20>(c32 (&v)[20]) { dft_pq<4, 5>(v); }
 template <> __device__ __forceinline__ void dft<28>(c32 (&v)[28]) { dft_pq<4, 7>(v); }

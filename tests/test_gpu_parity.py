@@ -32,7 +32,7 @@ def both(PM, p):
 
 
 # ---------------------------------------------------------------------------------- FFT
-@pytest.mark.parametrize("n", [8, 16, 20, 28, 40, 44, 52, 68, 76, 80, 112, 176])
+@pytest.mark.parametrize("n", [8, 16, 20, 28, 40, 44, 52, 64, 68, 76, 80, 96, 112, 128, 160, 176, 192, 208, 224, 256, 304, 320, 512])
 def test_fft_forward_and_inverse_vs_oracle(PM, n):
     g = PM(cfg1(), set_kernels=False)
     rng = np.random.default_rng(n)
@@ -511,3 +511,22 @@ def test_bench_sized_tile_force_and_fft_vs_oracle(PM):
     assert np.abs(got - sub).max() / np.abs(sub).max() < 2e-6
     back = g.fft3d(hat, n, -1)
     assert np.abs(back[:, :, :n] - rho[:, :, :n]).max() < 1e-4 and np.all(back[:, :, n:] == 0)
+
+
+@pytest.mark.parametrize("n", [64, 96, 128, 160, 192, 208, 224, 256, 304, 352, 384, 448, 608])   # (512: its coarse mesh, 116 = 4 * 29, has no radix)
+def test_tile_force_at_the_register_fft_sizes(PM, n):
+    """Every tile size with two-register-stage FFT kernels (fft.hip, P3M_LINES2_SIZES / P3M_X2_SIZES) through the whole fine
+    force: forward x and y passes, fused z pass, pruned inverse y and x passes, force box -- against the oracle."""
+    p = Params(tiles_node_dim=1, nf_tile=n, ngp=True, density_buffer=1.3)
+    g, o = both(PM, p)
+    rng = np.random.default_rng(n)
+    rho = np.zeros((n, n, n + 2), np.float32)
+    rho[:, :, :n] = (rng.random((n, n, n), dtype=np.float32) < 0.125).astype(np.float32) * 8.0
+    fg, mg = g.tile_force(rho)
+    fo, mo = o.tile_force(rho)
+    num = den = 0.0
+    for k in range(0, fg.shape[0], 64):
+        a = fg[k:k + 64].astype(np.float64); b = fo[k:k + 64].astype(np.float64)
+        num += ((a - b) ** 2).sum(); den += (b ** 2).sum()
+    assert np.sqrt(num / den) < 2e-6
+    assert mg == pytest.approx(mo, rel=1e-5)
