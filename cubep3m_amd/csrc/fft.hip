@@ -614,7 +614,7 @@ template <int R1, int R2> struct L2Cfg {
   static constexpr size_t lds = sizeof(float2) * ((size_t)R1 * R2P * BXC + n);
 };
 template <int R1, int R2, bool INV, bool TR>
-__global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) void k_fft_lines2(LinesArgs a, const float2 *__restrict__ tw_g) {
+__global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft_lines2(LinesArgs a, const float2 *__restrict__ tw_g) {
   using C = L2Cfg<R1, R2>;
   constexpr int n = C::n, R2P = C::R2P;
   extern __shared__ float2 lds[];
@@ -637,9 +637,9 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) void k_fft_lines2(LinesArgs a,
     for (int m = 0; m < R1; m++) v[m] = TR ? src[m * (R2 * BXC)] : __builtin_nontemporal_load(src + m * (R2 * BXC));   // in place, read once and written once: past the caches
   };
   int w = blockIdx.x;
-  fetch(w, w < nwork && s1);
   __syncthreads();
   for (; w < nwork; w += gridDim.x) {
+    fetch(w, s1);
     if (s1) {
       if (INV) {
 #pragma unroll
@@ -652,7 +652,6 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) void k_fft_lines2(LinesArgs a,
       for (int k1 = 0; k1 < R1; k1++) px[k1 * (R2P * BXC)] = k1 ? vmul(v[k1], tw[__mul24(gq, k1)]) : v[0];
     }
     __syncthreads();
-    { const int wn = w + gridDim.x; fetch(wn, wn < nwork && s1); }   // in flight during stage 2
     if (s2) {
       c32 u[R2];
       const c32 *px = X + (g * R2P) * BXC + col;
