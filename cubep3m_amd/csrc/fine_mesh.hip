@@ -184,6 +184,71 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   return P3M_OK;
 }
 
+// ------------------------------------------------------------------ projection.f90
+// build_projection (:126-188): the CIC density of a tile (fine_cic_mass.f90, whatever the deposit of the force path is)
+// summed along each axis into global nf_physical_dim^2 maps.  One thread owns one map cell and adds the tile's
+// interior cells in the reference's order (k, j or i ascending; tiles in launch order), so that the sums differ from the
+// reference's only through the deposit's own addition order.  Maps: pxy[y][x], pxz[z][x], pyz[z][y] (the reference's
+// column-major (x,y), (x,z), (y,z)).
+__global__ __launch_bounds__(256) void k_project(const float *__restrict__ rho, int nf, int rp, int nb, int pt, int Np, int osx, int osy, int osz,
+                                                 float *__restrict__ pxy, float *__restrict__ pxz, float *__restrict__ pyz, int do_xy, int do_xz, int do_yz) {
+  const int t = blockIdx.x * 256 + threadIdx.x, which = blockIdx.y;
+  if (t >= pt * pt) return;
+  const int a = t % pt, b = t / pt;
+  auto R = [&](int i, int j, int k) { return rho[((int64_t)(nb + k) * nf + (nb + j)) * rp + (nb + i)]; };
+  if (which == 0 && do_xy) {          // (i, j) = (a, b), sum over k (:171-172)
+    float *o = pxy + (int64_t)(osy + b) * Np + (osx + a); float acc = *o;
+    for (int k = 0; k < pt; k++) acc = acc + R(a, b, k);
+    *o = acc;
+  } else if (which == 1 && do_xz) {   // (i, k) = (a, b), sum over j (:175-176)
+    float *o = pxz + (int64_t)(osz + b) * Np + (osx + a); float acc = *o;
+    for (int j = 0; j < pt; j++) acc = acc + R(a, j, b);
+    *o = acc;
+  } else if (which == 2 && do_yz) {   // (j, k) = (a, b), sum over i (:179-180)
+    float *o = pyz + (int64_t)(osz + b) * Np + (osy + a); float acc = *o;
+    for (int i = 0; i < pt; i++) acc = acc + R(i, a, b);
+    *o = acc;
+  }
+}
+__global__ __launch_bounds__(256) void k_project_mass(const float *__restrict__ rho, int nf, int rp, int nb, int pt, double *__restrict__ out) {
+  __shared__ double sh[4];
+  double part = 0.0;
+  const int64_t tot = (int64_t)pt * pt * pt;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tot; t += (int64_t)gridDim.x * 256) {
+    const int i = (int)(t % pt), j = (int)((t / pt) % pt), k = (int)(t / ((int64_t)pt * pt));
+    part += (double)rho[((int64_t)(nb + k) * nf + (nb + j)) * rp + (nb + i)];                      // :183
+  }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out + p3m_slot() * 8, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+// adds this context's tiles to the device maps (Np^2 floats each); the records must be sorted with their ghosts
+int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz) {
+  const Geometry &g = c->g;
+  TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
+  const int Np = g.Nn * g.nodes_dim;
+  const size_t S = (size_t)(2 * g.px) * g.nf * g.nf;
+  c->rho_from_sort = false;
+  for (int t0 = 0; t0 < g.ntiles; t0 += c->tile_batch) {
+    const int nt = std::min(c->tile_batch, g.ntiles - t0);
+    hipLaunchKernelGGL(k_fine_deposit<false>, dim3((unsigned)((int64_t)nt * g.nf * g.nf)), dim3(64), sizeof(float) * (2 * g.px), c->stream,
+                       (const float4 *)c->spos, (const int *)c->cell_end, c->rho, t0, G, mass_p, (double *)nullptr);
+    HIP_TRY(hipGetLastError());
+    for (int t = 0; t < nt; t++) {   // tile order of :24-32 (x fastest)
+      const int tl = t0 + t, tz = tl / (g.T * g.T), ty = (tl / g.T) % g.T, tx = tl % g.T;
+      const float *rho = c->rho + (size_t)t * S;
+      hipLaunchKernelGGL(k_project, dim3(cdiv(g.pt * g.pt, 256), 3), dim3(256), 0, c->stream, rho, g.nf, 2 * g.px, g.nb, g.pt, Np, tx * g.pt + g.cart[2] * g.Nn,
+                         ty * g.pt + g.cart[1] * g.Nn, tz * g.pt + g.cart[0] * g.Nn, d_pxy, d_pxz, d_pyz, g.cart[0] == 0, g.cart[1] == 0, g.cart[2] == 0);
+      HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL(k_project_mass, dim3(std::min(1024, cdiv((int64_t)g.pt * g.pt * g.pt, 256))), dim3(256), 0, c->stream, rho, g.nf, 2 * g.px, g.nb, g.pt,
+                         c->d_sums + 3 * P3M_SUM_SPAN);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  return P3M_OK;
+}
+
 // ------------------------------------------------------------------ :176-204 forward FFT, 3 x (i K_c multiply, inverse FFT, box extract)
 int fine_force(p3m_ctx *c, int tile0, int ntile) {
   const Geometry &g = c->g;

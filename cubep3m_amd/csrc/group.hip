@@ -757,6 +757,42 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   return P3M_OK;
 }
 
+// projection.f90 at a projection step (cubepm.f90:193-228): link_list + particle_pass, projection, delete_particles
+int projection_rank(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz, double *rho_node);   // p3m_api.hip
+extern "C" int p3m_hip_group_projection(p3m_group *G, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_tot) {
+  if (!G || !pxy || !pxz || !pyz) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  const Geometry &g = G->ctx[0]->g;
+  const size_t n2 = (size_t)g.Nn * g.nodes_dim * g.Nn * g.nodes_dim;
+  float *d = nullptr;
+  HIP_TRY(hipMalloc(&d, 3 * n2 * sizeof(float)));
+  auto body = [&]() -> int {
+    HIP_TRY(hipMemsetAsync(d, 0, 3 * n2 * sizeof(float), G->stream));
+    if (G->nodes == 1) P3M_TRY(p3m_hip_link_list_and_pass(G->ctx[0]));
+    else { P3M_TRY(ghost_pass(G)); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort(c, -1.f)); }
+    double tot = 0.0;
+    for (p3m_ctx *c : G->ctx) { double t = 0.0; P3M_TRY(projection_rank(c, mass_p, d, d + n2, d + 2 * n2, &t)); tot += t; }
+    for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize(c, nullptr));
+    if (G->nodes > 1 && G->nprocs > 1) {
+      if (G->have_tr) { if (G->tr.allreduce_sum_f64(G->tr.user, &tot, 1)) return P3M_ECOMM; }
+      else {
+        HIP_TRY(hipMemcpyAsync(G->d_sum3, &tot, sizeof(double), hipMemcpyHostToDevice, G->stream));
+        NCCL_TRY(ncclAllReduce(G->d_sum3, G->d_sum3, 1, ncclDouble, ncclSum, G->comm, G->stream));
+        HIP_TRY(hipMemcpyAsync(&tot, G->d_sum3, sizeof(double), hipMemcpyDeviceToHost, G->stream));
+        HIP_TRY(hipStreamSynchronize(G->stream));
+      }
+    }
+    if (rho_tot) *rho_tot = tot;
+    HIP_TRY(hipMemcpy(pxy, d, n2 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pxz, d + n2, n2 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pyz, d + 2 * n2, n2 * sizeof(float), hipMemcpyDeviceToHost));
+    return P3M_OK;
+  };
+  const int r = body();
+  (void)hipFree(d);
+  return r;
+}
+
 // probes for the parity tests: local coarse density / force of local rank i in the reference layout
 extern "C" int p3m_hip_group_probe_coarse(p3m_group *G, float mass_p, int32_t i, float *rho_c, float *force_c) {
   if (!G || i < 0 || i >= (int)G->ctx.size()) return P3M_EINVAL;

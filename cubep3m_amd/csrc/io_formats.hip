@@ -96,6 +96,19 @@ extern "C" int p3m_hip_read_pid_checkpoint(const char *path, p3m_ckpt_header *h,
     if (!get(F.f, pid + j, 8, binary != 0)) { p3m_set_error("%s: truncated at particle %lld", path, (long long)j); return P3M_EINVAL; }
   return P3M_OK;
 }
+// projection.f90:62-113: `write(u) a` then `write(u) rho_pxy` -- two records (or, -DBINARY, the bare bytes)
+extern "C" int p3m_hip_write_projection(const char *path, float a, const float *map, int32_t n, int32_t binary) {
+  if (!path || !map || n < 1) return P3M_EINVAL;
+  File F; if (!F.open(path, "wb")) return P3M_EINVAL;
+  if (!put(F.f, &a, 4, binary != 0) || !put(F.f, map, (size_t)4 * n * n, binary != 0)) { p3m_set_error("write error on %s", path); return P3M_EINVAL; }
+  return P3M_OK;
+}
+extern "C" int p3m_hip_read_projection(const char *path, float *a, float *map, int32_t n, int32_t binary) {
+  if (!path || !a || !map || n < 1) return P3M_EINVAL;
+  File F; if (!F.open(path, "rb")) return P3M_EINVAL;
+  if (!get(F.f, a, 4, binary != 0) || !get(F.f, map, (size_t)4 * n * n, binary != 0)) { p3m_set_error("%s: truncated or not a %d^2 projection", path, n); return P3M_EINVAL; }
+  return P3M_OK;
+}
 extern "C" int p3m_hip_write_ic(const char *path, const float *xv6, int32_t np_local, int32_t binary) {
   if (!path || np_local < 0 || (np_local > 0 && !xv6)) return P3M_EINVAL;
   File F; if (!F.open(path, "wb")) return P3M_EINVAL;

@@ -345,6 +345,32 @@ extern "C" int p3m_hip_delete_particles(p3m_ctx *c, const float *move_back) {
   return particles_finalize(c, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr);
 }
 
+// shared by the group variant: maps on the device, zeroed by the caller; returns the rank's projected mass
+int projection_rank(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz, double *rho_node) {
+  HIP_TRY(hipMemsetAsync(c->d_sums + 3 * P3M_SUM_SPAN, 0, P3M_SUM_SPAN * sizeof(double), c->stream));
+  P3M_TRY(fine_projection(c, mass_p, d_pxy, d_pxz, d_pyz));
+  HIP_TRY(hipMemcpyAsync(c->h_sums_raw + 3 * P3M_SUM_SPAN, c->d_sums + 3 * P3M_SUM_SPAN, P3M_SUM_SPAN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double t = 0.0;
+  for (int sl = 0; sl < P3M_NSLOT; sl++) t += c->h_sums_raw[3 * P3M_SUM_SPAN + sl * 8];
+  if (rho_node) *rho_node = t;
+  return P3M_OK;
+}
+extern "C" int p3m_hip_projection(p3m_ctx *c, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_node) {
+  if (!c || !pxy || !pxz || !pyz) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n2 = (size_t)c->g.Nn * c->g.nodes_dim * c->g.Nn * c->g.nodes_dim;
+  float *d = nullptr;
+  HIP_TRY(hipMalloc(&d, 3 * n2 * sizeof(float)));
+  int r = P3M_OK;
+  if (hipMemsetAsync(d, 0, 3 * n2 * sizeof(float), c->stream) != hipSuccess) r = P3M_EDEVICE;
+  if (!r) r = projection_rank(c, mass_p, d, d + n2, d + 2 * n2, rho_node);
+  if (!r && (hipMemcpy(pxy, d, n2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(pxz, d + n2, n2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+             hipMemcpy(pyz, d + 2 * n2, n2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) { p3m_set_error("projection: download failed"); r = P3M_EDEVICE; }
+  (void)hipFree(d);
+  return r;
+}
+
 extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) {
   if (!c || !out) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));

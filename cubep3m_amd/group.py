@@ -196,6 +196,15 @@ class ParticleMeshGroup:
 
         return ParticleMesh.from_handle(self.L.p3m_hip_group_ctx(self.h, i), self.params)
 
+    def projection(self, mass_p):
+        """projection.f90 at a projection step (ghost pass, sort, CIC projection, ghost removal): the maps summed over this
+        process's logical ranks and the projected mass summed over all ranks; several processes add their maps up."""
+        n = self.params.nf_physical_node_dim * self.params.nodes_dim
+        maps = [np.empty((n, n), np.float32) for _ in range(3)]
+        tot = C.c_double()
+        _lib.check(self.L.p3m_hip_group_projection(self.h, mass_p, *(m.ctypes.data_as(C.c_void_p) for m in maps), C.byref(tot)))
+        return maps[0], maps[1], maps[2], tot.value
+
     def coarse(self, mass_p, i, want_force=True):
         p = self.params
         rho = np.empty((p.nc_node_dim,) * 3, np.float32)

@@ -25,8 +25,28 @@ def checkpoint_names(z, rank):
     return "%sxv%d.dat" % (zs, rank), "%sPID%d.dat" % (zs, rank)
 
 
+def projection_names(z):
+    """File names of projection.f90:59-87: z as f7.3, left-adjusted, then proj_xy / proj_xz / proj_yz."""
+    zs = ("%7.3f" % z).strip()
+    return tuple("%sproj_%s.dat" % (zs, ax) for ax in ("xy", "xz", "yz"))
+
+
 def _b(path):
     return str(path).encode()
+
+
+def write_projection(path, a, m, binary=False):
+    """One projection file (projection.f90:104-113): the scale factor, then the square map in the reference's order."""
+    m = np.ascontiguousarray(m, np.float32)
+    assert m.ndim == 2 and m.shape[0] == m.shape[1]
+    _lib.check(_lib.load().p3m_hip_write_projection(_b(path), float(a), m.ctypes.data_as(C.c_void_p), m.shape[0], int(binary)))
+
+
+def read_projection(path, n, binary=False):
+    a = C.c_float()
+    m = np.empty((n, n), np.float32)
+    _lib.check(_lib.load().p3m_hip_read_projection(_b(path), C.byref(a), m.ctypes.data_as(C.c_void_p), n, int(binary)))
+    return a.value, m
 
 
 def write_checkpoint(path, header: P3MCkptHeader, xv, shake_offset=None, binary=False, ppint=False):

@@ -30,6 +30,7 @@ EXPORTS = [
     "p3m_hip_read_pid_checkpoint", "p3m_hip_write_ic", "p3m_hip_read_ic", "p3m_hip_group_nlocal", "p3m_hip_group_local_rank",
     "p3m_hip_group_ctx", "p3m_hip_group_set_kernel_tables", "p3m_hip_group_upload_particles", "p3m_hip_group_download_particles",
     "p3m_hip_group_particle_mesh", "p3m_hip_group_update_position", "p3m_hip_group_probe_coarse",
+    "p3m_hip_projection", "p3m_hip_group_projection", "p3m_hip_write_projection", "p3m_hip_read_projection",
 ]
 
 
@@ -91,6 +92,10 @@ def load():
     L.p3m_hip_write_pid_checkpoint.argtypes = [C.c_char_p, vp, vp, i32, i32]
     L.p3m_hip_read_pid_checkpoint.argtypes = [C.c_char_p, vp, vp, C.c_int64, i32, i32]
     L.p3m_hip_write_ic.argtypes = [C.c_char_p, vp, i32, i32]
+    L.p3m_hip_projection.argtypes = [vp, f32, vp, vp, vp, C.POINTER(C.c_double)]
+    L.p3m_hip_group_projection.argtypes = [vp, f32, vp, vp, vp, C.POINTER(C.c_double)]
+    L.p3m_hip_write_projection.argtypes = [C.c_char_p, f32, vp, i32, i32]
+    L.p3m_hip_read_projection.argtypes = [C.c_char_p, C.POINTER(f32), vp, i32, i32]
     L.p3m_hip_read_ic.argtypes = [C.c_char_p, vp, C.c_int64, C.POINTER(i32), i32]
     L.p3m_hip_group_nlocal.argtypes = [vp]
     L.p3m_hip_group_local_rank.argtypes = [vp, i32]

@@ -145,6 +145,15 @@ class ParticleMesh:
         _lib.check(self.L.p3m_hip_probe_tile_force(self.h, np.ascontiguousarray(rho, np.float32), f, C.byref(m)))
         return f, m.value
 
+    def projection(self, mass_p):
+        """projection.f90 on the sorted records with ghosts (call link_list_and_pass before, delete_particles after):
+        (pxy[y][x], pxz[z][x], pyz[z][y], projected mass) of this rank."""
+        n = self.params.nf_physical_node_dim * self.params.nodes_dim
+        maps = [np.empty((n, n), np.float32) for _ in range(3)]
+        tot = C.c_double()
+        _lib.check(self.L.p3m_hip_projection(self.h, mass_p, *(m.ctypes.data_as(C.c_void_p) for m in maps), C.byref(tot)))
+        return maps[0], maps[1], maps[2], tot.value
+
     def coarse(self, mass_p, want_force=True):
         p = self.params
         rho = np.empty((p.nc_node_dim,) * 3, np.float32)

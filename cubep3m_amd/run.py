@@ -27,6 +27,7 @@ def main(argv=None):
     ap.add_argument("--nf-tile", type=int, default=80)
     ap.add_argument("--z-i", type=float, required=True, help="initial redshift (parameters: z_i)")
     ap.add_argument("--checkpoints", required=True, help="comma separated redshifts, descending (input/checkpoints)")
+    ap.add_argument("--projections", default="", help="comma separated redshifts of the density projections (input/projections)")
     ap.add_argument("--omega-m", type=float, default=0.24)
     ap.add_argument("--omega-l", type=float, default=0.76)
     ap.add_argument("--ppint", action="store_true")
@@ -46,14 +47,28 @@ def main(argv=None):
         npart += len(xv)
     mass_p = float(p.nf_physical_dim) ** 3 / npart            # particle_initialization.f90:382
     zs = [float(z) for z in a.checkpoints.split(",")]
-    tp = TimeParams(omega_m=a.omega_m, omega_l=a.omega_l, a_checkpoint=[1.0 / (1.0 + z) for z in zs])
+    zp = [float(z) for z in a.projections.split(",") if z]
+    tp = TimeParams(omega_m=a.omega_m, omega_l=a.omega_l, a_checkpoint=[1.0 / (1.0 + z) for z in zs], a_projection=[1.0 / (1.0 + z) for z in zp])
     st = new_state(1.0 / (1.0 + a.z_i))
     os.makedirs(a.out_dir, exist_ok=True)
 
+    def on_projection(sim):   # cubepm.f90:189-204: link_list, particle_pass, projection; projection.f90:56-113 writes the files
+        s = sim.st
+        z = zp[s.cur_projection - 1]
+        pxy, pxz, pyz, tot = g.projection(mass_p)
+        for name, m in zip(iof.projection_names(z), (pxy, pxz, pyz)):
+            iof.write_projection(os.path.join(a.out_dir, name), s.a, m, binary=a.binary)
+        print("projection z=%.3f  a=%.6f  total projected mass=%.6g" % (z, s.a, tot), flush=True)
+
     def on_output(sim):
         s = sim.st
-        if not s.checkpoint_step:
-            return
+        if s.checkpoint_step:
+            on_checkpoint(sim)
+        if s.projection_step:
+            on_projection(sim)
+
+    def on_checkpoint(sim):
+        s = sim.st
         z = zs[s.cur_checkpoint - 1]
         for i, r in enumerate(g.local_ranks):
             xv, pid = g.download_particles(i)

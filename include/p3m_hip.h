@@ -169,6 +169,13 @@ int p3m_hip_fine_mesh(p3m_ctx *ctx, float a_mid, float dt, float mass_p);   /* :
 int p3m_hip_coarse_mesh(p3m_ctx *ctx, float a_mid, float dt, float mass_p); /* coarse_mesh.f90 */
 int p3m_hip_delete_particles(p3m_ctx *ctx, const float *move_back);        /* delete_particles.f90 */
 int p3m_hip_get_step_out(p3m_ctx *ctx, float a_mid, p3m_step_out *out);
+/* projection.f90:2-188 (density projections).  Call between p3m_hip_link_list_and_pass and
+ * p3m_hip_delete_particles, as cubepm.f90:193-228 does.  pxy / pxz / pyz: host arrays of nf_physical_dim^2 floats each
+ * (nf_physical_dim = nodes_dim * nf_physical_node_dim), in the reference's memory order rho_pxy(x,y), rho_pxz(x,z),
+ * rho_pyz(y,z) with the first index fastest; they receive THIS rank's contribution (:170-181: only ranks at coordinate 0
+ * of the projected axis add anything) -- the sum over ranks is the host's mpi_reduce (:41-54).  rho_node: the
+ * rank's projected mass (:183).  The deposit is the CIC of fine_cic_mass.f90 whatever P3M_FLAG_NGP says. */
+int p3m_hip_projection(p3m_ctx *ctx, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_node);
 
 /* -- mesh-level probes for parity tests and the roofline benchmark ----------------------- */
 /* One tile's density after deposit, reference layout rho_f(nf_tile+2, nf_tile, nf_tile)
@@ -239,6 +246,9 @@ int p3m_hip_read_checkpoint(const char *path, p3m_ckpt_header *h, float *xv6, in
 int p3m_hip_write_pid_checkpoint(const char *path, const p3m_ckpt_header *h, const int64_t *pid, int32_t binary, int32_t ppint);
 int p3m_hip_read_pid_checkpoint(const char *path, p3m_ckpt_header *h, int64_t *pid, int64_t cap, int32_t binary, int32_t ppint);
 /* xv<rank>.ic: np_local, then xv(:,i) per particle (unformatted) or as one block (binary) (particle_initialization.f90:296-332) */
+/* projection.f90:62-113: one projection file = the scalar a, then the nf_physical_dim^2 map; `binary` as for the checkpoints */
+int p3m_hip_write_projection(const char *path, float a, const float *map, int32_t nf_physical_dim, int32_t binary);
+int p3m_hip_read_projection(const char *path, float *a, float *map, int32_t nf_physical_dim, int32_t binary);
 int p3m_hip_write_ic(const char *path, const float *xv6, int32_t np_local, int32_t binary);
 int p3m_hip_read_ic(const char *path, float *xv6, int64_t cap, int32_t *np_local, int32_t binary);
 
@@ -268,6 +278,10 @@ int p3m_hip_group_update_position(p3m_group *g, float dt, float dt_old, const fl
 int p3m_hip_group_particle_mesh(p3m_group *g, float a_mid, float dt, float dt_old, float mass_p,
                                 const float *offset, const float *move_back, p3m_step_out *out);
 int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho_c, float *force_c);
+/* projection.f90 for every logical rank of this process: ghost pass, sort, CIC projection, ghost removal (the sequence of
+ * cubepm.f90:193-228); the maps receive the sum over THIS process's ranks, rho_tot the sum over all ranks (:34-35); a host
+ * running several processes adds the maps up (the reference's mpi_reduce, :41-54). */
+int p3m_hip_group_projection(p3m_group *g, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_tot);
 
 /* -- F77-ABI one-call wrapper in the style of pp_force_c_ (nbody-ueli.cu:368) ------------ */
 /* Single-rank hosts: uploads xv/PID, runs the step, downloads, returns the four dt limits.

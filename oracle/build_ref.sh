@@ -18,7 +18,7 @@ MPI_LIB=/opt/conda/lib
 
 SRCS="update_position link_list particle_pass delete_particles move_grid_back mpi_initialization \
       fine_ngp_mass fine_cic_mass fine_cic_mass_buffer coarse_mass coarse_cic_mass \
-      coarse_cic_mass_buffer coarse_force_buffer coarse_max_dt coarse_velocity timestep checkpoint particle_initialization"
+      coarse_cic_mass_buffer coarse_force_buffer coarse_max_dt coarse_velocity timestep checkpoint particle_initialization projection"
 
 build_cfg () {  # name nodes_dim tiles nf_tile cores density_buffer "cpp flags"
   local name=$1 nd=$2 T=$3 nf=$4 cores=$5 dens=$6 flags=$7

@@ -838,6 +838,57 @@ void orc_fine_mesh(orc_ctx *c, float a_mid, float dt, float mass_p) {
   c->sum_rho_f = sm;
 }
 
+/* projection.f90:2-188: CIC fine density of every tile (fine_cic_mass.f90 over the chains of the
+   tile's coarse cells plus one on either side, build_projection :147-156), summed along each axis into the global
+   nf_physical_dim^2 maps; only the ranks at coordinate 0 of the projected axis contribute (:170-181); the MPI sum over
+   ranks (:41-54) adds exact zeros from everyone else.  Maps in the reference's memory order: pxy[y][x], pxz[z][x], pyz[z][y]. */
+void orc_projection(orc_ctx *c, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_tot) {
+  const int nf = c->p.nf_tile, nb = c->p.nf_buf, pt = c->nf_physical_tile_dim, nct = c->nc_tile_dim, T = c->p.tiles_node_dim;
+  const int Nn = c->nf_physical_node_dim, Np = Nn * c->p.nodes_dim;
+  memset(pxy, 0, sizeof(float) * (size_t)Np * Np); memset(pxz, 0, sizeof(float) * (size_t)Np * Np); memset(pyz, 0, sizeof(float) * (size_t)Np * Np);
+  double tot = 0.0;
+  tile_ws *w = ws_alloc(c);
+  for (int rk = 0; rk < c->nodes; rk++) {
+    orc_rank *R = &c->r[rk];
+    double rho_node = 0.0;
+    for (int cur = 1; cur <= T * T * T; cur++) {                            /* :24-32 */
+      int tile[3]; tile_coords(c, cur, tile);
+      memset(w->rho_f, 0, sizeof(float) * (size_t)(nf + 2) * nf * nf);      /* :139 */
+      float offset[3];
+      for (int d = 0; d < 3; d++) offset[d] = (float)(-tile[d] * pt + nb);  /* fine_cic_mass.f90:13 */
+      for (int k = nct * tile[2]; k <= nct * (tile[2] + 1) + 1; k++)        /* :144-156 */
+        for (int j = nct * tile[1]; j <= nct * (tile[1] + 1) + 1; j++)
+          for (int i = nct * tile[0]; i <= nct * (tile[0] + 1) + 1; i++) {
+            int pp = HOC(c, R, i, j, k);
+            while (pp != 0) {
+              int i1[3], i2[3]; float dx1[3], dx2[3];
+              for (int d = 0; d < 3; d++) {
+                float x = XV(R, d + 1, pp) + offset[d];                     /* fine_cic_mass.f90:17-21 */
+                i1[d] = (int)floorf(x) + 1; i2[d] = i1[d] + 1; dx1[d] = (float)i1[d] - x; dx2[d] = 1.f - dx1[d];
+              }
+              dx1[0] = mass_p * dx1[0]; dx2[0] = mass_p * dx2[0];           /* :23-24 */
+              for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
+                int ii = cx ? i2[0] : i1[0], jj = cy ? i2[1] : i1[1], kk = cz ? i2[2] : i1[2];
+                RHOF(w, ii, jj, kk) = RHOF(w, ii, jj, kk) + (cx ? dx2[0] : dx1[0]) * (cy ? dx2[1] : dx1[1]) * (cz ? dx2[2] : dx1[2]);
+              }
+              pp = R->ll[pp - 1];
+            }
+          }
+      const int os_x = tile[0] * pt + R->cart[2] * Nn, os_y = tile[1] * pt + R->cart[1] * Nn, os_z = tile[2] * pt + R->cart[0] * Nn;   /* :160-165 */
+      for (int k = 1; k <= pt; k++) for (int j = 1; j <= pt; j++) for (int i = 1; i <= pt; i++) {   /* :169-186 */
+        const float v = RHOF(w, nb + i, nb + j, nb + k);
+        if (R->cart[0] == 0) pxy[(size_t)(os_y + j - 1) * Np + (os_x + i - 1)] += v;
+        if (R->cart[1] == 0) pxz[(size_t)(os_z + k - 1) * Np + (os_x + i - 1)] += v;
+        if (R->cart[2] == 0) pyz[(size_t)(os_z + k - 1) * Np + (os_y + j - 1)] += v;
+        rho_node = rho_node + (double)v;
+      }
+    }
+    tot += rho_node;                                                        /* :34-35 */
+  }
+  ws_free(w);
+  if (rho_tot) *rho_tot = tot;
+}
+
 /* probes */
 void orc_tile_density(orc_ctx *c, int rank, int tx, int ty, int tz, float mass_p, float *rho_f) {
   tile_ws *w = ws_alloc(c); int tile[3] = {tx, ty, tz};

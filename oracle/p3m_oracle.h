@@ -64,6 +64,8 @@ int orc_particle_mesh(orc_ctx *c, float a_mid, float dt, float dt_old, float mas
                       const float *offset, const float *move_back, p3m_step_out *out);
 
 /* probes */
+/* projection.f90: the three density projections (global nf_physical_dim^2 each, reference memory order) and the projected mass; needs link_list + particle_pass */
+void orc_projection(orc_ctx *c, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_tot);
 void orc_tile_density(orc_ctx *c, int rank, int tx, int ty, int tz, float mass_p, float *rho_f);
 void orc_tile_force(orc_ctx *c, const float *rho_f, float *force_f, float *force_max2);
 void orc_coarse_density(orc_ctx *c, float mass_p);           /* coarse_mass on all ranks */

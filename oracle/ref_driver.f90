@@ -273,3 +273,19 @@ end subroutine ref_checkpoint
 subroutine ref_particle_initialize() bind(C, name="ref_particle_initialize")
   call particle_initialize
 end subroutine
+
+! --- projection.f90 (density projections, SURVEY section 8f rank 3) ------------------------------
+! needs link_list + particle_pass; writes <z>proj_{xy,xz,yz}.dat into output_path and leaves the maps in rho_pxy/pxz/pyz
+! rv_in : a, mass_p, z_projection
+subroutine ref_projection(rv_in, pxy, pxz, pyz) bind(C, name="ref_projection")
+  use iso_c_binding
+  implicit none
+  include 'cubepm.fh'
+  real(c_float) :: rv_in(3)
+  real(c_float) :: pxy(nf_physical_dim, nf_physical_dim), pxz(nf_physical_dim, nf_physical_dim), pyz(nf_physical_dim, nf_physical_dim)
+  a = rv_in(1); mass_p = rv_in(2)
+  cur_projection = 1
+  z_projection(1) = rv_in(3)
+  call projection
+  pxy = rho_pxy; pxz = rho_pxz; pyz = rho_pyz
+end subroutine ref_projection

@@ -57,6 +57,7 @@ def lib():
         L.orc_particle_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(P3MStepOut)]
         L.orc_tile_density.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, f32p]
         L.orc_tile_force.argtypes = [C.c_void_p, f32p, f32p, C.POINTER(C.c_float)]
+        L.orc_projection.argtypes = [C.c_void_p, C.c_float, f32p, f32p, f32p, C.POINTER(C.c_double)]
         L.orc_coarse_density.argtypes = [C.c_void_p, C.c_float]
         L.orc_rho_c.restype = C.POINTER(C.c_float)
         L.orc_rho_c.argtypes = [C.c_void_p, C.c_int]
@@ -164,6 +165,13 @@ class Oracle:
         rho = np.empty((nf, nf, nf + 2), np.float32)
         self.L.orc_tile_density(self.h, rank, tile[0], tile[1], tile[2], mass_p, rho)
         return rho
+
+    def projection(self, mass_p):
+        n = self.p.nf_physical_node_dim * self.p.nodes_dim
+        maps = [np.empty((n, n), np.float32) for _ in range(3)]
+        tot = C.c_double()
+        self.L.orc_projection(self.h, mass_p, maps[0], maps[1], maps[2], C.byref(tot))
+        return maps[0], maps[1], maps[2], tot.value
 
     def tile_force(self, rho):
         pt = self.p.nf_physical_tile_dim
