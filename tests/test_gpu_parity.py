@@ -530,3 +530,20 @@ def test_tile_force_at_the_register_fft_sizes(PM, n):
         num += ((a - b) ** 2).sum(); den += (b ** 2).sum()
     assert np.sqrt(num / den) < 2e-6
     assert mg == pytest.approx(mo, rel=1e-5)
+
+
+@pytest.mark.parametrize("switch", ["P3M_FFT_STOCKHAM", "P3M_SEPARATE_COARSE_KICK"])
+def test_fallback_paths_stay_at_parity(switch):
+    """The run-time switches select the LDS Stockham FFT kernels for every size, and the coarse kick in its own pass: both
+    are the paths other tile sizes / PP runs take, so they are held to the same parity tests (in a child process: the
+    switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "test_tile_force_vs_oracle or config1_kick_parity or register_fft_sizes and 176 or test_fft_forward and 176 or two_steps_with_drift"],
+                       env=dict(os.environ, **{switch: "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
