@@ -14,6 +14,7 @@
 // transpose FFTW's NORMAL_ORDER pays; kern_c is built through the same pipeline and is therefore
 // stored consistently.
 #include "p3m_internal.h"
+#include <stdlib.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -52,6 +53,10 @@ struct p3m_group {
   p3m_params base{};
   int proc = 0, nprocs = 1, nodes = 1, nd = 1, device = 0;
   hipStream_t stream = nullptr;
+  // PM-only steps: the coarse slab transform with its all-to-all exchanges (many small kernels, launch- and
+  // latency-bound) runs on `stream2` underneath the fine-mesh force sweeps of the local ranks, which need the coarse force
+  // only when they kick
+  hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;
   std::vector<p3m_ctx *> ctx; std::vector<int> lrank, owner, lidx;
   std::vector<CoarseDist> cd;
   ncclComm_t comm = nullptr; bool force_nccl = false;
@@ -196,6 +201,9 @@ extern "C" void p3m_hip_group_destroy(p3m_group *G) {
   if (G->h_sum3) (void)hipHostFree(G->h_sum3);
   for (int k = 0; k < 2; k++) if (G->h_stage[k]) (void)hipHostFree(G->h_stage[k]);
   fft_plan_destroy(&G->plan_c);
+  if (G->stream2) (void)hipStreamDestroy(G->stream2);
+  if (G->ev_dep) (void)hipEventDestroy(G->ev_dep);
+  if (G->ev_cf) (void)hipEventDestroy(G->ev_cf);
   if (G->stream) (void)hipStreamDestroy(G->stream);
   delete G;
 }
@@ -223,6 +231,10 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     if (rc) return fail(rc);
     (void)hipStreamDestroy(c->stream); c->stream = G->stream;   // one stream for the whole group
     G->lidx[r] = (int)G->ctx.size(); G->ctx.push_back(c); G->lrank.push_back(r);
+  }
+  if (nodes > 1 && !(getenv("P3M_ONE_STREAM") && getenv("P3M_ONE_STREAM")[0] == '1')) {
+    if (hipStreamCreateWithFlags(&G->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&G->ev_dep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&G->ev_cf, hipEventDisableTiming) != hipSuccess) return fail(P3M_EDEVICE);
   }
   const Geometry &g = G->ctx[0]->g;
   if (nodes > 1 && g.Nn < 2 * g.nb) {   // one ghost shift per axis (k_ghost_pack)
@@ -737,10 +749,24 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   if (!G->ctx.empty() && coarse_kick_rides_on_fine(G->ctx[0])) {
     // PM-only NGP: coarse force first (it depends on positions only), its kick rides on the fine kick's pass (k_fine_kick_rows<true>)
     for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                   // coarse_mass
-    P3M_TRY(coarse_force_dist(G));                                                                  // coarse_force, _buffer, max
+    if (G->stream2) {
+      HIP_TRY(hipEventRecord(G->ev_dep, G->stream));
+      for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p));                          // :72-204 of every tile, queued first
+      HIP_TRY(hipStreamWaitEvent(G->stream2, G->ev_dep, 0));
+      hipStream_t main = G->stream;
+      G->stream = G->stream2; for (p3m_ctx *c : G->ctx) c->stream = G->stream2;
+      int r = coarse_force_dist(G);                                                                 // coarse_force, _buffer, max: underneath the sweeps
+      if (r == P3M_OK && hipEventRecord(G->ev_cf, G->stream2) != hipSuccess) r = P3M_EDEVICE;
+      G->stream = main; for (p3m_ctx *c : G->ctx) c->stream = main;
+      if (r != P3M_OK) { (void)hipStreamSynchronize(G->stream2); return r; }
+      HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
+    } else {
+      P3M_TRY(coarse_force_dist(G));                                                                // coarse_force, _buffer, max
+      for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p));
+    }
     for (p3m_ctx *c : G->ctx) {
       c->coarse_first = true;
-      const int r = p3m_hip_fine_mesh(c, a_mid, dt, mass_p);                                        // :72-628 + coarse_velocity
+      const int r = fine_mesh_kick_phase(c, a_mid, dt, mass_p);                                     // :208-319 + coarse_velocity
       c->coarse_first = false;
       P3M_TRY(r);
     }

@@ -316,17 +316,24 @@ bool coarse_kick_rides_on_fine(const p3m_ctx *c) {
   return !off && (c->p.flags & P3M_FLAG_NGP) && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT));
 }
 
-extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
-  if (!c) return P3M_EINVAL;
+// the two halves of the fine mesh step: density + force of every tile (positions only), then everything that moves velocities
+int fine_mesh_force_phase(p3m_ctx *c, float mass_p) {
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
   if (!c->rho_from_sort) P3M_TRY(reductions_clear(c));   // else cleared before the sort, which already added the NGP mass sum
   HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
-  P3M_TRY(fine_sweep(c, mass_p));
+  return fine_sweep(c, mass_p);
+}
+int fine_mesh_kick_phase(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   P3M_TRY(fine_max_and_kick(c, a_mid, dt));
   if ((c->p.flags & P3M_FLAG_PPINT) && (c->p.flags & P3M_FLAG_NGP)) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
   if (c->p.flags & P3M_FLAG_PP_EXT) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
   return P3M_OK;
+}
+extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+  if (!c) return P3M_EINVAL;
+  P3M_TRY(fine_mesh_force_phase(c, mass_p));
+  return fine_mesh_kick_phase(c, a_mid, dt, mass_p);
 }
 
 extern "C" int p3m_hip_coarse_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
