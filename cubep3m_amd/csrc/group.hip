@@ -53,7 +53,7 @@ struct p3m_group {
   p3m_params base{};
   int proc = 0, nprocs = 1, nodes = 1, nd = 1, device = 0;
   hipStream_t stream = nullptr;
-  // PM-only steps: the coarse slab transform with its all-to-all exchanges (many small kernels, launch- and
+  // the coarse slab transform with its all-to-all exchanges (many small kernels, launch- and
   // latency-bound) runs on `stream2` underneath the fine-mesh force sweeps of the local ranks, which need the coarse force
   // only when they kick
   hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;
@@ -746,24 +746,28 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
   P3M_TRY(ghost_pass(G));                                                                           // :61-63
   for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort(c, mass_p)); }
-  if (!G->ctx.empty() && coarse_kick_rides_on_fine(G->ctx[0])) {
-    // PM-only NGP: coarse force first (it depends on positions only), its kick rides on the fine kick's pass (k_fine_kick_rows<true>)
-    for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                   // coarse_mass
-    if (G->stream2) {
-      HIP_TRY(hipEventRecord(G->ev_dep, G->stream));
-      for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p));                          // :72-204 of every tile, queued first
-      HIP_TRY(hipStreamWaitEvent(G->stream2, G->ev_dep, 0));
-      hipStream_t main = G->stream;
-      G->stream = G->stream2; for (p3m_ctx *c : G->ctx) c->stream = G->stream2;
-      int r = coarse_force_dist(G);                                                                 // coarse_force, _buffer, max: underneath the sweeps
-      if (r == P3M_OK && hipEventRecord(G->ev_cf, G->stream2) != hipSuccess) r = P3M_EDEVICE;
-      G->stream = main; for (p3m_ctx *c : G->ctx) c->stream = main;
-      if (r != P3M_OK) { (void)hipStreamSynchronize(G->stream2); return r; }
-      HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
-    } else {
-      P3M_TRY(coarse_force_dist(G));                                                                // coarse_force, _buffer, max
-      for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p));
-    }
+  // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
+  // fine-mesh force sweeps (many small kernels and the all-to-all exchanges against bandwidth-bound FFT passes).  PM-only
+  // NGP runs then apply its kick inside the fine kick's pass (k_fine_kick_rows<true>); with a PP kick in between
+  // (reference order fine, PP, coarse) it keeps its own pass.
+  const bool ride = !G->ctx.empty() && coarse_kick_rides_on_fine(G->ctx[0]);
+  for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                     // coarse_mass
+  if (G->stream2) {
+    HIP_TRY(hipEventRecord(G->ev_dep, G->stream));
+    for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p, false));                     // :72-204 of every tile, queued first
+    HIP_TRY(hipStreamWaitEvent(G->stream2, G->ev_dep, 0));
+    hipStream_t main = G->stream;
+    G->stream = G->stream2; for (p3m_ctx *c : G->ctx) c->stream = G->stream2;
+    int r = coarse_force_dist(G);                                                                   // coarse_force, _buffer, max
+    if (r == P3M_OK && hipEventRecord(G->ev_cf, G->stream2) != hipSuccess) r = P3M_EDEVICE;
+    G->stream = main; for (p3m_ctx *c : G->ctx) c->stream = main;
+    if (r != P3M_OK) { (void)hipStreamSynchronize(G->stream2); return r; }
+  } else {
+    P3M_TRY(coarse_force_dist(G));
+    for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p, false));
+  }
+  if (ride) {
+    if (G->stream2) HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
     for (p3m_ctx *c : G->ctx) {
       c->coarse_first = true;
       const int r = fine_mesh_kick_phase(c, a_mid, dt, mass_p);                                     // :208-319 + coarse_velocity
@@ -771,9 +775,8 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
       P3M_TRY(r);
     }
   } else {
-    for (p3m_ctx *c : G->ctx) P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));                     // :72-628
-    for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                   // coarse_mass
-    P3M_TRY(coarse_force_dist(G));                                                                  // coarse_force, _buffer, max
+    for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_kick_phase(c, a_mid, dt, mass_p));                  // :208-628
+    if (G->stream2) HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
     for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt));                                   // coarse_velocity
   }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));  // :716-720

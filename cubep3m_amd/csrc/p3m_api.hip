@@ -317,10 +317,10 @@ bool coarse_kick_rides_on_fine(const p3m_ctx *c) {
 }
 
 // the two halves of the fine mesh step: density + force of every tile (positions only), then everything that moves velocities
-int fine_mesh_force_phase(p3m_ctx *c, float mass_p) {
+int fine_mesh_force_phase(p3m_ctx *c, float mass_p, bool may_clear) {
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
-  if (!c->rho_from_sort) P3M_TRY(reductions_clear(c));   // else cleared before the sort, which already added the NGP mass sum
+  if (may_clear && !c->rho_from_sort) P3M_TRY(reductions_clear(c));   // else cleared before the sort, which already added the NGP mass sum
   HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
   return fine_sweep(c, mass_p);
 }
@@ -332,7 +332,7 @@ int fine_mesh_kick_phase(p3m_ctx *c, float a_mid, float dt, float mass_p) {
 }
 extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (!c) return P3M_EINVAL;
-  P3M_TRY(fine_mesh_force_phase(c, mass_p));
+  P3M_TRY(fine_mesh_force_phase(c, mass_p, true));
   return fine_mesh_kick_phase(c, a_mid, dt, mass_p);
 }
 

@@ -148,7 +148,7 @@ int fine_kick(p3m_ctx *c, float a_mid, float dt);
 int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt);
 int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz);   // projection.f90: adds this rank's tiles to the device maps
 bool coarse_kick_rides_on_fine(const p3m_ctx *c);   // p3m_api.hip
-int fine_mesh_force_phase(p3m_ctx *c, float mass_p);                          // p3m_api.hip: density + force box of every tile
+int fine_mesh_force_phase(p3m_ctx *c, float mass_p, bool may_clear);          // p3m_api.hip: density + force box of every tile; may_clear: phase-level call, the reductions were not cleared before the sort
 int fine_mesh_kick_phase(p3m_ctx *c, float a_mid, float dt, float mass_p);    // maximum, kick, PP
 int fine_force_max(p3m_ctx *c);
 int fine_sum_mass(p3m_ctx *c, int tile0, int ntile);
