@@ -74,6 +74,10 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   auto fail = [&](int code) { p3m_hip_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { p3m_set_error("hipSetDevice(%d) failed", c->device); return fail(P3M_EDEVICE); }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { p3m_set_error("stream creation failed"); return fail(P3M_EDEVICE); }
+  if (g.nodes == 1 && !(getenv("P3M_ONE_STREAM") && getenv("P3M_ONE_STREAM")[0] == '1')) {
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_cf, hipEventDisableTiming) != hipSuccess) { p3m_set_error("stream creation failed"); return fail(P3M_EDEVICE); }
+  }
   c->cap = g.max_np;
 #define A(x) do { int _r = (x); if (_r) return fail(_r); } while (0)
   A(dalloc(&c->pos, c->cap)); A(dalloc(&c->vel, c->cap)); A(dalloc(&c->pid, c->cap));
@@ -136,6 +140,9 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   if (c->h_tile_ext) (void)hipHostFree(c->h_tile_ext);
   if (c->h_sums_raw) (void)hipHostFree(c->h_sums_raw);
   fft_plan_destroy(&c->plan_f); fft_plan_destroy(&c->plan_c);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
+  if (c->ev_cf) (void)hipEventDestroy(c->ev_cf);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -428,19 +435,35 @@ extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt
   P3M_TRY(reductions_clear(c));
   P3M_TRY(particles_pass_self(c));                           // :61-63
   P3M_TRY(particles_sort(c, mass_p));
-  if (coarse_kick_rides_on_fine(c)) {
-    // PM-only NGP: the coarse force does not depend on the fine kick (positions only), so it is formed first and its
-    // kick is applied by the fine kick's pass over the records (fine_mesh.hip, k_fine_kick_rows<true>)
-    P3M_TRY(need_kernels(c));
-    P3M_TRY(coarse_deposit(c, mass_p));
+  // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
+  // fine-mesh force sweep.  PM-only NGP runs then apply its kick inside the fine kick's pass (k_fine_kick_rows<true>); with a
+  // PP kick in between (reference order fine, PP, coarse) it keeps its own pass.
+  const bool ride = coarse_kick_rides_on_fine(c);
+  P3M_TRY(coarse_deposit(c, mass_p));                        // coarse_mass
+  if (c->stream2) {
+    HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
+    P3M_TRY(fine_mesh_force_phase(c, mass_p, false));        // :72-204 of every tile, queued first
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_dep, 0));
+    hipStream_t main = c->stream;
+    c->stream = c->stream2;
+    int r = coarse_force(c);                                 // coarse_force, _buffer, max
+    if (r == P3M_OK && hipEventRecord(c->ev_cf, c->stream2) != hipSuccess) r = P3M_EDEVICE;
+    c->stream = main;
+    if (r != P3M_OK) { (void)hipStreamSynchronize(c->stream2); return r; }
+  } else {
     P3M_TRY(coarse_force(c));
+    P3M_TRY(fine_mesh_force_phase(c, mass_p, false));
+  }
+  if (ride) {
+    if (c->stream2) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_cf, 0));
     c->coarse_first = true;
-    const int r = p3m_hip_fine_mesh(c, a_mid, dt, mass_p);
+    const int r = fine_mesh_kick_phase(c, a_mid, dt, mass_p);   // :208-319 + coarse_velocity
     c->coarse_first = false;
     P3M_TRY(r);
   } else {
-    P3M_TRY(p3m_hip_fine_mesh(c, a_mid, dt, mass_p));          // :72-628
-    P3M_TRY(p3m_hip_coarse_mesh(c, a_mid, dt, mass_p));        // :712
+    P3M_TRY(fine_mesh_kick_phase(c, a_mid, dt, mass_p));     // :208-628
+    if (c->stream2) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_cf, 0));
+    P3M_TRY(coarse_kick(c, a_mid, dt));                      // coarse_velocity (coarse_vel_update = .true., cubepm.par:87)
   }
   P3M_TRY(p3m_hip_delete_particles(c, move_back));           // :716-720
   p3m_step_out o;

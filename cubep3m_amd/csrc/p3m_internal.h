@@ -84,6 +84,7 @@ struct p3m_ctx {
   // ---- fine mesh, all tiles batched
   int tile_batch = 0;          // tiles processed per sweep
   bool pending_compact = false; int pend_n = 0; float pend_mb[3] = {0, 0, 0};   // deferred ghost removal (particles.hip)
+  hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;   // single-rank whole steps: the coarse force forms on stream2 underneath the fine-mesh force sweep
   bool coarse_first = false;   // whole-step PM-only NGP runs: the coarse force is ready before the fine kick, which then adds the coarse kick in the same pass
   bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
