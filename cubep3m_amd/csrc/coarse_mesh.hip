@@ -21,7 +21,7 @@ struct CGeo { int nb, E, Nn, ms, ncn, nc; };
 // The chain window hoc(0:ncn+1) of coarse_mass.f90:85-87 is implied: i1 in [0,ncn] <=> x in [-ms/2, Nn+ms/2).
 #define CROWS 4   // fine rows whose range / first record loads are in flight together
 __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ mom, CGeo G,
-                                                       float mass_p, float *__restrict__ rho_c) {
+                                                       float mass_p, float *__restrict__ rho_c, const int *__restrict__ crow, int crow_w) {
   const int m1 = G.ncn + 1;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)m1 * m1 * m1;
   if (t >= tot) return;
@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
     for (int u = 0; u < CROWS; u++) {
       const int r = r0 + u, zz = r / G.ms, yy = r - zz * G.ms;
       p0[u] = 0; p1[u] = 0;
-      if (r < nrow) { const int *row = cs + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * G.E + x0; p0[u] = row[0]; p1[u] = row[G.ms]; }
+      if (r < nrow) {
+        if (crow) { const int *row = crow + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * crow_w + ci; p0[u] = row[0]; p1[u] = row[1]; }   // compact table: entry ci = start(x0)
+        else { const int *row = cs + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * G.E + x0; p0[u] = row[0]; p1[u] = row[G.ms]; }
+      }
     }
     float4 first[CROWS];
 #pragma unroll
@@ -101,7 +104,7 @@ int coarse_deposit(p3m_ctx *c, float mass_p) {
   const int64_t m1 = g.ncn + 1, tot = m1 * m1 * m1, n3 = (int64_t)g.ncn * g.ncn * g.ncn;
   HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));
   hipLaunchKernelGGL(k_coarse_moments, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G,
-                     mass_p, c->rho_c);
+                     mass_p, c->rho_c, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_coarse_collect, dim3((unsigned)std::min<int64_t>(1024, cdiv(n3, 256))), dim3(256), 0, c->stream, (const float *)c->cmom, c->rho_c, g.ncn, c->d_sums + 1 * P3M_SUM_SPAN);
   HIP_TRY(hipGetLastError());

@@ -165,6 +165,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   if (c->p.flags & P3M_FLAG_NGP) {
     const bool have = c->rho_from_sort && tile0 == 0 && ntile == g.ntiles;   // written by k_row_sort of this step
     c->rho_from_sort = false;
+    if (!have) P3M_TRY(particles_full_cells(c));
     if (!have) hipLaunchKernelGGL(k_ngp_counts, dim3(cdiv(g.nf, 8), g.nf, ntile), dim3(256), 0, c->stream, (const int *)c->cell_end,
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
     HIP_TRY(hipGetLastError());
@@ -176,6 +177,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
     }
     return P3M_OK;
   }
+  P3M_TRY(particles_full_cells(c));
   const unsigned blocks = (unsigned)((int64_t)ntile * g.nf * g.nf);
   const size_t lds = sizeof(float) * (2 * g.px);
   hipLaunchKernelGGL(k_fine_deposit<false>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
@@ -230,6 +232,7 @@ int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float 
   const int Np = g.Nn * g.nodes_dim;
   const size_t S = (size_t)(2 * g.px) * g.nf * g.nf;
   c->rho_from_sort = false;
+  P3M_TRY(particles_full_cells(c));
   for (int t0 = 0; t0 < g.ntiles; t0 += c->tile_batch) {
     const int nt = std::min(c->tile_batch, g.ntiles - t0);
     hipLaunchKernelGGL(k_fine_deposit<false>, dim3((unsigned)((int64_t)nt * g.nf * g.nf)), dim3(64), sizeof(float) * (2 * g.px), c->stream,
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 template <bool COARSE>
 __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, TileGeo G,
                                                       int Nn, int ms, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
-                                                      float *__restrict__ fmax_out, const float *__restrict__ fc, int ncn) {
+                                                      float *__restrict__ fmax_out, const float *__restrict__ fc, int ncn, const int *__restrict__ crow, int crow_w) {
   extern __shared__ float frow[];   // [3][fbp]
   const int fb = G.fb, fbp = G.fbp, lo = G.nb - 2, lane = threadIdx.x;
   const int jj = blockIdx.x % fb, kk = (blockIdx.x / fb) % fb, tile = blockIdx.x / (fb * fb);
@@ -350,8 +353,9 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
   if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out) + p3m_slot() * 16, __float_as_uint(m));
   __syncthreads();
   // tile-local cell l <-> extended cell l + t*pt; the box row (jj,kk) is the local cell row (jj+lo, kk+lo)
-  const int64_t row = ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * G.E + tx * G.pt + lo;
-  const int p0 = cs[row], p1 = cs[row + fb];
+  int p0, p1;
+  if (crow) { const int *t = crow + ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * crow_w + ncn + 2 + 2 * tx; p0 = t[0]; p1 = t[1]; }   // compact table
+  else { const int64_t row = ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * G.E + tx * G.pt + lo; p0 = cs[row]; p1 = cs[row + fb]; }
   const float fNn = (float)Nn;
   const int nct = G.pt / ms;
   const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
@@ -414,11 +418,11 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
   if (c->coarse_first)
     hipLaunchKernelGGL(k_fine_kick_rows<true>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
                        (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
-                       (const float *)c->force_c, g.ncn);
+                       (const float *)c->force_c, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w);
   else
     hipLaunchKernelGGL(k_fine_kick_rows<false>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
                        (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
-                       (const float *)nullptr, g.ncn);
+                       (const float *)nullptr, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

@@ -88,6 +88,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // every entry of [0, ncell] is rewritten by each sort; the pads stay zero
   if (hipMemset(raw, 0, (size_t)(ncell + 16) * sizeof(int)) != hipSuccess) return fail(P3M_EDEVICE);
   raw = nullptr; A(dalloc(&raw, (size_t)g.E * g.E + 16)); c->row_end = raw + 3;   // (row_end+1) is 16-byte aligned for the scan
+  c->crow_w = (g.ncn + 2 + 2 * g.T + 3) & ~3; A(dalloc(&c->crow, (size_t)g.E * g.E * c->crow_w));
   A(dalloc(&c->d_counters, 16));
   { const int64_t ec = g.E / g.ms; A(dalloc(&c->cflag, (size_t)(ec * ec * ec + 16))); }
   if (hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 16 * sizeof(int)) != hipSuccess) return fail(P3M_ENOMEM);
@@ -132,6 +133,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   dfree(c->tpos); dfree(c->tidx); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
+  dfree(c->crow);
   dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->kern_f);
   dfree(c->rho_c); dfree(c->cmom); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->slab_o); dfree(c->kern_c);
   dfree(c->d_red); dfree(c->d_tile_ext); dfree(c->d_sums);

@@ -74,6 +74,11 @@ struct p3m_ctx {
   float4 *spos = nullptr, *svel = nullptr; int64_t *spid = nullptr;    // sorted by extended fine cell
   int *cell_end = nullptr;     // [E^3+1] inclusive prefix of per-cell counts, shifted by one: start(c)=cell_end[c], end(c)=cell_end[c+1]
   int *row_end = nullptr;      // [E^2+1] the same for whole x-rows of cells (first level of the sort)
+  // PM-only NGP whole steps need cell offsets at few places only: per x-row the ncn+2 starts at stride mesh_scale the
+  // coarse deposit reads and, per tile column, the start and end of the force-box row the kick walks.  The sort then
+  // writes this compact table instead of the 4 E^3 bytes of cell_end (cells_compact == true); anything else that reads
+  // cell_end calls particles_full_cells first, which rebuilds it from the sorted records.
+  int *crow = nullptr; int crow_w = 0; bool cells_compact = false;
   float4 *tpos = nullptr; int *tidx = nullptr;    // row-bucketed intermediate of the sort: position and arrival index
   int *scan_tmp = nullptr; size_t scan_tmp_n = 0;
   int *flags = nullptr;        // [cap] compaction flags / offsets
@@ -136,6 +141,7 @@ int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset);
 int particles_pass_and_sort(p3m_ctx *c);
 int particles_pass_self(p3m_ctx *c);
 int particles_sort(p3m_ctx *c, float deposit_mass);
+int particles_full_cells(p3m_ctx *c);   // cell_end valid again after a sort that wrote the compact table only
 int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts);
 int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);

@@ -7,6 +7,7 @@
 // Records are SoA float4 pos, float4 vel, int64 pid.  Everything here is HBM-bound streaming
 // (the row histogram / scatter aggregate their atomics per block in LDS).
 #include "p3m_internal.h"
+#include <stdlib.h>
 #include <algorithm>
 
 #define PT 256
@@ -220,10 +221,13 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
 
 // one wavefront per row: bins[] = LDS histogram of the row's x cells -> exclusive prefix (the row of cs) -> cursors
 struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, rp; };   // fused NGP deposit (rho == nullptr: off)
+// compact cell table (p3m_internal.h, crow): entry ci < ncn+2 = start of cell ms*ci - ms/2 + nb (what k_coarse_moments reads),
+// entries ncn+2 + 2*tx, +1 = start of cells tx*pt + lo and tx*pt + lo + fb (the force-box row of tile column tx)
+struct RowCompact { int *crow; int w, ncn, ms, T, pt, lo, fb; };   // crow == nullptr: write the full cell_end row
 __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ tidx, const float4 *__restrict__ vel,
                                                  const int64_t *__restrict__ pid, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
                                                  float4 *__restrict__ spos, float4 *__restrict__ svel, int64_t *__restrict__ spid,
-                                                 int *__restrict__ cand, int *__restrict__ ncand, int cand_cap, RowDep dep) {
+                                                 int *__restrict__ cand, int *__restrict__ ncand, int cand_cap, RowDep dep, RowCompact cc) {
   extern __shared__ int bins[];
   const int row = blockIdx.x, lane = threadIdx.x;
   const int r0 = rs[row], r1 = rs[row + 1];
@@ -256,9 +260,20 @@ __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos
   int run = r0 + inc - sum;
   for (int j = j0; j < j1; j++) { const int t = bins[j]; bins[j] = run; run += t; }
   __syncthreads();
-  int *csr = cs + (int64_t)row * E;
-  for (int j = lane; j < E; j += 64) csr[j] = bins[j];
-  if (row == nrows - 1 && lane == 0) csr[E] = r1;
+  if (cc.crow) {
+    int *o = cc.crow + (int64_t)row * cc.w;
+    const int nbi = (int)nb, ntab = cc.ncn + 2 + 2 * cc.T;
+    for (int e = lane; e < ntab; e += 64) {
+      int x;
+      if (e < cc.ncn + 2) x = cc.ms * e - cc.ms / 2 + nbi;
+      else { const int q = e - (cc.ncn + 2); x = (q >> 1) * cc.pt + cc.lo + ((q & 1) ? cc.fb : 0); }
+      o[e] = x < E ? bins[x] : r1;
+    }
+  } else {
+    int *csr = cs + (int64_t)row * E;
+    for (int j = lane; j < E; j += 64) csr[j] = bins[j];
+    if (row == nrows - 1 && lane == 0) csr[E] = r1;
+  }
   // NGP deposit straight from the row histogram (particle_mesh_threaded.f90:131-151): rho(cell) = mass_p added
   // count(cell) times, cells outside the chain window [4, nf-4) zero (:120-121).  Every row of every tile is
   // the image of exactly one extended row, so each rho row is written once, here, while its counts are in
@@ -305,6 +320,37 @@ __global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos
 #pragma unroll
   for (int u = 0; u < RR; u++) if (rin[u]) place(rp[u], rv[u], rid[u]);
   for (int i = r0 + RR * 64 + lane; i < r1; i += 64) { const int src = tidx[i]; place(tpos[i], vel[src], pid[src]); }
+}
+
+// cell_end from the sorted records (after a sort that wrote only the compact table): one wavefront per row, as k_row_sort
+__global__ __launch_bounds__(64) void k_cells_from_sorted(const float4 *__restrict__ spos, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs) {
+  extern __shared__ int bins[];
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int r0 = rs[row], r1 = rs[row + 1];
+  for (int j = lane; j < E; j += 64) bins[j] = 0;
+  __syncthreads();
+  for (int i = r0 + lane; i < r1; i += 64) atomicAdd(&bins[(int)floorf(spos[i].x) + (int)nb], 1);
+  __syncthreads();
+  const int chunk = (E + 63) / 64, j0 = min(lane * chunk, E), j1 = min(j0 + chunk, E);
+  int sum = 0;
+  for (int j = j0; j < j1; j++) sum += bins[j];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  int run = r0 + inc - sum;
+  int *csr = cs + (int64_t)row * E;
+  for (int j = j0; j < j1; j++) { const int t = bins[j]; csr[j] = run; run += t; }
+  if (row == nrows - 1 && lane == 0) csr[E] = r1;
+}
+int particles_full_cells(p3m_ctx *c) {
+  if (!c->cells_compact) return P3M_OK;
+  const Geometry &g = c->g;
+  const int nrows = g.E * g.E;
+  hipLaunchKernelGGL(k_cells_from_sorted, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->spos, (const int *)c->row_end, g.E, nrows,
+                     (float)g.nb, c->cell_end);
+  HIP_TRY(hipGetLastError());
+  c->cells_compact = false;
+  return P3M_OK;
 }
 
 // single rank: all ghost images in one kernel; leaves c->np_all = records incl. ghosts (unsorted)
@@ -360,9 +406,14 @@ int particles_sort(p3m_ctx *c, float deposit_mass) {
   if (deposit_mass >= 0.f && (c->p.flags & P3M_FLAG_NGP) && c->tile_batch == g.ntiles) {
     dep.rho = c->rho; dep.sum_interior = c->d_sums; dep.mass_p = deposit_mass; c->rho_from_sort = true;
   }
+  // whole-step PM-only NGP calls: nothing downstream reads per-cell offsets, only the compact table (p3m_internal.h)
+  static const bool full_always = getenv("P3M_FULL_CELLS") && getenv("P3M_FULL_CELLS")[0] == '1';
+  RowCompact cc{nullptr, c->crow_w, g.ncn, g.ms, g.T, g.pt, g.nb - 2, g.fb};
+  c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT)) && !full_always;
+  if (c->cells_compact) cc.crow = c->crow;
   hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos, (const int *)c->tidx,
                      (const float4 *)c->vel, (const int64_t *)c->pid, (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5,
-                     (int)c->cap, dep);
+                     (int)c->cap, dep, cc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
 }
 
 int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+  P3M_TRY(particles_full_cells(c));
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
@@ -336,6 +337,7 @@ static float first_r2_with_root_above(float t) {
 }
 
 int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+  P3M_TRY(particles_full_cells(c));
   const Geometry &g = c->g;
   if (g.pp_range == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
