@@ -224,7 +224,7 @@ struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, r
 // compact cell table (p3m_internal.h, crow): entry ci < ncn+2 = start of cell ms*ci - ms/2 + nb (what k_coarse_moments reads),
 // entries ncn+2 + 2*tx, +1 = start of cells tx*pt + lo and tx*pt + lo + fb (the force-box row of tile column tx)
 struct RowCompact { int *crow; int w, ncn, ms, T, pt, lo, fb; };   // crow == nullptr: write the full cell_end row
-__global__ __launch_bounds__(64) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ tidx, const float4 *__restrict__ vel,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ tidx, const float4 *__restrict__ vel,
                                                  const int64_t *__restrict__ pid, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
                                                  float4 *__restrict__ spos, float4 *__restrict__ svel, int64_t *__restrict__ spid,
                                                  int *__restrict__ cand, int *__restrict__ ncand, int cand_cap, RowDep dep, RowCompact cc) {
