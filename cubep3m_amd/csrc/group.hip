@@ -745,7 +745,8 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   for (p3m_ctx *c : G->ctx) if (!c->have_kf || !c->have_kc) { p3m_set_error("particle_mesh before the Green's functions were set"); return P3M_ESTATE; }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
   P3M_TRY(ghost_pass(G));                                                                           // :61-63
-  for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort(c, mass_p)); }
+  for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); }   // every rank's sort queued ...
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort_finish(c));                                             // ... before the host waits for the counters
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
   // fine-mesh force sweeps (many small kernels and the all-to-all exchanges against bandwidth-bound FFT passes).  PM-only
   // NGP runs then apply its kick inside the fine kick's pass (k_fine_kick_rows<true>); with a PP kick in between
@@ -779,7 +780,8 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
     if (G->stream2) HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
     for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt));                                   // coarse_velocity
   }
-  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));  // :716-720
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_enqueue(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));  // :716-720
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_finish(c));
   p3m_step_out o;
   P3M_TRY(reduce_step_out(G, a_mid, &o));
   if (out) *out = o;

@@ -90,6 +90,7 @@ struct p3m_ctx {
   int tile_batch = 0;          // tiles processed per sweep
   bool pending_compact = false; int pend_n = 0; float pend_mb[3] = {0, 0, 0};   // deferred ghost removal (particles.hip)
   hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;   // single-rank whole steps: the coarse force forms on stream2 underneath the fine-mesh force sweep
+  int sort_ncur = 0;           // records handed to the sort queued by particles_sort_enqueue
   bool coarse_first = false;   // whole-step PM-only NGP runs: the coarse force is ready before the fine kick, which then adds the coarse kick in the same pass
   bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
@@ -141,10 +142,14 @@ int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset);
 int particles_pass_and_sort(p3m_ctx *c);
 int particles_pass_self(p3m_ctx *c);
 int particles_sort(p3m_ctx *c, float deposit_mass);
+int particles_sort_enqueue(p3m_ctx *c, float deposit_mass);   // the device half ...
+int particles_sort_finish(p3m_ctx *c);                        // ... and the host half (one stream sync, counters)
 int particles_full_cells(p3m_ctx *c);   // cell_end valid again after a sort that wrote the compact table only
 int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts);
 int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);
+int particles_finalize_enqueue(p3m_ctx *c, const float *move_back);
+int particles_finalize_finish(p3m_ctx *c);
 int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset);
 int particles_resolve(p3m_ctx *c);   // finish a deferred ghost removal before the arrival arrays are read
 

@@ -378,7 +378,7 @@ int particles_pass_self(p3m_ctx *c) {
 
 // sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell; deposit_mass >= 0 (whole-step
 // entry points, where mass_p is known here) also writes the NGP density of every tile (c->rho_from_sort)
-int particles_sort(p3m_ctx *c, float deposit_mass) {
+int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   P3M_TRY(particles_resolve(c));
   const Geometry &g = c->g;
   int *cnt = c->d_counters;
@@ -416,11 +416,20 @@ int particles_sort(p3m_ctx *c, float deposit_mass) {
                      (int)c->cap, dep, cc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->sort_ncur = n_cur;
+  return P3M_OK;
+}
+// the host half: counters of the sort queued by particles_sort_enqueue (a group queues every rank's sort before it waits)
+int particles_sort_finish(p3m_ctx *c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->np_deleted = c->h_counters[4];
   c->ncand = (int)std::min<int64_t>(c->h_counters[5], c->cap);
-  c->np_all = n_cur - c->np_deleted;  // sorted records
+  c->np_all = c->sort_ncur - c->np_deleted;  // sorted records
   return P3M_OK;
+}
+int particles_sort(p3m_ctx *c, float deposit_mass) {
+  P3M_TRY(particles_sort_enqueue(c, deposit_mass));
+  return particles_sort_finish(c);
 }
 
 int particles_pass_and_sort(p3m_ctx *c) {
@@ -588,9 +597,10 @@ __global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos,
 // delete_particles: the survivors are counted now (the step's np_local), but the copy back to the arrival arrays is
 // deferred: the next step's drift does it in the same pass (particles_drift), anything else that reads the arrival
 // arrays first calls particles_resolve.
-int particles_finalize(p3m_ctx *c, const float *move_back) {
+int particles_finalize_enqueue(p3m_ctx *c, const float *move_back) {
   const int n = c->np_all;
   c->pending_compact = false;
+  c->pend_n = n;
   if (n == 0) { c->np_local = 0; return P3M_OK; }
   float mx = 0, my = 0, mz = 0;
   if (move_back) { mx = move_back[0]; my = move_back[1]; mz = move_back[2]; }
@@ -598,10 +608,19 @@ int particles_finalize(p3m_ctx *c, const float *move_back) {
   HIP_TRY(hipGetLastError());
   P3M_TRY(exclusive_scan_i32(c, c->flags, n));
   HIP_TRY(hipMemcpyAsync(c->h_counters, c->flags + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->pend_mb[0] = mx; c->pend_mb[1] = my; c->pend_mb[2] = mz;
+  return P3M_OK;
+}
+int particles_finalize_finish(p3m_ctx *c) {
+  if (c->pend_n == 0) return P3M_OK;
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->np_local = c->h_counters[0];
-  c->pending_compact = true; c->pend_n = n; c->pend_mb[0] = mx; c->pend_mb[1] = my; c->pend_mb[2] = mz;
+  c->pending_compact = true;
   return P3M_OK;
+}
+int particles_finalize(p3m_ctx *c, const float *move_back) {
+  P3M_TRY(particles_finalize_enqueue(c, move_back));
+  return particles_finalize_finish(c);
 }
 int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset) {
   if (!c->pending_compact) return P3M_OK;
