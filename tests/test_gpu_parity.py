@@ -84,6 +84,28 @@ def test_fine_deposit_vs_oracle(PM, ngp):
             assert float(rg.sum(dtype=np.float64)) == pytest.approx(float(ro.sum(dtype=np.float64)), rel=1e-7)
 
 
+def test_phase_level_calls_after_a_whole_step_rebuild_the_cell_offsets(PM):
+    """PM-only NGP whole steps write the compact per-row cell table instead of cell_end (particles.hip); a phase-level
+    deposit or projection afterwards must see the full offsets again (particles_full_cells): the NGP density of the
+    sorted records stays bit-exact, the projection matches the oracle."""
+    p = cfg1(ngp=True)
+    g, o = both(PM, p)
+    xv = clustered_particles(20000, 64.0, seed=6, frac=0.4, nblobs=10, sigma=0.8)
+    g.upload_particles(xv)
+    o.set_particles(0, xv)
+    out = g.particle_mesh(0.5, 0.0, 0.0, 8.0)             # dt = 0: nothing moves; leaves the sorted records and the compact table
+    assert out.np_total == len(xv)
+    o.link_list()
+    assert o.particle_pass() == 0
+    for tile in [(0, 0, 0), (1, 0, 1), (1, 1, 1)]:
+        assert np.array_equal(g.tile_density(tile, 8.0), o.tile_density(0, tile, 8.0))
+    g.particle_mesh(0.5, 0.0, 0.0, 8.0)
+    got, want = g.projection(8.0), o.projection(8.0)
+    for a, b in zip(got[:3], want[:3]):
+        assert rel_rms(a, b) < 1e-6
+    assert got[3] == pytest.approx(want[3], rel=1e-6)
+
+
 def test_tile_force_vs_oracle(PM):
     p = cfg1()
     g, o = both(PM, p)
