@@ -229,12 +229,17 @@ def main():
         achieved = alg_bytes / (passes[dom] * 1e-3) / 1e9
         traffic = None
         kname = None
+        sweep_traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                rec = json.load(open(tf)).get(args.config, {}).get("passes", {}).get(dom, {})
+                allp = json.load(open(tf)).get(args.config, {}).get("passes", {})
+                rec = allp.get(dom, {})
                 traffic = rec.get("hbm_bytes_per_launch")
                 kname = rec.get("kernel")
+                step_passes = ("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_extract")
+                if all(k in allp for k in step_passes):   # the five launches of one sweep: PMC bytes and their own launch times
+                    sweep_traffic = sum(allp[k]["hbm_bytes_per_launch"] for k in step_passes)
             except Exception:
                 traffic = None
         if not kname:
@@ -247,7 +252,12 @@ def main():
                     "traffic_frac": (traffic / (passes[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     "fine_sweep": {"ms": sweep_ms, "algorithmic_bytes": 10.5 * S * ntile,
                                    "achieved_GBs": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9,
-                                   "frac": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                                   "frac": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   # the five FFT launches against the HBM bytes rocprofv3's counters report for them
+                                   "fft_passes_ms": sum(passes[k] for k in ("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_extract")),
+                                   "fft_traffic": sweep_traffic,
+                                   "fft_traffic_GBs": (sweep_traffic / (sum(passes[k] for k in ("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_extract")) * 1e-3) / 1e9) if sweep_traffic else None,
+                                   "fft_traffic_frac": (sweep_traffic / (sum(passes[k] for k in ("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_extract")) * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_traffic else None}}
         res = {
             "metric": "particle_updates_per_sec", "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong",
