@@ -88,6 +88,8 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // every entry of [0, ncell] is rewritten by each sort; the pads stay zero
   if (hipMemset(raw, 0, (size_t)(ncell + 16) * sizeof(int)) != hipSuccess) return fail(P3M_EDEVICE);
   raw = nullptr; A(dalloc(&raw, (size_t)g.E * g.E + 16)); c->row_end = raw + 3;   // (row_end+1) is 16-byte aligned for the scan
+  if (particles_preload() != P3M_OK) return fail(P3M_EDEVICE);
+  if (scan_reserve(c, std::max<int64_t>(c->cap, (int64_t)g.E * g.E) + 8) != P3M_OK) return fail(P3M_ENOMEM);
   c->crow_w = (g.ncn + 2 + 2 * g.T + 3) & ~3; A(dalloc(&c->crow, (size_t)g.E * g.E * c->crow_w));
   A(dalloc(&c->d_counters, 16));
   { const int64_t ec = g.E / g.ms; A(dalloc(&c->cflag, (size_t)(ec * ec * ec + 16))); }

@@ -150,6 +150,8 @@ int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, c
 int particles_finalize(p3m_ctx *c, const float *move_back);
 int particles_finalize_enqueue(p3m_ctx *c, const float *move_back);
 int particles_finalize_finish(p3m_ctx *c);
+int particles_preload();
+int scan_reserve(p3m_ctx *c, int64_t n_max);   // scan.hip
 int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset);
 int particles_resolve(p3m_ctx *c);   // finish a deferred ghost removal before the arrival arrays are read
 

@@ -89,10 +89,24 @@ static int scan_rec(p3m_ctx *c, int *d, int64_t n, int *tmp, int *total_out) {
 }
 
 // data must be 16-byte aligned and hold n+1 ints: data[n] receives the total.
-int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n) {
+static size_t scan_tmp_ints(int64_t n) {
   size_t need = 0;
   for (int64_t m = (n + SCAN_CH - 1) / SCAN_CH; m > 1; m = (m + SCAN_CH - 1) / SCAN_CH) need += (size_t)((m + 3) & ~(int64_t)3);
-  need += 8;
+  return need + 8;
+}
+// sized once for the longest scan a context runs (the record flags): a hipFree / hipMalloc pair in the middle of a step
+// is a device-wide synchronisation (28 ms on the default workload, every time the record count set a new maximum)
+int scan_reserve(p3m_ctx *c, int64_t n_max) {
+  const size_t need = scan_tmp_ints(n_max);
+  if (need > c->scan_tmp_n) {
+    if (c->scan_tmp) (void)hipFree(c->scan_tmp);
+    HIP_TRY(hipMalloc(&c->scan_tmp, need * sizeof(int)));
+    c->scan_tmp_n = need;
+  }
+  return P3M_OK;
+}
+int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n) {
+  const size_t need = scan_tmp_ints(n);
   if (need > c->scan_tmp_n) {
     if (c->scan_tmp) (void)hipFree(c->scan_tmp);
     HIP_TRY(hipMalloc(&c->scan_tmp, need * sizeof(int)));
