@@ -18,7 +18,7 @@ MPI_LIB=/opt/conda/lib
 
 SRCS="update_position link_list particle_pass delete_particles move_grid_back mpi_initialization \
       fine_ngp_mass fine_cic_mass fine_cic_mass_buffer coarse_mass coarse_cic_mass \
-      coarse_cic_mass_buffer coarse_force_buffer coarse_max_dt coarse_velocity timestep checkpoint particle_initialization projection"
+      coarse_cic_mass_buffer coarse_force_buffer coarse_max_dt coarse_velocity fine_velocity timestep checkpoint particle_initialization projection"
 
 build_cfg () {  # name nodes_dim tiles nf_tile cores density_buffer "cpp flags"
   local name=$1 nd=$2 T=$3 nf=$4 cores=$5 dens=$6 flags=$7
@@ -84,5 +84,7 @@ build_cfg  cfg1_1rank  1  2 80  2     2.0  "-DNGP -DPID_FLAG"
 build_cfg  cfg1_8rank  2  2 80  2     2.0  "-DNGP"
 # the PP switches change which limits timestep.f90 takes the minimum of (:93-115)
 build_cfg  cfg1_pp     1  2 80  2     2.0  "-DNGP -DPPINT -DPP_EXT -DPID_FLAG"
+# fine CIC build (no -DNGP): the #else branch of fine_velocity.f90:175-203 (CIC gather + kick)
+build_cfg  cfg1_cic    1  2 80  2     2.0  "-DPID_FLAG"
 # the MPI host of tests/test_gpu_group.py (hip_mpi_driver): 8 ranks, PP switches on, DISP_MESH off
 build_cfg  cfg1_8rank_pp 2 2 80 2     2.0  "-DNGP -DPPINT -DPP_EXT"

@@ -896,6 +896,24 @@ void orc_tile_density(orc_ctx *c, int rank, int tx, int ty, int tz, float mass_p
   memcpy(rho_f, w->rho_f, sizeof(float) * (size_t)(c->p.nf_tile + 2) * c->p.nf_tile * c->p.nf_tile);
   ws_free(w);
 }
+/* fine_velocity on a caller-supplied force_f (stands where :202 would have filled it from the FFT): the maximum of
+   :208-223 over the force box, then gather + kick + intra-cell PP of one tile (:227-368; twin fine_velocity.f90:39-235).
+   out[0] = max |F|^2 over the box, out[1] = pp_force_max of this tile.  Needs link_list (+ particle_pass). */
+void orc_tile_velocity(orc_ctx *c, int rank, int tx, int ty, int tz, const float *force_f, float a_mid, float dt, float mass_p, float *out) {
+  int pt = c->nf_physical_tile_dim; size_t n = 3 * (size_t)(pt + 3) * (pt + 3) * (pt + 3);
+  tile_ws *w = ws_alloc(c); int tile[3] = {tx, ty, tz};
+  memcpy(w->force_f, force_f, sizeof(float) * n);
+  float fmax2 = 0.f;
+  for (size_t i = 0; i < n; i += 3) {
+    float fm = w->force_f[i] * w->force_f[i] + w->force_f[i + 1] * w->force_f[i + 1] + w->force_f[i + 2] * w->force_f[i + 2];
+    if (fm > fmax2) fmax2 = fm;
+  }
+  float pm = 0.f;
+  tile_velocity(c, &c->r[rank], tile, a_mid, dt, mass_p, w, &pm);
+  out[0] = fmax2; out[1] = pm;
+  ws_free(w);
+}
+
 void orc_tile_force(orc_ctx *c, const float *rho_f, float *force_f, float *force_max2) {
   tile_ws *w = ws_alloc(c); int pt = c->nf_physical_tile_dim;
   memcpy(w->rho_f, rho_f, sizeof(float) * (size_t)(c->p.nf_tile + 2) * c->p.nf_tile * c->p.nf_tile);

@@ -68,6 +68,9 @@ int orc_particle_mesh(orc_ctx *c, float a_mid, float dt, float dt_old, float mas
 void orc_projection(orc_ctx *c, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_tot);
 void orc_tile_density(orc_ctx *c, int rank, int tx, int ty, int tz, float mass_p, float *rho_f);
 void orc_tile_force(orc_ctx *c, const float *rho_f, float *force_f, float *force_max2);
+/* gather + kick + intra-cell PP of one tile on a caller-supplied force box (3,(pt+3)^3 component fastest);
+   out[0] = max |F|^2 over the box (:208-223), out[1] = pp_force_max (:355-358) */
+void orc_tile_velocity(orc_ctx *c, int rank, int tx, int ty, int tz, const float *force_f, float a_mid, float dt, float mass_p, float *out);
 void orc_coarse_density(orc_ctx *c, float mass_p);           /* coarse_mass on all ranks */
 const float *orc_rho_c(orc_ctx *c, int rank);                /* (ncn,ncn,ncn)            */
 const float *orc_force_c(orc_ctx *c, int rank);              /* (3,0:ncn+1,0:ncn+1,0:ncn+1) */

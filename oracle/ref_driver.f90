@@ -147,6 +147,26 @@ subroutine ref_fine_deposit(tile, use_ngp, rho_out) bind(C, name="ref_fine_depos
   rho_out(:, :, :) = rho_f(:, :, :, thread)
 end subroutine ref_fine_deposit
 
+! fine_velocity.f90:6-237 (the non-inlined twin of particle_mesh_threaded.f90:208-368: force maximum, NGP/CIC gather +
+! kick, intra-cell PP) on a caller-supplied force_f, which stands where :202 would have filled it from the FFT.
+! out = f_force_max(1) (fine_velocity.f90:39-50: the maximum of |F|, not of |F|^2), pp_force_max(1)
+subroutine ref_fine_velocity(tile, f_in, out) bind(C, name="ref_fine_velocity")
+  use iso_c_binding
+  implicit none
+  include 'cubepm.fh'
+  integer(c_int) :: tile(3)
+  real(c_float) :: f_in(3, nf_buf-1:nf_tile-nf_buf+1, nf_buf-1:nf_tile-nf_buf+1, nf_buf-1:nf_tile-nf_buf+1)
+  real(c_float) :: out(2)
+  integer(4) :: thread
+  thread = 1
+  force_f(:, :, :, :, thread) = f_in
+  f_force_max(thread) = 0.0
+  pp_force_max(thread) = 0.0
+  call fine_velocity(tile, thread)
+  out(1) = f_force_max(thread)
+  out(2) = pp_force_max(thread)
+end subroutine ref_fine_velocity
+
 subroutine ref_coarse_mass(rho_out) bind(C, name="ref_coarse_mass")
   use iso_c_binding
   implicit none

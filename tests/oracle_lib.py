@@ -57,6 +57,7 @@ def lib():
         L.orc_particle_mesh.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(P3MStepOut)]
         L.orc_tile_density.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, f32p]
         L.orc_tile_force.argtypes = [C.c_void_p, f32p, f32p, C.POINTER(C.c_float)]
+        L.orc_tile_velocity.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_float, C.c_float, C.c_float, f32p]
         L.orc_projection.argtypes = [C.c_void_p, C.c_float, f32p, f32p, f32p, C.POINTER(C.c_double)]
         L.orc_coarse_density.argtypes = [C.c_void_p, C.c_float]
         L.orc_rho_c.restype = C.POINTER(C.c_float)
@@ -179,6 +180,12 @@ class Oracle:
         m = C.c_float()
         self.L.orc_tile_force(self.h, np.ascontiguousarray(rho, np.float32), f, C.byref(m))
         return f, m.value
+
+    def tile_velocity(self, rank, tile, f, a_mid, dt, mass_p):
+        """gather + kick + intra-cell PP of one tile on the force box f [k][j][i][3]; -> (max |F|^2, pp_force_max)"""
+        out = np.zeros(2, np.float32)
+        self.L.orc_tile_velocity(self.h, rank, tile[0], tile[1], tile[2], np.ascontiguousarray(f, np.float32), a_mid, dt, mass_p, out)
+        return float(out[0]), float(out[1])
 
     def coarse_density(self, mass_p):
         self.L.orc_coarse_density(self.h, mass_p)

@@ -35,6 +35,8 @@ class Ref:
         L.ref_get_lists.argtypes = [i32p, i32p]
         L.ref_fine_deposit.argtypes = [i32p, C.c_int, f32p]
         L.ref_coarse_mass.argtypes = [f32p]
+        if hasattr(L, "ref_fine_velocity"):
+            L.ref_fine_velocity.argtypes = [i32p, f32p, f32p]
         L.ref_set_force_c.argtypes = [f32p]
         L.ref_get_force_c.argtypes = [f32p]
         L.ref_coarse_max_dt.restype = C.c_float
@@ -89,6 +91,12 @@ class Ref:
         rho = np.empty((nf, nf, nf + 2), np.float32)
         self.L.ref_fine_deposit(np.asarray(tile, np.int32), 1 if ngp else 0, rho)
         return rho
+
+    def fine_velocity(self, tile, f):
+        """f: force box [k][j][i][3] of (pt+3)^3 cells -> (max |F|, pp_force_max) after fine_velocity.f90 ran on it."""
+        out = np.zeros(2, np.float32)
+        self.L.ref_fine_velocity(np.asarray(tile, np.int32), np.ascontiguousarray(f, np.float32), out)
+        return float(out[0]), float(out[1])
 
     def coarse_mass(self):
         n = self.nc_node_dim

@@ -64,3 +64,21 @@ def test_oracle_reproduces_reference_stage_outputs(nd):
         assert np.array_equal(x, d[key(r, "xv_final")])
         if nd == 1:
             assert np.array_equal(q, d["pid_final"])
+
+
+@pytest.mark.parametrize("cfg,ngp,ppint", [("cfg1_pp", True, True), ("cfg1_1rank", True, False), ("cfg1_cic", False, False)])
+def test_oracle_reproduces_reference_fine_velocity(cfg, ngp, ppint):
+    """fine_velocity.f90 (force maximum, NGP / CIC gather + kick, intra-cell PP: SURVEY 8a rows a10-a12) as the
+    reference's object code computed it on a synthetic force box (generator tests/golden/make_ref_fine_velocity.py)."""
+    from test_oracle_vs_ref import oracle_fine_velocity
+
+    d = np.load(os.path.join(G, "ref_fine_velocity.npz"))
+    xv, pid = d["xv_in"], d["pid_in"]
+    fmax2, ppmax, x, q = oracle_fine_velocity(cfg1(ngp=ngp, ppint=ppint), xv, pid, tuple(float(v) for v in d["scal"]))
+    n = len(xv)
+    assert len(x) == int(d[cfg + "_np_passed"])
+    assert np.array_equal(q[:n], pid) and np.array_equal(x[:n, :3], xv[:, :3])
+    assert np.array_equal(x[:n, 3:], d[cfg + "_vel"])
+    assert np.array_equal(np.sqrt(fmax2), d[cfg + "_f_force_max"])
+    assert np.array_equal(ppmax, d[cfg + "_pp_force_max"])
+    assert (ppmax.max() > 10.0) == ppint

@@ -108,3 +108,22 @@ def test_pair_force_vanishes_below_rsoft():
 def test_pair_force_mesh_envelope(r, lo, hi):
     ratios = [_pair_ratio(r, 7 * s + int(r))[0] for s in range(3)]
     assert all(lo <= q <= hi for q in ratios), ratios
+
+
+# --- PM + PP + extended PP on the clustered input of SURVEY Appendix C (second row of its table): 30 % of 32 768
+#     particles in 48 Gaussian blobs of sigma 0.6 (default_rng(2024)), reference built -DNGP -DPPINT -DPP_EXT.
+#     Recorded from that run: dt_pp_acc = 0.085387, dt_pp_ext_acc = 0.0936061 ("reproduced to all printed digits"),
+#     kick rms 1.564e-2.
+def test_pm_pp_ext_clustered_matches_reference_run():
+    from common import clustered_particles
+
+    o = ol.Oracle(cfg1(ngp=True, ppint=True, pp_ext=True))
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    xv = clustered_particles(32768, 64.0, seed=2024, frac=0.3, nblobs=48, sigma=0.6)
+    o.set_particles(0, xv)
+    out = o.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    xo, pid = o.get_particles(0)
+    assert out.np_total == 32768
+    assert out.dt_pp_acc == pytest.approx(0.085387, rel=2e-6)
+    assert out.dt_pp_ext_acc == pytest.approx(0.0936061, rel=2e-6)
+    assert rms(xo[:, 3:]) == pytest.approx(1.564e-2, rel=5e-4)

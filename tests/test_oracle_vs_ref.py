@@ -137,3 +137,61 @@ def test_eight_rank_ghost_pass_and_deposits_bitwise():
     for rk in range(8):
         assert list(refs[rk]["cart_coords"]) == [rk // 4, (rk // 2) % 2, rk % 2]
     compare_with_oracle(p, parts, refs, pids_travel=False)
+
+
+# ---- fine_velocity.f90: force maximum, NGP / CIC gather + kick, intra-cell PP -------------------
+def fine_velocity_input(n=5000, seed=99):
+    # 35 % of the particles in tight blobs: dozens of fine cells hold 2...40 particles (the PPINT pair loops), a few pairs
+    # closer than rsoft (the hard cut of :340)
+    xv = clustered_particles(n, 64.0, seed=seed, frac=0.35, nblobs=10, sigma=0.5, vel_sigma=0.5)
+    xv[1::97, :3] = xv[0:-1:97, :3] + np.float32(0.01)       # pairs inside rsoft = 0.1
+    xv[:, :3] = np.clip(xv[:, :3], 0, np.float32(63.999))
+    pid = np.arange(1, n + 1, dtype=np.int64) * 3 + 1
+    return xv, pid
+
+
+def oracle_fine_velocity(p, xv, pid, scal):
+    from ref_fv_run import all_tiles, synth_force_f
+
+    a_mid, dt, dt_old, mass_p = scal
+    o = ol.Oracle(p)
+    o.set_particles(0, xv, pid)
+    o.link_list()
+    assert o.particle_pass() == 0
+    fb = p.nf_physical_tile_dim + 3
+    fmax2, ppmax = [], []
+    for t in all_tiles(p.tiles_node_dim):
+        a, b = o.tile_velocity(0, t, synth_force_f(fb, t), a_mid, dt, mass_p)
+        fmax2.append(a)
+        ppmax.append(b)
+    x, q = o.get_particles(0)
+    return np.asarray(fmax2, np.float32), np.asarray(ppmax, np.float32), x, q
+
+
+def check_fine_velocity(p, xv, pid, scal, ref):
+    fmax2, ppmax, x, q = oracle_fine_velocity(p, xv, pid, scal)
+    assert np.array_equal(q, ref["pid_kicked"])
+    assert np.array_equal(x[:, :3], ref["xv_kicked"][:, :3])
+    assert np.array_equal(x[:, 3:], ref["xv_kicked"][:, 3:]), "fine kick / intra-cell PP kick differ from fine_velocity.f90"
+    # fine_velocity.f90:39-50 keeps max |F|, the threaded file max |F|^2 (:208-223) and takes the root later (:643-652):
+    # the correctly rounded square root is monotonic, so the two agree exactly
+    assert np.array_equal(np.sqrt(fmax2), ref["f_force_max"])
+    assert np.array_equal(ppmax, ref["pp_force_max"])
+    return ppmax
+
+
+@pytest.mark.parametrize("cfg,ngp,ppint", [("cfg1_pp", True, True), ("cfg1_1rank", True, False), ("cfg1_cic", False, False)])
+def test_fine_velocity_bitwise(cfg, ngp, ppint):
+    if not ref_lib.available(cfg):
+        pytest.skip("oracle/_ref not built")
+    xv, pid = fine_velocity_input()
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), xv=xv, pid=pid, scal=np.asarray(SCAL, np.float32))
+        subprocess.check_call([sys.executable, os.path.join(HERE, "ref_fv_run.py"), cfg, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")],
+                              stdout=subprocess.DEVNULL, preexec_fn=_big_stack, env=CHILD_ENV)
+        ref = dict(np.load(os.path.join(td, "out.npz")))
+    ppmax = check_fine_velocity(cfg1(ngp=ngp, ppint=ppint), xv, pid, SCAL, ref)
+    if ppint:
+        assert ppmax.max() > 100.0   # the pair loops did run on dense cells
+    else:
+        assert ppmax.max() == 0.0
