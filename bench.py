@@ -72,16 +72,23 @@ def make_particles(nside, box, seed=12345):
 
 
 def cpu_baseline(scal):
-    """The CPU oracle (tests/oracle_lib.py: a C port of the reference path, OpenMP like the reference's `!$omp do`)
-    on a bounded sample: a 256^3-cell sub-volume (BASELINE configs[1]: 128^3 particles of the same uniform density,
-    nf_tile=176, 2^3 tiles), full particle_mesh steps.  Checker-side code, used here only as the reported baseline."""
+    """The CPU oracle (tests/oracle_lib.py: a C port of the reference path, OpenMP over fine tiles like the reference's
+    `!$omp do`) on a bounded sample: a 256^3-cell sub-volume (BASELINE configs[1]: 128^3 particles of the same uniform
+    density), full particle_mesh steps, on ALL host cores of this box: 2^3 tiles of 176 when the box has <= 8 cores,
+    4^3 tiles of 112 (64 work items) otherwise.  Checker-side code, used here only as the reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
-    p = Params(**CONFIGS["cfg2"]["params"])
-    fine, coarse = default_tables()
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 8))
+    try:
+        cores_avail = len(os.sched_getaffinity(0))
+    except Exception:
+        cores_avail = cores
+    key = "cfg2" if cores_avail <= 8 else "cfg2_t4"
+    p = Params(**CONFIGS[key]["params"])
+    ntile = p.tiles_node_dim ** 3
+    fine, coarse = default_tables()
+    threads = max(1, min(cores_avail, ntile))
     os.environ["OMP_NUM_THREADS"] = str(threads)
     xv = make_particles(128, 256.0)
     o = ol.Oracle(p)
@@ -93,12 +100,17 @@ def cpu_baseline(scal):
     while True:
         o.particle_mesh(a_mid, dt, dt_old, mass_p)
         steps += 1
-        if time.perf_counter() - t0 > 12.0 or steps >= 12:
+        if time.perf_counter() - t0 > 15.0 or steps >= 12:
             break
     el = time.perf_counter() - t0
     return {"value": len(xv) * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "sample": "%d full particle_mesh step(s) of a 256^3-cell / 128^3-particle sub-volume (same density, nf_tile=176, 2^3 tiles) on the "
-                      "CPU oracle (C port of the reference path, OpenMP over fine tiles as the reference does), %.1f s" % (steps, el)}
+            "host_cpus": cores, "host_cpus_usable": cores_avail,
+            "sample": "%d full particle_mesh step(s) of a 256^3-cell / 128^3-particle sub-volume (same density, nf_tile=%d, %d^3 tiles = %d work "
+                      "items) on the CPU oracle (C port of the reference path, OpenMP over fine tiles as the reference does) with %d threads "
+                      "on a box with %d CPUs, %.1f s.  Context (survey-time probe of the reference Fortran itself, amdflang + MKL FFT shim, "
+                      "dev container, 4 OpenMP threads, same 256^3/128^3 problem, BASELINE.md section 2): 1.65e6 particle-updates/s PM-only, "
+                      "0.96e6 with PP + extended PP; the reference's own 2007 log (8 cores, 128^3 particles, PM+PP): 8.8e4"
+                      % (steps, p.nf_tile, p.tiles_node_dim, ntile, threads, cores, el)}
 
 
 def main():
@@ -233,7 +245,12 @@ def main():
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                allp = json.load(open(tf)).get(args.config, {}).get("passes", {})
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                from make_traffic import fft_source_sha16
+
+                recj = json.load(open(tf)).get(args.config, {})
+                # byte counts recorded for other FFT sources than the ones running now are stale: traffic stays null
+                allp = recj.get("passes", {}) if recj.get("fft_source_sha16") == fft_source_sha16() else {}
                 rec = allp.get(dom, {})
                 traffic = rec.get("hbm_bytes_per_launch")
                 kname = rec.get("kernel")

@@ -227,7 +227,9 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
   for (int r = proc * per; r < (proc + 1) * per; r++) {
     p3m_params p = *base; p.rank = r; p.device = G->device;
     p3m_ctx *c = nullptr;
+    p3m_ctx_share_hint = (proc + 1) * per - r;   // this context and the ones still to come share what is free now
     int rc = p3m_hip_create(&p, &c);
+    p3m_ctx_share_hint = 1;
     if (rc) return fail(rc);
     (void)hipStreamDestroy(c->stream); c->stream = G->stream;   // one stream for the whole group
     G->lidx[r] = (int)G->ctx.size(); G->ctx.push_back(c); G->lrank.push_back(r);
@@ -310,11 +312,6 @@ extern "C" int p3m_hip_group_set_transport(p3m_group *G, const p3m_transport *t)
   if (!G || !t || !t->exchange || !t->allreduce_max_f32 || !t->allreduce_sum_f64) return P3M_EINVAL;
   G->tr = *t; G->have_tr = true;
   return P3M_OK;
-}
-extern "C" int p3m_hip_comm_init_rccl(p3m_ctx *ctx, const void *unique_id_128) {
-  (void)ctx; (void)unique_id_128;
-  p3m_set_error("multi-rank contexts are driven through p3m_hip_group_* (p3m_hip_group_comm_init_rccl)");
-  return P3M_ECOMM;
 }
 extern "C" int32_t p3m_hip_group_nlocal(const p3m_group *G) { return G ? (int32_t)G->ctx.size() : -1; }
 extern "C" int32_t p3m_hip_group_local_rank(const p3m_group *G, int32_t i) { return (G && i >= 0 && i < (int)G->lrank.size()) ? G->lrank[i] : -1; }

@@ -11,9 +11,13 @@ struct File {
   FILE *f = nullptr;
   ~File() { if (f) fclose(f); }
   bool open(const char *path, const char *mode) { f = fopen(path, mode); if (!f) p3m_set_error("cannot open %s", path); return f != nullptr; }
+  // writers: an ENOSPC / EIO often only surfaces when stdio's buffer is flushed, so the file counts as written only once
+  // both the flush and the close succeeded
+  bool finish() { if (!f) return false; const bool ok = fflush(f) == 0; const bool ok2 = fclose(f) == 0; f = nullptr; return ok && ok2; }
 };
 // one record: payload of n bytes, framed unless binary
 bool put(FILE *f, const void *p, size_t n, bool binary) {
+  if (!binary && n > 0x7fffffffu) { p3m_set_error("record of %zu bytes does not fit a Fortran sequential record (4-byte markers)", n); return false; }
   const int32_t m = (int32_t)n;
   if (!binary && fwrite(&m, 4, 1, f) != 1) return false;
   if (n && fwrite(p, 1, n, f) != n) return false;
@@ -64,6 +68,7 @@ extern "C" int p3m_hip_write_checkpoint(const char *path, const p3m_ckpt_header 
     const float rec[6] = {p[0] - s0, p[1] - s1, p[2] - s2, p[3], p[4], p[5]};
     ok = put(F.f, rec, sizeof(rec), binary != 0);
   }
+  ok = F.finish() && ok;
   if (!ok) { p3m_set_error("write error on %s", path); return P3M_EINVAL; }
   return P3M_OK;
 }
@@ -83,6 +88,7 @@ extern "C" int p3m_hip_write_pid_checkpoint(const char *path, const p3m_ckpt_hea
   unsigned char hb[48];
   bool ok = put(F.f, hb, pack_header(h, ppint != 0, hb), binary != 0);
   for (int64_t j = 0; ok && j < h->np_local; j++) ok = put(F.f, pid + j, 8, binary != 0);   // checkpoint.f90:118-123
+  ok = F.finish() && ok;
   if (!ok) { p3m_set_error("write error on %s", path); return P3M_EINVAL; }
   return P3M_OK;
 }
@@ -100,7 +106,10 @@ extern "C" int p3m_hip_read_pid_checkpoint(const char *path, p3m_ckpt_header *h,
 extern "C" int p3m_hip_write_projection(const char *path, float a, const float *map, int32_t n, int32_t binary) {
   if (!path || !map || n < 1) return P3M_EINVAL;
   File F; if (!F.open(path, "wb")) return P3M_EINVAL;
-  if (!put(F.f, &a, 4, binary != 0) || !put(F.f, map, (size_t)4 * n * n, binary != 0)) { p3m_set_error("write error on %s", path); return P3M_EINVAL; }
+  if (!binary && (size_t)4 * n * n > 0x7fffffffu) { p3m_set_error("%s: a %d^2 map does not fit one Fortran sequential record", path, n); return P3M_EINVAL; }
+  bool ok = put(F.f, &a, 4, binary != 0) && put(F.f, map, (size_t)4 * n * n, binary != 0);
+  ok = F.finish() && ok;
+  if (!ok) { p3m_set_error("write error on %s", path); return P3M_EINVAL; }
   return P3M_OK;
 }
 extern "C" int p3m_hip_read_projection(const char *path, float *a, float *map, int32_t n, int32_t binary) {
@@ -115,6 +124,7 @@ extern "C" int p3m_hip_write_ic(const char *path, const float *xv6, int32_t np_l
   bool ok = put(F.f, &np_local, 4, binary != 0);                                   // dist_init writes np_local first
   if (binary) ok = ok && put(F.f, xv6, (size_t)24 * np_local, true);               // read(20) xv(:,:np_local), :330
   else for (int64_t i = 0; ok && i < np_local; i++) ok = put(F.f, xv6 + 6 * i, 24, false);   // read(20) xv(:,i) per particle, :326-328
+  ok = F.finish() && ok;
   if (!ok) { p3m_set_error("write error on %s", path); return P3M_EINVAL; }
   return P3M_OK;
 }

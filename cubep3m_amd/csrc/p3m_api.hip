@@ -60,6 +60,7 @@ static int fill_geometry(const p3m_params *p, Geometry *g) {
 
 extern "C" int32_t p3m_hip_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
+int p3m_ctx_share_hint = 1;   // contexts still to be created on this device, set by p3m_hip_group_create around its p3m_hip_create calls
 extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   if (!params || !out) return P3M_EINVAL;
   *out = nullptr;
@@ -94,9 +95,11 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   A(dalloc(&c->d_counters, 16));
   { const int64_t ec = g.E / g.ms; A(dalloc(&c->cflag, (size_t)(ec * ec * ec + 16))); }
   if (hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), 16 * sizeof(int)) != hipSuccess) return fail(P3M_ENOMEM);
-  // fine mesh: as many tiles per sweep as fit a 48 GiB budget for rho+work
+  // fine mesh: as many tiles per sweep as fit the budget for rho+work: 64 GiB, or this context's share (a group places
+  // several logical ranks on one device: p3m_ctx_share_hint) of 60 % of what is free on the device now, whichever is less
   const size_t S = (size_t)(2 * g.px) * g.nf * g.nf;
   size_t budget = (size_t)64 << 30;
+  { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) budget = std::min(budget, (size_t)(0.6 * (double)fr) / (size_t)std::max(1, p3m_ctx_share_hint)); }
   c->tile_batch = (int)std::max<size_t>(1, std::min<size_t>(g.ntiles, budget / (4 * S * sizeof(float))));
   A(dalloc(&c->rho, S * c->tile_batch)); A(dalloc(&c->work, 3 * S * c->tile_batch));
   if (hipMemset(c->rho, 0, S * c->tile_batch * sizeof(float)) != hipSuccess || hipMemset(c->work, 0, 3 * S * c->tile_batch * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
@@ -433,9 +436,10 @@ extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt
                                      const float *move_back, p3m_step_out *out) {
   if (!c) return P3M_EINVAL;
   P3M_TRY(need_kernels(c));
+  // every parameter / state check comes before the first state change (the drift)
+  if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }
   P3M_TRY(p3m_hip_update_position(c, dt, dt_old, offset));   // :56
   HIP_TRY(hipSetDevice(c->device));
-  if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }
   P3M_TRY(reductions_clear(c));
   P3M_TRY(particles_pass_self(c));                           // :61-63
   P3M_TRY(particles_sort(c, mass_p));
@@ -593,13 +597,6 @@ extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, fl
   *ms_per_launch = ms / reps;
   if (batch) *batch = nt;
   return P3M_OK;
-}
-
-// ------------------------------------------------------------------ transport (multi-rank) -- see group.hip
-extern "C" int p3m_hip_set_transport(p3m_ctx *c, const p3m_transport *t) {
-  (void)c; (void)t;
-  p3m_set_error("multi-rank contexts are driven through p3m_hip_group_* (p3m_hip_group_set_transport)");
-  return P3M_ECOMM;
 }
 
 // ------------------------------------------------------------------ F77-ABI wrapper (style of pp_force_c_, nbody-ueli.cu:368)

@@ -126,6 +126,7 @@ struct p3m_ctx {
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- fft.hip
+extern int p3m_ctx_share_hint;   // p3m_api.hip: contexts that share the device's free memory (set by group.hip around p3m_hip_create)
 int fft_plan_create(FftPlan *pl, int n);
 void fft_plan_destroy(FftPlan *pl);
 // batched 3-D r2c: data holds real ROWS ([n][n][2*px]) on entry and rho-hat in the bundle layout LZ on

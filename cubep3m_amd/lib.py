@@ -20,8 +20,8 @@ f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 # every entry point include/p3m_hip.h declares
 EXPORTS = [
-    "p3m_hip_create", "p3m_hip_destroy", "p3m_hip_last_error", "p3m_hip_device_count", "p3m_hip_derived", "p3m_hip_set_transport",
-    "p3m_hip_rccl_unique_id", "p3m_hip_comm_init_rccl", "p3m_hip_set_kernel_tables", "p3m_hip_set_kernels_raw",
+    "p3m_hip_create", "p3m_hip_destroy", "p3m_hip_last_error", "p3m_hip_device_count", "p3m_hip_derived",
+    "p3m_hip_rccl_unique_id", "p3m_hip_set_kernel_tables", "p3m_hip_set_kernels_raw",
     "p3m_hip_get_kernels", "p3m_hip_upload_particles", "p3m_hip_download_particles", "p3m_hip_particle_mesh",
     "p3m_hip_update_position", "p3m_hip_link_list_and_pass", "p3m_hip_fine_mesh", "p3m_hip_coarse_mesh",
     "p3m_hip_delete_particles", "p3m_hip_get_step_out", "p3m_hip_probe_tile_density", "p3m_hip_probe_tile_force",

@@ -130,11 +130,9 @@ int32_t p3m_hip_device_count(void);   /* GPUs visible to this process (an MPI ho
    2 nc_node_dim, 3 nf_physical_node_dim, 4 nc_slab, 5 nf_physical_tile_dim */
 int64_t p3m_hip_derived(const p3m_ctx *ctx, int32_t what);
 
-int p3m_hip_set_transport(p3m_ctx *ctx, const p3m_transport *t);   /* always P3M_ECOMM: use p3m_hip_group_set_transport */
 /* RCCL over xGMI: unique_id is the 128-byte ncclUniqueId the host broadcast from rank 0
-   (p3m_hip_rccl_unique_id fills it on rank 0). */
+   (p3m_hip_rccl_unique_id fills it on rank 0); handed to p3m_hip_group_comm_init_rccl. */
 int p3m_hip_rccl_unique_id(void *unique_id_128);
-int p3m_hip_comm_init_rccl(p3m_ctx *ctx, const void *unique_id_128); /* always P3M_ECOMM: use p3m_hip_group_comm_init_rccl */
 
 /* -- Green's functions (kernel_initialization.f90) -------------------------------------- */
 /* fine_table: the 16^3 rows of kernels/wfxyzf.3.ascii as float[16][16][16][3] with the file's

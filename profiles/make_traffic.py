@@ -7,7 +7,17 @@ bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB; on gfx950 
 64 bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section), hence the factor 2 on the read side.
 Writes <out prefix>_pmc_hbm.csv and updates profiles/pmc_traffic.json[config] (read by bench.py for roofline.traffic).
 """
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
+
+
+def fft_source_sha16():
+    """Identity of the FFT pass kernels the byte counts belong to: bench.py reports roofline.traffic only while the
+    sources it runs hash to the same value (anything else is a stale file and reads as null)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("fft.hip", "fft_core.h"):
+        h.update(open(os.path.join(root, "cubep3m_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 PASS_OF = [  # kernel-name prefix (template arguments included where they tell passes apart) -> FFT pass of the fine sweep
     ("void k_fft_x_fwd", "x_fwd"), ("void k_fft_x_inv", "x_inv_extract"), ("void k_fft_lines3", "z_inv_fused"),
@@ -55,7 +65,7 @@ def main(prefix, config, out):
             passes[ps] = {"kernel": k, "launches": nl, "hbm_bytes_per_launch": b, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024}
     tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
     allj = json.load(open(tf)) if os.path.exists(tf) else {}
-    allj[config] = {"passes": passes, "source": os.path.relpath(out + "_pmc_hbm.csv", os.path.dirname(tf) + "/.."),
+    allj[config] = {"passes": passes, "fft_source_sha16": fft_source_sha16(), "source": os.path.relpath(out + "_pmc_hbm.csv", os.path.dirname(tf) + "/.."),
                     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 --warmup 2 --no-cpu`; "
                               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 counts a 128-byte read request as 64 bytes)"}
     json.dump(allj, open(tf, "w"), indent=1)

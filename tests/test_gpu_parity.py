@@ -535,7 +535,7 @@ def test_bench_sized_tile_force_and_fft_vs_oracle(PM):
     assert np.abs(back[:, :, :n] - rho[:, :, :n]).max() < 1e-4 and np.all(back[:, :, n:] == 0)
 
 
-@pytest.mark.parametrize("n", [64, 96, 128, 160, 192, 208, 224, 256, 304, 352, 384, 448, 608])   # (512: its coarse mesh, 116 = 4 * 29, has no radix)
+@pytest.mark.parametrize("n", [64, 80, 96, 112, 128, 160, 176, 192, 208, 224, 256, 304, 320, 352, 384, 448, 608])   # (512: its coarse mesh, 116 = 4 * 29, has no radix)
 def test_tile_force_at_the_register_fft_sizes(PM, n):
     """Every tile size with two-register-stage FFT kernels (fft.hip, P3M_LINES2_SIZES / P3M_X2_SIZES) through the whole fine
     force: forward x and y passes, fused z pass, pruned inverse y and x passes, force box -- against the oracle."""
@@ -569,3 +569,150 @@ def test_fallback_paths_stay_at_parity(switch):
                        env=dict(os.environ, **{switch: "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+# ---------------------------------------------------------------------------------- the reference's own force-accuracy harness on the HIP path
+def _pair_setup(r, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.random(3) * 40 + 12
+    u = rng.normal(size=3)
+    u /= np.linalg.norm(u)
+    xv = np.zeros((2, 6), np.float32)
+    xv[0, :3] = c - 0.5 * r * u
+    xv[1, :3] = c + 0.5 * r * u
+    return xv
+
+
+@pytest.mark.parametrize("r", [0.05, 0.3, 1.0, 2.0, 3.0, 4.0, 8.0, 16.0, 28.0])
+def test_report_pair_two_particle_force_on_the_hip_path(PM, r):
+    """report_pair.f90:50-63 (pairwise_ic: two particles of mass 10000, a = dt = 1, particle_initialization.f90:388,
+    timestep.f90:200-217): F_sim = v/dt/mass_p against Newton's F = -G r/r^3 -- through the HIP path, held to the
+    ORACLE's value of the same quantities (the reference's mesh force scatters by 5-20 % at 3-16 cells; parity means the
+    same scatter, SURVEY 'Pair-force envelope'), and to the closed form where the reference itself is Newtonian."""
+    p = cfg1(ngp=True, ppint=True, pp_ext=True)
+    mass, a_mid, dt = 10000.0, 1.0, 1.0
+    G = 1.0 / 6.0 / 3.141592654
+    for s in range(2):
+        xv = _pair_setup(r, 10 * s + int(10 * r))
+        g, o = both(PM, p)
+        g.upload_particles(xv)
+        o.set_particles(0, xv)
+        g.particle_mesh(a_mid, dt, 0.0, mass)
+        o.particle_mesh(a_mid, dt, 0.0, mass)
+        xg, _ = by_pid(*g.download_particles())
+        xo, _ = by_pid(*o.get_particles(0))
+        sep = (xv[0, :3] - xv[1, :3]).astype(np.float64)
+        rr = np.linalg.norm(sep)
+        newton = G * mass * a_mid * dt / rr ** 2
+        fg, fo = xg[:, 3:].astype(np.float64), xo[:, 3:].astype(np.float64)
+        # magF_sim, magF_sim_r (radial), magF_sim_t (tangential) of report_pair.f90:54-61, in units of the Newtonian force
+        assert np.abs(fg - fo).max() <= 2e-5 * max(np.abs(fo).max(), 1e-30) + 1e-7 * newton
+        radial = -np.dot(fg[0], sep / rr) / newton
+        if r <= 0.1:
+            assert abs(radial) < 1e-6                     # hard cut at rsoft (:340, :558)
+        elif r <= 2.0:
+            assert radial == pytest.approx(1.0, abs=3e-4)   # inside the PP range: Newtonian
+            assert np.allclose(fg[0], -fg[1], rtol=0, atol=2e-4 * np.abs(fg).max() + 1e-12)   # pairwise PP: momentum
+
+
+def test_report_force_superposition_on_the_hip_path(PM):
+    """report_force.f90:31-103: kick every particle from rest, remove ONE particle from a dense region (dig a hole),
+    kick again from rest; the difference of the two kicks is the force of the removed particle alone.  Held to the
+    oracle's difference particle by particle, and to -G m r/r^3 for the partners inside the PP range (where the reference
+    is Newtonian); linearity of the whole path in the density is what the test exercises."""
+    p = cfg1(ngp=True, ppint=True, pp_ext=True)
+    a_mid, dt, mass = 1.0, 1.0, 8.0
+    xv = clustered_particles(20000, 64.0, seed=77, frac=0.3, nblobs=8, sigma=0.9)
+    pid = np.arange(1, len(xv) + 1, dtype=np.int64)
+    hole = 5                                          # a blob member: the first 30 % of the records sit in the blobs
+    keep = np.ones(len(xv), bool)
+    keep[hole] = False
+    dv = {}
+    for name, (mk, eng) in {"gpu": (lambda: PM(p, FINE_TABLE, COARSE_TABLE), "g"), "orc": (lambda: both(PM, p)[1], "o")}.items():
+        res = []
+        for sel in (np.ones(len(xv), bool), keep):
+            e = mk()
+            if eng == "g":
+                e.upload_particles(xv[sel], pid[sel])
+                e.particle_mesh(a_mid, dt, 0.0, mass)
+                x, q = by_pid(*e.download_particles())
+            else:
+                e.set_particles(0, xv[sel], pid[sel])
+                e.particle_mesh(a_mid, dt, 0.0, mass)
+                x, q = by_pid(*e.get_particles(0))
+            res.append((x, q))
+        (x1, q1), (x2, q2) = res
+        m = np.isin(q1, q2)
+        assert np.array_equal(q1[m], q2)
+        dv[name] = (x1[m, 3:].astype(np.float64) - x2[:, 3:].astype(np.float64), x2[:, :3].astype(np.float64))
+    d_g, pos = dv["gpu"]
+    d_o, _ = dv["orc"]
+    # the difference of two kicks of size ~|v| carries their rounding: compare on the scale of the kick itself
+    x1g = np.abs(d_g).max()
+    assert rel_rms(d_g, d_o) < 2e-3 and np.abs(d_g - d_o).max() < 2e-4 * x1g + 1e-7
+    sep = pos - xv[hole, :3].astype(np.float64)
+    sep -= 64.0 * np.round(sep / 64.0)
+    rr = np.linalg.norm(sep, axis=1)
+    near = (rr > 0.15) & (rr < 1.5)
+    assert near.sum() > 20
+    G = 1.0 / 6.0 / 3.141592654
+    newton = -G * mass * a_mid * dt * sep[near] / rr[near, None] ** 3
+    assert rel_rms(d_g[near], newton) < 2e-2          # cell-boundary cases of the PP range keep this from being 1e-4
+
+
+# ---------------------------------------------------------------------------------- BASELINE configs 2 and 5 at full size
+def test_config2_pm_only_full_size_properties(PM):
+    """BASELINE config 2: 256^3 fine mesh / 128^3 particles, PM only (NGP), 2^3 tiles of 176 (the tile size every cfg2
+    bench line runs): size-independent properties of a whole step, and the kick against the oracle on a sample."""
+    p = Params(tiles_node_dim=2, nf_tile=176, ngp=True, density_buffer=1.5)
+    n = 128 ** 3
+    xv = grid_jitter_particles(128, 256.0, seed=778, sigma=0.4)
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    g.upload_particles(xv)
+    out = g.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    assert out.np_total == n and out.np_deleted == 0
+    assert out.sum_rho_f == 8.0 * n                               # NGP: integer counts times mass_p, exact
+    assert out.sum_rho_c == pytest.approx(8.0 * n, rel=1e-6)
+    assert np.isfinite(out.dt_f_acc) and np.isfinite(out.dt_c_acc) and out.dt_f_acc > 0 and out.dt_c_acc > 0
+    xo, pid = g.download_particles()
+    assert np.array_equal(np.sort(pid), np.arange(1, n + 1))
+    o = np.argsort(pid)
+    assert np.array_equal(xo[o, :3], xv[:, :3])                   # dt_old = 0
+    dv = xo[:, 3:].astype(np.float64)
+    assert np.abs(dv.mean(0)).max() < 2e-3 * rms(dv)
+    # idempotence of the particle set under a zero-length step
+    out2 = g.particle_mesh(0.005, 0.0, 0.0, 8.0)
+    assert out2.np_total == n and out2.np_ghost == out.np_ghost
+    assert out2.dt_f_acc == pytest.approx(out.dt_f_acc, rel=1e-6)
+
+
+def test_config5_one_gpu_share_properties(PM):
+    """BASELINE config 5 (2048^3 mesh / 1024^3 particles, PM + PP + extended PP on 8 GPUs): ONE GPU's share -- 1024^3
+    fine cells, 512^3 particles, 2^3 tiles of 560, PPINT + PP_EXT -- through size-independent properties: every particle
+    back exactly once, mass on both meshes, momentum, finite limits."""
+    p = Params(tiles_node_dim=2, nf_tile=560, ngp=True, ppint=True, pp_ext=True, density_buffer=1.3)
+    n = 512 ** 3
+    rng = np.random.default_rng(5)
+    xv = np.zeros((n, 6), np.float32)
+    xv[:, :3] = rng.random((n, 3), dtype=np.float32) * np.float32(1024.0)
+    np.minimum(xv[:, :3], np.float32(1023.999), out=xv[:, :3])
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    g.upload_particles(xv)
+    out = g.particle_mesh(0.005, 0.2, 0.0, 8.0)
+    assert out.np_total == n and out.np_deleted == 0
+    assert out.sum_rho_f == 8.0 * n
+    assert out.sum_rho_c == pytest.approx(8.0 * n, rel=1e-6)
+    for name in ("dt_f_acc", "dt_pp_acc", "dt_pp_ext_acc", "dt_c_acc"):
+        v = getattr(out, name)
+        assert np.isfinite(v) and v > 0, name
+    xo, pid = g.download_particles()
+    del g
+    assert len(pid) == n
+    seen = np.zeros(n + 1, bool)
+    seen[pid] = True
+    assert seen[1:].all()
+    o = np.argsort(pid)
+    assert np.array_equal(xo[o, :3], xv[:, :3])
+    sv = xo[:, 3:].sum(0, dtype=np.float64)
+    sq = np.sqrt((xo[:, 3:].astype(np.float64) ** 2).mean())
+    assert np.abs(sv / n).max() < 2e-3 * sq
