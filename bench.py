@@ -52,6 +52,10 @@ CONFIGS = {
     # configs[1] with the CIC mass assignment / interpolation (the reference built without -DNGP)
     "cfg2_cic": dict(params=dict(tiles_node_dim=2, nf_tile=176, ngp=False, density_buffer=1.5), nside_rank=128,
                      workload="256^3 fine mesh / 128^3 particles, PM-only (CIC), nf_tile=176, 2^3 tiles, 64^3 coarse"),
+    # configs[3]'s problem with the short-range forces on (the P3M step of the north star; configs[4]'s flags at configs[3]'s size)
+    "cfg4_pp": dict(params=dict(nodes_dim=2, tiles_node_dim=1, nf_tile=560, ngp=True, ppint=True, pp_ext=True, density_buffer=1.3), nside_rank=256,
+                    workload="1024^3 fine mesh / 512^3 particles, PM+PP+PP_EXT (NGP), 2x2x2 logical ranks, nf_tile=560 (one tile per rank), "
+                             "256^3 coarse mesh with slab FFT + all-to-all transpose"),
     # one rank's share of configs[3] on its own
     "big512": dict(params=dict(tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3), nside_rank=256,
                    workload="512^3 fine mesh / 256^3 particles (one rank's share of 1024^3/512^3), PM-only, nf_tile=560, 1 tile"),
@@ -69,6 +73,56 @@ def make_particles(nside, box, seed=12345):
     np.minimum(xv[:, :3], np.float32(box * (1 - 2e-6)), out=xv[:, :3])
     xv[:, 3:] = rng.normal(0, 0.05, (n, 3)).astype(np.float32)
     return xv
+
+
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector), spec
+# flop per pair evaluation as the kernels spend them (sub 3, r^2 5, rsqrt 1, magnitudes 5, force 6, accumulate 3 = 23; the
+# extended kernel adds the polynomial taper: q 1, q^3 2, q^5 2, taper 4, scaling 3 = 35)
+PP_FLOP_INTRA, PP_FLOP_EXT = 23.0, 35.0
+
+
+def clustered(nside, box, seed, frac, nblobs, sigma):
+    n = nside ** 3
+    rng = np.random.default_rng(seed)
+    nb = int(frac * n)
+    pos = rng.random((n, 3)) * box
+    centers = rng.random((nblobs, 3)) * box
+    pos[:nb] = centers[rng.integers(0, nblobs, nb)] + rng.normal(0, sigma, (nb, 3))
+    pos = np.mod(pos, box).astype(np.float32)
+    np.minimum(pos, np.float32(box * (1 - 2e-6)), out=pos)
+    xv = np.zeros((n, 6), np.float32)
+    xv[:, :3] = pos
+    return xv
+
+
+def pp_leg():
+    """The two short-range kernels on their own (BASELINE configs[2] geometry: 256^3 cells / 128^3 particles, PPINT + PP_EXT):
+    pair evaluations per launch, evaluations/s and the fraction of the FP32 vector peak they amount to, for the uniform IC and
+    for the clustered IC of SURVEY Appendix C (30 % of the particles in Gaussian blobs of sigma 0.6 cells, default_rng(2024))
+    at two blob sizes."""
+    from cubep3m_amd.particle_mesh import ParticleMesh
+
+    p = Params(**CONFIGS["cfg3"]["params"])
+    fine, coarse = default_tables()
+    out = {"geometry": CONFIGS["cfg3"]["workload"], "peak_fp32_valu_TFLOPs": FP32_VALU_PEAK_TFLOPS,
+           "flop_per_evaluation": {"intra": PP_FLOP_INTRA, "extended": PP_FLOP_EXT},
+           "note": "an evaluation is one partner summed into one kicked record (a pair of two kicked records is evaluated twice)"}
+    ics = {"uniform": lambda: make_particles(128, 256.0),
+           "clustered_205_per_blob": lambda: clustered(128, 256.0, 2024, 0.3, 3072, 0.6),     # Appendix C's blobs at Appendix C's density
+           "clustered_13k_per_blob": lambda: clustered(128, 256.0, 2024, 0.3, 48, 0.6)}      # the same 48 blobs holding 64x the particles
+    for name, gen in ics.items():
+        g = ParticleMesh(p, fine, coarse)
+        g.upload_particles(gen())
+        g.link_list_and_pass()
+        ms_i, ms_e, n_i, n_e = g.time_pp(0.5, 0.0, 8.0, reps=5)       # dt = 0: the repeated kicks leave the velocities alone
+        g.delete_particles()
+        g.close()
+        out[name] = {
+            "intra": {"evaluations": n_i, "ms": ms_i, "evaluations_per_s": n_i / (ms_i * 1e-3) if ms_i > 0 else None,
+                      "valu_frac": n_i * PP_FLOP_INTRA / (ms_i * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12) if ms_i > 0 else None},
+            "extended": {"evaluations": n_e, "ms": ms_e, "evaluations_per_s": n_e / (ms_e * 1e-3) if ms_e > 0 else None,
+                         "valu_frac": n_e * PP_FLOP_EXT / (ms_e * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12) if ms_e > 0 else None}}
+    return out
 
 
 def cpu_baseline(scal):
@@ -120,6 +174,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the non-headline legs of the default run (PM+PP step at the headline's size, PP kernel rates)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the host side (gloo: debugging on fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -284,6 +339,32 @@ def main():
                        "flags": {"ngp": p.ngp, "ppint": p.ppint, "pp_ext": p.pp_ext}},
             "roofline": roofline,
         }
+        if world == 1 and args.config == "cfg4" and not args.no_extra:
+            # non-headline legs (rank 0, one GPU): the same 512^3-particle problem with PPINT + PP_EXT on, and the two
+            # short-range kernels on their own
+            grp.close()
+            p2 = Params(**CONFIGS["cfg4_pp"]["params"])
+            p2.device = local_dev
+            g2 = ParticleMeshGroup(p2, 0, 1, fine, coarse)
+            for i, r in enumerate(g2.local_ranks):
+                xv = make_particles(nside, box, seed=12345 + r)
+                g2.upload_particles(i, xv, np.arange(1, len(xv) + 1, dtype=np.int64) + r * len(xv))
+                del xv
+            for _ in range(2):
+                g2.particle_mesh(a_mid, dt, dt_old, mass_p)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            k2 = max(3, min(args.steps, 6))
+            for _ in range(k2):
+                o2 = g2.particle_mesh(a_mid, dt, dt_old, mass_p)
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            assert o2.np_total == n_total
+            g2.close()
+            res["pm_pp"] = {"metric": "particle_updates_per_sec", "value": n_total * k2 / el2, "ms_per_step": 1e3 * el2 / k2, "steps": k2,
+                            "workload": CONFIGS["cfg4_pp"]["workload"], "data": "synthetic uniform (the headline's particles)",
+                            "dt_pp_acc": o2.dt_pp_acc, "dt_pp_ext_acc": o2.dt_pp_ext_acc}
+            res["pp"] = pp_leg()
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(scal)
         print(json.dumps(res), flush=True)

@@ -135,7 +135,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->pid); dfree(c->spos); dfree(c->svel); dfree(c->spid);
-  dfree(c->tpos); dfree(c->tidx); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters);
+  dfree(c->tpos); dfree(c->tidx); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);

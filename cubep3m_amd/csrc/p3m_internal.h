@@ -84,6 +84,7 @@ struct p3m_ctx {
   int *flags = nullptr;        // [cap] compaction flags / offsets
   unsigned char *cflag = nullptr; // [(E/ms)^3] coarse cells holding a record whose tile-local cell differs from floor(x)
   int *cand = nullptr; int ncand = 0; // [cap] sorted indices of records within 2^-10 below a cell face
+  int *pp_plan = nullptr, *pp_task_group = nullptr, *pp_counter = nullptr;   // extended PP (pp.hip): first task of every row group, task -> group, task counter
   int *d_counters = nullptr;   // small device counter block
   int *h_counters = nullptr;   // pinned mirror
   // ---- fine mesh, all tiles batched

@@ -328,6 +328,222 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
   }
 }
 
+// ------------------------------------------------------------------ extended PP, version 2: one wavefront per 64 home records
+// No block-level staging, no barriers between wavefronts: at the reference's density (1/8 particle per fine cell, ~15
+// partners per record) k_pp_ext_tiled spent 94 % of its instructions on staging and on walking 25 mostly empty row
+// windows per record (rocprofv3: 530 lane-instructions per pair evaluation), and with strong clustering a few workgroups
+// did all the work.  Here a TASK is 64 consecutive home records of a group of PP_RG x-rows of one tile's extended region;
+// k_pp_plan counts the tasks of every group, a scan turns the counts into first-task numbers, k_pp_fill writes the
+// task -> group table, and persistent wavefronts draw tasks from a counter (dense tasks take thousands of times longer
+// than sparse ones: no static split balances them).  One lane per home record:
+//   sparse path: the lane collects the sorted indices of its partners (the clipped row windows of k_pp_ext, read straight
+//     from cell_end through L1/L2) in a list in LDS, then sums over the list -- every lane busy with its own partners;
+//   dense path (a lane's list would overflow): the wavefront walks the union of its lanes' windows row by row, loads 64
+//     partners at a time (one per lane, coalesced) and broadcasts them one by one (v_readlane); each lane keeps the
+//     partners inside its own window.  Neighbouring home records share almost all partners, so each partner is loaded once
+//     per 64 home records.
+#define PP_RG 16
+#define PP_LCAP 40
+#define PP_CHUNK 4
+#define PP_NSEG 64
+__global__ __launch_bounds__(256) void k_pp_plan(const int *__restrict__ cs, PPGeo G, int ngy, int ngroups, int *__restrict__ plan) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const int e = G.pt + 2 * G.ppr;
+  const int gy = g % ngy, rz = (g / ngy) % e, tile = g / (ngy * e);
+  const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+  const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
+  int count = 0;
+  for (int j = 0; j < PP_RG; j++) {
+    const int ry = gy * PP_RG + j;
+    if (ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count += cs[rb + lox + e] - cs[rb + lox]; }
+  }
+  plan[g] = (count + 63) >> 6;
+}
+__global__ __launch_bounds__(256) void k_pp_fill(const int *__restrict__ plan, int ngroups, int *__restrict__ task_group, int cap) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const int k1 = min(plan[g + 1], cap);
+  for (int k = plan[g]; k < k1; k++) task_group[k] = g;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+struct PPForce { float mass_p, pp_bias, ibias, incut, r2_soft, r2_taper; };
+__device__ __forceinline__ void pp_ext_eval(const float4 &p, float ox, float oy, float oz, const PPForce &F, float &ax, float &ay, float &az) {
+  const float sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
+  const float r2 = sx * sx + sy * sy + sz * sz;
+  if (r2 >= F.r2_soft) {                                                 // :558, decided exactly on r^2 (see k_pp_ext_tiled)
+    const float ir = __builtin_amdgcn_rsqf(r2), rb1 = (r2 * ir) * F.pp_bias, ib = ir * F.ibias, irb3 = ib * ib * ib;
+    float fx = F.mass_p * (sx * irb3), fy = F.mass_p * (sy * irb3), fz = F.mass_p * (sz * irb3);
+    if (r2 < F.r2_taper) {                                               // :559-564
+      const float qq = rb1 * F.incut;
+      const float taper = 1.f - (7.0f / 4.0f) * (qq * qq * qq) + (3.0f / 4.0f) * (qq * qq * qq * qq * qq);
+      fx *= taper; fy *= taper; fz *= taper;
+    }
+    ax -= fx; ay -= fy; az -= fz;                                        // :571
+  }
+}
+template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
+__global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G, PPForce F,
+                                                float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
+                                                const int *__restrict__ task_group, int ngroups, int ngy, int ntask_cap, int *__restrict__ counter) {
+  __shared__ int list[PP_LCAP][64];
+  __shared__ int rstart[PP_RG], roff[PP_RG];
+  const int lane = threadIdx.x;
+  const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E;
+  const int ntask = min(plan[ngroups], ntask_cap);
+  // PP_NSEG task counters on cache lines of their own, each handing out the tasks of one contiguous segment (atomics on ONE
+  // address serialise at ~12 ns each: 145 000 fetches from a single counter were half of this kernel's run time); a
+  // wavefront starts at its own segment and moves on round robin when a segment runs dry
+  const int per = (ntask + PP_NSEG - 1) / PP_NSEG;
+  int seg = blockIdx.x % PP_NSEG;
+  for (int tried = 0; tried < PP_NSEG;) {
+    const int sbeg = min(seg * per, ntask), send = min(sbeg + per, ntask);
+    int tf = 0;
+    if (lane == 0) {   // a plain (agent-coherent) load first: a dry segment costs no read-modify-write
+      tf = __hip_atomic_load(counter + 32 * seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tf < send - sbeg) tf = atomicAdd(counter + 32 * seg, PP_CHUNK);
+    }
+    tf = sbeg + __builtin_amdgcn_readfirstlane(tf);
+    if (tf >= send) { seg = (seg + 1) % PP_NSEG; tried++; continue; }
+    tried = 0;
+    const int tl = min(tf + PP_CHUNK, send);
+    for (int t = tf; t < tl; t++) {
+      const int g = task_group[t], sub = t - plan[g];
+      const int gy = g % ngy, rz = (g / ngy) % e, tile = g / (ngy * e);
+      const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+      const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
+      const int cz = loz + rz;
+      // the group's rows: first record and exclusive prefix of the home counts
+      int cnt = 0, st = 0;
+      if (lane < PP_RG) {
+        const int ry = gy * PP_RG + lane;
+        if (ry < e) { const int64_t rb = ((int64_t)cz * E + (loy + ry)) * E; st = cs[rb + lox]; cnt = cs[rb + lox + e] - st; }
+      }
+      int inc = cnt;
+#pragma unroll
+      for (int o = 1; o < PP_RG; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+      const int total = __shfl(inc, PP_RG - 1, 64);
+      __syncthreads();                                    // the previous task's readers of rstart / roff / list are done
+      if (lane < PP_RG) { rstart[lane] = st; roff[lane] = inc - cnt; }
+      __syncthreads();
+      const int h = sub * 64 + lane;
+      const bool valid = h < total;
+      int j = 0;
+#pragma unroll
+      for (int k = 1; k < PP_RG; k++) j += (roff[k] <= h) ? 1 : 0;
+      const int s = valid ? rstart[j] + (h - roff[j]) : 0;
+      const float4 p = valid ? spos[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int cx = valid ? (int)floorf(p.x) + G.nb : lox + ppr;                // :412
+      const int cy = loy + gy * PP_RG + (valid ? j : 0);
+      int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);               // uniform over the wavefront
+      // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): see k_pp_ext
+      if (cz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
+      const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1);
+      const int x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      // ---- sparse attempt: list the partners
+      int n = 0;
+      if (PPR > 0) {
+        // compile-time reach: every window of the (2 PPR + 1)^2 partner rows is loaded before the first one is used
+        constexpr int NW = PPR > 0 ? (2 * PPR + 1) * (2 * PPR + 1) : 1, ND = 2 * PPR + 1;
+        int wa[NW], wb[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const int zz = cz - PPR + w / ND, yy = cy - PPR + w % ND;
+          const bool ok = valid && zz >= z0 && zz <= z1 && yy >= y0 && yy <= y1;
+          const int64_t rb = ((int64_t)(ok ? zz : cz) * E + (ok ? yy : cy)) * E;
+          wa[w] = 0; wb[w] = 0;
+          if (ok) { wa[w] = cs[rb + x0]; wb[w] = cs[rb + x1 + 1]; }
+        }
+        int s0 = 0, s1 = 0;
+        if (valid) { const int64_t rb = ((int64_t)cz * E + cy) * E; s0 = cs[rb + cx]; s1 = cs[rb + cx + 1]; }   // own cell is excluded (:515-516)
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const bool own = (w == NW / 2);
+          for (int q = wa[w]; q < wb[w]; q++) {
+            if (own && q >= s0 && q < s1) { q = s1 - 1; continue; }
+            if (n < PP_LCAP) list[n][lane] = q;
+            n++;
+          }
+        }
+      } else {
+        for (int zz = z0; zz <= z1; zz++)
+          for (int dy = -ppr; dy <= ppr; dy++) {
+            const int yy = cy + dy;
+            const bool yok = valid && yy >= y0 && yy <= y1;
+            const int64_t rb = ((int64_t)zz * E + (yok ? yy : cy)) * E;
+            int a = 0, b = 0, s0 = 0, s1 = 0;
+            if (yok) { a = cs[rb + x0]; b = cs[rb + x1 + 1]; }
+            if (yok && zz == cz && dy == 0) { s0 = cs[rb + cx]; s1 = cs[rb + cx + 1]; }    // own cell is excluded (:515-516)
+            for (int q = a; q < b; q++) {
+              if (q >= s0 && q < s1) { q = s1 - 1; continue; }
+              if (n < PP_LCAP) list[n][lane] = q;
+              n++;
+            }
+          }
+      }
+      const int nmax = wave_max_i(n);
+      if (nmax <= PP_LCAP) {
+        // four partners in flight at a time
+        for (int k = 0; k < nmax; k += 4) {
+          float4 o[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { o[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (k + u < n) o[u] = spos[list[k + u][lane]]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (k + u < n) pp_ext_eval(p, o[u].x, o[u].y, o[u].z, F, ax, ay, az);
+        }
+      } else {
+        // ---- dense path: the union of the lanes' windows, 64 partners at a time
+        const int Y0 = wave_min_i(valid ? y0 : 0x7fffffff), Y1 = wave_max_i(valid ? y1 : -1);
+        const int X0 = wave_min_i(valid ? x0 : 0x7fffffff), X1 = wave_max_i(valid ? x1 : -1);
+        for (int zz = z0; zz <= z1; zz++)
+          for (int yy = Y0; yy <= Y1; yy++) {
+            const int64_t rb = ((int64_t)zz * E + yy) * E;
+            const int A = cs[rb + X0], B = cs[rb + X1 + 1];
+            const bool rowok = valid && yy >= y0 && yy <= y1;
+            const bool ownrow = (zz == cz && yy == cy);
+            for (int base = A; base < B; base += 64) {
+              const int m = min(64, B - base);
+              float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (lane < m) o = spos[base + lane];
+              const int ocx = (int)floorf(o.x) + G.nb;
+              for (int jj = 0; jj < m; jj++) {
+                const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), jj));
+                const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), jj));
+                const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), jj));
+                const int pcx = __builtin_amdgcn_readlane(ocx, jj);
+                if (rowok && pcx >= x0 && pcx <= x1 && !(ownrow && pcx == cx)) pp_ext_eval(p, px, py, pz, F, ax, ay, az);
+              }
+            }
+          }
+      }
+      float mag = 0.f;
+      if (valid) {
+        const int ry = cy - loy;
+        const bool phys = (cx >= lox + ppr && cx < lox + ppr + G.pt && ry >= ppr && ry < ppr + G.pt && rz >= ppr && rz < ppr + G.pt);
+        if (phys) {                                                                   // :576-582
+          float4 v = svel[s];
+          v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
+          svel[s] = v;
+        }
+        mag = sqrtf(ax * ax + ay * ay + az * az);                                     // :617
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
+      if (lane == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(mag));
+    }
+  }
+}
+
 // the smallest float r2 with sqrtf(r2) > t (sqrtf is correctly rounded and monotone): "rmag > t" becomes "r2 >= this"
 static float first_r2_with_root_above(float t) {
   float r2 = t * t;
@@ -342,6 +558,39 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (g.pp_range == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   const int e = g.pt + 2 * g.pp_range;
+  static const bool v1 = getenv("P3M_PP_EXT_V1") && getenv("P3M_PP_EXT_V1")[0] == '1';   // A/B switch: the LDS-tiled kernel of round 1
+  if (!v1) {
+    const int ngy = (e + PP_RG - 1) / PP_RG;
+    const int64_t ngroups64 = (int64_t)g.ntiles * e * ngy;
+    // a record is a home record of every tile whose extended region holds its cell: per axis at most 2 + 2*ppr/pt tiles
+    const int64_t mult1 = std::min<int64_t>(g.T, 2 + (2 * g.pp_range) / g.pt), mult = mult1 * mult1 * mult1;
+    const int64_t ntask_cap64 = mult * (c->cap / 64 + 1) + ngroups64 + 64;
+    if (ngroups64 > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many row groups"); return P3M_EINVAL; }
+    const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
+    if (!c->pp_plan) {
+      HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups + 8)));
+      HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)ntask_cap));
+      HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
+      P3M_TRY(scan_reserve(c, ngroups + 8));
+    }
+    HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
+    hipLaunchKernelGGL(k_pp_plan, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, ngy, ngroups, c->pp_plan);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
+    hipLaunchKernelGGL(k_pp_fill, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, c->pp_task_group, ntask_cap);
+    HIP_TRY(hipGetLastError());
+    PPForce F{mass_p, G.pp_bias, 1.0f / G.pp_bias, 1.0f / G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f))};
+    static const int wpc = getenv("P3M_PP_WPC") ? atoi(getenv("P3M_PP_WPC")) : 15;          // resident wavefronts per CU (10.4 KB of LDS each)
+    static const bool unr = getenv("P3M_PP_UNROLL") && getenv("P3M_PP_UNROLL")[0] == '1';    // compile-time reach: all 25 windows loaded up front (116 VGPRs)
+    if (g.pp_range == 2 && unr)
+      hipLaunchKernelGGL(k_pp_ext2<2>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, F, a_mid, dt,
+                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, ntask_cap, c->pp_counter);
+    else
+      hipLaunchKernelGGL(k_pp_ext2<0>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, F, a_mid, dt,
+                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, ntask_cap, c->pp_counter);
+    HIP_TRY(hipGetLastError());
+    return P3M_OK;
+  }
   if (g.pp_range <= 4) {
     // x extent of a block: about 200 busy lanes (home records x PP_LPH) at the mean density, at most 128 cells
     const double rho = (double)c->np_all / ((double)g.E * g.E * g.E);
@@ -362,5 +611,86 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   hipLaunchKernelGGL(k_pp_ext, dim3(blocks), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, mass_p, a_mid,
                      dt, c->d_tile_ext);
   HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+
+
+// ------------------------------------------------------------------ measurement hook (bench.py: pairs/s of the two PP kernels)
+// Pair EVALUATIONS as the kernels perform them: every kicked record sums over all its partners, so a pair of two
+// kicked records is evaluated twice (the reference's loops visit it once and update both members).
+//   intra    : sum over physical fine cells of n*(n-1)
+//   extended : sum over the records of every tile's extended region of the records in their partner cells (same
+//              clipping and the same half-shell reach as k_pp_ext)
+__global__ __launch_bounds__(256) void k_pp_count_intra(const float4 *__restrict__ spos, const int *__restrict__ cs, int n, PPGeo G, unsigned long long *__restrict__ out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long c = 0;
+  if (s < n) {
+    const float4 p = spos[s];
+    const float fNn = (float)G.Nn;
+    if (p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn) {
+      const int bx = (int)floorf(p.x) + G.nb, by = (int)floorf(p.y) + G.nb, bz = (int)floorf(p.z) + G.nb;
+      const int64_t cell = ((int64_t)bz * G.E + by) * G.E + bx;
+      c = (unsigned long long)(cs[cell + 1] - cs[cell] - 1);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+__global__ __launch_bounds__(64) void k_pp_count_ext(const float4 *__restrict__ spos, const int *__restrict__ cs, PPGeo G, unsigned long long *__restrict__ out) {
+  const int e = G.pt + 2 * G.ppr;
+  const int ry = blockIdx.x % e, rz = (blockIdx.x / e) % e, tile = blockIdx.x / (e * e);
+  const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+  const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
+  const int cy = loy + ry, cz = loz + rz;
+  const int64_t rowb = ((int64_t)cz * G.E + cy) * G.E;
+  const int p0 = cs[rowb + lox], p1 = cs[rowb + lox + e];
+  unsigned long long c = 0;
+  for (int s = p0 + threadIdx.x; s < p1; s += 64) {
+    const int cx = (int)floorf(spos[s].x) + G.nb;
+    int z0 = max(cz - G.ppr, loz), z1 = min(cz + G.ppr, loz + e - 1);
+    if (cz - loz >= G.pt + G.ppr) z1 = min(z1, loz + G.pt + G.ppr - 1);
+    const int y0 = max(cy - G.ppr, loy), y1 = min(cy + G.ppr, loy + e - 1);
+    const int x0 = max(cx - G.ppr, lox), x1 = min(cx + G.ppr, lox + e - 1);
+    for (int zz = z0; zz <= z1; zz++)
+      for (int yy = y0; yy <= y1; yy++) {
+        const int64_t rb = ((int64_t)zz * G.E + yy) * G.E;
+        c += (unsigned long long)(cs[rb + x1 + 1] - cs[rb + x0]);
+        if (zz == cz && yy == cy) c -= (unsigned long long)(cs[rb + cx + 1] - cs[rb + cx]);
+      }
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if (threadIdx.x == 0 && c) atomicAdd(out, c);
+}
+
+extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, int32_t reps, float *ms_intra, float *ms_ext, int64_t *evals_intra,
+                               int64_t *evals_ext) {
+  if (!c || reps < 1 || !ms_intra || !ms_ext || !evals_intra || !evals_ext) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(c->device));
+  P3M_TRY(particles_full_cells(c));
+  const Geometry &g = c->g;
+  PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
+  unsigned long long *d_cnt = nullptr, h_cnt[2] = {0, 0};
+  HIP_TRY(hipMalloc(&d_cnt, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
+  if (c->np_all > 0) {
+    hipLaunchKernelGGL(k_pp_count_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->np_all, G, d_cnt);
+    const int e = g.pt + 2 * g.pp_range;
+    if (g.pp_range > 0)
+      hipLaunchKernelGGL(k_pp_count_ext, dim3((unsigned)((int64_t)g.ntiles * e * e)), dim3(64), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, G, d_cnt + 1);
+  }
+  HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, c->stream));
+  hipEvent_t e0, e1, e2;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+  P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); P3M_TRY(pp_extended(c, a_mid, dt, mass_p));   // warm-up
+  HIP_TRY(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < reps; i++) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  for (int i = 0; i < reps; i++) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
+  HIP_TRY(hipEventRecord(e2, c->stream));
+  HIP_TRY(hipEventSynchronize(e2));
+  float a = 0.f, b = 0.f;
+  HIP_TRY(hipEventElapsedTime(&a, e0, e1)); HIP_TRY(hipEventElapsedTime(&b, e1, e2));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipFree(d_cnt);
+  *ms_intra = a / reps; *ms_ext = b / reps; *evals_intra = (int64_t)h_cnt[0]; *evals_ext = (int64_t)h_cnt[1];
   return P3M_OK;
 }

@@ -172,6 +172,13 @@ class ParticleMesh:
         _lib.check(self.L.p3m_hip_time_fine_sweep(self.h, mass_p, reps, C.byref(ms)))
         return ms.value
 
+    def time_pp(self, a_mid, dt, mass_p, reps=5):
+        """(ms per k_pp_intra launch, ms per extended-PP launch, pair evaluations of each) on the sorted records with
+        ghosts (after link_list_and_pass)."""
+        a, b, na, nb = C.c_float(), C.c_float(), C.c_int64(), C.c_int64()
+        _lib.check(self.L.p3m_hip_time_pp(self.h, a_mid, dt, mass_p, reps, C.byref(a), C.byref(b), C.byref(na), C.byref(nb)))
+        return a.value, b.value, na.value, nb.value
+
     FFT_PASSES = ("x_fwd", "y_fwd", "z_fwd", "z_inv_fused", "y_inv", "x_inv_extract")
 
     def time_fft_pass(self, which, reps=20):

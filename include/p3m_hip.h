@@ -196,6 +196,11 @@ int p3m_hip_time_fine_sweep(p3m_ctx *ctx, float mass_p, int32_t reps, float *ms_
    the i*K multiply, 4 y-inverse lines, 5 x-inverse (c2r rows) + force-box extraction.  *batch returns
    the number of tiles one launch processed. */
 int p3m_hip_time_fft_pass(p3m_ctx *ctx, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch);
+/* Benchmark hook for the two PP kernels (particle_mesh_threaded.f90:324-361 and :378-624) on the sorted records with ghosts
+   (call p3m_hip_link_list_and_pass first; velocities are kicked `reps`+1 times): average ms per launch and the number of
+   pair evaluations one launch performs (a pair of two kicked records counts twice: each member sums over its partners). */
+int p3m_hip_time_pp(p3m_ctx *ctx, float a_mid, float dt, float mass_p, int32_t reps, float *ms_intra, float *ms_ext, int64_t *evals_intra,
+                    int64_t *evals_ext);
 /* HIP stream the kernels are launched on (for hipEvent timing by the host). */
 void *p3m_hip_stream(p3m_ctx *ctx);
 
