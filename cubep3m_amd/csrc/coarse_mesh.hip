@@ -286,3 +286,84 @@ int build_coarse_kernel(p3m_ctx *c, const float *table4_host) {
   c->have_kc = true;
   return P3M_OK;
 }
+
+
+// ------------------------------------------------------------------ coarse_power.f90:2-139: mass power spectrum of the coarse density
+// The reference transforms rho-hat back, forms the overdensity rho_c / rho_c_mean - 1 and transforms again (:27-35): away
+// from k = 0 that is rho-hat / rho_c_mean, which is what is binned here (the k = 0 mode is skipped by :62 anyway), straight
+// from the rho-hat the coarse force pass left in LZ order ([ky][chunk][kz][16 kx]).  Per mode as the reference writes it
+// (:60-98): the kx = 0 plane counts each conjugate pair once, bin k1 = ceiling(|k|) with weight 1, and the sinc^4
+// deconvolution divides the imaginary part's square only.  Sums in double (the reference adds in real(4)).
+// ps_acc: [2][nc+2] doubles (weights, power); `planes` ky rows starting at ky0 (a whole mesh, or one rank's ky slab).
+__global__ __launch_bounds__(256) void k_coarse_power(const float2 *__restrict__ lz, int planes, int ky0, int nc, int nchunk, float inv_mean,
+                                                      double *__restrict__ ps_acc) {
+  extern __shared__ double bins[];   // [2][nc+2]
+  const int nb = nc + 2;
+  for (int i = threadIdx.x; i < 2 * nb; i += 256) bins[i] = 0.0;
+  __syncthreads();
+  const int64_t tot = (int64_t)planes * nchunk * nc * 16;
+  const int hc = nc / 2;
+  const float fnc = (float)nc, n3 = fnc * fnc * fnc;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
+    const int l = (int)(idx & 15), kzi = (int)((idx >> 4) % nc), chunk = (int)((idx / (16 * (int64_t)nc)) % nchunk), o = (int)(idx / (16 * (int64_t)nc * nchunk));
+    const int kxi = chunk * 16 + l, kyi = ky0 + o;
+    if (kxi > hc) continue;                                                  // pad columns
+    const float kx = (float)kxi, ky = (kyi < hc + 1) ? (float)kyi : (float)(kyi - nc), kz = (kzi < hc + 1) ? (float)kzi : (float)(kzi - nc);   // :45-56
+    if (kxi == 0 && ky <= 0.f && kz <= 0.f) continue;                        // :60
+    if (kxi == 0 && ky > 0.f && kz < 0.f) continue;                          // :61
+    const float kr = sqrtf(kx * kx + ky * ky + kz * kz);
+    if (kr == 0.0f) continue;
+    const int k1 = (int)ceilf(kr);
+    const float x = P3M_PI_F * kx / fnc, y = P3M_PI_F * ky / fnc, z = P3M_PI_F * kz / fnc;
+    const float sx = (x == 0.f) ? 1.f : sinf(x) / x, sy = (y == 0.f) ? 1.f : sinf(y) / y, sz = (z == 0.f) ? 1.f : sinf(z) / z;
+    const float kernel = sx * sy * sz, k2 = kernel * kernel;
+    const float2 h = lz[idx];
+    const float re = (h.x * inv_mean) / n3, im = (h.y * inv_mean) / n3;
+    const float pw = re * re + im * im / (k2 * k2);                          // :96
+    atomicAdd(&bins[k1 - 1], 1.0);
+    atomicAdd(&bins[nb + k1 - 1], (double)pw);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * nb; i += 256) if (bins[i] != 0.0) atomicAdd(&ps_acc[i], bins[i]);
+}
+int coarse_power_accumulate(p3m_ctx *c, const float *lz, int planes, int ky0, int nc, int nchunk, float rho_c_mean, double *d_ps) {
+  const int64_t tot = (int64_t)planes * nchunk * nc * 16;
+  const int grid = (int)std::min<int64_t>(1024, cdiv(tot, 256));
+  hipLaunchKernelGGL(k_coarse_power, dim3(grid), dim3(256), sizeof(double) * 2 * (nc + 2), c->stream, reinterpret_cast<const float2 *>(lz), planes, ky0, nc, nchunk,
+                     1.0f / rho_c_mean, d_ps);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+// the last step of coarse_power.f90 (:112-119): weights and sums -> the (k, Delta^2) rows of <z>ps.dat
+void coarse_power_finish(const double *acc, int nc, float box, float *ps) {
+  const int nb = nc + 2;
+  for (int k = 1; k <= nc; k++) {
+    const float w = (float)acc[k - 1], pwr = (float)acc[nb + k - 1];
+    ps[2 * (k - 1)] = w; ps[2 * (k - 1) + 1] = pwr;
+    if (acc[k - 1] != 0.0) {
+      const float km = (float)k - 1.f;
+      ps[2 * (k - 1) + 1] = (float)(4.0 * (double)P3M_PI_F * (double)(km * km * km) * acc[nb + k - 1] / acc[k - 1]);
+      ps[2 * (k - 1)] = 2.0f * P3M_PI_F * km / box;
+    }
+  }
+}
+extern "C" int p3m_hip_coarse_power(p3m_ctx *c, float mass_p, float box, float *ps) {
+  if (!c || !ps) return P3M_EINVAL;
+  const Geometry &g = c->g;
+  if (g.nodes != 1) { p3m_set_error("multi-rank contexts: p3m_hip_group_coarse_power"); return P3M_ECOMM; }
+  HIP_TRY(hipSetDevice(c->device));
+  const int nc = g.nc, nb = nc + 2;
+  double *d_ps = nullptr;
+  HIP_TRY(hipMalloc(&d_ps, sizeof(double) * 2 * nb));
+  HIP_TRY(hipMemsetAsync(d_ps, 0, sizeof(double) * 2 * nb, c->stream));
+  const float nfp = (float)(g.Nn * g.nodes_dim / 2), fnc = (float)nc;
+  const float rho_c_mean = nfp * nfp * nfp * mass_p / (fnc * fnc * fnc);   // :24
+  int r = coarse_power_accumulate(c, c->slab, nc, 0, nc, g.pxc / 16, rho_c_mean, d_ps);
+  std::vector<double> acc(2 * nb);
+  if (r == P3M_OK && hipMemcpyAsync(acc.data(), d_ps, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) r = P3M_EDEVICE;
+  if (r == P3M_OK && hipStreamSynchronize(c->stream) != hipSuccess) r = P3M_EDEVICE;
+  (void)hipFree(d_ps);
+  if (r != P3M_OK) return r;
+  coarse_power_finish(acc.data(), nc, box, ps);
+  return P3M_OK;
+}

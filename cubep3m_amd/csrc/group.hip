@@ -840,3 +840,43 @@ extern "C" int p3m_hip_group_probe_coarse(p3m_group *G, float mass_p, int32_t i,
   HIP_TRY(hipStreamSynchronize(G->stream));
   return P3M_OK;
 }
+
+
+// ------------------------------------------------------------------ coarse_power.f90 on the distributed rho-hat
+// every local rank bins its own ky slab (d.lz, left by the last step's forward transform); the weights and sums of all
+// processes are added by one all-reduce (the reference's mpi_reduce, :109), then every process holds the spectrum.
+int coarse_power_accumulate(p3m_ctx *c, const float *lz, int planes, int ky0, int nc, int nchunk, float rho_c_mean, double *d_ps);
+void coarse_power_finish(const double *acc, int nc, float box, float *ps);
+extern "C" int p3m_hip_group_coarse_power(p3m_group *G, float mass_p, float box, float *ps) {
+  if (!G || !ps) return P3M_EINVAL;
+  if (G->nodes == 1) return p3m_hip_coarse_power(G->ctx[0], mass_p, box, ps);
+  HIP_TRY(hipSetDevice(G->device));
+  const Geometry &g = G->ctx[0]->g;
+  const int nc = g.nc, nb = nc + 2;
+  double *d_ps = nullptr;
+  HIP_TRY(hipMalloc(&d_ps, sizeof(double) * 2 * nb));
+  std::vector<double> acc(2 * nb);
+  auto body = [&]() -> int {
+    HIP_TRY(hipMemsetAsync(d_ps, 0, sizeof(double) * 2 * nb, G->stream));
+    const float nfp = (float)(g.Nn * g.nodes_dim / 2), fnc = (float)nc;
+    const float rho_c_mean = nfp * nfp * nfp * mass_p / (fnc * fnc * fnc);   // coarse_power.f90:24
+    for (size_t i = 0; i < G->ctx.size(); i++) {
+      p3m_ctx *c = G->ctx[i];
+      hipStream_t keep = c->stream; c->stream = G->stream;
+      const int r = coarse_power_accumulate(c, G->cd[i].lz, G->s, G->lrank[i] * G->s, nc, G->nchunk, rho_c_mean, d_ps);
+      c->stream = keep;
+      P3M_TRY(r);
+    }
+    if (G->nprocs > 1 && G->comm && !G->have_tr) NCCL_TRY(ncclAllReduce(d_ps, d_ps, 2 * nb, ncclDouble, ncclSum, G->comm, G->stream));
+    HIP_TRY(hipMemcpyAsync(acc.data(), d_ps, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, G->stream));
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    if (G->nprocs > 1 && G->have_tr) { if (G->tr.allreduce_sum_f64(G->tr.user, acc.data(), 2 * nb)) { p3m_set_error("host transport: all-reduce callback failed"); return P3M_ECOMM; } }
+    else if (G->nprocs > 1 && !G->comm) { p3m_set_error("group reduction between processes needs RCCL or a host transport"); return P3M_ECOMM; }
+    return P3M_OK;
+  };
+  const int r = body();
+  (void)hipFree(d_ps);
+  if (r != P3M_OK) return r;
+  coarse_power_finish(acc.data(), nc, box, ps);
+  return P3M_OK;
+}

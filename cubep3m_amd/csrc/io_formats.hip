@@ -140,3 +140,14 @@ extern "C" int p3m_hip_read_ic(const char *path, float *xv6, int64_t cap, int32_
   else for (int64_t i = 0; i < n; i++) if (!get(F.f, xv6 + 6 * i, 24, false)) { p3m_set_error("%s: truncated at particle %lld", path, (long long)i); return P3M_EINVAL; }
   return P3M_OK;
 }
+
+// coarse_power.f90:121-133: <z>ps.dat, formatted, one line '(2f20.10)' per bin: k = 2 pi (bin-1) / box, Delta^2(k)
+extern "C" int p3m_hip_write_power(const char *path, const float *ps, int32_t nc_dim) {
+  if (!path || !ps || nc_dim < 1) return P3M_EINVAL;
+  File F; if (!F.open(path, "w")) return P3M_EINVAL;
+  bool ok = true;
+  for (int k = 0; ok && k < nc_dim; k++) ok = fprintf(F.f, "%20.10f%20.10f\n", (double)ps[2 * k], (double)ps[2 * k + 1]) > 0;
+  ok = F.finish() && ok;
+  if (!ok) { p3m_set_error("write error on %s", path); return P3M_EINVAL; }
+  return P3M_OK;
+}

@@ -19,6 +19,16 @@ __device__ __forceinline__ float3 pair_force(const float4 &a, const float4 &b, f
   return make_float3(mass_p * (sx / rb3), mass_p * (sy / rb3), mass_p * (sz / rb3));
 }
 
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
 // ------------------------------------------------------------------ intra-cell PP
 // One thread per physical record.  The reference buckets the chain of hoc coarse cell
 // floor(x/mesh_scale) by sub-cell mod(i1-1,mesh_scale), i1 = floor(x + offset_tile) + 1
@@ -38,63 +48,133 @@ __device__ __forceinline__ void ref_bucket(const float4 &p, const PPGeo &G, int 
   }
 }
 
+// Dense cells: when a wavefront's records sit in cells of more than PP_INTRA_DENSE records, the wavefront walks the union of
+// its lanes' cell ranges (contiguous in the sorted order) 64 partners at a time -- one coalesced load, then one broadcast
+// (v_readlane) per partner, each lane keeping the partners of its own cell -- instead of every lane streaming its whole
+// cell from global memory.  Same partner order per lane (ascending sorted index) as the per-lane loop.
+#define PP_INTRA_DENSE 12
 __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs,
                                                   const unsigned char *__restrict__ cflag, int n, PPGeo G, float mass_p, float a_mid, float dt,
-                                                  float *__restrict__ fmax_out) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
+                                                  float *__restrict__ fmax_out, float r2_soft) {
+  const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
   float mag = 0.f;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool phys = false, slow = false;
+  int cc[3] = {0, 0, 0}, sub[3] = {0, 0, 0}, q0 = 0, q1 = 0;
   if (s < n) {
-    const float4 p = spos[s];
+    p = spos[s];
     const float fNn = (float)G.Nn;
-    if (p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn) {
-      int cc[3], sub[3];
+    phys = p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;
+    if (phys) {
       ref_bucket(p, G, cc, sub);
       const int Ec = G.E / G.ms, cb = G.nb / G.ms;
-      const bool slow = cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] != 0;
-      float ax = 0.f, ay = 0.f, az = 0.f;
+      slow = cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] != 0;
       if (!slow) {
         const int bx = (int)floorf(p.x) + G.nb, by = (int)floorf(p.y) + G.nb, bz = (int)floorf(p.z) + G.nb;
         const int64_t cell = ((int64_t)bz * G.E + by) * G.E + bx;
-        const int q0 = cs[cell], q1 = cs[cell + 1];
-        for (int q = q0; q < q1; q++) {
-          if (q == s) continue;
-          const float3 f = pair_force(p, spos[q], mass_p, G.rsoft, G.pp_bias);
-          ax -= f.x; ay -= f.y; az -= f.z;                            // :346-347
+        q0 = cs[cell]; q1 = cs[cell + 1];
+      }
+    }
+  }
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  const bool fast = phys && !slow;
+  const int maxc = wave_max_i(fast ? q1 - q0 : 0);
+  if (maxc > PP_INTRA_DENSE) {
+    const int Q0 = wave_min_i(fast ? q0 : 0x7fffffff), Q1 = wave_max_i(fast ? q1 : 0);
+    const float ibias = 1.0f / G.pp_bias;
+    for (int base = Q0; base < Q1; base += 64) {
+      const int m = min(64, Q1 - base);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < m) o = spos[base + lane];
+      for (int jj = 0; jj < m; jj++) {
+        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), jj));
+        const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), jj));
+        const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), jj));
+        const int q = base + jj;
+        if (fast && q >= q0 && q < q1 && q != s) {
+          const float sx = p.x - px, sy = p.y - py, sz = p.z - pz;                 // :336
+          const float r2 = sx * sx + sy * sy + sz * sz;
+          if (r2 >= r2_soft) {                                                     // :340 rmag > rsoft, decided exactly on r^2
+            const float ib = __builtin_amdgcn_rsqf(r2) * ibias, irb3 = ib * ib * ib;
+            ax -= mass_p * (sx * irb3); ay -= mass_p * (sy * irb3); az -= mass_p * (sz * irb3);   // :344-347
+          }
         }
-      } else {
-        const int x0 = cc[0] * G.ms + G.nb;
-        for (int dz = 0; dz < G.ms; dz++)
-          for (int dy = 0; dy < G.ms; dy++) {
-            const int64_t rb = ((int64_t)(cc[2] * G.ms + G.nb + dz) * G.E + (cc[1] * G.ms + G.nb + dy)) * G.E;
-            const int q0 = cs[rb + x0], q1 = cs[rb + x0 + G.ms];
-            for (int q = q0; q < q1; q++) {
-              if (q == s) continue;
-              const float4 o = spos[q];
+      }
+    }
+  } else if (fast) {
+    for (int q = q0; q < q1; q++) {
+      if (q == s) continue;
+      const float3 f = pair_force(p, spos[q], mass_p, G.rsoft, G.pp_bias);
+      ax -= f.x; ay -= f.y; az -= f.z;                            // :346-347
+    }
+  }
+  // Records of flagged coarse cells (some record's reference bucket differs from its sorted cell): partners are the records
+  // of the whole coarse cell with the same reference bucket.  Wavefront-cooperative: one flagged coarse cell at a time, its
+  // ms*ms x-rows 64 candidates at a time, each candidate's bucket computed once by the lane that loaded it and broadcast
+  // with its position (a thousand-particle cell made every lane stream and re-bucket the whole coarse cell on its own).
+  {
+    const int nct = G.pt / G.ms;
+    const int mykey = (sub[2] * G.ms + sub[1]) * G.ms + sub[0];
+    const float ibias = 1.0f / G.pp_bias;
+    bool todo = phys && slow;
+    unsigned long long pending;
+    while ((pending = __ballot(todo)) != 0ull) {
+      const int lead = __ffsll((long long)pending) - 1;
+      const int c0 = __builtin_amdgcn_readlane(cc[0], lead), c1 = __builtin_amdgcn_readlane(cc[1], lead), c2 = __builtin_amdgcn_readlane(cc[2], lead);
+      const bool mine = todo && cc[0] == c0 && cc[1] == c1 && cc[2] == c2;
+      const int x0 = c0 * G.ms + G.nb;
+      for (int dz = 0; dz < G.ms; dz++)
+        for (int dy = 0; dy < G.ms; dy++) {
+          const int64_t rb = ((int64_t)(c2 * G.ms + G.nb + dz) * G.E + (c1 * G.ms + G.nb + dy)) * G.E;
+          const int r0 = cs[rb + x0], r1 = cs[rb + x0 + G.ms];
+          for (int base = r0; base < r1; base += 64) {
+            const int m = min(64, r1 - base);
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            int okey = -1;
+            if (lane < m) {
+              o = spos[base + lane];
               int oc[3], os[3];
               ref_bucket(o, G, oc, os);
-              if (oc[0] != cc[0] || oc[1] != cc[1] || oc[2] != cc[2] || os[0] != sub[0] || os[1] != sub[1] || os[2] != sub[2]) continue;
-              const float3 f = pair_force(p, o, mass_p, G.rsoft, G.pp_bias);
-              ax -= f.x; ay -= f.y; az -= f.z;
+              if (oc[0] == c0 && oc[1] == c1 && oc[2] == c2) okey = (os[2] * G.ms + os[1]) * G.ms + os[0];
+            }
+            for (int jj = 0; jj < m; jj++) {
+              const int pk = __builtin_amdgcn_readlane(okey, jj);
+              const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), jj));
+              const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), jj));
+              const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), jj));
+              if (mine && pk == mykey && base + jj != s) {
+                const float sx = p.x - px, sy = p.y - py, sz = p.z - pz;
+                const float r2 = sx * sx + sy * sy + sz * sz;
+                if (r2 >= r2_soft) {
+                  const float ib = __builtin_amdgcn_rsqf(r2) * ibias, irb3 = ib * ib * ib;
+                  ax -= mass_p * (sx * irb3); ay -= mass_p * (sy * irb3); az -= mass_p * (sz * irb3);
+                }
+              }
             }
           }
-      }
-      float4 v = svel[s];
-      v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
-      svel[s] = v;
-      mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356
+        }
+      todo = todo && !mine;
     }
+    (void)nct;
+  }
+  if (phys) {
+    float4 v = svel[s];
+    v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
+    svel[s] = v;
+    mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356
   }
   for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_down(mag, o, 64));
   if ((threadIdx.x & 63) == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out) + p3m_slot() * 16, __float_as_uint(mag));
 }
 
+static float first_r2_with_root_above(float t);
 int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   P3M_TRY(particles_full_cells(c));
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   hipLaunchKernelGGL(k_pp_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end,
-                     (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1 * P3M_RED_SPAN);
+                     (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1 * P3M_RED_SPAN, first_r2_with_root_above(G.rsoft));
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -365,16 +445,6 @@ __global__ __launch_bounds__(256) void k_pp_fill(const int *__restrict__ plan, i
   if (g >= ngroups) return;
   const int k1 = min(plan[g + 1], cap);
   for (int k = plan[g]; k < k1; k++) task_group[k] = g;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
 }
 struct PPForce { float mass_p, pp_bias, ibias, incut, r2_soft, r2_taper; };
 __device__ __forceinline__ void pp_ext_eval(const float4 &p, float ox, float oy, float oz, const PPForce &F, float &ax, float &ay, float &az) {

@@ -6,6 +6,13 @@
 !! The host keeps cubep3m's decomposition, time-step loop, RNG, I/O; this file is a thin
 !! ISO_C_BINDING shim over include/p3m_hip.h.  Single-rank builds (nodes_dim = 1); multi-rank hosts
 !! additionally hand the library a transport (include/p3m_hip.h, p3m_transport).
+!! RESIDENT PARTICLES: between output steps the host never reads xv (cubepm.f90:103-236 only touches it through
+!! particle_mesh, and on checkpoint / projection / halofind steps through update_position, checkpoint, link_list, ...), so
+!! the particles stay on the device: they are uploaded when the host's copy is the newer one (first call, and the call after
+!! an output step, where cubepm.f90:175-176 drifted xv on the host) and downloaded only when the host is about to read them
+!! (checkpoint_step .or. projection_step .or. halofind_step .or. final_step, COMMON /lvar/; or the loop's other exits, nts ==
+!! max_nts and a > 1, cubepm.f90:235).  np_local follows the device every step.  P3M_HIP_RESIDENT=0 in the environment
+!! restores the copy-in / copy-out of every step (hosts with other readers of xv).
 !! Compile with the reference's own flags, e.g.
 !!   flang -cpp -ffree-form -I<source_threads> -DNGP -DPPINT -DPP_EXT -DDISP_MESH -c particle_mesh_hip.f90
 subroutine particle_mesh
@@ -67,6 +74,11 @@ subroutine particle_mesh
   end interface
 
   type(c_ptr), save :: ctx = c_null_ptr
+  logical, save :: device_current = .false.   ! the device holds the particles the host's xv describes
+  logical, save :: resident = .true.
+  logical :: host_reads
+  character(len=8) :: envv
+  integer :: envl
   type(p3m_params) :: par
   type(p3m_step_out) :: sout
   real(c_float) :: offset(3), fine_tab(3, 16, 16, 16), coarse_tab(3, 4, 4, 4), rt(3)
@@ -97,6 +109,8 @@ subroutine particle_mesh
     par%rank = rank; par%device = -1
     ierr_c = p3m_hip_create(par, ctx)
     if (ierr_c /= 0) stop 'p3m_hip_create failed'
+    call get_environment_variable('P3M_HIP_RESIDENT', envv, envl)
+    if (envl > 0) resident = (envv(1:1) /= '0')
     ! the same tables fine_kernel / coarse_kernel read (kernel_initialization.f90:15,344)
     open(unit=18, file=kernel_path//'wfxyzf.3.ascii', status='old', iostat=fstat)
     if (fstat /= 0) stop 'error opening fine mesh kernel'
@@ -132,13 +146,19 @@ subroutine particle_mesh
 #endif
 
   np_c = np_local
-  ierr_c = p3m_hip_upload_particles(ctx, xv, PID, np_c)
+  ierr_c = 0
+  if (.not. device_current) ierr_c = p3m_hip_upload_particles(ctx, xv, PID, np_c)
   if (ierr_c == 0) ierr_c = p3m_hip_particle_mesh(ctx, a_mid, dt, dt_old, mass_p, offset, shake_offset, sout)
-  if (ierr_c == 0) ierr_c = p3m_hip_download_particles(ctx, xv, PID, np_c)
+  np_c = sout%np_local
+  ! who reads xv next?  the host, on output steps and when the loop ends (cubepm.f90:171-235); otherwise the next particle_mesh
+  host_reads = checkpoint_step .or. projection_step .or. halofind_step .or. final_step .or. nts == max_nts .or. a > 1.0 &
+               .or. .not. resident
+  if (ierr_c == 0 .and. host_reads) ierr_c = p3m_hip_download_particles(ctx, xv, PID, np_c)
   if (ierr_c /= 0) then
     write(*,*) 'particle_mesh (HIP) failed with code', ierr_c
     stop
   endif
+  device_current = .not. host_reads
   np_local = np_c
   dt_f_acc = sout%dt_f_acc; dt_c_acc = sout%dt_c_acc
 #ifdef PPINT

@@ -4,7 +4,8 @@
 !! fftw3ds.f90, coarse_force_buffer.f90 and the mpi_reduce/mpi_bcast pairs do in the reference) go through the three
 !! host-transport callbacks of include/p3m_hip.h, implemented below with the MPI calls the host already has.
 !! (A host that links RCCL instead calls p3m_hip_group_comm_init_rccl with an id broadcast by MPI_Bcast and needs none
-!! of the callbacks.)  Link instead of particle_mesh_threaded.o, with -lp3m_hip.  Compile like the reference:
+!! of the callbacks.)  Particles stay resident on the device between output steps exactly as in particle_mesh_hip.f90 (see
+!! there); P3M_HIP_RESIDENT=0 restores the per-step copies.  Link instead of particle_mesh_threaded.o, with -lp3m_hip.  Compile like the reference:
 !!   mpif90 -cpp -ffree-form -I<source_threads> -DNGP -DPPINT -DPP_EXT -DDISP_MESH -c particle_mesh_hip_mpi.f90
 module p3m_mpi_transport
   use iso_c_binding
@@ -126,6 +127,11 @@ subroutine particle_mesh
   end interface
 
   type(c_ptr), save :: grp = c_null_ptr
+  logical, save :: device_current = .false.   ! the device holds the particles the host's xv describes
+  logical, save :: resident = .true.
+  logical :: host_reads
+  character(len=8) :: envv
+  integer :: envl
   type(p3m_params) :: par
   type(p3m_transport) :: tr
   type(p3m_step_out) :: sout
@@ -157,6 +163,8 @@ subroutine particle_mesh
     par%device = mod(rank, max(1, p3m_hip_device_count()))   ! one GPU per MPI rank of the node (ranks share GPUs if there are fewer)
     ierr_c = p3m_hip_group_create(par, int(rank, c_int32_t), int(nodes, c_int32_t), grp)   ! process `rank` of `nodes`: one logical rank each
     if (ierr_c /= 0) stop 'p3m_hip_group_create failed'
+    call get_environment_variable('P3M_HIP_RESIDENT', envv, envl)
+    if (envl > 0) resident = (envv(1:1) /= '0')
     tr%user = c_null_ptr
     tr%exchange = c_funloc(p3m_exchange)
     tr%allreduce_max_f32 = c_funloc(p3m_allreduce_max_f32)
@@ -202,13 +210,19 @@ subroutine particle_mesh
 #endif
 
   np_c = np_local
-  ierr_c = p3m_hip_group_upload_particles(grp, 0_c_int32_t, xv, PID, np_c)
+  ierr_c = 0
+  if (.not. device_current) ierr_c = p3m_hip_group_upload_particles(grp, 0_c_int32_t, xv, PID, np_c)
   if (ierr_c == 0) ierr_c = p3m_hip_group_particle_mesh(grp, a_mid, dt, dt_old, mass_p, offset, shake_offset, sout)   ! collective
-  if (ierr_c == 0) ierr_c = p3m_hip_group_download_particles(grp, 0_c_int32_t, xv, PID, np_c)
+  np_c = sout%np_local
+  ! the same flags on every rank (timestep.f90:228-235 broadcasts them): all ranks download, or none
+  host_reads = checkpoint_step .or. projection_step .or. halofind_step .or. final_step .or. nts == max_nts .or. a > 1.0 &
+               .or. .not. resident
+  if (ierr_c == 0 .and. host_reads) ierr_c = p3m_hip_group_download_particles(grp, 0_c_int32_t, xv, PID, np_c)
   if (ierr_c /= 0) then
     write(*,*) 'particle_mesh (HIP) failed with code', ierr_c, ' on rank', rank
     call mpi_abort(mpi_comm_world, ierr, ierr)
   endif
+  device_current = .not. host_reads
   np_local = np_c
   dt_f_acc = sout%dt_f_acc; dt_c_acc = sout%dt_c_acc       ! already reduced over all ranks
 #ifdef PPINT

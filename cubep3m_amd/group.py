@@ -138,6 +138,12 @@ class ParticleMeshGroup:
         _lib.check(self.L.p3m_hip_group_set_kernel_tables(self.h, np.ascontiguousarray(fine_table, np.float32),
                                                           np.ascontiguousarray(coarse_table, np.float32)))
 
+    def coarse_power(self, mass_p, box):
+        """coarse_power.f90 on the coarse density of the last particle_mesh step: (nc_dim, 2) rows (k, Delta^2(k))."""
+        ps = np.zeros((self.params.nc_dim, 2), np.float32)
+        _lib.check(self.L.p3m_hip_group_coarse_power(self.h, mass_p, box, ps))
+        return ps
+
     def close(self):
         if getattr(self, "h", None):
             self.L.p3m_hip_group_destroy(self.h)

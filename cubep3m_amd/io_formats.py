@@ -94,3 +94,9 @@ def read_ic(path, binary=False, max_np=None):
     xv = np.empty((min(n.value, cap) if max_np is None else n.value, 6), np.float32)
     _lib.check(L.p3m_hip_read_ic(_b(path), xv.ctypes.data_as(C.c_void_p), cap, C.byref(n), int(binary)))
     return xv
+
+
+def write_power(path, ps):
+    """<z>ps.dat of coarse_power.f90:121-133: one formatted '(2f20.10)' line per bin."""
+    ps = np.ascontiguousarray(ps, np.float32)
+    _lib.check(_lib.load().p3m_hip_write_power(_b(path), ps, ps.shape[0]))

@@ -154,6 +154,12 @@ class ParticleMesh:
         _lib.check(self.L.p3m_hip_projection(self.h, mass_p, *(m.ctypes.data_as(C.c_void_p) for m in maps), C.byref(tot)))
         return maps[0], maps[1], maps[2], tot.value
 
+    def coarse_power(self, mass_p, box):
+        """coarse_power.f90 on the coarse density of the last particle_mesh step: (nc_dim, 2) rows (k, Delta^2(k))."""
+        ps = np.zeros((self.params.nc_dim, 2), np.float32)
+        _lib.check(self.L.p3m_hip_coarse_power(self.h, mass_p, box, ps))
+        return ps
+
     def coarse(self, mass_p, want_force=True):
         p = self.params
         rho = np.empty((p.nc_node_dim,) * 3, np.float32)

@@ -189,6 +189,8 @@ int p3m_hip_probe_coarse(p3m_ctx *ctx, float mass_p, float *rho_c, float *force_
 int p3m_hip_fft3d(p3m_ctx *ctx, float *data, int32_t n, int32_t dir);
 /* Fine-mesh sweep over all tiles `reps` times with device-resident inputs, timed with HIP
    events on the library's stream; returns average milliseconds per sweep (benchmark leg). */
+/* coarse_power.f90 for a single-rank context (see p3m_hip_group_coarse_power) */
+int p3m_hip_coarse_power(p3m_ctx *ctx, float mass_p, float box, float *ps);
 int p3m_hip_time_fine_sweep(p3m_ctx *ctx, float mass_p, int32_t reps, float *ms_per_sweep);
 /* One pass kernel of the fine-mesh FFT over the whole tile batch, launched `reps` times between
    HIP events on the library's stream; returns the average milliseconds per launch.
@@ -251,6 +253,8 @@ int p3m_hip_read_pid_checkpoint(const char *path, p3m_ckpt_header *h, int64_t *p
 /* xv<rank>.ic: np_local, then xv(:,i) per particle (unformatted) or as one block (binary) (particle_initialization.f90:296-332) */
 /* projection.f90:62-113: one projection file = the scalar a, then the nf_physical_dim^2 map; `binary` as for the checkpoints */
 int p3m_hip_write_projection(const char *path, float a, const float *map, int32_t nf_physical_dim, int32_t binary);
+/* coarse_power.f90:121-133: <z>ps.dat, formatted, one '(2f20.10)' line per bin of the spectrum p3m_hip_coarse_power returns */
+int p3m_hip_write_power(const char *path, const float *ps, int32_t nc_dim);
 int p3m_hip_read_projection(const char *path, float *a, float *map, int32_t nf_physical_dim, int32_t binary);
 int p3m_hip_write_ic(const char *path, const float *xv6, int32_t np_local, int32_t binary);
 int p3m_hip_read_ic(const char *path, float *xv6, int64_t cap, int32_t *np_local, int32_t binary);
@@ -285,6 +289,11 @@ int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho
  * cubepm.f90:193-228); the maps receive the sum over THIS process's ranks, rho_tot the sum over all ranks (:34-35); a host
  * running several processes adds the maps up (the reference's mpi_reduce, :41-54). */
 int p3m_hip_group_projection(p3m_group *g, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_tot);
+/* coarse_power.f90:2-139 (called from coarse_force.f90:108 when coarse_ps is set): the mass power spectrum of the coarse
+ * density of the LAST particle_mesh step (its rho-hat is still on the device).  ps: float[nc_dim][2] = the rows of <z>ps.dat,
+ * (k = 2 pi (bin-1) / box, Delta^2(k) = 4 pi (bin-1)^3 <P>), bins without modes (count, 0).  `box` is the parameter of the
+ * reference's `parameters` file.  Every process of a group receives the full spectrum. */
+int p3m_hip_group_coarse_power(p3m_group *g, float mass_p, float box, float *ps);
 
 /* -- F77-ABI one-call wrapper in the style of pp_force_c_ (nbody-ueli.cu:368) ------------ */
 /* Single-rank hosts: uploads xv/PID, runs the step, downloads, returns the four dt limits.

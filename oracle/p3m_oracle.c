@@ -991,6 +991,69 @@ void orc_coarse_force(orc_ctx *c) {
   free(slab); free(cr); free(fg);
 }
 
+/* coarse_power.f90:2-139: the mass power spectrum of the coarse density.  cmplx_rho_c (the
+   transform of rho_c kept by coarse_force.f90:20) goes back to real space, becomes the overdensity rho_c/rho_c_mean - 1
+   (:27-31), is transformed again (:35), and every mode of the half spectrum adds its power to the bin k1 = ceiling(|k|)
+   (w1 = 1, w2 = 0, :92-95), each rank over its own z-slab (:41-47), the ranks' bins summed by mpi_reduce (:109).  Kept as
+   written: the sinc^4 deconvolution divides only the IMAGINARY part's square (:96, operator precedence), and the kx = 0
+   plane counts each conjugate pair once (:60-61).  ps: (2, nc_dim) as the reference writes it to <z>ps.dat (:112-133):
+   ps[2k] = 2 pi (k-1) / box, ps[2k+1] = Delta^2 = 4 pi (k-1)^3 <P>; bins without modes stay 0.  Needs coarse_mass. */
+void orc_coarse_power(orc_ctx *c, float mass_p, float box, float *ps) {
+  const int nc = c->nc_dim, ncn = c->nc_node_dim, hc = nc / 2, nslab = nc / c->nodes; const size_t pitch = (size_t)nc + 2;
+  const size_t S = pitch * nc * nc;
+  float *slab = (float *)calloc(S, sizeof(float));
+  float *psr = (float *)calloc((size_t)2 * (nc + 2), sizeof(float)), *sum = (float *)calloc((size_t)2 * (nc + 2), sizeof(float));
+#define SL(a, i, j, k) a[((size_t)((k) - 1) * nc + ((j) - 1)) * pitch + ((i) - 1)]
+  for (int rk = 0; rk < c->nodes; rk++) {
+    orc_rank *R = &c->r[rk]; int ox = R->cart[2] * ncn, oy = R->cart[1] * ncn, oz = R->cart[0] * ncn;
+    for (int k = 1; k <= ncn; k++) for (int j = 1; j <= ncn; j++) for (int i = 1; i <= ncn; i++) SL(slab, ox + i, oy + j, oz + k) = RHOC(R, i, j, k);
+  }
+  orc_fft3d(slab, nc, +1);                                                /* cmplx_rho_c, coarse_force.f90:18-20 */
+  const float nfp = (float)(c->nf_physical_node_dim * c->p.nodes_dim / 2), fnc = (float)nc;
+  const float rho_c_mean = nfp * nfp * nfp * mass_p / (fnc * fnc * fnc);  /* :24 */
+  orc_fft3d(slab, nc, -1);                                                /* :29 cubepm_fftw(-1), incl. / nc^3 */
+  for (int k = 1; k <= nc; k++) for (int j = 1; j <= nc; j++) for (int i = 1; i <= nc; i++) SL(slab, i, j, k) = SL(slab, i, j, k) / rho_c_mean - 1.0f;   /* :30 */
+  for (int k = 1; k <= nc; k++) for (int j = 1; j <= nc; j++) { SL(slab, nc + 1, j, k) = 0.f; SL(slab, nc + 2, j, k) = 0.f; }
+  orc_fft3d(slab, nc, +1);                                                /* :35 */
+  const float pi = PI_F, n3 = fnc * fnc * fnc;
+  for (int rk = 0; rk < c->nodes; rk++) {
+    memset(psr, 0, sizeof(float) * 2 * (size_t)(nc + 2));                 /* :40 */
+    for (int k = 1; k <= nslab; k++) {
+      const int kg = k + nslab * rk;                                      /* :44 */
+      const float kz = (kg < hc + 2) ? (float)(kg - 1) : (float)(kg - 1 - nc);
+      for (int j = 1; j <= nc; j++) {
+        const float ky = (j < hc + 2) ? (float)(j - 1) : (float)(j - 1 - nc);
+        for (int i = 1; i <= nc + 2; i += 2) {
+          const float kx = (float)(i - 1) / 2.0f;
+          const float kr = sqrtf(kx * kx + ky * ky + kz * kz);
+          if (kx == 0.f && ky <= 0.f && kz <= 0.f) continue;              /* :60 */
+          if (kx == 0.f && ky > 0.f && kz < 0.f) continue;                /* :61 */
+          if (kr != 0.0f) {
+            const int k1 = (int)ceilf(kr);
+            const float x = pi * kx / fnc, y = pi * ky / fnc, z = pi * kz / fnc;
+            const float sx = (x == 0.f) ? 1.f : sinf(x) / x, sy = (y == 0.f) ? 1.f : sinf(y) / y, sz = (z == 0.f) ? 1.f : sinf(z) / z;
+            const float kernel = sx * sy * sz;
+            const float re = SL(slab, i, j, kg) / n3, im = SL(slab, i + 1, j, kg) / n3;
+            const float k2 = kernel * kernel, pw = re * re + im * im / (k2 * k2);            /* :96 */
+            psr[2 * (k1 - 1)] += 1.0f; psr[2 * (k1 - 1) + 1] += pw;                           /* :97-98, w1 = 1 */
+          }
+        }
+      }
+    }
+    for (int k = 0; k < 2 * nc; k++) sum[k] += psr[k];                    /* :109 */
+  }
+  for (int k = 1; k <= nc; k++) {                                         /* :114-119 */
+    ps[2 * (k - 1)] = sum[2 * (k - 1)]; ps[2 * (k - 1) + 1] = sum[2 * (k - 1) + 1];
+    if (sum[2 * (k - 1)] != 0.f) {
+      const float km = (float)k - 1.f;
+      ps[2 * (k - 1) + 1] = 4.0f * pi * (km * km * km) * sum[2 * (k - 1) + 1] / sum[2 * (k - 1)];
+      ps[2 * (k - 1)] = 2.0f * pi * km / box;
+    }
+  }
+#undef SL
+  free(slab); free(psr); free(sum);
+}
+
 /* force_c(:,0:ncn+1,...) = own cube (coarse_force.f90:52,71,90) + the 1-cell periodic halo that the six
    mpi_sendrecv_replace calls of coarse_force_buffer.f90:19-63 deliver (x, then y incl. x-halo, then z:
    edges and corners arrive too).  fg: global (3,nc,nc,nc), component fastest. */

@@ -74,7 +74,9 @@ void orc_tile_velocity(orc_ctx *c, int rank, int tx, int ty, int tz, const float
 void orc_coarse_density(orc_ctx *c, float mass_p);           /* coarse_mass on all ranks */
 const float *orc_rho_c(orc_ctx *c, int rank);                /* (ncn,ncn,ncn)            */
 const float *orc_force_c(orc_ctx *c, int rank);              /* (3,0:ncn+1,0:ncn+1,0:ncn+1) */
-void orc_coarse_force(orc_ctx *c);                           /* coarse_force + buffer     */
+void orc_coarse_force(orc_ctx *c);
+/* coarse_power.f90: ps (2, nc_dim) = (k, Delta^2(k)) rows of <z>ps.dat; needs coarse_density */
+void orc_coarse_power(orc_ctx *c, float mass_p, float box, float *ps);                           /* coarse_force + buffer     */
 void orc_distribute_force(orc_ctx *c, const float *force_global); /* coarse_force_buffer.f90 */
 void orc_coarse_max_dt_and_velocity(orc_ctx *c, float a_mid, float dt); /* coarse_max_dt + coarse_velocity */
 void orc_fft3d(float *data, int n, int dir);                 /* fftw2.f90 semantics       */

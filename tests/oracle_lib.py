@@ -65,6 +65,7 @@ def lib():
         L.orc_force_c.restype = C.POINTER(C.c_float)
         L.orc_force_c.argtypes = [C.c_void_p, C.c_int]
         L.orc_coarse_force.argtypes = [C.c_void_p]
+        L.orc_coarse_power.argtypes = [C.c_void_p, C.c_float, C.c_float, f32p]
         L.orc_distribute_force.argtypes = [C.c_void_p, f32p]
         L.orc_coarse_max_dt_and_velocity.argtypes = [C.c_void_p, C.c_float, C.c_float]
         L.orc_fft3d.argtypes = [f32p, C.c_int, C.c_int]
@@ -193,6 +194,17 @@ class Oracle:
     def rho_c(self, rank=0):
         n = self.p.nc_node_dim
         return np.ctypeslib.as_array(self.L.orc_rho_c(self.h, rank), shape=(n, n, n)).copy()
+
+    def rho_c_view(self, rank=0):
+        """writable view of the rank's coarse density (known-answer tests set it directly)"""
+        n = self.p.nc_node_dim
+        return np.ctypeslib.as_array(self.L.orc_rho_c(self.h, rank), shape=(n, n, n))
+
+    def coarse_power(self, mass_p, box):
+        """coarse_power.f90 on the current coarse density: (nc_dim, 2) rows (k, Delta^2(k)) of <z>ps.dat"""
+        ps = np.zeros((self.p.nc_dim, 2), np.float32)
+        self.L.orc_coarse_power(self.h, mass_p, box, ps)
+        return ps
 
     def force_c(self, rank=0):
         n = self.p.nc_node_dim + 2
