@@ -131,31 +131,33 @@ __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, 
   }
 }
 // candidates: sorted indices of records within 2^-10 below a cell face in some coordinate (k_row_sort)
-__global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, const int *__restrict__ cand, int ncand, float *__restrict__ rho,
-                                                   int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
-  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (id >= (int64_t)ncand * ntile) return;
-  const int tl = (int)(id / ncand); const int ci = (int)(id - (int64_t)tl * ncand);
-  const float4 p = spos[cand[ci]];
+__global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, const int *__restrict__ cand, const int *__restrict__ ncand_dev, int cand_cap,
+                                                   float *__restrict__ rho, int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
+  // the candidate count stays on the device (written by k_row_sort of this step): no host round trip between sort and deposit
+  const int ncand = min(*ncand_dev, cand_cap);
   const int nf = G.nf, pt = G.pt, nb = G.nb;
-  int t3[3]; tile_xyz(tile0 + tl, G.T, t3[0], t3[1], t3[2]);
-  const float xs[3] = {p.x, p.y, p.z};
-  int gl[3], rr[3]; bool member = true, moved = false;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)ncand * ntile; id += (int64_t)gridDim.x * 256) {
+    const int tl = (int)(id / ncand); const int ci = (int)(id - (int64_t)tl * ncand);
+    const float4 p = spos[cand[ci]];
+    int t3[3]; tile_xyz(tile0 + tl, G.T, t3[0], t3[1], t3[2]);
+    const float xs[3] = {p.x, p.y, p.z};
+    int gl[3], rr[3]; bool member = true, moved = false;
 #pragma unroll
-  for (int d = 0; d < 3; d++) {
-    gl[d] = (int)floorf(xs[d]) + nb - t3[d] * pt;                       // cell the count-based deposit used
-    member = member && gl[d] >= 4 && gl[d] < nf - 4;                     // chain window (:120-121)
-    rr[d] = (int)floorf(xs[d] + (float)(-t3[d] * pt + nb));             // the reference's cell (:134,:139,:143)
-    moved = moved || (rr[d] != gl[d]);
-  }
-  if (!member || !moved) return;
-  float *base = rho + (int64_t)tl * nf * nf * G.rp;
-  atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0]], -mass_p);
-  atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0]], mass_p);
-  if (sum_interior) {
-    const bool ig = gl[0] >= nb && gl[0] < nf - nb && gl[1] >= nb && gl[1] < nf - nb && gl[2] >= nb && gl[2] < nf - nb;
-    const bool ir = rr[0] >= nb && rr[0] < nf - nb && rr[1] >= nb && rr[1] < nf - nb && rr[2] >= nb && rr[2] < nf - nb;
-    if (ig != ir) atomicAdd(sum_interior, ir ? (double)mass_p : -(double)mass_p);
+    for (int d = 0; d < 3; d++) {
+      gl[d] = (int)floorf(xs[d]) + nb - t3[d] * pt;                       // cell the count-based deposit used
+      member = member && gl[d] >= 4 && gl[d] < nf - 4;                     // chain window (:120-121)
+      rr[d] = (int)floorf(xs[d] + (float)(-t3[d] * pt + nb));             // the reference's cell (:134,:139,:143)
+      moved = moved || (rr[d] != gl[d]);
+    }
+    if (!member || !moved) continue;
+    float *base = rho + (int64_t)tl * nf * nf * G.rp;
+    atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0]], -mass_p);
+    atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0]], mass_p);
+    if (sum_interior) {
+      const bool ig = gl[0] >= nb && gl[0] < nf - nb && gl[1] >= nb && gl[1] < nf - nb && gl[2] >= nb && gl[2] < nf - nb;
+      const bool ir = rr[0] >= nb && rr[0] < nf - nb && rr[1] >= nb && rr[1] < nf - nb && rr[2] >= nb && rr[2] < nf - nb;
+      if (ig != ir) atomicAdd(sum_interior, ir ? (double)mass_p : -(double)mass_p);
+    }
   }
 }
 
@@ -169,10 +171,11 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
     if (!have) hipLaunchKernelGGL(k_ngp_counts, dim3(cdiv(g.nf, 8), g.nf, ntile), dim3(256), 0, c->stream, (const int *)c->cell_end,
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
     HIP_TRY(hipGetLastError());
-    if (c->ncand > 0) {
-      const int64_t work = (int64_t)c->ncand * ntile;
-      hipLaunchKernelGGL(k_ngp_fixup, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cand,
-                         c->ncand, c->rho, tile0, ntile, G, mass_p, c->d_sums);
+    if (c->np_all > 0) {
+      // records within 2^-10 below a cell face: ~0.3 % of the records; the grid is sized for that share, the loop covers any count
+      const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256) * ntile;
+      hipLaunchKernelGGL(k_ngp_fixup, dim3((unsigned)std::min<int64_t>(4096, cdiv(guess, 256))), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cand,
+                         (const int *)(c->d_counters + 5), (int)std::min<int64_t>(c->cap, 0x7fffffff), c->rho, tile0, ntile, G, mass_p, c->d_sums);
       HIP_TRY(hipGetLastError());
     }
     return P3M_OK;

@@ -65,6 +65,7 @@ struct p3m_group {
   FftPlan plan_c; int s = 0, nchunk = 0;
   int seg_off[54] = {0}, seg_cap[54] = {0}; int64_t seg_total = 0;   // segments by slot (2m ghosts, 2m+1 migrants), offsets in float4 units
   int *h_cnt = nullptr;        // pinned [nlocal*4]
+  int *d_gather = nullptr, *h_gather = nullptr, *h_hdr = nullptr;   // ghost pass: [nodes][64] counts of every rank (device, pinned), [nlocal] pinned headers
   float *d_red4 = nullptr; double *d_sum3 = nullptr; float *h_red4 = nullptr; double *h_sum3 = nullptr;
   bool have_k = false;
   p3m_step_out last{};
@@ -197,6 +198,9 @@ extern "C" void p3m_hip_group_destroy(p3m_group *G) {
   if (G->comm) (void)ncclCommDestroy(G->comm);
   gfree(G->d_red4); gfree(G->d_sum3);
   if (G->h_cnt) (void)hipHostFree(G->h_cnt);
+  gfree(G->d_gather);
+  if (G->h_gather) (void)hipHostFree(G->h_gather);
+  if (G->h_hdr) (void)hipHostFree(G->h_hdr);
   if (G->h_red4) (void)hipHostFree(G->h_red4);
   if (G->h_sum3) (void)hipHostFree(G->h_sum3);
   for (int k = 0; k < 2; k++) if (G->h_stage[k]) (void)hipHostFree(G->h_stage[k]);
@@ -250,21 +254,27 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     G->nchunk = G->plan_c.px / 16;
     // ghost segments, sized from the rank's capacity: a face shell holds nb/Nn of the particles, an edge (nb/Nn)^2, ...
     {
-      const double f = std::min(1.0, 2.5 * (double)g.nb / (double)g.Nn);   // 2.5x the uniform-density share
+      // 2.5x the uniform-density share to start with; ghost_pass grows a segment that a clustered shell overfills
+      // (P3M_GHOST_SEG_FACTOR: another starting factor, for tests of that path)
+      const double f0 = getenv("P3M_GHOST_SEG_FACTOR") ? atof(getenv("P3M_GHOST_SEG_FACTOR")) : 2.5;
+      const double f = std::min(1.0, f0 * (double)g.nb / (double)g.Nn);
       int64_t run = 0;
       for (int m = 0; m < 27; m++) {
         const int nz = (m % 3 != 0) + ((m / 3) % 3 != 0) + (m / 9 != 0);
-        int64_t cap = nz == 0 ? 0 : (int64_t)((double)g.max_np * (nz == 1 ? f : (nz == 2 ? f * f : f * f * f))) + 4096;
+        int64_t cap = nz == 0 ? 0 : (int64_t)((double)g.max_np * (nz == 1 ? f : (nz == 2 ? f * f : f * f * f))) + (f0 < 1.0 ? 16 : 4096);
         cap = std::min<int64_t>(cap, g.max_np);
         // migrants: records that left the rank through this face / edge / corner in one step -- or, with -DMOVE_GRID_BACK
         // (ghosts can turn physical when the grid moves back), every image
-        const int64_t capm = nz == 0 ? 0 : ((base->flags & P3M_FLAG_MOVE_GRID_BACK) ? cap : cap / 4 + 4096);
+        const int64_t capm = nz == 0 ? 0 : ((base->flags & P3M_FLAG_MOVE_GRID_BACK) ? cap : cap / 4 + (f0 < 1.0 ? 16 : 4096));
         G->seg_off[2 * m] = (int)run; G->seg_cap[2 * m] = (int)cap; run += cap;                 // ghosts: one float4 each
         G->seg_off[2 * m + 1] = (int)run; G->seg_cap[2 * m + 1] = (int)capm; run += 2 * capm;   // migrants: two
       }
       if (run > 0x3fffffff) return fail(P3M_ECAPACITY);
       G->seg_total = run;
     }
+    if (galloc(&G->d_gather, (size_t)64 * nodes) != P3M_OK) return fail(P3M_ENOMEM);
+    if (hipHostMalloc(reinterpret_cast<void **>(&G->h_gather), (size_t)64 * nodes * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&G->h_hdr), (size_t)(per + 1) * sizeof(int)) != hipSuccess) return fail(P3M_ENOMEM);
     const size_t NB = (size_t)G->s * G->nchunk * g.nc * 16 * 2;          // floats of one component's complex slab
     const size_t blk = (size_t)G->s * g.ncn * g.ncn;
     G->cd.resize(G->ctx.size());
@@ -325,61 +335,92 @@ static int shift_neighbour(const p3m_group *G, int r, int m) {
   auto mv = [&](int v, int s) { return s == 1 ? (v + 1) % nd : (s == 2 ? (v - 1 + nd) % nd : v); };
   return mv(c1, c) * nd * nd + mv(c2, b) * nd + mv(c3, a);
 }
+// segment layout from the capacities: slot k = 2m (ghosts, one float4 each) or 2m+1 (migrants, two)
+static int64_t layout_segments(p3m_group *G) {
+  int64_t run = 0;
+  for (int k = 0; k < 54; k++) { G->seg_off[k] = (int)run; run += (int64_t)G->seg_cap[k] * ((k & 1) ? 2 : 1); }
+  return run;
+}
 static int ghost_pass(p3m_group *G) {
   const int nl = (int)G->ctx.size();
   if (G->nodes == 1) return particles_pass_self(G->ctx[0]);
-  // slot k = 2m (ghosts of shift m, 16 B each) or 2m+1 (migrants, 32 B each); d_cnt: [0..53] own counts, [64..117] announced
+  // slot k = 2m (ghosts of shift m, 16 B each) or 2m+1 (migrants, 32 B each); d_cnt[0..53]: own counts, [54]: np_local
   // 1. pack every image into the segment of its slot
+  auto pack_all = [&]() -> int {
+    for (int i = 0; i < nl; i++) {
+      CoarseDist &d = G->cd[i];
+      HIP_TRY(hipMemsetAsync(d.d_cnt, 0, 64 * sizeof(int), G->stream));
+      P3M_TRY(particles_ghost_pack(G->ctx[i], d.sb, G->seg_off, G->seg_cap, d.d_cnt));
+    }
+    return P3M_OK;
+  };
+  P3M_TRY(pack_all());
+  // 2. every process learns EVERY rank's counts (and record count): 64 ints per rank, gathered at each process.  All
+  //    decisions below -- capacity errors, growing the segments, message sizes -- are then taken from the same numbers by
+  //    every process: nobody walks into a payload exchange that a peer has already abandoned.
+  const int per = G->nodes / G->nprocs;
   for (int i = 0; i < nl; i++) {
-    CoarseDist &d = G->cd[i];
-    HIP_TRY(hipMemsetAsync(d.d_cnt, 0, 128 * sizeof(int), G->stream));
-    P3M_TRY(particles_ghost_pack(G->ctx[i], d.sb, G->seg_off, G->seg_cap, d.d_cnt));
+    G->h_hdr[i] = G->ctx[i]->np_local;
+    HIP_TRY(hipMemcpyAsync(G->cd[i].d_cnt + 54, G->h_hdr + i, sizeof(int), hipMemcpyHostToDevice, G->stream));
   }
-  // 2. announce the counts: shift m of rank r lands in the slots of m at the rank at r + shift (one source per slot)
   std::vector<XMsg> cm;
   for (int r = 0; r < G->nodes; r++)
-    for (int m = 1; m < 27; m++) {
-      const int dst = shift_neighbour(G, r, m), li = G->lidx[r], ld = G->lidx[dst];
-      cm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].d_cnt + 2 * m) : nullptr, ld >= 0 ? (void *)(G->cd[ld].d_cnt + 64 + 2 * m) : nullptr, 2 * sizeof(int)});
+    for (int q = 0; q < G->nprocs; q++) {
+      const int li = G->lidx[r];
+      cm.push_back({r, q * per, li >= 0 ? (const void *)G->cd[li].d_cnt : nullptr, q == G->proc ? (void *)(G->d_gather + 64 * r) : nullptr, 64 * sizeof(int)});
     }
   P3M_TRY(do_exchange(G, cm));
-  for (int i = 0; i < nl; i++) HIP_TRY(hipMemcpyAsync(G->h_cnt + 128 * i, G->cd[i].d_cnt, 128 * sizeof(int), hipMemcpyDeviceToHost, G->stream));
+  HIP_TRY(hipMemcpyAsync(G->h_gather, G->d_gather, (size_t)64 * G->nodes * sizeof(int), hipMemcpyDeviceToHost, G->stream));
   HIP_TRY(hipStreamSynchronize(G->stream));
-  for (int i = 0; i < nl; i++) {
-    const int *h = G->h_cnt + 128 * i;
-    int64_t in = 0;
-    for (int k = 2; k < 54; k++) {
-      if (h[k] > G->seg_cap[k] || h[64 + k] > G->seg_cap[k]) {
-        p3m_set_error("rank %d: not enough buffer space in pass (shift %d, %s: %d out, %d in > %d) (particle_pass.f90:96-99)", G->lrank[i], k / 2,
-                      (k & 1) ? "migrants" : "ghosts", h[k], h[64 + k], G->seg_cap[k]);
-        return P3M_ECAPACITY;
-      }
-      in += h[64 + k];
-    }
-    if ((int64_t)G->ctx[i]->np_local + in > G->ctx[i]->cap) {
-      p3m_set_error("rank %d: exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139)", G->lrank[i], (long long)G->ctx[i]->np_local + in, (long long)G->ctx[i]->cap);
+  const int *hg = G->h_gather;
+  const int64_t cap = G->ctx[0]->cap;
+  // 3. the same checks for every rank on every process (particle_pass.f90:96-99, :136-139)
+  std::vector<int64_t> in(G->nodes, 0);
+  int need[54] = {0};
+  for (int r = 0; r < G->nodes; r++)
+    for (int k = 2; k < 54; k++) { in[shift_neighbour(G, r, k / 2)] += hg[64 * r + k]; need[k] = std::max(need[k], hg[64 * r + k]); }
+  for (int r = 0; r < G->nodes; r++)
+    if ((int64_t)hg[64 * r + 54] + in[r] > cap) {
+      p3m_set_error("rank %d: exceeded max_np in pass: %lld > %lld (particle_pass.f90:136-139); raise density_buffer", r, (long long)hg[64 * r + 54] + in[r], (long long)cap);
       return P3M_ECAPACITY;
     }
+  bool grow = false;
+  for (int k = 2; k < 54; k++) grow = grow || need[k] > G->seg_cap[k];
+  if (grow) {
+    // a segment was too small for this step's (clustered) shell: the reference's per-direction buffer holds max_buf = 2.2
+    // max_np floats (cubepm.par:174); here the segments grow to what is needed (+25 %), identically on every process, and
+    // the pack runs again (it counts past a full segment but does not write there)
+    for (int k = 2; k < 54; k++)
+      if (need[k] > G->seg_cap[k]) G->seg_cap[k] = (int)std::min<int64_t>(cap, (int64_t)need[k] + need[k] / 4 + 1024);
+    const int64_t run = layout_segments(G);
+    if (run > 0x3fffffff) { p3m_set_error("ghost segments of %lld records exceed the exchange buffer limit", (long long)run); return P3M_ECAPACITY; }
+    G->seg_total = run;
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    for (int i = 0; i < nl; i++) {
+      CoarseDist &d = G->cd[i];
+      gfree(d.sb); gfree(d.rb);
+      P3M_TRY(galloc(&d.sb, (size_t)run)); P3M_TRY(galloc(&d.rb, (size_t)run));
+    }
+    P3M_TRY(pack_all());
   }
-  // 3. payloads.  Sizes: the sender knows its own counts, the receiver the announced ones (they agree).
+  // 4. payloads: sender and receiver read the size of every message from the gathered counts
   std::vector<XMsg> pm;
   for (int r = 0; r < G->nodes; r++)
     for (int k = 2; k < 54; k++) {
       const int dst = shift_neighbour(G, r, k / 2), li = G->lidx[r], ld = G->lidx[dst];
-      const size_t rec = (k & 1) ? 32 : 16;
-      size_t bytes = 0;
-      if (li >= 0) bytes = (size_t)G->h_cnt[128 * li + k] * rec;
-      if (ld >= 0) bytes = (size_t)G->h_cnt[128 * ld + 64 + k] * rec;
+      const size_t bytes = (size_t)hg[64 * r + k] * ((k & 1) ? 32 : 16);
       pm.push_back({r, dst, li >= 0 ? (const void *)(G->cd[li].sb + (size_t)G->seg_off[k]) : nullptr,
                     ld >= 0 ? (void *)(G->cd[ld].rb + (size_t)G->seg_off[k]) : nullptr, bytes});
     }
   P3M_TRY(do_exchange(G, pm));
-  // 4. append
+  // 5. append: slot k of rank d is filled by the one rank whose shift k/2 lands on d
   for (int i = 0; i < nl; i++) {
-    const int *h = G->h_cnt + 128 * i;
-    P3M_TRY(particles_ghost_unpack(G->ctx[i], G->cd[i].rb, G->seg_off, h + 64, G->ctx[i]->np_local));
-    int in = 0; for (int k = 2; k < 54; k++) in += h[64 + k];
-    G->ctx[i]->np_all = G->ctx[i]->np_local + in;
+    const int d = G->lrank[i];
+    int cnt_in[64] = {0};
+    for (int r = 0; r < G->nodes; r++)
+      for (int k = 2; k < 54; k++) if (shift_neighbour(G, r, k / 2) == d) cnt_in[k] = hg[64 * r + k];
+    P3M_TRY(particles_ghost_unpack(G->ctx[i], G->cd[i].rb, G->seg_off, cnt_in, G->ctx[i]->np_local));
+    G->ctx[i]->np_all = G->ctx[i]->np_local + (int)in[d];
   }
   return P3M_OK;
 }
@@ -681,14 +722,16 @@ extern "C" int p3m_hip_group_download_particles(p3m_group *G, int32_t i, float *
   return p3m_hip_download_particles(G->ctx[i], xv6, pid, np);
 }
 
-static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out) {
+static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out, bool downloaded = false) {
   const Geometry &g = G->ctx[0]->g;
   float v[4] = {0, 0, 0, 0}; double sums[3] = {0, 0, 0}; int ng = 0, ndel = 0;
-  for (p3m_ctx *c : G->ctx) {
-    P3M_TRY(reductions_download(c));
-    HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+  if (!downloaded) {
+    for (p3m_ctx *c : G->ctx) {
+      P3M_TRY(reductions_download(c));
+      HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(G->stream));
   }
-  HIP_TRY(hipStreamSynchronize(G->stream));
   for (p3m_ctx *c : G->ctx) {
     reductions_fold(c);
     v[0] = std::max(v[0], sqrtf(c->h_red[0])); v[1] = std::max(v[1], c->h_red[1]); v[3] = std::max(v[3], c->h_red[2]);
@@ -743,7 +786,7 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
   P3M_TRY(ghost_pass(G));                                                                           // :61-63
   for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); }   // every rank's sort queued ...
-  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort_finish(c));                                             // ... before the host waits for the counters
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort_finish(c, false));                                      // ... and nobody waits: the counters come in with the step's results
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
   // fine-mesh force sweeps (many small kernels and the all-to-all exchanges against bandwidth-bound FFT passes).  PM-only
   // NGP runs then apply its kick inside the fine kick's pass (k_fine_kick_rows<true>); with a PP kick in between
@@ -778,9 +821,12 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
     for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt));                                   // coarse_velocity
   }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_enqueue(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));  // :716-720
-  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_finish(c));
+  // ONE host wait for everything the host reads back: survivor counts, the sort's counters, maxima and sums
+  for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_download(c)); HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, c->g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream)); }
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_finish(c, false));
   p3m_step_out o;
-  P3M_TRY(reduce_step_out(G, a_mid, &o));
+  P3M_TRY(reduce_step_out(G, a_mid, &o, true));
   if (out) *out = o;
   return P3M_OK;
 }

@@ -399,6 +399,8 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
   P3M_TRY(reductions_download(c));
   HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->finalize_queued) P3M_TRY(particles_finalize_finish(c, false));   // a ghost removal queued by the whole-step call
+  particles_collect_counters(c);
   reductions_fold(c);
   p3m_step_out o; memset(&o, 0, sizeof(o));
   float fmax = sqrtf(c->h_red[0]);                         // :643
@@ -442,7 +444,8 @@ extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(reductions_clear(c));
   P3M_TRY(particles_pass_self(c));                           // :61-63
-  P3M_TRY(particles_sort(c, mass_p));
+  P3M_TRY(particles_sort_enqueue(c, mass_p));
+  P3M_TRY(particles_sort_finish(c, false));                  // no host wait: the sort's counters come in with the step's results
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
   // fine-mesh force sweep.  PM-only NGP runs then apply its kick inside the fine kick's pass (k_fine_kick_rows<true>); with a
   // PP kick in between (reference order fine, PP, coarse) it keeps its own pass.
@@ -473,9 +476,10 @@ extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt
     if (c->stream2) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_cf, 0));
     P3M_TRY(coarse_kick(c, a_mid, dt));                      // coarse_velocity (coarse_vel_update = .true., cubepm.par:87)
   }
-  P3M_TRY(p3m_hip_delete_particles(c, move_back));           // :716-720
+  // :716-720; the survivor count, the sort's counters and the step's maxima and sums reach the host behind ONE wait
+  P3M_TRY(particles_finalize_enqueue(c, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));
   p3m_step_out o;
-  P3M_TRY(p3m_hip_get_step_out(c, a_mid, &o));               // :643-706
+  P3M_TRY(p3m_hip_get_step_out(c, a_mid, &o));               // :643-706 (synchronises the stream)
   if (out) *out = o;
   return P3M_OK;
 }

@@ -92,6 +92,8 @@ struct p3m_ctx {
   bool pending_compact = false; int pend_n = 0; float pend_mb[3] = {0, 0, 0};   // deferred ghost removal (particles.hip)
   hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;   // single-rank whole steps: the coarse force forms on stream2 underneath the fine-mesh force sweep
   int sort_ncur = 0;           // records handed to the sort queued by particles_sort_enqueue
+  bool finalize_queued = false; // particles_finalize_enqueue ran, particles_finalize_finish has not
+  bool lazy_counters = false;  // whole steps: the sort's deleted count has not been read yet, np_all is its upper bound (the tail is padded)
   bool coarse_first = false;   // whole-step PM-only NGP runs: the coarse force is ready before the fine kick, which then adds the coarse kick in the same pass
   bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
@@ -145,13 +147,14 @@ int particles_pass_and_sort(p3m_ctx *c);
 int particles_pass_self(p3m_ctx *c);
 int particles_sort(p3m_ctx *c, float deposit_mass);
 int particles_sort_enqueue(p3m_ctx *c, float deposit_mass);   // the device half ...
-int particles_sort_finish(p3m_ctx *c);                        // ... and the host half (one stream sync, counters)
+int particles_sort_finish(p3m_ctx *c, bool wait);             // ... and the host half (wait: one stream sync for the exact counters; else deferred)
+void particles_collect_counters(p3m_ctx *c);                  // deferred counters, after the step's synchronisation
 int particles_full_cells(p3m_ctx *c);   // cell_end valid again after a sort that wrote the compact table only
 int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts);
 int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);
 int particles_finalize_enqueue(p3m_ctx *c, const float *move_back);
-int particles_finalize_finish(p3m_ctx *c);
+int particles_finalize_finish(p3m_ctx *c, bool wait);
 int particles_preload();
 int scan_reserve(p3m_ctx *c, int64_t n_max);   // scan.hip
 int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset);

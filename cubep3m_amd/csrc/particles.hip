@@ -376,6 +376,9 @@ int particles_pass_self(p3m_ctx *c) {
   return P3M_OK;
 }
 
+__global__ __launch_bounds__(PT) void k_pad_tail(float4 *__restrict__ spos, const int *__restrict__ nsorted, int n) {
+  for (int i = *nsorted + blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) spos[i] = make_float4(-1.0e30f, -1.0e30f, -1.0e30f, 0.f);
+}
 // sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell; deposit_mass >= 0 (whole-step
 // entry points, where mass_p is known here) also writes the NGP density of every tile (c->rho_from_sort)
 int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
@@ -415,21 +418,39 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
                      (const float4 *)c->vel, (const int64_t *)c->pid, (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5,
                      (int)c->cap, dep, cc);
   HIP_TRY(hipGetLastError());
+  // records that left the chaining mesh were dropped (link_list.f90:26-53): the sorted arrays hold n_cur - deleted records.
+  // The slots behind them get a position no range test accepts, so everything downstream may run over n_cur records
+  // without the host knowing the deleted count (whole steps read it with the step's other results, particles_sort_finish)
+  if (n_cur > 0) {
+    hipLaunchKernelGGL(k_pad_tail, dim3(32), dim3(PT), 0, c->stream, c->spos, (const int *)(c->row_end + 1 + nrows), n_cur);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sort_ncur = n_cur;
   return P3M_OK;
 }
-// the host half: counters of the sort queued by particles_sort_enqueue (a group queues every rank's sort before it waits)
-int particles_sort_finish(p3m_ctx *c) {
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->np_deleted = c->h_counters[4];
-  c->ncand = (int)std::min<int64_t>(c->h_counters[5], c->cap);
-  c->np_all = c->sort_ncur - c->np_deleted;  // sorted records
+// the host half: counters of the sort queued by particles_sort_enqueue.  wait = false (whole steps): no host wait here; the
+// record count stays at its upper bound (the padded tail is inert) and the deleted count is collected by
+// particles_collect_counters once the step's last synchronisation has happened.
+int particles_sort_finish(p3m_ctx *c, bool wait) {
+  if (wait) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->np_deleted = c->h_counters[4];
+    c->np_all = c->sort_ncur - c->np_deleted;  // sorted records
+    c->lazy_counters = false;
+  } else {
+    c->np_deleted = 0;
+    c->np_all = c->sort_ncur;
+    c->lazy_counters = true;
+  }
   return P3M_OK;
+}
+void particles_collect_counters(p3m_ctx *c) {   // after a stream synchronisation that followed the sort
+  if (c->lazy_counters) { c->np_deleted = c->h_counters[4]; c->lazy_counters = false; }
 }
 int particles_sort(p3m_ctx *c, float deposit_mass) {
   P3M_TRY(particles_sort_enqueue(c, deposit_mass));
-  return particles_sort_finish(c);
+  return particles_sort_finish(c, true);
 }
 
 int particles_pass_and_sort(p3m_ctx *c) {
@@ -601,6 +622,7 @@ int particles_finalize_enqueue(p3m_ctx *c, const float *move_back) {
   const int n = c->np_all;
   c->pending_compact = false;
   c->pend_n = n;
+  c->finalize_queued = true;
   if (n == 0) { c->np_local = 0; return P3M_OK; }
   float mx = 0, my = 0, mz = 0;
   if (move_back) { mx = move_back[0]; my = move_back[1]; mz = move_back[2]; }
@@ -611,16 +633,18 @@ int particles_finalize_enqueue(p3m_ctx *c, const float *move_back) {
   c->pend_mb[0] = mx; c->pend_mb[1] = my; c->pend_mb[2] = mz;
   return P3M_OK;
 }
-int particles_finalize_finish(p3m_ctx *c) {
-  if (c->pend_n == 0) return P3M_OK;
-  HIP_TRY(hipStreamSynchronize(c->stream));
+int particles_finalize_finish(p3m_ctx *c, bool wait) {   // wait = false: the caller synchronised the stream after particles_finalize_enqueue
+  c->finalize_queued = false;
+  if (c->pend_n == 0) { particles_collect_counters(c); return P3M_OK; }
+  if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
+  particles_collect_counters(c);
   c->np_local = c->h_counters[0];
   c->pending_compact = true;
   return P3M_OK;
 }
 int particles_finalize(p3m_ctx *c, const float *move_back) {
   P3M_TRY(particles_finalize_enqueue(c, move_back));
-  return particles_finalize_finish(c);
+  return particles_finalize_finish(c, true);
 }
 // the first launch of a kernel pays for loading it: the deferred-compaction kernels are first needed in the SECOND step,
 // where that shows up as a host stall in the middle of a timed run; ask for their attributes at context creation instead

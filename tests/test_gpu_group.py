@@ -377,3 +377,48 @@ def test_bench_multi_process_launch_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["ranks_per_gpu"] == 4 and "roofline" in d and "cpu_baseline" not in d      # cpu_baseline: rank 0 at N = 1 only
+
+
+def test_ghost_segments_grow_when_a_clustered_shell_overfills_them(monkeypatch):
+    """The exchange segments start at a multiple of the uniform-density share of a face / edge / corner shell; a clustered
+    shell that overfills one makes every process grow it (the counts of every rank are gathered first, so all processes
+    take the same decision) and pack again -- the reference would have taken up to max_buf = 2.2 max_np floats per
+    direction (cubepm.par:174).  Started here at 5 % of the uniform share so that every segment overflows."""
+    monkeypatch.setenv("P3M_GHOST_SEG_FACTOR", "0.05")
+    p = cfg1(nodes_dim=2, ngp=True, ppint=True, pp_ext=True)
+    xv, pid = global_ic("clustered", 60000, float(p.nf_physical_dim), 123)
+    g, o, og, oo = run_both(p, xv, pid, (0.01, 0.3, 0.3, 8.0), steps=2)
+    assert og.np_total == oo.np_total == len(xv) and og.np_ghost == oo.np_ghost
+    for name in ("dt_f_acc", "dt_c_acc", "dt_pp_acc", "dt_pp_ext_acc"):
+        assert getattr(og, name) == pytest.approx(getattr(oo, name), rel=1e-5), name
+    for i, r in enumerate(g.local_ranks):
+        xg, pg = by_pid(*g.download_particles(i))
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po) and np.abs(xg[:, :3] - xo[:, :3]).max() <= 1e-4
+        assert rel_rms(xg[:, 3:], xo[:, 3:]) <= 1e-5
+
+
+def test_capacity_overflow_in_the_ghost_pass_is_one_error_for_the_whole_group():
+    """particle_pass.f90:136-139 (mpi_abort when np_local + np_buf > max_np) as an error code: with the counts of all ranks
+    gathered, every process -- here every logical rank -- sees the same overflow and the step returns P3M_ECAPACITY
+    before any payload moves."""
+    from cubep3m_amd import lib
+    from cubep3m_amd.group import ParticleMeshGroup
+
+    p = cfg1(nodes_dim=2, ngp=True, density_buffer=1.0)
+    g = ParticleMeshGroup(p, 0, 1, FINE_TABLE, COARSE_TABLE)
+    cap = g.rank_context(0).derived(0)                    # max_np, cubepm.par:170-172
+    # rank 0 nearly full, its neighbours' face shells packed: the arrivals no longer fit rank 0
+    rng = np.random.default_rng(5)
+    Nn = float(p.nf_physical_node_dim)
+    for i, r in enumerate(g.local_ranks):
+        n = cap - 10 if r == 0 else 30000
+        xv = np.zeros((n, 6), np.float32)
+        xv[:, :3] = rng.random((n, 3), dtype=np.float32) * np.float32(Nn)
+        if r != 0:
+            xv[:, :3] = xv[:, :3] * np.float32(0.3)          # near the low faces: ghosts of the neighbour at -x, -y, -z
+        np.minimum(xv[:, :3], np.float32(Nn * (1 - 2e-6)), out=xv[:, :3])
+        g.upload_particles(i, xv, np.arange(1, n + 1, dtype=np.int64) + r * 10 ** 7)
+    with pytest.raises(lib.P3MError) as e:
+        g.particle_mesh(0.01, 0.1, 0.0, 8.0)
+    assert e.value.code == -3 and "max_np" in str(e.value)
