@@ -56,6 +56,9 @@ CONFIGS = {
     "cfg4_pp": dict(params=dict(nodes_dim=2, tiles_node_dim=1, nf_tile=560, ngp=True, ppint=True, pp_ext=True, density_buffer=1.3), nside_rank=256,
                     workload="1024^3 fine mesh / 512^3 particles, PM+PP+PP_EXT (NGP), 2x2x2 logical ranks, nf_tile=560 (one tile per rank), "
                              "256^3 coarse mesh with slab FFT + all-to-all transpose"),
+    # configs[3]'s problem as ONE rank of 2^3 tiles (what a single-GPU user of the reference would build: nodes_dim = 1)
+    "cfg4_1rank": dict(params=dict(nodes_dim=1, tiles_node_dim=2, nf_tile=560, ngp=True, density_buffer=1.3), nside_rank=512,
+                       workload="1024^3 fine mesh / 512^3 particles, PM-only (NGP), one rank of 2^3 tiles of nf_tile=560, 256^3 coarse mesh"),
     # one rank's share of configs[3] on its own
     "big512": dict(params=dict(tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3), nside_rank=256,
                    workload="512^3 fine mesh / 256^3 particles (one rank's share of 1024^3/512^3), PM-only, nf_tile=560, 1 tile"),
