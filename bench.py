@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the non-headline legs of the default run (PM+PP step at the headline's size, PP kernel rates)")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="multi-GPU runs: exit non-zero instead of falling back to the host-callback transport when RCCL cannot be set up")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the host side (gloo: debugging on fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -234,6 +236,8 @@ def main():
         flag = torch.tensor([ok], device=ddev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
+            if args.require_rccl:
+                raise SystemExit("RCCL transport unavailable and --require-rccl given")
             if grp is not None:
                 grp.close()
             gloo = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else None
@@ -337,6 +341,9 @@ def main():
             "metric": "particle_updates_per_sec", "value": value, "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # true: the exchanges between processes did NOT go over RCCL/xGMI but through host callbacks over gloo -- such a
+            # line is no statement about xGMI scaling
+            "transport_fallback": transport.startswith("host callbacks"),
             "config": {"workload": cfg["workload"], "name": args.config, "particles": n_total, "logical_ranks": p.nodes,
                        "ranks_per_gpu": p.nodes // world, "tiles_per_rank": ntile, "nf_tile": p.nf_tile, "transport": transport,
                        "flags": {"ngp": p.ngp, "ppint": p.ppint, "pp_ext": p.pp_ext}},
