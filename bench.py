@@ -353,27 +353,45 @@ def main():
             # non-headline legs (rank 0, one GPU): the same 512^3-particle problem with PPINT + PP_EXT on, and the two
             # short-range kernels on their own
             grp.close()
-            p2 = Params(**CONFIGS["cfg4_pp"]["params"])
-            p2.device = local_dev
-            g2 = ParticleMeshGroup(p2, 0, 1, fine, coarse)
-            for i, r in enumerate(g2.local_ranks):
-                xv = make_particles(nside, box, seed=12345 + r)
-                g2.upload_particles(i, xv, np.arange(1, len(xv) + 1, dtype=np.int64) + r * len(xv))
-                del xv
-            for _ in range(2):
-                g2.particle_mesh(a_mid, dt, dt_old, mass_p)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            k2 = max(3, min(args.steps, 6))
-            for _ in range(k2):
-                o2 = g2.particle_mesh(a_mid, dt, dt_old, mass_p)
-            torch.cuda.synchronize()
-            el2 = time.perf_counter() - t1
-            assert o2.np_total == n_total
-            g2.close()
-            res["pm_pp"] = {"metric": "particle_updates_per_sec", "value": n_total * k2 / el2, "ms_per_step": 1e3 * el2 / k2, "steps": k2,
-                            "workload": CONFIGS["cfg4_pp"]["workload"], "data": "synthetic uniform (the headline's particles)",
-                            "dt_pp_acc": o2.dt_pp_acc, "dt_pp_ext_acc": o2.dt_pp_ext_acc}
+
+            def side_leg(cfg_name, gen, data):
+                """full steps of another flag set / another IC on the headline's geometry, timed like the headline"""
+                p2 = Params(**CONFIGS[cfg_name]["params"])
+                p2.device = local_dev
+                g2 = ParticleMeshGroup(p2, 0, 1, fine, coarse)
+                for i, r in enumerate(g2.local_ranks):
+                    xv = gen(r)
+                    g2.upload_particles(i, xv, np.arange(1, len(xv) + 1, dtype=np.int64) + r * len(xv))
+                    del xv
+                for _ in range(2):
+                    g2.particle_mesh(a_mid, dt, dt_old, mass_p)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                k2 = max(3, min(args.steps, 6))
+                for _ in range(k2):
+                    o2 = g2.particle_mesh(a_mid, dt, dt_old, mass_p)
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t1
+                assert o2.np_total == n_total
+                g2.close()
+                leg = {"metric": "particle_updates_per_sec", "value": n_total * k2 / el2, "ms_per_step": 1e3 * el2 / k2, "steps": k2,
+                       "workload": CONFIGS[cfg_name]["workload"], "data": data}
+                if p2.ppint:
+                    leg.update(dt_pp_acc=o2.dt_pp_acc, dt_pp_ext_acc=o2.dt_pp_ext_acc)
+                return leg
+
+            def uniform_ic(r):
+                return make_particles(nside, box, seed=12345 + r)
+
+            def clustered_ic(r):   # SURVEY Appendix C's recipe at its density: 30 % of the particles in blobs of ~205, sigma 0.6 cells
+                xv = clustered(nside, box, 2024 + r, 0.3, 48 * (nside // 32) ** 3, 0.6)
+                xv[:, 3:] = np.random.default_rng(99 + r).normal(0, 0.05, (len(xv), 3)).astype(np.float32)
+                return xv
+
+            res["pm_pp"] = side_leg("cfg4_pp", uniform_ic, "synthetic uniform (the headline's particles)")
+            # the same two step types on a clustered particle set: dense cells, unequal rows, heavy pair lists
+            cdata = "synthetic clustered: 30 % of the particles in Gaussian blobs of ~205 particles, sigma 0.6 cells (SURVEY Appendix C's recipe at its density)"
+            res["clustered"] = {"pm": side_leg("cfg4", clustered_ic, cdata), "pm_pp": side_leg("cfg4_pp", clustered_ic, cdata)}
             res["pp"] = pp_leg()
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(scal)

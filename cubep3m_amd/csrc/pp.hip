@@ -426,17 +426,18 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
 #define PP_LCAP 40
 #define PP_CHUNK 4
 #define PP_NSEG 64
-__global__ __launch_bounds__(256) void k_pp_plan(const int *__restrict__ cs, PPGeo G, int ngy, int ngroups, int *__restrict__ plan) {
+__global__ __launch_bounds__(256) void k_pp_plan(const int *__restrict__ cs, PPGeo G, int ngy, int nxb, int xbw, int ngroups, int *__restrict__ plan) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= ngroups) return;
   const int e = G.pt + 2 * G.ppr;
-  const int gy = g % ngy, rz = (g / ngy) % e, tile = g / (ngy * e);
+  const int xb = g % nxb, gy = (g / nxb) % ngy, rz = (g / (nxb * ngy)) % e, tile = g / (nxb * ngy * e);
   const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
   const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
+  const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);   // the group's home cells
   int count = 0;
   for (int j = 0; j < PP_RG; j++) {
     const int ry = gy * PP_RG + j;
-    if (ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count += cs[rb + lox + e] - cs[rb + lox]; }
+    if (ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count += cs[rb + hx1] - cs[rb + hx0]; }
   }
   plan[g] = (count + 63) >> 6;
 }
@@ -464,7 +465,7 @@ __device__ __forceinline__ void pp_ext_eval(const float4 &p, float ox, float oy,
 template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
 __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G, PPForce F,
                                                 float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
-                                                const int *__restrict__ task_group, int ngroups, int ngy, int ntask_cap, int *__restrict__ counter) {
+                                                const int *__restrict__ task_group, int ngroups, int ngy, int nxb, int xbw, int ntask_cap, int *__restrict__ counter) {
   __shared__ int list[PP_LCAP][64];
   __shared__ int rstart[PP_RG], roff[PP_RG];
   const int lane = threadIdx.x;
@@ -488,15 +489,16 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
     const int tl = min(tf + PP_CHUNK, send);
     for (int t = tf; t < tl; t++) {
       const int g = task_group[t], sub = t - plan[g];
-      const int gy = g % ngy, rz = (g / ngy) % e, tile = g / (ngy * e);
+      const int xb = g % nxb, gy = (g / nxb) % ngy, rz = (g / (nxb * ngy)) % e, tile = g / (nxb * ngy * e);
       const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
       const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
       const int cz = loz + rz;
+      const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);   // the group's home cells: a patch of PP_RG rows x xbw cells
       // the group's rows: first record and exclusive prefix of the home counts
       int cnt = 0, st = 0;
       if (lane < PP_RG) {
         const int ry = gy * PP_RG + lane;
-        if (ry < e) { const int64_t rb = ((int64_t)cz * E + (loy + ry)) * E; st = cs[rb + lox]; cnt = cs[rb + lox + e] - st; }
+        if (ry < e) { const int64_t rb = ((int64_t)cz * E + (loy + ry)) * E; st = cs[rb + hx0]; cnt = cs[rb + hx1] - st; }
       }
       int inc = cnt;
 #pragma unroll
@@ -561,25 +563,33 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
             }
           }
       }
-      const int nmax = wave_max_i(n);
-      if (nmax <= PP_LCAP) {
-        // four partners in flight at a time
-        for (int k = 0; k < nmax; k += 4) {
-          float4 o[4];
+      // lanes whose partners fit their list sum over it; the others (records in or next to dense cells) are served in
+      // GROUPS of lanes that are close in x -- a blob's members -- by the broadcast path over the union of the group's
+      // windows only: a row that crosses a blob holds a few dozen blob members and a few dozen background records spread
+      // over hundreds of cells, and one union over all of them would test every lane against every record of 25 whole rows
+      const bool big = n > PP_LCAP;
+      const int nl = big ? 0 : n;
+      const int nmax = wave_max_i(nl);
+      for (int k = 0; k < nmax; k += 4) {   // four partners in flight at a time
+        float4 o[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { o[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (k + u < n) o[u] = spos[list[k + u][lane]]; }
+        for (int u = 0; u < 4; u++) { o[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (k + u < nl) o[u] = spos[list[k + u][lane]]; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) if (k + u < n) pp_ext_eval(p, o[u].x, o[u].y, o[u].z, F, ax, ay, az);
-        }
-      } else {
-        // ---- dense path: the union of the lanes' windows, 64 partners at a time
-        const int Y0 = wave_min_i(valid ? y0 : 0x7fffffff), Y1 = wave_max_i(valid ? y1 : -1);
-        const int X0 = wave_min_i(valid ? x0 : 0x7fffffff), X1 = wave_max_i(valid ? x1 : -1);
+        for (int u = 0; u < 4; u++) if (k + u < nl) pp_ext_eval(p, o[u].x, o[u].y, o[u].z, F, ax, ay, az);
+      }
+      bool todo = big;
+      unsigned long long pend;
+      while ((pend = __ballot(todo)) != 0ull) {
+        const int lead = __ffsll((long long)pend) - 1;
+        const int xa = __builtin_amdgcn_readlane(cx, lead);
+        const bool mine = todo && cx >= xa - 4 && cx <= xa + 8;          // the group: dense lanes within a dozen cells of the first one
+        const int Y0 = wave_min_i(mine ? y0 : 0x7fffffff), Y1 = wave_max_i(mine ? y1 : -1);
+        const int X0 = wave_min_i(mine ? x0 : 0x7fffffff), X1 = wave_max_i(mine ? x1 : -1);
         for (int zz = z0; zz <= z1; zz++)
           for (int yy = Y0; yy <= Y1; yy++) {
             const int64_t rb = ((int64_t)zz * E + yy) * E;
             const int A = cs[rb + X0], B = cs[rb + X1 + 1];
-            const bool rowok = valid && yy >= y0 && yy <= y1;
+            const bool rowok = mine && yy >= y0 && yy <= y1;
             const bool ownrow = (zz == cz && yy == cy);
             for (int base = A; base < B; base += 64) {
               const int m = min(64, B - base);
@@ -595,6 +605,7 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
               }
             }
           }
+        todo = todo && !mine;
       }
       float mag = 0.f;
       if (valid) {
@@ -630,21 +641,32 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   const int e = g.pt + 2 * g.pp_range;
   static const bool v1 = getenv("P3M_PP_EXT_V1") && getenv("P3M_PP_EXT_V1")[0] == '1';   // A/B switch: the LDS-tiled kernel of round 1
   if (!v1) {
+    // a group is a patch of PP_RG rows x xbw cells holding ~192 records (three tasks) at the mean density.  Measured on a 560
+    // tile (ms per launch, uniform / 30 % of the particles in blobs of 205): whole rows 3.85 / 13.1, 96 cells 4.02 / 9.9,
+    // 24 cells 4.83 / 10.0: compact patches keep a blob's members in one wavefront (the broadcast path then serves dozens
+    // of lanes at once instead of a handful), whole rows keep the window loads of a uniform task on the fewest rows
+    static const int xbw_env = getenv("P3M_PP_XBW") ? atoi(getenv("P3M_PP_XBW")) : 0;
+    const double rho_mean = (double)c->np_all / ((double)g.E * g.E * g.E);
+    int xbw = xbw_env > 0 ? xbw_env : (int)std::lround(192.0 / std::max(1e-9, rho_mean * PP_RG));
+    xbw = std::max(4, std::min(xbw, e));
+    const int nxb = (e + xbw - 1) / xbw;
     const int ngy = (e + PP_RG - 1) / PP_RG;
-    const int64_t ngroups64 = (int64_t)g.ntiles * e * ngy;
+    const int64_t ngroups64 = (int64_t)g.ntiles * e * ngy * nxb;
     // a record is a home record of every tile whose extended region holds its cell: per axis at most 2 + 2*ppr/pt tiles
     const int64_t mult1 = std::min<int64_t>(g.T, 2 + (2 * g.pp_range) / g.pt), mult = mult1 * mult1 * mult1;
     const int64_t ntask_cap64 = mult * (c->cap / 64 + 1) + ngroups64 + 64;
     if (ngroups64 > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many row groups"); return P3M_EINVAL; }
     const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
+    const int64_t ngroups_max = (int64_t)g.ntiles * e * ngy * ((e + 3) / 4);
+    if (ngroups_max > 0x3fffffff) { p3m_set_error("extended PP: too many row groups"); return P3M_EINVAL; }
     if (!c->pp_plan) {
-      HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups + 8)));
-      HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)ntask_cap));
+      HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
+      HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)(mult * (c->cap / 64 + 1) + ngroups_max + 64)));   // any patch width
       HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
-      P3M_TRY(scan_reserve(c, ngroups + 8));
+      P3M_TRY(scan_reserve(c, ngroups_max + 8));
     }
     HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
-    hipLaunchKernelGGL(k_pp_plan, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, ngy, ngroups, c->pp_plan);
+    hipLaunchKernelGGL(k_pp_plan, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, ngy, nxb, xbw, ngroups, c->pp_plan);
     HIP_TRY(hipGetLastError());
     P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
     hipLaunchKernelGGL(k_pp_fill, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, c->pp_task_group, ntask_cap);
@@ -654,10 +676,10 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     static const bool unr = getenv("P3M_PP_UNROLL") && getenv("P3M_PP_UNROLL")[0] == '1';    // compile-time reach: all 25 windows loaded up front (116 VGPRs)
     if (g.pp_range == 2 && unr)
       hipLaunchKernelGGL(k_pp_ext2<2>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, F, a_mid, dt,
-                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, ntask_cap, c->pp_counter);
+                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, nxb, xbw, ntask_cap, c->pp_counter);
     else
       hipLaunchKernelGGL(k_pp_ext2<0>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, F, a_mid, dt,
-                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, ntask_cap, c->pp_counter);
+                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, nxb, xbw, ntask_cap, c->pp_counter);
     HIP_TRY(hipGetLastError());
     return P3M_OK;
   }
