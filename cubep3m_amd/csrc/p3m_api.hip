@@ -248,7 +248,7 @@ extern "C" int p3m_hip_upload_particles(p3m_ctx *c, const float *xv6, const int6
   if (!c || np_local < 0 || (np_local > 0 && !xv6)) return P3M_EINVAL;
   if (np_local > c->cap) { p3m_set_error("np_local %d exceeds max_np %lld", np_local, (long long)c->cap); return P3M_ECAPACITY; }
   HIP_TRY(hipSetDevice(c->device));
-  c->np_local = np_local; c->np_all = 0; c->pending_compact = false;
+  c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false;
   if (np_local == 0) return P3M_OK;
   float *stage = reinterpret_cast<float *>(c->spos);  // 16 B/record of scratch >= ... 24 B/record needs svel too
   // spos and svel are separate allocations: stage through a temporary instead

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(PT) void k_drift(float4 *__restrict__ pos, const fl
 
 int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset) {
   if (c->pending_compact) return particles_compact(c, true, dt, dt_old, offset);   // ghost removal of the last step + this drift in one pass
+  c->hist_done = false;                                                             // positions change in place: no row counts carried
   if (c->np_local == 0) return P3M_OK;
   hipLaunchKernelGGL(k_drift, dim3(cdiv(c->np_local, PT)), dim3(PT), 0, c->stream, c->pos, (const float4 *)c->vel, c->np_local, dt, dt_old,
                      offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0);
@@ -58,44 +59,6 @@ __device__ __forceinline__ int axis_images(float x, float Nn, float nb, float ou
   }
   return n;
 }
-__global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid, int n_cur,
-                                                    int cap, float Nn, float nb, int *__restrict__ counter, int *__restrict__ overflow) {
-  __shared__ int wsum[PT / 64];
-  __shared__ int base_sh;
-  const int i = blockIdx.x * PT + threadIdx.x;
-  float ox[3], oy[3], oz[3]; int nx = 1, ny = 1, nz = 1, cnt = 0;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n_cur) {
-    p = pos[i];
-    if (in_hoc_range(p, -nb, Nn + nb)) {  // else dropped by link_list ("PARTICLE DELETED")
-      nx = axis_images(p.x, Nn, nb, ox); ny = axis_images(p.y, Nn, nb, oy); nz = axis_images(p.z, Nn, nb, oz);
-      cnt = nx * ny * nz - 1;
-    }
-  }
-  // block exclusive scan of cnt
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int off = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < PT / 64; k++) { if (k < w) off += wsum[k]; tot += wsum[k]; }
-  if (threadIdx.x == 0) base_sh = tot ? atomicAdd(counter, tot) : 0;
-  __syncthreads();
-  if (cnt == 0) return;
-  int s = n_cur + base_sh + off + inc - cnt;
-  const float4 v = vel[i]; const int64_t id = pid[i];
-  for (int c = 0; c < nz; c++)
-    for (int b = 0; b < ny; b++)
-      for (int a = 0; a < nx; a++) {
-        if ((a | b | c) == 0) continue;
-        if (s < cap) { pos[s] = make_float4(ox[a], oy[b], oz[c], p.w); vel[s] = v; pid[s] = id; } else *overflow = 1;
-        s++;
-      }
-}
-
 // ------------------------------------------------------------------ sort by extended fine cell
 // cell = ((cz*E + cy)*E + cx), c_d = floor(x_d) + nb in [0,E).  cs[c] = start(c), cs[c+1] = end(c).
 // Two levels, because a device-scope atomic costs a fabric transaction and the cell array (E^3 ints) is ten
@@ -138,6 +101,81 @@ __device__ __forceinline__ bool row_run(int row, int &hl, int &cnt) {
   cnt = (above ? __ffsll((long long)above) - 1 : 64) - lane;
   return head;
 }
+// Row-histogram pieces for the kernels that PRODUCE the arrival arrays (k_compact_drift_hist, k_ghost_unpack, k_make_images):
+// in steady state every record passes through one of them right before the sort, so they count the x-rows on the way and
+// k_row_hist's pass over the positions (16 B per record) is skipped.
+__device__ __forceinline__ void hist_row(int *key, int *val, int *rs, int row) {   // every lane of the wavefront calls (row < 0: nothing to count)
+  int hl, cnt;
+  if (row_run(row, hl, cnt) && row >= 0) {
+    const int e = rowtab_slot(key, row);
+    if (e >= 0) atomicAdd(&val[e], cnt); else atomicAdd(&rs[row + 1], cnt);
+  }
+}
+__device__ __forceinline__ void hist_row_one(int *key, int *val, int *rs, int row) {   // callers in divergent code
+  const int e = rowtab_slot(key, row);
+  if (e >= 0) atomicAdd(&val[e], 1); else atomicAdd(&rs[row + 1], 1);
+}
+__device__ __forceinline__ void hist_flush(const int *key, const int *val, int *rs) {   // behind a __syncthreads()
+  for (int e = threadIdx.x; e < SORT_HB; e += blockDim.x) if (val[e] > 0) atomicAdd(&rs[key[e] + 1], val[e]);
+}
+// the coarse cell of a physical record whose tile-local fine cell differs from floor(x) (see k_row_hist) is flagged
+__device__ __forceinline__ void flag_displaced(const float4 &p, float nb, int E, int ms, int pt, unsigned char *cflag) {
+  const int nct = pt / ms; const float xs[3] = {p.x, p.y, p.z}; bool displaced = false; int cc[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    cc[d] = (int)floorf(xs[d] / (float)ms);
+    const int t = cc[d] / nct;
+    const float xl = xs[d] + (nb - (float)(t * pt));
+    displaced = displaced || ((int)floorf(xl) != (int)floorf(xs[d]) + (int)nb - t * pt);
+  }
+  if (displaced) { const int Ec = E / ms, cb = (int)nb / ms; cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] = 1; }
+}
+template <bool HIST>   // HIST: the images' x-rows are counted on the way (rs; the originals were counted by k_compact_drift_hist)
+__global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid, int n_cur,
+                                                    int cap, float Nn, float nb, int *__restrict__ counter, int *__restrict__ overflow, int E, int *__restrict__ rs) {
+  __shared__ int wsum[PT / 64];
+  __shared__ int base_sh;
+  __shared__ int key[HIST ? SORT_HB : 1], val[HIST ? SORT_HB : 1];
+  if (HIST) { for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; } }
+  const int i = blockIdx.x * PT + threadIdx.x;
+  float ox[3], oy[3], oz[3]; int nx = 1, ny = 1, nz = 1, cnt = 0;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n_cur) {
+    p = pos[i];
+    if (in_hoc_range(p, -nb, Nn + nb)) {  // else dropped by link_list ("PARTICLE DELETED")
+      nx = axis_images(p.x, Nn, nb, ox); ny = axis_images(p.y, Nn, nb, oy); nz = axis_images(p.z, Nn, nb, oz);
+      cnt = nx * ny * nz - 1;
+    }
+  }
+  // block exclusive scan of cnt
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < PT / 64; k++) { if (k < w) off += wsum[k]; tot += wsum[k]; }
+  if (threadIdx.x == 0) base_sh = tot ? atomicAdd(counter, tot) : 0;
+  __syncthreads();
+  if (cnt != 0) {
+    int s = n_cur + base_sh + off + inc - cnt;
+    const float4 v = vel[i]; const int64_t id = pid[i];
+    for (int c = 0; c < nz; c++)
+      for (int b = 0; b < ny; b++)
+        for (int a = 0; a < nx; a++) {
+          if ((a | b | c) == 0) continue;
+          if (s < cap) {
+            pos[s] = make_float4(ox[a], oy[b], oz[c], p.w); vel[s] = v; pid[s] = id;
+            if (HIST) hist_row_one(key, val, rs, ((int)floorf(oz[c]) + (int)nb) * E + (int)floorf(oy[b]) + (int)nb);   // images lie inside [-nb, Nn+nb)
+          } else *overflow = 1;
+          s++;
+        }
+  }
+  if (HIST) { __syncthreads(); hist_flush(key, val, rs); }
+}
+
 __global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos, int n, int np_orig, float Nn, float nb, int E,
                                                  int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt) {
   __shared__ int key[SORT_HB], val[SORT_HB];
@@ -357,12 +395,16 @@ int particles_full_cells(p3m_ctx *c) {
 int particles_pass_self(p3m_ctx *c) {
   P3M_TRY(particles_resolve(c));
   const Geometry &g = c->g;
-  int *cnt = c->d_counters;  // [0] image count, [3] overflow, [4] deleted, [5] candidates
-  HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(int), c->stream));
+  int *cnt = c->d_counters;  // [0] image count, [3] overflow, [4] deleted, [5] candidates (the last two belong to the sort / the row histogram)
+  HIP_TRY(hipMemsetAsync(cnt, 0, 4 * sizeof(int), c->stream));
   int n_cur = c->np_local;
   if (n_cur > 0) {
-    hipLaunchKernelGGL(k_make_images, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
-                       (float)g.nb, cnt, cnt + 3);
+    if (c->hist_done)
+      hipLaunchKernelGGL(k_make_images<true>, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
+                         (float)g.nb, cnt, cnt + 3, g.E, c->row_end);
+    else
+      hipLaunchKernelGGL(k_make_images<false>, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
+                         (float)g.nb, cnt, cnt + 3, g.E, c->row_end);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -387,13 +429,17 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   int *cnt = c->d_counters;
   const int n_cur = c->np_all;
   c->np_ghost = n_cur - c->np_local;
-  HIP_TRY(hipMemsetAsync(cnt + 4, 0, 2 * sizeof(int), c->stream));
   const int nrows = g.E * g.E;
-  HIP_TRY(hipMemsetAsync(c->row_end - 3, 0, (size_t)(nrows + 8) * sizeof(int), c->stream));
   const bool want_cflag = (c->p.flags & P3M_FLAG_PPINT) != 0;
-  if (want_cflag) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
   const int nblk = cdiv(n_cur, PT * SORT_RPT);
-  if (n_cur > 0) {
+  const bool counted = c->hist_done;   // the rows were counted by the kernels that wrote the arrival arrays (k_compact_drift_hist, ...)
+  c->hist_done = false;
+  if (!counted) {
+    HIP_TRY(hipMemsetAsync(cnt + 4, 0, 2 * sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->row_end - 3, 0, (size_t)(nrows + 8) * sizeof(int), c->stream));
+    if (want_cflag) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
+  }
+  if (n_cur > 0 && !counted) {
     hipLaunchKernelGGL(k_row_hist, dim3(nblk), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, c->np_local, (float)g.Nn, (float)g.nb, g.E,
                        c->row_end, cnt + 4, want_cflag ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
     HIP_TRY(hipGetLastError());
@@ -550,21 +596,34 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
 }
 // appends the received segments: blockIdx.y = slot - 2; dst[k] = first record index of that segment in pos/vel/pid
 struct GhostIn { int off[GSLOTS]; int cnt[GSLOTS]; int dst[GSLOTS]; };
+template <bool HIST>   // HIST: the arrivals' x-rows are counted on the way (see hist_row)
 __global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ rbuf, GhostIn T, float4 *__restrict__ pos, float4 *__restrict__ vel,
-                                                     int64_t *__restrict__ pid) {
+                                                     int64_t *__restrict__ pid, float Nn, float nb, int E, int *__restrict__ rs) {
+  __shared__ int key[HIST ? SORT_HB : 1], val[HIST ? SORT_HB : 1];
+  if (HIST) { for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; } __syncthreads(); }
   const int k = blockIdx.y + 2, n = T.cnt[k];
-  if (k & 1) {
-    for (int i = blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) {
-      const float4 *r = rbuf + (int64_t)T.off[k] + 2 * (int64_t)i;
-      const float4 r0 = r[0], r1 = r[1];
-      const int o = T.dst[k] + i;
-      pos[o] = make_float4(r0.x, r0.y, r0.z, 0.f); vel[o] = make_float4(r0.w, r1.x, r1.y, 0.f);
-      pid[o] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
+  for (int base = blockIdx.x * PT; base < n; base += gridDim.x * PT) {   // uniform trip count: hist_row is a wavefront operation
+    const int i = base + threadIdx.x;
+    int row = -1;
+    if (i < n) {
+      float4 q;
+      if (k & 1) {
+        const float4 *r = rbuf + (int64_t)T.off[k] + 2 * (int64_t)i;
+        const float4 r0 = r[0], r1 = r[1];
+        const int o = T.dst[k] + i;
+        q = make_float4(r0.x, r0.y, r0.z, 0.f);
+        pos[o] = q; vel[o] = make_float4(r0.w, r1.x, r1.y, 0.f);
+        pid[o] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
+      } else {
+        // ghosts: the velocity / PID slots stay unwritten -- nothing reads them before delete_particles drops the record
+        q = rbuf[(int64_t)T.off[k] + i];
+        pos[T.dst[k] + i] = q;
+      }
+      if (HIST && in_hoc_range(q, -nb, Nn + nb)) row = ((int)floorf(q.z) + (int)nb) * E + (int)floorf(q.y) + (int)nb;
     }
-  } else {
-    // ghosts: the velocity / PID slots stay unwritten -- nothing reads them before delete_particles drops the record
-    for (int i = blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) pos[T.dst[k] + i] = rbuf[(int64_t)T.off[k] + i];
+    if (HIST) hist_row(key, val, rs, row);
   }
+  if (HIST) { __syncthreads(); hist_flush(key, val, rs); }
 }
 int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts) {
   P3M_TRY(particles_resolve(c));
@@ -579,7 +638,12 @@ int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, c
   GhostIn T; int mx = 0, run = base;
   for (int k = 0; k < GSLOTS; k++) { T.off[k] = seg_off[k]; T.cnt[k] = k >= 2 ? cnt[k] : 0; T.dst[k] = run; run += T.cnt[k]; mx = std::max(mx, T.cnt[k]); }
   if (mx == 0) return P3M_OK;
-  hipLaunchKernelGGL(k_ghost_unpack, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid);
+  if (c->hist_done)
+    hipLaunchKernelGGL(k_ghost_unpack<true>, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid, (float)c->g.Nn,
+                       (float)c->g.nb, c->g.E, c->row_end);
+  else
+    hipLaunchKernelGGL(k_ghost_unpack<false>, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid, (float)c->g.Nn,
+                       (float)c->g.nb, c->g.E, c->row_end);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -613,6 +677,47 @@ __global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos,
     else { p.x = p.x + v.x * hs; p.y = p.y + v.y * hs; p.z = p.z + v.z * hs; }                           // :73
   }
   pos[o] = p; vel[o] = v; pid[o] = spid[i];
+}
+
+// k_compact<true> with the row histogram of the sort that follows (k_row_hist) counted on the way: SORT_RPT records per
+// thread like k_row_hist, so that a block's 2048 consecutive (cell-sorted) records hit a few dozen rows of the LDS table.
+// Records that the drift carries out of the chaining mesh are counted as deleted (link_list.f90:26-53), coarse cells with a
+// displaced record are flagged (see k_row_hist).
+__global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restrict__ spos, const float4 *__restrict__ svel, const int64_t *__restrict__ spid,
+                                                           const int *__restrict__ offs, int n, float Nn, float4 *__restrict__ pos, float4 *__restrict__ vel,
+                                                           int64_t *__restrict__ pid, float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off,
+                                                           float nb, int E, int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt) {
+  __shared__ int key[SORT_HB], val[SORT_HB];
+  for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
+  __syncthreads();
+  float4 pl[SORT_RPT];
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {   // all position loads first
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    pl[u] = make_float4(-1.f, -1.f, -1.f, 0.f);
+    if (i < n) pl[u] = spos[i];
+  }
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    float4 p = pl[u];
+    p.x -= mx; p.y -= my; p.z -= mz;
+    int row = -1;
+    if (i < n && p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn) {   // delete_particles.f90:17-47
+      const int o = offs[i];
+      const float4 v = svel[i];
+      if (use_off) { p.x = p.x + v.x * hs + ox; p.y = p.y + v.y * hs + oy; p.z = p.z + v.z * hs + oz; }  // update_position.f90:71
+      else { p.x = p.x + v.x * hs; p.y = p.y + v.y * hs; p.z = p.z + v.z * hs; }                           // :73
+      pos[o] = p; vel[o] = v; pid[o] = spid[i];
+      if (in_hoc_range(p, -nb, Nn + nb)) {
+        row = ((int)floorf(p.z) + (int)nb) * E + (int)floorf(p.y) + (int)nb;
+        if (cflag && p.x >= 0.f && p.x < Nn && p.y >= 0.f && p.y < Nn && p.z >= 0.f && p.z < Nn) flag_displaced(p, nb, E, ms, pt, cflag);
+      } else atomicAdd(ndeleted, 1);
+    }
+    hist_row(key, val, rs, row);
+  }
+  __syncthreads();
+  hist_flush(key, val, rs);
 }
 
 // delete_particles: the survivors are counted now (the step's np_local), but the copy back to the arrival arrays is
@@ -654,12 +759,31 @@ int particles_preload() {
   HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_compact<false>)));
   return P3M_OK;
 }
+// zeroes what the row histogram of the next sort accumulates into (k_row_hist's preamble) -- for the kernels that count on the way
+static int particles_hist_begin(p3m_ctx *c) {
+  const Geometry &g = c->g;
+  const int nrows = g.E * g.E;
+  HIP_TRY(hipMemsetAsync(c->d_counters + 4, 0, 2 * sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(c->row_end - 3, 0, (size_t)(nrows + 8) * sizeof(int), c->stream));
+  if (c->p.flags & P3M_FLAG_PPINT) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
+  return P3M_OK;
+}
 int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset) {
   if (!c->pending_compact) return P3M_OK;
   c->pending_compact = false;
   const int n = c->pend_n;
   const float hs = 0.5f * (dt + dt_old);
-  if (drift)
+  static const bool nofuse = getenv("P3M_SEPARATE_HIST") && getenv("P3M_SEPARATE_HIST")[0] == '1';   // A/B: k_row_hist as its own pass
+  if (drift && !nofuse) {
+    // the sort follows: count its x-rows here and in the kernels that append the ghosts (c->hist_done)
+    P3M_TRY(particles_hist_begin(c));
+    const Geometry &g = c->g;
+    hipLaunchKernelGGL(k_compact_drift_hist, dim3(cdiv(n, PT * SORT_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel, (const int64_t *)c->spid,
+                       (const int *)c->flags, n, (float)g.Nn, c->pos, c->vel, c->pid, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
+                       offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0, (float)g.nb, g.E, c->row_end, c->d_counters + 4,
+                       (c->p.flags & P3M_FLAG_PPINT) ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
+    c->hist_done = true;
+  } else if (drift)
     hipLaunchKernelGGL(k_compact<true>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel, (const int64_t *)c->spid,
                        (const int *)c->flags, n, (float)c->g.Nn, c->pos, c->vel, c->pid, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
                        offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0);
