@@ -294,8 +294,9 @@ int build_coarse_kernel(p3m_ctx *c, const float *table4_host) {
 // from the rho-hat the coarse force pass left in LZ order ([ky][chunk][kz][16 kx]).  Per mode as the reference writes it
 // (:60-98): the kx = 0 plane counts each conjugate pair once, bin k1 = ceiling(|k|) with weight 1, and the sinc^4
 // deconvolution divides the imaginary part's square only.  Sums in double (the reference adds in real(4)).
-// ps_acc: [2][nc+2] doubles (weights, power); `planes` ky rows starting at ky0 (a whole mesh, or one rank's ky slab).
-__global__ __launch_bounds__(256) void k_coarse_power(const float2 *__restrict__ lz, int planes, int ky0, int nc, int nchunk, float inv_mean,
+// ps_acc: [2][nc+2] doubles (weights, power); `planes` ky rows starting at ky0 and nchunk*16 kx columns starting at kx0 (a
+// whole mesh, one rank's ky slab, or one rank's ky slab of its own kx chunks in the pencil decomposition).
+__global__ __launch_bounds__(256) void k_coarse_power(const float2 *__restrict__ lz, int planes, int ky0, int kx0, int nc, int nchunk, float inv_mean,
                                                       double *__restrict__ ps_acc) {
   extern __shared__ double bins[];   // [2][nc+2]
   const int nb = nc + 2;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void k_coarse_power(const float2 *__restrict__
   const float fnc = (float)nc, n3 = fnc * fnc * fnc;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
     const int l = (int)(idx & 15), kzi = (int)((idx >> 4) % nc), chunk = (int)((idx / (16 * (int64_t)nc)) % nchunk), o = (int)(idx / (16 * (int64_t)nc * nchunk));
-    const int kxi = chunk * 16 + l, kyi = ky0 + o;
+    const int kxi = kx0 + chunk * 16 + l, kyi = ky0 + o;
     if (kxi > hc) continue;                                                  // pad columns
     const float kx = (float)kxi, ky = (kyi < hc + 1) ? (float)kyi : (float)(kyi - nc), kz = (kzi < hc + 1) ? (float)kzi : (float)(kzi - nc);   // :45-56
     if (kxi == 0 && ky <= 0.f && kz <= 0.f) continue;                        // :60
@@ -326,10 +327,10 @@ __global__ __launch_bounds__(256) void k_coarse_power(const float2 *__restrict__
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * nb; i += 256) if (bins[i] != 0.0) atomicAdd(&ps_acc[i], bins[i]);
 }
-int coarse_power_accumulate(p3m_ctx *c, const float *lz, int planes, int ky0, int nc, int nchunk, float rho_c_mean, double *d_ps) {
+int coarse_power_accumulate(p3m_ctx *c, const float *lz, int planes, int ky0, int kx0, int nc, int nchunk, float rho_c_mean, double *d_ps) {
   const int64_t tot = (int64_t)planes * nchunk * nc * 16;
   const int grid = (int)std::min<int64_t>(1024, cdiv(tot, 256));
-  hipLaunchKernelGGL(k_coarse_power, dim3(grid), dim3(256), sizeof(double) * 2 * (nc + 2), c->stream, reinterpret_cast<const float2 *>(lz), planes, ky0, nc, nchunk,
+  hipLaunchKernelGGL(k_coarse_power, dim3(grid), dim3(256), sizeof(double) * 2 * (nc + 2), c->stream, reinterpret_cast<const float2 *>(lz), planes, ky0, kx0, nc, nchunk,
                      1.0f / rho_c_mean, d_ps);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
@@ -358,7 +359,7 @@ extern "C" int p3m_hip_coarse_power(p3m_ctx *c, float mass_p, float box, float *
   HIP_TRY(hipMemsetAsync(d_ps, 0, sizeof(double) * 2 * nb, c->stream));
   const float nfp = (float)(g.Nn * g.nodes_dim / 2), fnc = (float)nc;
   const float rho_c_mean = nfp * nfp * nfp * mass_p / (fnc * fnc * fnc);   // :24
-  int r = coarse_power_accumulate(c, c->slab, nc, 0, nc, g.pxc / 16, rho_c_mean, d_ps);
+  int r = coarse_power_accumulate(c, c->slab, nc, 0, 0, nc, g.pxc / 16, rho_c_mean, d_ps);
   std::vector<double> acc(2 * nb);
   if (r == P3M_OK && hipMemcpyAsync(acc.data(), d_ps, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) r = P3M_EDEVICE;
   if (r == P3M_OK && hipStreamSynchronize(c->stream) != hipSuccess) r = P3M_EDEVICE;

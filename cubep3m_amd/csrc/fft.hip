@@ -58,7 +58,7 @@ static bool lines2_off() { static const bool off = getenv("P3M_FFT_STOCKHAM") &&
 constexpr int XTB = 256, XLU = 6;
 template <int RSET, int RB>
 __global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src, float2 *__restrict__ dst, int n, int px, int rows_total,
-                                                   Factors fac, const float2 *__restrict__ tw_g) {
+                                                   Factors fac, const float2 *__restrict__ tw_g, int rpp) {   // rpp: rows per plane of the LY output (n; fewer for a y-split pencil)
   extern __shared__ float2 lds[];
   constexpr int RBP = RB + 1, LRB = __builtin_ctz(RB);
   const int h = n >> 1, q4 = n >> 2, nchunk = px / BXC;
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src
     __syncthreads();
     { const int wn = w + gridDim.x; if (wn < nbatch) fetch(wn); }
     if ((int)threadIdx.x < nrows) {   // LY offset of (row, chunk 0, column 0); read after the barriers of fft_lds
-      const unsigned row = (unsigned)row0 + threadIdx.x, bz = row / (unsigned)n;   // bz = b*n + z; rows_total is an int
-      drow[threadIdx.x] = (((int64_t)bz * nchunk) * n + (row - bz * n)) * BXC;
+      const unsigned row = (unsigned)row0 + threadIdx.x, bz = row / (unsigned)rpp;   // bz = b*n + z; rows_total is an int
+      drow[threadIdx.x] = (((int64_t)bz * nchunk) * rpp + (row - bz * rpp)) * BXC;
     }
     const float2 *Z = fft_lds<false, RSET, RB>(A, B, h, RB, RBP, 1, fac, tw, 2);
     // X[k] = E + W_n^k O,  E = (Z[k]+conj Z[h-k])/2,  O = (Z[k]-conj Z[h-k])/(2i); lanes run over the 16
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src
         const float2 wk = (k == h) ? make_float2(-1.f, 0.f) : tw[k];
         X = cadd(E, cmul(O, wk));
       }
-      if (r < nrows) dst[drow[r] + ((int64_t)chunk * n) * BXC + l] = X;
+      if (r < nrows) dst[drow[r] + ((int64_t)chunk * rpp) * BXC + l] = X;
     }
     __syncthreads();
   }
@@ -125,10 +125,11 @@ __global__ __launch_bounds__(XTB) void k_fft_x_fwd(const float *__restrict__ src
 template <int RSET, int RB>
 __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ src, float *__restrict__ out, int n, int px, int rows_total,
                                                    Factors fac, const float2 *__restrict__ tw_g, float inv_scale, int mode,
-                                                   float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
+                                                   float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride, int rpp) {   // rpp: rows per plane of the LY input (mode 0)
   extern __shared__ float2 lds[];
   constexpr int RBP = RB + 1, LRB = __builtin_ctz(RB);
   const int h = n >> 1, nchunk = px / BXC, fbp = (fb + 3) & ~3;
+  const int lrows = mode == 1 ? n : rpp;   // line length of the LY bundles this pass reads
   float2 *A = lds, *B = A + (h + 1) * RBP, *tw = B + (h + 1) * RBP;
   __shared__ int64_t src_row[2][RB], dst_off[2][RB];   // element offset of (row, chunk 0, column 0) in LY; chunks are n*16 apart
   for (int i = threadIdx.x; i < n; i += XTB) tw[i] = tw_g[i];
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
         src_row[buf][threadIdx.x] = (((b * n + (kk + lo)) * nchunk) * n + (jj + lo)) * BXC;
         dst_off[buf][threadIdx.x] = comp * box_comp_stride + (((int64_t)tl * fb + kk) * fb + jj) * fbp;
       } else {
-        const unsigned bz = (unsigned)srow / (unsigned)n;
-        src_row[buf][threadIdx.x] = (((int64_t)bz * nchunk) * n + ((unsigned)srow - bz * n)) * BXC;
+        const unsigned bz = (unsigned)srow / (unsigned)rpp;
+        src_row[buf][threadIdx.x] = (((int64_t)bz * nchunk) * rpp + ((unsigned)srow - bz * rpp)) * BXC;
         dst_off[buf][threadIdx.x] = srow * (int64_t)(2 * px);
       }
     }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
       const int e = (int)threadIdx.x + u * XTB;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int l4 = e & 7, r = (e >> 3) & (RB - 1), chunk = e >> (3 + LRB);
-      if (e < ne && r < nrows) v[u] = reinterpret_cast<const float4 *>(src + src_row[buf][r] + (int64_t)chunk * n * BXC)[l4];
+      if (e < ne && r < nrows) v[u] = reinterpret_cast<const float4 *>(src + src_row[buf][r] + (int64_t)chunk * lrows * BXC)[l4];
     }
   };
   int w = blockIdx.x, buf = 0;
@@ -241,7 +242,7 @@ template <int R1, int R2> struct X2Cfg {
 // in k_fft_x_inv2; the next batch's rows are in flight during stage 2 and the split.
 template <int R1, int R2>
 __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ src, float2 *__restrict__ dst_, int n, int px, int rows_total,
-                                                    const float2 *__restrict__ tw_g) {
+                                                    const float2 *__restrict__ tw_g, int rpp) {   // rpp: rows per plane of the LY output (n; fewer for a y-split pencil)
   using C = X2Cfg<R1, R2>;
   constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P;
   extern __shared__ float2 lds[];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ sr
   const int r = (threadIdx.x >> 6) * C::RPW + rw;
   const bool act = rw < C::RPW, s1 = act && q < R2, s2 = act && q < R1;
   const int nbatch = (rows_total + RB - 1) / RB;
-  const int64_t cstride = (int64_t)n * BXC;
+  const int64_t cstride = (int64_t)rpp * BXC;
   c32 twq[R1];   // W_h^{q*k1}
 #pragma unroll
   for (int k1 = 0; k1 < R1; k1++) twq[k1] = reinterpret_cast<const c32 *>(tw_g)[s1 ? 2 * q * k1 : 0];
@@ -278,8 +279,8 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ sr
     const int64_t row0 = (int64_t)w * RB;
     const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - row0);
     if ((int)threadIdx.x < nrows) {   // LY offset of (row, chunk 0, column 0)
-      const unsigned row = (unsigned)row0 + threadIdx.x, bz = row / (unsigned)n;   // bz = b*n + z; rows_total is an int
-      drow[buf][threadIdx.x] = (((int64_t)bz * nchunk) * n + (row - bz * n)) * BXC;
+      const unsigned row = (unsigned)row0 + threadIdx.x, bz = row / (unsigned)rpp;   // bz = b*n + z; rows_total is an int
+      drow[buf][threadIdx.x] = (((int64_t)bz * nchunk) * rpp + (row - bz * rpp)) * BXC;
     }
     if (s1) {
       dft<R1>(v);
@@ -861,25 +862,25 @@ static int rset_of(int nfac, const int *fac) {
   for (int i = 0; i < nfac; i++) { if (fac[i] >= 17) r = 2; else if (fac[i] >= 11 && r < 1) r = 1; }
   return r;
 }
-template <int RSET, int RB> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+template <int RSET, int RB> static int x_fwd_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp) {
   const int n = pl.n;
   if (n > 8 * XLU * XTB / 2 || rows > 0x7fffffffLL) { p3m_set_error("fft x pass: n=%d or %lld rows out of range", n, (long long)rows); return P3M_EINVAL; }
   const size_t lds = sizeof(float2) * ((size_t)2 * (n / 2) * (RB + 1) + n);
   P3M_TRY((set_lds(k_fft_x_fwd<RSET, RB>, lds)));
   hipLaunchKernelGGL((k_fft_x_fwd<RSET, RB>), dim3(x_grid(k_fft_x_fwd<RSET, RB>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream, src,
-                     reinterpret_cast<float2 *>(dst), n, pl.px, (int)rows, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw);
+                     reinterpret_cast<float2 *>(dst), n, pl.px, (int)rows, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw, rpp);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-template <int RSET> static int x_fwd_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+template <int RSET> static int x_fwd_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp) {
   switch (x_rows(pl.n)) {
-    case 8: return x_fwd_impl<RSET, 8>(c, pl, src, dst, rows);
-    case 16: return x_fwd_impl<RSET, 16>(c, pl, src, dst, rows);
-    case 32: return x_fwd_impl<RSET, 32>(c, pl, src, dst, rows);
-    default: return x_fwd_impl<RSET, 64>(c, pl, src, dst, rows);
+    case 8: return x_fwd_impl<RSET, 8>(c, pl, src, dst, rows, rpp);
+    case 16: return x_fwd_impl<RSET, 16>(c, pl, src, dst, rows, rpp);
+    case 32: return x_fwd_impl<RSET, 32>(c, pl, src, dst, rows, rpp);
+    default: return x_fwd_impl<RSET, 64>(c, pl, src, dst, rows, rpp);
   }
 }
-template <int R1, int R2> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+template <int R1, int R2> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp) {
   using C = X2Cfg<R1, R2>;
   if (rows > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)rows); return P3M_EINVAL; }
   P3M_TRY((set_lds(k_fft_x_fwd2<R1, R2>, C::lds)));
@@ -890,27 +891,29 @@ template <int R1, int R2> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, 
   }
   const int64_t nbatch = cdiv(rows, C::RB), g = (int64_t)256 * occ;
   hipLaunchKernelGGL((k_fft_x_fwd2<R1, R2>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, src, reinterpret_cast<float2 *>(dst), pl.n,
-                     pl.px, (int)rows, pl.d_tw);
+                     pl.px, (int)rows, pl.d_tw, rpp);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows) {
+// rpp: rows per plane of the LY output; 0 = pl.n (whole planes).  A pencil decomposition hands in planes of fewer rows.
+int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp) {
+  if (rpp <= 0) rpp = pl.n;
   if (!lines2_off()) {
-#define X(H, A, B) if (pl.n == 2 * H) return x_fwd2_impl<A, B>(c, pl, src, dst, rows);
+#define X(H, A, B) if (pl.n == 2 * H) return x_fwd2_impl<A, B>(c, pl, src, dst, rows, rpp);
     P3M_X2_SIZES(X)
 #undef X
   }
   switch (rset_of(pl.nfac_half, pl.fac_half)) {
-    case 0: return x_fwd_rb<0>(c, pl, src, dst, rows);
-    case 1: return x_fwd_rb<1>(c, pl, src, dst, rows);
-    default: return x_fwd_rb<2>(c, pl, src, dst, rows);
+    case 0: return x_fwd_rb<0>(c, pl, src, dst, rows, rpp);
+    case 1: return x_fwd_rb<1>(c, pl, src, dst, rows, rpp);
+    default: return x_fwd_rb<2>(c, pl, src, dst, rows, rpp);
   }
 }
 int fft_x_forward(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int batch) {
-  return fft_x_forward_rows(c, pl, src, dst, (int64_t)batch * pl.n * pl.n);
+  return fft_x_forward_rows(c, pl, src, dst, (int64_t)batch * pl.n * pl.n, 0);
 }
 template <int RSET, int RB>
-static int x_inv_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
+static int x_inv_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp) {
   const int n = pl.n;
   // mode 0: `batch` counts ROWS when negative (distributed slabs), whole n^2 arrays otherwise
   const int64_t rows = mode == 0 ? (batch < 0 ? -(int64_t)batch : (int64_t)batch * n * n) : (int64_t)batch * fb * fb;
@@ -920,17 +923,17 @@ static int x_inv_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *ou
   P3M_TRY((set_lds(k_fft_x_inv<RSET, RB>, lds)));
   hipLaunchKernelGGL((k_fft_x_inv<RSET, RB>), dim3(x_grid(k_fft_x_inv<RSET, RB>, lds, cdiv(rows, RB))), dim3(XTB), lds, c->stream,
                      reinterpret_cast<const float2 *>(src), out, n, pl.px, (int)rows, mkfac(pl.nfac_half, pl.fac_half), pl.d_tw, scale, mode, box, fb, lo,
-                     ntile, bcs);
+                     ntile, bcs, rpp);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
 template <int RSET>
-static int x_inv_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
+static int x_inv_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp) {
   switch (x_rows(pl.n)) {
-    case 8: return x_inv_impl<RSET, 8>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
-    case 16: return x_inv_impl<RSET, 16>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
-    case 32: return x_inv_impl<RSET, 32>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
-    default: return x_inv_impl<RSET, 64>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    case 8: return x_inv_impl<RSET, 8>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
+    case 16: return x_inv_impl<RSET, 16>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
+    case 32: return x_inv_impl<RSET, 32>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
+    default: return x_inv_impl<RSET, 64>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
   }
 }
 template <int R1, int R2> static int x_inv2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, int batch, float *box, int fb, int lo, int ntile, int64_t bcs) {
@@ -952,17 +955,18 @@ template <int R1, int R2> static int x_inv2_impl(p3m_ctx *c, const FftPlan &pl, 
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
-// src in LY; mode 0 writes real ROWS to out, mode 1 the force box
-int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs) {
+// src in LY; mode 0 writes real ROWS to out, mode 1 the force box; rpp (mode 0): rows per plane of the LY input, 0 = pl.n
+int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp) {
+  if (rpp <= 0) rpp = pl.n;
   if (mode == 1 && (lo & 1) == 0 && !lines2_off()) {
 #define X(H, A, B) if (pl.n == 2 * H) return x_inv2_impl<A, B>(c, pl, src, batch, box, fb, lo, ntile, bcs);
     P3M_X2_SIZES(X)
 #undef X
   }
   switch (rset_of(pl.nfac_half, pl.fac_half)) {
-    case 0: return x_inv_rb<0>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
-    case 1: return x_inv_rb<1>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
-    default: return x_inv_rb<2>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs);
+    case 0: return x_inv_rb<0>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
+    case 1: return x_inv_rb<1>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
+    default: return x_inv_rb<2>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
   }
 }
 template <bool INV, bool TR, int NC, int RSET, int TB, int LUX> static int lines_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
@@ -1106,7 +1110,7 @@ int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, const float *hat, float *tmp, f
   if (kern) { z.kern = kern; P3M_TRY((launch_lines<true, true, 1>(c, pl, z, batch))); }
   else P3M_TRY((launch_lines<true, true, 0>(c, pl, z, batch)));
   P3M_TRY((launch_lines<true, false, 0>(c, pl, full_args(pl, tmp, tmp), batch)));
-  return fft_x_inverse(c, pl, tmp, out, batch, 0, nullptr, 0, 0, 1, 0);
+  return fft_x_inverse(c, pl, tmp, out, batch, 0, nullptr, 0, 0, 1, 0, 0);
 }
 
 // fine mesh: the three force components of `batch` tiles from rho-hat (LZ), pruned to the force box.
@@ -1133,7 +1137,7 @@ int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float 
                      int64_t bcs, bool zfwd) {
   P3M_TRY(fft_inverse3_box_z(c, pl, rho_hat, work, kern3, batch, fb, lo, zfwd));
   P3M_TRY(fft_inverse3_box_y(c, pl, work, batch, fb, lo));
-  return fft_x_inverse(c, pl, work, nullptr, 3 * batch, 1, box, fb, lo, batch, bcs);
+  return fft_x_inverse(c, pl, work, nullptr, 3 * batch, 1, box, fb, lo, batch, bcs, 0);
 }
 
 int fft_rows_to_lz(p3m_ctx *c, const FftPlan &pl, const float *rows, float *lz) {
@@ -1158,7 +1162,7 @@ int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float
     case 2: return launch_lines<false, false, 0>(c, pl, full_args(pl, data, data), batch);
     case 3: return fft_inverse3_box_z(c, pl, data, work, kern, batch, fb, lo, true);   // as the step runs it: forward z pass fused in (data: rho after x,y)
     case 4: return fft_inverse3_box_y(c, pl, work, batch, fb, lo);
-    case 5: return fft_x_inverse(c, pl, work, nullptr, 3 * batch, 1, box, fb, lo, batch, bcs);
+    case 5: return fft_x_inverse(c, pl, work, nullptr, 3 * batch, 1, box, fb, lo, batch, bcs, 0);
   }
   p3m_set_error("fft_single_pass: bad selector %d", which);
   return P3M_EINVAL;

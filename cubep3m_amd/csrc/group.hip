@@ -20,8 +20,8 @@
 #include <cstring>
 #include <rccl/rccl.h>
 
-int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows);
-int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs);
+int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp = 0);
+int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp = 0);
 int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes);
 int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, float *lz, int planes);
 int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3, const float *kern3, int planes, int64_t kern_comp_stride,
@@ -34,16 +34,16 @@ int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, float *ly3, int planes, int ba
     if (_r != ncclSuccess) { p3m_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); return P3M_ECOMM; } \
   } while (0)
 
-struct CoarseDist {            // per local logical rank
-  float *blocks_in = nullptr;  // [nd^2][s][ncn][ncn]      cube -> slab arrivals
-  float *rows = nullptr;       // [3][s][nc][2*pxc]        real slab rows
-  float *ly = nullptr;         // [3][s][nchunk][nc][16]   complex, LY of the local planes
-  float *send = nullptr;       // [3][nc][nchunk][s][16]   complex, all-to-all send layout
+struct CoarseDist {            // per local logical rank; slabs: nxb = nd^2, rpp = nc, ncl = nchunk; pencils: nxb = nd, rpp = ncn, ncl = nchunk/nd
+  float *blocks_in = nullptr;  // [nxb][s][ncn][ncn]       cube -> slab / pencil arrivals
+  float *rows = nullptr;       // [3][s][rpp][2*px]        real rows of the local planes
+  float *ly = nullptr;         // [3][s][nchunk][rpp][16]  complex, LY of the local planes (pencils: also [3][s][ncl][nc][16] after the x<->y transpose)
+  float *send = nullptr;       // [3][nc][ncl][s][16]      complex, all-to-all send layout
   float *recv = nullptr;       // same
-  float *lz = nullptr;         // [s][nchunk][nc][16]      complex rho-hat, own ky slab
-  float *kern = nullptr;       // [3][s*nchunk*nc*16]      Im K_c, same order as lz
-  float *blocks_out = nullptr; // [nd^2][3][s][ncn][ncn]   slab -> cube departures
-  float *blocks_back = nullptr;// [nd^2][3][s][ncn][ncn]   arrivals at the cube
+  float *lz = nullptr;         // [s][ncl][nc][16]         complex rho-hat, own ky slab (pencils: of the own kx chunks)
+  float *kern = nullptr;       // [3][s*ncl*nc*16]         Im K_c, same order as lz
+  float *blocks_out = nullptr; // [nxb][3][s][ncn][ncn]    slab / pencil -> cube departures
+  float *blocks_back = nullptr;// [nxb][3][s][ncn][ncn]    arrivals at the cube
   float *halo_s[2] = {nullptr, nullptr}, *halo_r[2] = {nullptr, nullptr};  // [3][(ncn+2)^2]
   float4 *sb = nullptr, *rb = nullptr;   // ghost (16 B) and migrant (32 B) records, 52 segments (G->seg_off, in float4 units)
   int *d_cnt = nullptr;        // [0..53] own send counts per slot, [64..117] counts announced by the neighbours
@@ -63,6 +63,10 @@ struct p3m_group {
   p3m_transport tr{}; bool have_tr = false;
   char *h_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};   // pinned send / receive staging of the host transport
   FftPlan plan_c; int s = 0, nchunk = 0;
+  // P3M_FLAG_PENCIL: x-pencils of (nc, ncn, s = ncn/nd) cells as pack_pencils leaves them (p3dfft_coarse.f90:69-127); the
+  // transform then splits the kx chunks over the nd ranks that hold the same z planes (x<->y transpose) and ky over the nd^2
+  // ranks that hold the same chunks (y<->z transpose).  plan_l: plan_c with the row pitch of the local chunks (shares the twiddles)
+  bool pencil = false; int ncl = 0, rpp = 0, nxb = 0; FftPlan plan_l;
   int seg_off[54] = {0}, seg_cap[54] = {0}; int64_t seg_total = 0;   // segments by slot (2m ghosts, 2m+1 migrants), offsets in float4 units
   int *h_cnt = nullptr;        // pinned [nlocal*4]
   int *d_gather = nullptr, *h_gather = nullptr, *h_hdr = nullptr;   // ghost pass: [nodes][64] counts of every rank (device, pinned), [nlocal] pinned headers
@@ -248,10 +252,16 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     return fail(P3M_EINVAL);
   }
   if (nodes > 1) {
-    G->s = g.nc_slab;
+    G->pencil = (base->flags & P3M_FLAG_PENCIL) != 0;
     int rc = fft_plan_create(&G->plan_c, g.nc);
     if (rc) return fail(rc);
-    G->nchunk = G->plan_c.px / 16;
+    if (G->pencil) {
+      G->plan_c.px = (G->plan_c.px + 16 * nd - 1) / (16 * nd) * (16 * nd);   // whole chunks for every rank of a y-row; the pad columns are zeros
+      G->s = g.ncn / nd; G->nchunk = G->plan_c.px / 16; G->ncl = G->nchunk / nd; G->rpp = g.ncn; G->nxb = nd;   // s = nc_pen (cubepm.par:212)
+    } else {
+      G->s = g.nc_slab; G->nchunk = G->plan_c.px / 16; G->ncl = G->nchunk; G->rpp = g.nc; G->nxb = nd * nd;
+    }
+    G->plan_l = G->plan_c; G->plan_l.px = 16 * G->ncl;
     // ghost segments, sized from the rank's capacity: a face shell holds nb/Nn of the particles, an edge (nb/Nn)^2, ...
     {
       // 2.5x the uniform-density share to start with; ghost_pass grows a segment that a clustered shell overfills
@@ -275,21 +285,22 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     if (galloc(&G->d_gather, (size_t)64 * nodes) != P3M_OK) return fail(P3M_ENOMEM);
     if (hipHostMalloc(reinterpret_cast<void **>(&G->h_gather), (size_t)64 * nodes * sizeof(int)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&G->h_hdr), (size_t)(per + 1) * sizeof(int)) != hipSuccess) return fail(P3M_ENOMEM);
-    const size_t NB = (size_t)G->s * G->nchunk * g.nc * 16 * 2;          // floats of one component's complex slab
+    const size_t NB = (size_t)G->s * G->ncl * g.nc * 16 * 2;             // floats of one component's complex slab / pencil
+    const size_t nrows = (size_t)3 * G->s * G->rpp * 2 * G->plan_c.px;
     const size_t blk = (size_t)G->s * g.ncn * g.ncn;
     G->cd.resize(G->ctx.size());
     for (CoarseDist &d : G->cd) {
 #define A(x) do { int _r = (x); if (_r) return fail(_r); } while (0)
-      A(galloc(&d.blocks_in, (size_t)nd * nd * blk)); A(galloc(&d.rows, (size_t)3 * G->s * g.nc * 2 * G->plan_c.px));
+      A(galloc(&d.blocks_in, (size_t)G->nxb * blk)); A(galloc(&d.rows, nrows));
       A(galloc(&d.ly, 3 * NB)); A(galloc(&d.send, 3 * NB)); A(galloc(&d.recv, 3 * NB)); A(galloc(&d.lz, NB)); A(galloc(&d.kern, 3 * NB / 2));
-      A(galloc(&d.blocks_out, (size_t)nd * nd * 3 * blk)); A(galloc(&d.blocks_back, (size_t)nd * nd * 3 * blk));
+      A(galloc(&d.blocks_out, (size_t)G->nxb * 3 * blk)); A(galloc(&d.blocks_back, (size_t)G->nxb * 3 * blk));
       for (int i = 0; i < 2; i++) {
         A(galloc(&d.halo_s[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2))); A(galloc(&d.halo_r[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2)));
       }
       A(galloc(&d.sb, (size_t)G->seg_total)); A(galloc(&d.rb, (size_t)G->seg_total));
       A(galloc(&d.d_cnt, 128));
 #undef A
-      if (hipMemset(d.rows, 0, sizeof(float) * 3 * G->s * g.nc * 2 * G->plan_c.px) != hipSuccess) return fail(P3M_EDEVICE);
+      if (hipMemset(d.rows, 0, sizeof(float) * nrows) != hipSuccess) return fail(P3M_EDEVICE);
     }
   }
   if (galloc(&G->d_red4, 8) || galloc(&G->d_sum3, 4)) return fail(P3M_ENOMEM);
@@ -426,10 +437,11 @@ static int ghost_pass(p3m_group *G) {
 }
 
 // ================================================================== coarse mesh, distributed
-__global__ __launch_bounds__(256) void k_blocks_to_rows(const float *__restrict__ blocks, float *__restrict__ rows, int s, int nc, int ncn, int nd, int rp) {
+// blocks [(j*nd+i)][zl][yy][xx] -> rows [zl][y][x], ny rows per plane (nc: slabs, blocks of nd x nd cubes; ncn: pencils, nd cubes along x)
+__global__ __launch_bounds__(256) void k_blocks_to_rows(const float *__restrict__ blocks, float *__restrict__ rows, int s, int nc, int ny, int ncn, int nd, int rp) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)s * nc * rp) return;
-  const int x = (int)(idx % rp), y = (int)((idx / rp) % nc), zl = (int)(idx / ((int64_t)rp * nc));
+  if (idx >= (int64_t)s * ny * rp) return;
+  const int x = (int)(idx % rp), y = (int)((idx / rp) % ny), zl = (int)(idx / ((int64_t)rp * ny));
   float v = 0.f;
   if (x < nc) {
     const int i = x / ncn, j = y / ncn;
@@ -447,9 +459,28 @@ __global__ __launch_bounds__(256) void k_a2a_permute(const float2 *__restrict__ 
   const int t = (int)(r / ((int64_t)16 * s * nchunk * s));
   out[comp * per + (((int64_t)p * nchunk + chunk) * nc + (t * s + q)) * 16 + l] = recv[idx];
 }
-// rows [comp][zl][y][x] -> blocks_out [(j*nd+i)][comp][zl][yy][xx]
-__global__ __launch_bounds__(256) void k_rows_to_blocks(const float *__restrict__ rows, float *__restrict__ blocks, int s, int nc, int ncn, int nd, int rp) {
-  const int64_t tot = (int64_t)nd * nd * 3 * s * ncn * ncn;
+// Index shuffle of 128-byte bundles (16 complex): source dims d[0..4] (outermost first, contiguous), destination strides
+// st[0..4] in bundles.  Packs and unpacks the x<->y transpose of the pencil decomposition.
+struct Perm5 { int d[5]; int64_t st[5]; };
+__global__ __launch_bounds__(256) void k_permute5(const float4 *__restrict__ src, float4 *__restrict__ dst, Perm5 p, int64_t nbundle) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nbundle * 8) return;
+  int64_t e = idx >> 3, off = 0;
+#pragma unroll
+  for (int k = 4; k >= 0; k--) { const int64_t q = e / p.d[k]; off += (e - q * p.d[k]) * p.st[k]; e = q; }
+  dst[off * 8 + (idx & 7)] = src[idx];
+}
+static int permute5(hipStream_t st, const float *src, float *dst, const int (&d)[5], const int64_t (&s5)[5]) {
+  Perm5 p; int64_t n = 1;
+  for (int k = 0; k < 5; k++) { p.d[k] = d[k]; p.st[k] = s5[k]; n *= d[k]; }
+  hipLaunchKernelGGL(k_permute5, dim3(cdiv(n * 8, 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), p, n);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+// rows [comp][zl][y][x] (ny = nj*ncn rows per plane) -> blocks_out [(j*nd+i)][comp][zl][yy][xx]
+__global__ __launch_bounds__(256) void k_rows_to_blocks(const float *__restrict__ rows, float *__restrict__ blocks, int s, int nj, int ncn, int nd, int rp) {
+  const int64_t tot = (int64_t)nj * nd * 3 * s * ncn * ncn;
+  const int nc = nj * ncn;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= tot) return;
   const int xx = (int)(idx % ncn), yy = (int)((idx / ncn) % ncn), zl = (int)((idx / ((int64_t)ncn * ncn)) % s);
@@ -521,11 +552,11 @@ __global__ __launch_bounds__(256) void k_take_imag_g(const float *__restrict__ h
   if (i < ncomplex) kern[i] = hat[2 * i + 1];
 }
 // LRCKCORR (kernel_initialization.f90:562-591) on the local ky-slab: kern/uncorr in [yl][chunk][z][16]
-__global__ __launch_bounds__(256) void k_lrck_slab(float *__restrict__ kern, const float *__restrict__ uncorr, int n, int s, int nchunk, int ky0, int comp) {
+__global__ __launch_bounds__(256) void k_lrck_slab(float *__restrict__ kern, const float *__restrict__ uncorr, int n, int s, int nchunk, int ky0, int kx0, int comp) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)s * nchunk * n * 16) return;
   const int l = (int)(idx % 16), k = (int)((idx / 16) % n), chunk = (int)((idx / (16 * (int64_t)n)) % nchunk), yl = (int)(idx / (16 * (int64_t)n * nchunk));
-  const int kx = chunk * 16 + l, j = ky0 + yl;
+  const int kx = kx0 + chunk * 16 + l, j = ky0 + yl;
   if (kx > n / 2) return;
   const int ky = (j < n / 2 + 1) ? j : j - n, kz = (k < n / 2 + 1) ? k : k - n;
   const float kr = sqrtf((float)(kx * kx + ky * ky + kz * kz));
@@ -538,54 +569,90 @@ __global__ __launch_bounds__(256) void k_lrck_slab(float *__restrict__ kern, con
   kern[idx] = kern[idx] * (wc / uncorr[idx]);
 }
 
-// forward distributed transform of every rank's cube `cube_of(i)` (ncn^3 floats) into d.lz (rho-hat, own ky slab)
+// ---- who exchanges with whom in the transposes of the coarse transform (rank = c1*nd^2 + c2*nd + c3, x <-> c3, z <-> c1)
+// cube <-> x-lines.  Slabs (pack_slab, fftw3ds.f90:24-52): z-slice q of r's cube goes to the q-th rank of the own z-layer.
+// Pencils (pack_pencils, p3dfft_coarse.f90:69-127 with pen_neighbor_to / pen_neighbor_fm of mpi_initialization_p3dfft.f90:48-51):
+// z-slice q goes to rank (c1, q, c2), so that rank (c1, c2, c3) holds the x-pencil of y block c3 and z planes
+// c1*ncn + c2*nc_pen ..: p3dfft's processor grid, rank = iy + nd*iz with iy = c3, iz = c1*nd + c2.  At the receiver the
+// block sits at the sender's x position, xl_index
+static inline int xl_peer(const p3m_group *G, int r, int q) {
+  const int nd = G->nd, layer = (r / (nd * nd)) * nd * nd;
+  return G->pencil ? layer + q * nd + (r / nd) % nd : layer + q;
+}
+static inline int xl_index(const p3m_group *G, int r) { return G->pencil ? r % G->nd : r % (G->nd * G->nd); }
+// x <-> y transpose (pencils only): kx chunk range j goes to the j-th of the nd ranks with the same z planes (same iz);
+// arrivals stack along y by the sender's iy
+static inline int xy_peer(const p3m_group *G, int r, int j) { return (r / G->nd) * G->nd + j; }
+static inline int xy_index(const p3m_group *G, int r) { return r % G->nd; }
+// y <-> z transpose: ky block j goes to yz_peer(r, j).  Slabs: all ranks.  Pencils: the nd^2 ranks that hold the same kx
+// chunks (same iy), in the order of their z planes
+static inline int yz_count(const p3m_group *G) { return G->pencil ? G->nd * G->nd : G->nodes; }
+static inline int yz_peer(const p3m_group *G, int r, int j) { return G->pencil ? j * G->nd + r % G->nd : j; }
+static inline int yz_index(const p3m_group *G, int r) { return G->pencil ? r / G->nd : r; }
+
+// the messages of one transpose among groups of `count` ranks: block j of r's `send` (bytes each) lands as block index(r) of
+// peer(r, j)'s `recv`
+template <typename P, typename I, typename S, typename R>
+static void group_msgs(p3m_group *G, std::vector<XMsg> &m, int count, size_t bytes, P peer, I index, S sendp, R recvp) {
+  for (int r = 0; r < G->nodes; r++)
+    for (int j = 0; j < count; j++) {
+      const int t = peer(r, j), lr = G->lidx[r], lt = G->lidx[t];
+      m.push_back({r, t, lr >= 0 ? (const void *)(sendp(lr) + (size_t)j * bytes) : nullptr, lt >= 0 ? (void *)(recvp(lt) + (size_t)index(r) * bytes) : nullptr, bytes});
+    }
+}
+template <typename P, typename I, typename S, typename R>
+static int group_exchange(p3m_group *G, int count, size_t bytes, P peer, I index, S sendp, R recvp) {
+  std::vector<XMsg> m;
+  group_msgs(G, m, count, bytes, peer, index, sendp, recvp);
+  return do_exchange(G, m);
+}
+
+// forward distributed transform of every rank's cube `cube_of(i)` (ncn^3 floats) into d.lz: rho-hat of the own ky slab and
+// (pencils) the own kx chunks, all kz
 template <typename F> static int dist_forward(p3m_group *G, F cube_of) {
   const Geometry &g = G->ctx[0]->g;
-  const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, nchunk = G->nchunk;
+  const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, ncl = G->ncl, rpp = G->rpp;
   const size_t blk = (size_t)s * ncn * ncn;
-  // cube -> slab (pack_slab, fftw3ds.f90:24-52): to every slab rank of the own z-layer
-  std::vector<XMsg> m1;
-  for (int r = 0; r < G->nodes; r++) {
-    const int c1 = r / (nd * nd), ji = r % (nd * nd);
-    for (int q = 0; q < nd * nd; q++) {
-      const int t = c1 * nd * nd + q;
-      const int li = G->lidx[r], lt = G->lidx[t];
-      m1.push_back({r, t, li >= 0 ? (const void *)(cube_of(li) + (size_t)q * blk) : nullptr, lt >= 0 ? (void *)(G->cd[lt].blocks_in + (size_t)ji * blk) : nullptr,
-                    blk * sizeof(float)});
-    }
-  }
-  P3M_TRY(do_exchange(G, m1));
-  const size_t NBc = (size_t)s * nchunk * nc * 16;   // complex elements of one component's slab
+  // cube -> x-lines
+  P3M_TRY(group_exchange(G, G->nxb, blk * sizeof(float), [&](int r, int q) { return xl_peer(G, r, q); }, [&](int r) { return xl_index(G, r); },
+                         [&](int li) { return (const char *)cube_of(li); }, [&](int li) { return (char *)G->cd[li].blocks_in; }));
+  const size_t NBc = (size_t)s * ncl * nc * 16;   // complex elements of one component's slab / pencil
+  const size_t xyb = (size_t)s * ncl * ncn * 16 * sizeof(float2);   // pencils: one block of the x<->y transpose
   for (int i = 0; i < nl; i++) {
     p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
-    const int64_t tot = (int64_t)s * nc * rp;
-    hipLaunchKernelGGL(k_blocks_to_rows, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)d.blocks_in, d.rows, s, nc, ncn, nd, rp);
+    const int64_t tot = (int64_t)s * rpp * rp;
+    hipLaunchKernelGGL(k_blocks_to_rows, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)d.blocks_in, d.rows, s, nc, rpp, ncn, nd, rp);
     HIP_TRY(hipGetLastError());
-    P3M_TRY(fft_x_forward_rows(c, G->plan_c, d.rows, d.ly, (int64_t)s * nc));        // ROWS -> LY (local planes)
-    P3M_TRY(fft_slab_y_fwd(c, G->plan_c, d.ly, d.send, s));                           // LY -> send layout [y][chunk][zl][16]
+    P3M_TRY(fft_x_forward_rows(c, G->plan_c, d.rows, d.ly, (int64_t)s * rpp, rpp));   // ROWS -> LY (local planes)
+    if (!G->pencil) P3M_TRY(fft_slab_y_fwd(c, G->plan_c, d.ly, d.send, s));           // LY -> send layout [y][chunk][zl][16]
+    else P3M_TRY(permute5(G->stream, d.ly, d.send, {s, nd, ncl, ncn, 1},              // [zl][iy'][cl][yl] -> [iy'][zl][cl][yl]
+                          {(int64_t)ncl * ncn, (int64_t)s * ncl * ncn, ncn, 1, 0}));
   }
-  // the one global transpose: block r' (ky in r'*s..) of every rank t goes to r'
-  std::vector<XMsg> m2;
-  const size_t ab = (size_t)s * nchunk * s * 16 * sizeof(float2);
-  for (int t = 0; t < G->nodes; t++) for (int r2 = 0; r2 < G->nodes; r2++) {
-    const int lt = G->lidx[t], lr = G->lidx[r2];
-    m2.push_back({t, r2, lt >= 0 ? (const void *)((const char *)G->cd[lt].send + (size_t)r2 * ab) : nullptr,
-                  lr >= 0 ? (void *)((char *)G->cd[lr].recv + (size_t)t * ab) : nullptr, ab});
+  if (G->pencil) {
+    P3M_TRY(group_exchange(G, nd, xyb, [&](int r, int j) { return xy_peer(G, r, j); }, [&](int r) { return xy_index(G, r); },
+                           [&](int li) { return (const char *)G->cd[li].send; }, [&](int li) { return (char *)G->cd[li].recv; }));
+    for (int i = 0; i < nl; i++) {
+      CoarseDist &d = G->cd[i];
+      P3M_TRY(permute5(G->stream, d.recv, d.ly, {nd, s, ncl, ncn, 1}, {ncn, (int64_t)ncl * nc, nc, 1, 0}));   // [iy][zl][cl][yl] -> LY of the own chunks, all y
+      P3M_TRY(fft_slab_y_fwd(G->ctx[i], G->plan_l, d.ly, d.send, s));
+    }
   }
-  P3M_TRY(do_exchange(G, m2));
+  // the y <-> z transpose: ky block j of every rank goes to the j-th rank of its group
+  P3M_TRY(group_exchange(G, yz_count(G), (size_t)s * ncl * s * 16 * sizeof(float2), [&](int r, int j) { return yz_peer(G, r, j); },
+                         [&](int r) { return yz_index(G, r); }, [&](int li) { return (const char *)G->cd[li].send; }, [&](int li) { return (char *)G->cd[li].recv; }));
   for (int i = 0; i < nl; i++) {
     p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
     hipLaunchKernelGGL(k_a2a_permute, dim3(cdiv((int64_t)NBc, 256)), dim3(256), 0, G->stream, reinterpret_cast<const float2 *>(d.recv),
-                       reinterpret_cast<float2 *>(d.lz), s, nchunk, nc, 1);
+                       reinterpret_cast<float2 *>(d.lz), s, ncl, nc, 1);
     HIP_TRY(hipGetLastError());
-    P3M_TRY(fft_slab_z_fwd(c, G->plan_c, d.lz, s));                                   // LZ in place: rho-hat(ky slab, all kz)
+    P3M_TRY(fft_slab_z_fwd(c, G->plan_l, d.lz, s));                                   // LZ in place: rho-hat(ky slab, all kz)
   }
   return P3M_OK;
 }
 
 static int build_coarse_kernel_dist(p3m_group *G, const float *table4_host) {
   const Geometry &g = G->ctx[0]->g;
-  const int nl = (int)G->ctx.size(), s = G->s, nc = g.nc, ncn = g.ncn, nchunk = G->nchunk;
+  const int nl = (int)G->ctx.size(), s = G->s, nc = g.nc, ncn = g.ncn, nchunk = G->ncl;
   float *d_table = nullptr; P3M_TRY(galloc(&d_table, 192));
   HIP_TRY(hipMemcpyAsync(d_table, table4_host, sizeof(float) * 192, hipMemcpyHostToDevice, G->stream));
   const int64_t NBc = (int64_t)s * nchunk * nc * 16;
@@ -605,7 +672,8 @@ static int build_coarse_kernel_dist(p3m_group *G, const float *table4_host) {
         float *dst = pass == 0 ? unc[i] : G->cd[i].kern + (size_t)comp * NBc;
         hipLaunchKernelGGL(k_take_imag_g, dim3(cdiv(NBc, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].lz, dst, NBc);
         if (pass == 1 && lr)
-          hipLaunchKernelGGL(k_lrck_slab, dim3(cdiv(NBc, 256)), dim3(256), 0, G->stream, dst, (const float *)unc[i], nc, s, nchunk, G->lrank[i] * s, comp);
+          hipLaunchKernelGGL(k_lrck_slab, dim3(cdiv(NBc, 256)), dim3(256), 0, G->stream, dst, (const float *)unc[i], nc, s, nchunk, yz_index(G, G->lrank[i]) * s,
+                             G->pencil ? xy_index(G, G->lrank[i]) * nchunk * 16 : 0, comp);
         HIP_TRY(hipGetLastError());
       }
     }
@@ -620,48 +688,56 @@ static int build_coarse_kernel_dist(p3m_group *G, const float *table4_host) {
 // coarse_force.f90 + coarse_force_buffer.f90 + coarse_max_dt.f90 for all local ranks
 static int coarse_force_dist(p3m_group *G) {
   const Geometry &g = G->ctx[0]->g;
-  const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, nchunk = G->nchunk;
-  const size_t NBc = (size_t)s * nchunk * nc * 16, blk = (size_t)s * ncn * ncn;
+  const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, ncl = G->ncl, rpp = G->rpp;
+  const size_t NBc = (size_t)s * ncl * nc * 16, blk = (size_t)s * ncn * ncn;
   P3M_TRY(dist_forward(G, [&](int li) { return G->ctx[li]->rho_c; }));                  // coarse_force.f90:18
   for (int i = 0; i < nl; i++)                                                           // :37-50 x3, fused multiply
-    P3M_TRY(fft_slab_z_inv3(G->ctx[i], G->plan_c, G->cd[i].lz, G->cd[i].send, G->cd[i].kern, s, (int64_t)NBc, (int64_t)NBc));
-  std::vector<XMsg> m2;                                                                  // transpose back, 3 components
-  const size_t ab = (size_t)s * nchunk * s * 16 * sizeof(float2);
-  for (int comp = 0; comp < 3; comp++)
-    for (int t = 0; t < G->nodes; t++) for (int r2 = 0; r2 < G->nodes; r2++) {
-      const int lt = G->lidx[t], lr = G->lidx[r2];
-      const size_t co = (size_t)comp * NBc * sizeof(float2);
-      m2.push_back({t, r2, lt >= 0 ? (const void *)((const char *)G->cd[lt].send + co + (size_t)r2 * ab) : nullptr,
-                    lr >= 0 ? (void *)((char *)G->cd[lr].recv + co + (size_t)t * ab) : nullptr, ab});
-    }
+    P3M_TRY(fft_slab_z_inv3(G->ctx[i], G->plan_l, G->cd[i].lz, G->cd[i].send, G->cd[i].kern, s, (int64_t)NBc, (int64_t)NBc));
+  const size_t ab = (size_t)s * ncl * s * 16 * sizeof(float2);
+  std::vector<XMsg> m2;                                                                  // transpose back, 3 components in one exchange
+  for (int comp = 0; comp < 3; comp++) {
+    const size_t co = (size_t)comp * NBc * sizeof(float2);
+    group_msgs(G, m2, yz_count(G), ab, [&](int r, int j) { return yz_peer(G, r, j); }, [&](int r) { return yz_index(G, r); },
+               [&](int li) { return (const char *)G->cd[li].send + co; }, [&](int li) { return (char *)G->cd[li].recv + co; });
+  }
   P3M_TRY(do_exchange(G, m2));
   for (int i = 0; i < nl; i++) {
     p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
     hipLaunchKernelGGL(k_a2a_permute, dim3(cdiv((int64_t)3 * NBc, 256)), dim3(256), 0, G->stream, reinterpret_cast<const float2 *>(d.recv),
-                       reinterpret_cast<float2 *>(d.ly), s, nchunk, nc, 3);
+                       reinterpret_cast<float2 *>(d.ly), s, ncl, nc, 3);
     HIP_TRY(hipGetLastError());
-    P3M_TRY(fft_slab_y_inv(c, G->plan_c, d.ly, s, 3));
-    P3M_TRY(fft_x_inverse(c, G->plan_c, d.ly, d.rows, -(3 * s * nc), 0, nullptr, 0, 0, 1, 0));   // incl. /nc^3 (fftw3ds.f90:161)
-    const int64_t tot = (int64_t)nd * nd * 3 * blk;
-    hipLaunchKernelGGL(k_rows_to_blocks, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)d.rows, d.blocks_out, s, nc, ncn, nd, rp);
+    P3M_TRY(fft_slab_y_inv(c, G->plan_l, d.ly, s, 3));
+    if (G->pencil) P3M_TRY(permute5(G->stream, d.ly, d.send, {3 * s, ncl, nd, ncn, 1},  // [comp,zl][cl][iy'][yl] -> [iy'][comp,zl][cl][yl]
+                                    {(int64_t)ncl * ncn, ncn, (int64_t)3 * s * ncl * ncn, 1, 0}));
+  }
+  if (G->pencil) {                                                                       // y -> x transpose of the three components
+    P3M_TRY(group_exchange(G, nd, (size_t)3 * s * ncl * ncn * 16 * sizeof(float2), [&](int r, int j) { return xy_peer(G, r, j); },
+                           [&](int r) { return xy_index(G, r); }, [&](int li) { return (const char *)G->cd[li].send; }, [&](int li) { return (char *)G->cd[li].recv; }));
+    for (int i = 0; i < nl; i++)                                                         // [iy][comp,zl][cl][yl] -> LY [comp,zl][chunk = iy*ncl + cl][yl]
+      P3M_TRY(permute5(G->stream, G->cd[i].recv, G->cd[i].ly, {nd, 3 * s, ncl, ncn, 1}, {(int64_t)ncl * ncn, (int64_t)G->nchunk * ncn, ncn, 1, 0}));
+  }
+  for (int i = 0; i < nl; i++) {
+    p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
+    P3M_TRY(fft_x_inverse(c, G->plan_c, d.ly, d.rows, -(3 * s * rpp), 0, nullptr, 0, 0, 1, 0, rpp));   // incl. /nc^3 (fftw3ds.f90:161, p3dfft_coarse.f90:57)
+    const int64_t tot = (int64_t)G->nxb * 3 * blk;
+    hipLaunchKernelGGL(k_rows_to_blocks, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)d.rows, d.blocks_out, s, rpp / ncn, ncn, nd, rp);
     HIP_TRY(hipGetLastError());
   }
-  // slab -> cube (unpack_slab, fftw3ds.f90:69-99)
-  std::vector<XMsg> m3;
-  for (int t = 0; t < G->nodes; t++) {
-    const int c1 = t / (nd * nd), q = t % (nd * nd);
-    for (int ji = 0; ji < nd * nd; ji++) {
-      const int r = c1 * nd * nd + ji;
-      const int lt = G->lidx[t], lr = G->lidx[r];
-      m3.push_back({t, r, lt >= 0 ? (const void *)(G->cd[lt].blocks_out + (size_t)ji * 3 * blk) : nullptr,
-                    lr >= 0 ? (void *)(G->cd[lr].blocks_back + (size_t)q * 3 * blk) : nullptr, 3 * blk * sizeof(float)});
-    }
+  // x-lines -> cube (unpack_slab, fftw3ds.f90:69-99; unpack_pencils, p3dfft_coarse.f90:129-183): the pack exchange backwards
+  {
+    std::vector<XMsg> m3;
+    for (int r = 0; r < G->nodes; r++)
+      for (int q = 0; q < G->nxb; q++) {
+        const int t = xl_peer(G, r, q), lt = G->lidx[t], lr = G->lidx[r];   // t holds z-slice q of r's cube as block xl_index(r)
+        m3.push_back({t, r, lt >= 0 ? (const void *)(G->cd[lt].blocks_out + (size_t)xl_index(G, r) * 3 * blk) : nullptr,
+                      lr >= 0 ? (void *)(G->cd[lr].blocks_back + (size_t)q * 3 * blk) : nullptr, 3 * blk * sizeof(float)});
+      }
+    P3M_TRY(do_exchange(G, m3));
   }
-  P3M_TRY(do_exchange(G, m3));
   const int m = ncn + 2; const size_t face = (size_t)3 * m * m;
   for (int i = 0; i < nl; i++) {
-    const int64_t tot = (int64_t)nd * nd * 3 * blk;
-    hipLaunchKernelGGL(k_blocks_to_force, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].blocks_back, G->ctx[i]->force_c, s, ncn, nd * nd);
+    const int64_t tot = (int64_t)G->nxb * 3 * blk;
+    hipLaunchKernelGGL(k_blocks_to_force, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].blocks_back, G->ctx[i]->force_c, s, ncn, G->nxb);
     HIP_TRY(hipGetLastError());
   }
   // one-cell halo: x, then y (carrying the x halo), then z (coarse_force_buffer.f90:19-63)
@@ -888,10 +964,25 @@ extern "C" int p3m_hip_group_probe_coarse(p3m_group *G, float mass_p, int32_t i,
 }
 
 
+extern "C" int32_t p3m_hip_coarse_fft_schedule(int32_t nodes_dim, uint32_t flags, int32_t rank, int32_t which, int32_t j, int32_t *peer, int32_t *index) {
+  if (nodes_dim < 1 || !peer || !index) return P3M_EINVAL;
+  p3m_group G;
+  G.nd = nodes_dim; G.nodes = nodes_dim * nodes_dim * nodes_dim; G.pencil = (flags & P3M_FLAG_PENCIL) != 0;
+  G.nxb = G.pencil ? G.nd : G.nd * G.nd;
+  const int count = which == 0 ? G.nxb : (which == 1 ? (G.pencil ? G.nd : 0) : (which == 2 ? yz_count(&G) : -1));
+  if (count < 0 || rank < 0 || rank >= G.nodes) return P3M_EINVAL;
+  if (count == 0) return 0;
+  if (j < 0 || j >= count) return P3M_EINVAL;
+  if (which == 0) { *peer = xl_peer(&G, rank, j); *index = xl_index(&G, rank); }
+  else if (which == 1) { *peer = xy_peer(&G, rank, j); *index = xy_index(&G, rank); }
+  else { *peer = yz_peer(&G, rank, j); *index = yz_index(&G, rank); }
+  return count;
+}
+
 // ------------------------------------------------------------------ coarse_power.f90 on the distributed rho-hat
 // every local rank bins its own ky slab (d.lz, left by the last step's forward transform); the weights and sums of all
 // processes are added by one all-reduce (the reference's mpi_reduce, :109), then every process holds the spectrum.
-int coarse_power_accumulate(p3m_ctx *c, const float *lz, int planes, int ky0, int nc, int nchunk, float rho_c_mean, double *d_ps);
+int coarse_power_accumulate(p3m_ctx *c, const float *lz, int planes, int ky0, int kx0, int nc, int nchunk, float rho_c_mean, double *d_ps);
 void coarse_power_finish(const double *acc, int nc, float box, float *ps);
 extern "C" int p3m_hip_group_coarse_power(p3m_group *G, float mass_p, float box, float *ps) {
   if (!G || !ps) return P3M_EINVAL;
@@ -909,7 +1000,8 @@ extern "C" int p3m_hip_group_coarse_power(p3m_group *G, float mass_p, float box,
     for (size_t i = 0; i < G->ctx.size(); i++) {
       p3m_ctx *c = G->ctx[i];
       hipStream_t keep = c->stream; c->stream = G->stream;
-      const int r = coarse_power_accumulate(c, G->cd[i].lz, G->s, G->lrank[i] * G->s, nc, G->nchunk, rho_c_mean, d_ps);
+      const int r = coarse_power_accumulate(c, G->cd[i].lz, G->s, yz_index(G, G->lrank[i]) * G->s, G->pencil ? xy_index(G, G->lrank[i]) * G->ncl * 16 : 0, nc, G->ncl,
+                                            rho_c_mean, d_ps);
       c->stream = keep;
       P3M_TRY(r);
     }

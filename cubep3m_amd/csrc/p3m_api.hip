@@ -36,7 +36,9 @@ static int fill_geometry(const p3m_params *p, Geometry *g) {
   if (g->pp_range + 1 > g->ncut || g->pp_range > g->nb) { p3m_set_error("pp_range too large"); return P3M_EINVAL; }
   g->Nn = g->pt * g->T; g->E = g->Nn + 2 * g->nb;
   g->nc_buf = g->nb / g->ms; g->nct = g->pt / g->ms; g->ncn = g->nct * g->T; g->nc = g->ncn * g->nodes_dim;
-  if (g->nc % g->nodes) { p3m_set_error("cannot evenly decompose mesh into slabs (mpi_initialization.f90:26)"); return P3M_EINVAL; }
+  if (p->flags & P3M_FLAG_PENCIL) {
+    if (g->ncn % g->nodes_dim) { p3m_set_error("cannot evenly decompose mesh into pencils: mod(nc_dim, nodes_dim**2) != 0 (mpi_initialization_p3dfft.f90:27)"); return P3M_EINVAL; }
+  } else if (g->nc % g->nodes) { p3m_set_error("cannot evenly decompose mesh into slabs (mpi_initialization.f90:26)"); return P3M_EINVAL; }
   g->nc_slab = g->nc / g->nodes;
   g->hx = g->nf / 2 + 1; g->fb = g->pt + 3;
   g->fbp = (g->fb + 3) / 4 * 4;

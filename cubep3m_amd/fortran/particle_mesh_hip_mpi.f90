@@ -158,6 +158,10 @@ subroutine particle_mesh
 #ifdef MOVE_GRID_BACK
     par%flags = ior(par%flags, 16)
 #endif
+#ifdef PENCIL
+    ! the build that links p3dfft_coarse.f90 instead of fftw3ds.f90 (Makefile_p3dfft_nested): no macro of its own in the reference
+    par%flags = ior(par%flags, 32)
+#endif
     par%rsoft = rsoft; par%pp_bias = pp_bias; par%dt_pp_scale = dt_pp_scale; par%density_buffer = density_buffer
     par%rank = 0                       ! the group assigns the logical ranks
     par%device = mod(rank, max(1, p3m_hip_device_count()))   ! one GPU per MPI rank of the node (ranks share GPUs if there are fewer)

@@ -30,7 +30,7 @@ EXPORTS = [
     "p3m_hip_read_pid_checkpoint", "p3m_hip_write_ic", "p3m_hip_read_ic", "p3m_hip_group_nlocal", "p3m_hip_group_local_rank",
     "p3m_hip_group_ctx", "p3m_hip_group_set_kernel_tables", "p3m_hip_group_upload_particles", "p3m_hip_group_download_particles",
     "p3m_hip_group_particle_mesh", "p3m_hip_group_update_position", "p3m_hip_group_probe_coarse",
-    "p3m_hip_projection", "p3m_hip_group_projection", "p3m_hip_coarse_power", "p3m_hip_group_coarse_power", "p3m_hip_write_power", "p3m_hip_write_projection", "p3m_hip_read_projection",
+    "p3m_hip_projection", "p3m_hip_group_projection", "p3m_hip_coarse_power", "p3m_hip_group_coarse_power", "p3m_hip_coarse_fft_schedule", "p3m_hip_write_power", "p3m_hip_write_projection", "p3m_hip_read_projection",
 ]
 
 
@@ -80,6 +80,8 @@ def load():
     L.p3m_hip_time_fft_pass.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(i32)]
     L.p3m_hip_coarse_power.argtypes = [vp, f32, f32, f32p]
     L.p3m_hip_group_coarse_power.argtypes = [vp, f32, f32, f32p]
+    L.p3m_hip_coarse_fft_schedule.argtypes = [i32, C.c_uint32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.p3m_hip_coarse_fft_schedule.restype = i32
     L.p3m_hip_write_power.argtypes = [C.c_char_p, f32p, i32]
     L.p3m_hip_time_pp.argtypes = [vp, f32, f32, f32, i32, C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.p3m_hip_rccl_unique_id.argtypes = [vp]

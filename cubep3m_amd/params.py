@@ -13,6 +13,7 @@ FLAG_PPINT = 1 << 1
 FLAG_PP_EXT = 1 << 2
 FLAG_LRCKCORR = 1 << 3
 FLAG_MOVE_GRID_BACK = 1 << 4
+FLAG_PENCIL = 1 << 5
 
 P3M_OK, P3M_EINVAL, P3M_ENOMEM, P3M_ECAPACITY, P3M_EDEVICE, P3M_ESTATE, P3M_ECOMM = 0, -1, -2, -3, -4, -5, -6
 
@@ -80,6 +81,7 @@ class Params:
     pp_ext: bool = False
     lrckcorr: bool = False
     move_grid_back: bool = False
+    pencil: bool = False   # coarse FFT in 2-D pencils (p3dfft_coarse.f90) instead of slabs (fftw3ds.f90); multi-rank groups only
     rsoft: float = 0.1
     pp_bias: float = 1.0
     dt_pp_scale: float = 0.05
@@ -132,6 +134,7 @@ class Params:
             | (FLAG_PP_EXT if self.pp_ext else 0)
             | (FLAG_LRCKCORR if self.lrckcorr else 0)
             | (FLAG_MOVE_GRID_BACK if self.move_grid_back else 0)
+            | (FLAG_PENCIL if self.pencil else 0)
         )
 
     def validate(self):
@@ -140,7 +143,10 @@ class Params:
             raise ValueError("nf_tile - 2*nf_buf must be a positive multiple of mesh_scale")
         if self.nf_buf % self.mesh_scale:
             raise ValueError("nf_buf must be a multiple of mesh_scale")
-        if self.nc_dim % self.nodes:
+        if self.pencil:
+            if self.nc_node_dim % self.nodes_dim:
+                raise ValueError("cannot evenly decompose mesh into pencils (nc_pen = nc_node_dim / nodes_dim, cubepm.par:212)")
+        elif self.nc_dim % self.nodes:
             raise ValueError("cannot evenly decompose mesh into slabs")
         if self.ppint and not self.ngp:
             raise ValueError("PPINT is only compiled inside the NGP branch (particle_mesh_threaded.f90:260-287)")

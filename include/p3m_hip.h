@@ -47,6 +47,10 @@ extern "C" {
 #define P3M_FLAG_LRCKCORR   (1u << 3) /* -DLRCKCORR: long-range coarse kernel correction
                                          (kernel_initialization.f90:465-687)             */
 #define P3M_FLAG_MOVE_GRID_BACK (1u << 4) /* -DMOVE_GRID_BACK (move_grid_back.f90)       */
+#define P3M_FLAG_PENCIL     (1u << 5) /* coarse FFT decomposed in 2-D pencils instead of slabs: the build that links
+                                         p3dfft_coarse.f90 (:8-66, pack_pencils :69-127, unpack_pencils :129-183) with
+                                         dim_y = nodes_dim, dim_z = nodes_dim^2 (cubepm.par:210-215).  Needs
+                                         nc_node_dim % nodes_dim == 0 instead of nc_dim % nodes_dim^3 == 0; groups only */
 
 /* ---- error codes -------------------------------------------------------------------- */
 #define P3M_OK            0
@@ -294,6 +298,13 @@ int p3m_hip_group_projection(p3m_group *g, float mass_p, float *pxy, float *pxz,
  * (k = 2 pi (bin-1) / box, Delta^2(k) = 4 pi (bin-1)^3 <P>), bins without modes (count, 0).  `box` is the parameter of the
  * reference's `parameters` file.  Every process of a group receives the full spectrum. */
 int p3m_hip_group_coarse_power(p3m_group *g, float mass_p, float box, float *ps);
+/* Host-only (no device needed): the exchange schedule of the distributed coarse transform, for hosts that route the
+ * messages themselves and for tests.  which = 0: cube <-> x-lines (pack_slab, fftw3ds.f90:24-52; with P3M_FLAG_PENCIL
+ * pack_pencils, p3dfft_coarse.f90:69-127); 1: x <-> y transpose (pencils only); 2: y <-> z transpose.  Block j of `rank`
+ * goes to *peer, where it is block *index.  Returns the number of blocks (peers) of that exchange, 0 if it does not
+ * exist in this decomposition, or a negative P3M_E* code. */
+int32_t p3m_hip_coarse_fft_schedule(int32_t nodes_dim, uint32_t flags, int32_t rank, int32_t which, int32_t j,
+                                    int32_t *peer, int32_t *index);
 
 /* -- F77-ABI one-call wrapper in the style of pp_force_c_ (nbody-ueli.cu:368) ------------ */
 /* Single-rank hosts: uploads xv/PID, runs the step, downloads, returns the four dt limits.

@@ -67,11 +67,11 @@ def test_power_file_format(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nd", [1, 2])
-def test_hip_coarse_power_vs_oracle(nd):
+@pytest.mark.parametrize("nd,pencil", [(1, False), (2, False), (2, True)])
+def test_hip_coarse_power_vs_oracle(nd, pencil):
     from cubep3m_amd.group import ParticleMeshGroup
 
-    p = cfg1(nodes_dim=nd)
+    p = cfg1(nodes_dim=nd, pencil=pencil)
     box = 64.0 * nd
     xv = clustered_particles(40000 * nd ** 3, box, seed=17, frac=0.4, nblobs=30, sigma=1.5)
     g = ParticleMeshGroup(p, 0, 1, FINE_TABLE, COARSE_TABLE)

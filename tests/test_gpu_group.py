@@ -39,6 +39,8 @@ def run_both(p, xv, pid, scal, force_rccl=False, steps=1):
     ("clustered", dict(ngp=True, ppint=True, pp_ext=True, lrckcorr=True), False),
     ("uniform", dict(ngp=False), True),
     ("clustered", dict(ngp=True, ppint=True, pp_ext=True), True),
+    ("clustered", dict(ngp=True, ppint=True, pp_ext=True, lrckcorr=True, pencil=True), False),
+    ("uniform", dict(ngp=False, pencil=True), True),
 ])
 def test_eight_logical_ranks_match_oracle(kind, kw, force_rccl):
     p = cfg1(nodes_dim=2, **kw)
@@ -65,11 +67,13 @@ def test_eight_logical_ranks_match_oracle(kind, kw, force_rccl):
     assert np.sqrt(num / den) <= 1e-5, np.sqrt(num / den)
 
 
-def test_distributed_coarse_mesh_vs_oracle():
-    """Slab FFT with the all-to-all transpose, cube<->slab redistribution and the force halo, rank by rank."""
+@pytest.mark.parametrize("pencil", [False, True])
+def test_distributed_coarse_mesh_vs_oracle(pencil):
+    """Slab FFT (fftw3ds.f90) with the all-to-all transpose, cube<->slab redistribution and the force halo, rank by rank; and
+    the same through the pencil decomposition (p3dfft_coarse.f90: x-pencils, x<->y and y<->z transposes)."""
     from cubep3m_amd.group import ParticleMeshGroup
 
-    p = cfg1(nodes_dim=2, lrckcorr=True)
+    p = cfg1(nodes_dim=2, lrckcorr=True, pencil=pencil)
     xv, pid = global_ic("clustered", 40000, float(p.nf_physical_dim), 5)
     g = ParticleMeshGroup(p, 0, 1, FINE_TABLE, COARSE_TABLE)
     parts = g.scatter_global(xv, pid)
@@ -88,6 +92,55 @@ def test_distributed_coarse_mesh_vs_oracle():
         ro, fo = o.rho_c(i), o.force_c(i)
         assert np.abs(rg - ro).max() <= 4e-6 * np.abs(ro).max(), i
         assert rel_rms(fg, fo) < 3e-6, i      # interior and the one-cell halo from the neighbours
+
+
+def test_pencil_and_slab_decompositions_give_the_same_coarse_force():
+    """Both decompositions run the same line transforms on the same lines, only in different places: the coarse force and
+    the spectrum agree to rounding."""
+    from cubep3m_amd.group import ParticleMeshGroup
+
+    res = {}
+    for pencil in (False, True):
+        p = cfg1(nodes_dim=2, lrckcorr=True, pencil=pencil)
+        xv, pid = global_ic("clustered", 40000, float(p.nf_physical_dim), 5)
+        g = ParticleMeshGroup(p, 0, 1, FINE_TABLE, COARSE_TABLE)
+        g.scatter_global(xv, pid)
+        g.particle_mesh(0.01, 0.0, 0.0, 8.0)
+        res[pencil] = ([g.coarse(8.0, i)[1] for i in range(8)], g.coarse_power(8.0, 100.0))
+        g.close()
+    for a, b in zip(res[False][0], res[True][0]):
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
+    assert np.allclose(res[False][1], res[True][1], rtol=1e-6, atol=0)
+
+
+def test_pencils_where_slabs_cannot_decompose_the_mesh():
+    """3x3x3 ranks on a 36^3 coarse mesh: 36 is not a multiple of 27, so mpi_initialization.f90:26 refuses the slab build; the
+    pencil build (nc_pen = 12/3 = 4 planes, kx chunks padded to 3 x 16) runs, and matches the oracle's 27 ranks."""
+    from cubep3m_amd.group import ParticleMeshGroup
+    from cubep3m_amd.lib import P3MError
+    from cubep3m_amd.params import Params
+
+    kw = dict(nodes_dim=3, tiles_node_dim=1, nf_tile=96, cores=1, ngp=True, ppint=True, pp_ext=True)
+    with pytest.raises((ValueError, P3MError)):
+        ParticleMeshGroup(Params(**kw), 0, 1, FINE_TABLE, COARSE_TABLE)
+    p = Params(pencil=True, **kw)
+    assert p.nc_dim == 36 and p.nc_dim % p.nodes != 0
+    xv, pid = global_ic("clustered", 50000, float(p.nf_physical_dim), 17)
+    g, o, og, oo = run_both(p, xv, pid, (0.01, 0.3, 0.3, 8.0))
+    assert og.np_total == oo.np_total == len(xv) and og.np_ghost == oo.np_ghost
+    for name in ("dt_f_acc", "dt_c_acc", "dt_pp_acc", "dt_pp_ext_acc"):
+        assert getattr(og, name) == pytest.approx(getattr(oo, name), rel=1e-5), name
+    v0 = dict(zip(pid.tolist(), xv[:, 3:]))
+    num = den = 0.0
+    for i, r in enumerate(g.local_ranks):
+        xg, pg = by_pid(*g.download_particles(i))
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
+        vin = np.stack([v0[q] for q in pg.tolist()]) if len(pg) else np.zeros((0, 3), np.float32)
+        dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
+        num += ((dg - do) ** 2).sum()
+        den += (do ** 2).sum()
+    assert np.sqrt(num / den) <= 1e-5, np.sqrt(num / den)
 
 
 # ------------------------------------------------------------------ two PROCESSES (4 logical ranks each)
@@ -122,8 +175,8 @@ def _two_proc_worker(rank, world, port, outdir, kw):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_several_processes_host_transport_match_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,pencil", [(2, False), (8, False), (2, True), (8, True)])
+def test_several_processes_host_transport_match_oracle(tmp_path, world, pencil):
     """The process-level split (8/world logical ranks per process, remote peers, announced counts, the all-to-all and
     halo message lists, the dt reductions) driven by `world` processes sharing this one GPU through the host-callback
     transport over gloo -- RCCL refuses two ranks on one device, and an MPI host would take this same route.
@@ -132,7 +185,7 @@ def test_several_processes_host_transport_match_oracle(tmp_path, world):
 
     import torch.multiprocessing as mp
 
-    kw = dict(ngp=True, ppint=True, pp_ext=True)
+    kw = dict(ngp=True, ppint=True, pp_ext=True, pencil=pencil)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
