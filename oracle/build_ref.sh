@@ -88,6 +88,9 @@ build_cfg  cfg1_pp     1  2 80  2     2.0  "-DNGP -DPPINT -DPP_EXT -DPID_FLAG"
 build_cfg  cfg1_cic    1  2 80  2     2.0  "-DPID_FLAG"
 # the MPI host of tests/test_gpu_group.py (hip_mpi_driver): 8 ranks, PP switches on, DISP_MESH off
 build_cfg  cfg1_8rank_pp 2 2 80 2     2.0  "-DNGP -DPPINT -DPP_EXT"
+# the same host with the adapter's -DPENCIL (the reference's Makefile_p3dfft_nested build has no macro of its own; its
+# mpi_initialization_p3dfft.f90 needs cubepm_p3dfft_nested.fh in place of cubepm.fh, so the slab file's object is linked)
+build_cfg  cfg1_8rank_pencil 2 2 80 2 2.0  "-DNGP -DLRCKCORR -DPENCIL"
 # the host of tests/dropin_bench.py: 8 MPI ranks of 256^3 cells / 128^3 particles each (512^3 fine mesh, 256^3 particles),
 # the drop-in adapter timed with and without resident particles
 build_cfg  cfg2_8rank  2  2 176 1     1.5  "-DNGP"

@@ -299,7 +299,8 @@ def _write_kernel_ascii(path, table):
                     f.write("%4d%4d%4d%16.8E%16.8E%16.8E\n" % ((i + 1, j + 1, k + 1) + tuple(float(v) for v in table[k, j, i])))
 
 
-@pytest.mark.parametrize("cfg,kw", [("cfg1_8rank_pp", dict(ngp=True, ppint=True, pp_ext=True)), ("cfg1_8rank", dict(ngp=True))])
+@pytest.mark.parametrize("cfg,kw", [("cfg1_8rank_pp", dict(ngp=True, ppint=True, pp_ext=True)), ("cfg1_8rank", dict(ngp=True)),
+                                    ("cfg1_8rank_pencil", dict(ngp=True, lrckcorr=True, pencil=True))])
 def test_fortran_mpi_host_calls_particle_mesh_through_the_adapter(tmp_path, cfg, kw):
     """`mpiexec -n 8 hip_mpi_driver`: the reference's COMMON blocks and its own mpi_initialize, `call particle_mesh`
     resolved by cubep3m_amd/fortran/particle_mesh_hip_mpi.f90 (ISO_C_BINDING + the three MPI transport callbacks),
