@@ -8,7 +8,7 @@
 #include "p3m_internal.h"
 #include <algorithm>
 
-struct CGeo { int nb, E, Nn, ms, ncn, nc; };
+struct CGeo { int nb, E, Nn, ms, ncn, nc, cngp; };   // cngp: -DCOARSE_NGP (whole weight on cell i2; coarse_cic_mass.f90:21-24, coarse_velocity.f90:146-149)
 
 // CIC deposit without atomics.  A particle's footprint is the cells i1 = floor(x/ms - 0.5) + 1 and i1+1 per
 // axis (coarse_cic_mass.f90:18-21), clipped to 1..ncn (coarse_cic_mass_buffer.f90:59-113).  All particles with
@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
   auto add = [&](const float4 &p) {
     const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;     // coarse_cic_mass.f90:18
     const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;  // 1-based
-    float dx1 = (float)i1 - x; const float dy1 = (float)j1 - y, dz1 = (float)k1 - z;
-    float dx2 = 1.0f - dx1; const float dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+    float dx1 = (float)i1 - x, dy1 = (float)j1 - y, dz1 = (float)k1 - z;
+    float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+    if (G.cngp) { dx1 = dy1 = dz1 = 0.0f; dx2 = dy2 = dz2 = 1.0f; }                     // :21-24
     dx1 = mass_p * dx1; dx2 = mass_p * dx2;                                             // :32-33
     if (i1 == ci && j1 == cj && k1 == ck) {
       acc[0] += dx1 * dy1 * dz1; acc[1] += dx2 * dy1 * dz1; acc[2] += dx1 * dy2 * dz1; acc[3] += dx2 * dy2 * dz1;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_coarse_collect(const float *__restrict_
 
 int coarse_deposit(p3m_ctx *c, float mass_p) {
   const Geometry &g = c->g;
-  CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc};
+  CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc, (c->p.flags & P3M_FLAG_COARSE_NGP) ? 1 : 0};
   if (g.ms / 2 > g.nb) { p3m_set_error("coarse_deposit: mesh_scale/2 > nf_buf"); return P3M_EINVAL; }
   const int64_t m1 = g.ncn + 1, tot = m1 * m1 * m1, n3 = (int64_t)g.ncn * g.ncn * g.ncn;
   HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));
@@ -175,8 +176,9 @@ __global__ __launch_bounds__(256) void k_coarse_kick(const float4 *__restrict__ 
   const float inv = 1.0f / (float)G.ms;
   const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;             // :143
   const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;
-  const float dx1 = (float)i1 - x, dy1 = (float)j1 - y, dz1 = (float)k1 - z;
-  const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+  float dx1 = (float)i1 - x, dy1 = (float)j1 - y, dz1 = (float)k1 - z;
+  float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+  if (G.cngp) { dx1 = dy1 = dz1 = 0.0f; dx2 = dy2 = dz2 = 1.0f; }                           // :146-149
   const int m = G.ncn + 2; const int64_t cs = (int64_t)m * m * m;
   float4 v = svel[s];
 #pragma unroll
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void k_coarse_kick(const float4 *__restrict__ 
 int coarse_kick(p3m_ctx *c, float a_mid, float dt) {
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
-  CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc};
+  CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc, (c->p.flags & P3M_FLAG_COARSE_NGP) ? 1 : 0};
   hipLaunchKernelGGL(k_coarse_kick, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G,
                      (const float *)c->force_c, a_mid, dt);
   HIP_TRY(hipGetLastError());

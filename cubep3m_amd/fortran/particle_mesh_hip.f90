@@ -105,6 +105,9 @@ subroutine particle_mesh
 #ifdef MOVE_GRID_BACK
     par%flags = ior(par%flags, 16)
 #endif
+#ifdef COARSE_NGP
+    par%flags = ior(par%flags, 64)
+#endif
     par%rsoft = rsoft; par%pp_bias = pp_bias; par%dt_pp_scale = dt_pp_scale; par%density_buffer = density_buffer
     par%rank = rank; par%device = -1
     ierr_c = p3m_hip_create(par, ctx)

@@ -158,6 +158,9 @@ subroutine particle_mesh
 #ifdef MOVE_GRID_BACK
     par%flags = ior(par%flags, 16)
 #endif
+#ifdef COARSE_NGP
+    par%flags = ior(par%flags, 64)
+#endif
 #ifdef PENCIL
     ! the build that links p3dfft_coarse.f90 instead of fftw3ds.f90 (Makefile_p3dfft_nested): no macro of its own in the reference
     par%flags = ior(par%flags, 32)

@@ -47,6 +47,9 @@ extern "C" {
 #define P3M_FLAG_LRCKCORR   (1u << 3) /* -DLRCKCORR: long-range coarse kernel correction
                                          (kernel_initialization.f90:465-687)             */
 #define P3M_FLAG_MOVE_GRID_BACK (1u << 4) /* -DMOVE_GRID_BACK (move_grid_back.f90)       */
+#define P3M_FLAG_COARSE_NGP (1u << 6) /* -DCOARSE_NGP: the coarse deposit and the coarse gather put the whole weight on
+                                         cell i2 = floor(x/mesh_scale - 0.5) + 2 (coarse_cic_mass.f90:21-24,
+                                         coarse_cic_mass_buffer.f90:26-29, coarse_velocity.f90:146-149)              */
 #define P3M_FLAG_PENCIL     (1u << 5) /* coarse FFT decomposed in 2-D pencils instead of slabs: the build that links
                                          p3dfft_coarse.f90 (:8-66, pack_pencils :69-127, unpack_pencils :129-183) with
                                          dim_y = nodes_dim, dim_z = nodes_dim^2 (cubepm.par:210-215).  Needs

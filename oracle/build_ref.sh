@@ -86,6 +86,8 @@ build_cfg  cfg1_8rank  2  2 80  2     2.0  "-DNGP"
 build_cfg  cfg1_pp     1  2 80  2     2.0  "-DNGP -DPPINT -DPP_EXT -DPID_FLAG"
 # fine CIC build (no -DNGP): the #else branch of fine_velocity.f90:175-203 (CIC gather + kick)
 build_cfg  cfg1_cic    1  2 80  2     2.0  "-DPID_FLAG"
+# -DCOARSE_NGP: the three #ifdef branches of coarse_cic_mass.f90:21, coarse_cic_mass_buffer.f90:26, coarse_velocity.f90:146
+build_cfg  cfg1_cngp   1  2 80  2     2.0  "-DNGP -DCOARSE_NGP -DPID_FLAG"
 # the MPI host of tests/test_gpu_group.py (hip_mpi_driver): 8 ranks, PP switches on, DISP_MESH off
 build_cfg  cfg1_8rank_pp 2 2 80 2     2.0  "-DNGP -DPPINT -DPP_EXT"
 # the same host with the adapter's -DPENCIL (the reference's Makefile_p3dfft_nested build has no macro of its own; its

@@ -942,6 +942,7 @@ void orc_coarse_density(orc_ctx *c, float mass_p) {
           for (int d = 0; d < 3; d++) {
             float x = (1.0f / (float)ms) * XV(R, d + 1, pp) - 0.5f;       /* coarse_cic_mass.f90:18 */
             i1[d] = (int)floorf(x) + 1; i2[d] = i1[d] + 1; dx1[d] = (float)i1[d] - x; dx2[d] = 1.0f - dx1[d];
+            if (c->p.flags & P3M_FLAG_COARSE_NGP) { dx1[d] = 0.0f; dx2[d] = 1.0f; }   /* :21-24 (-DCOARSE_NGP) */
           }
           dx1[0] = mass_p * dx1[0]; dx2[0] = mass_p * dx2[0];             /* :32-33 */
           for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
@@ -1090,6 +1091,7 @@ void orc_coarse_max_dt_and_velocity(orc_ctx *c, float a_mid, float dt) {
         for (int d = 0; d < 3; d++) {
           float x = (1.0f / (float)ms) * XV(R, d + 1, pp) - 0.5f;         /* coarse_velocity.f90:143 */
           i1[d] = (int)floorf(x) + 1; i2[d] = i1[d] + 1; dx1[d] = (float)i1[d] - x; dx2[d] = 1.0f - dx1[d];
+          if (c->p.flags & P3M_FLAG_COARSE_NGP) { dx1[d] = 0.0f; dx2[d] = 1.0f; }     /* :146-149 (-DCOARSE_NGP) */
         }
         for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
           float dV = a_mid * G_F * dt * (cx ? dx2[0] : dx1[0]) * (cy ? dx2[1] : dx1[1]) * (cz ? dx2[2] : dx1[2]); /* :153-167 */

@@ -82,3 +82,35 @@ def test_oracle_reproduces_reference_fine_velocity(cfg, ngp, ppint):
     assert np.array_equal(np.sqrt(fmax2), d[cfg + "_f_force_max"])
     assert np.array_equal(ppmax, d[cfg + "_pp_force_max"])
     assert (ppmax.max() > 10.0) == ppint
+
+
+def test_oracle_reproduces_reference_coarse_ngp_build():
+    """-DCOARSE_NGP (coarse_cic_mass.f90:21-24, coarse_cic_mass_buffer.f90:26-29, coarse_velocity.f90:146-149): coarse
+    density and coarse kick of the reference's object code built with the switch (tests/golden/make_ref_coarse_ngp.py)."""
+    d = np.load(os.path.join(G, "ref_coarse_ngp.npz"))
+    a_mid, dt, dt_old, mass_p = (float(v) for v in d["scal"])
+    p = cfg1(coarse_ngp=True)
+    o = ol.Oracle(p)
+    o.set_particles(0, d["xv_in"], d["pid_in"])
+    o.update_position(dt, dt_old)
+    o.link_list()
+    assert o.particle_pass() == 0
+    assert np.array_equal(o.get_particles(0)[0], d["xv_passed"])
+    o.coarse_density(mass_p)
+    assert np.array_equal(o.rho_c(0), d["rho_c"])
+    plain = ol.Oracle(cfg1())                                    # the switch does change the answer
+    plain.set_particles(0, d["xv_in"], d["pid_in"])
+    plain.update_position(dt, dt_old)
+    plain.link_list()
+    plain.particle_pass()
+    plain.coarse_density(mass_p)
+    assert not np.array_equal(plain.rho_c(0), d["rho_c"])
+    ncn = p.nc_node_dim
+    o.distribute_force(synth_force_c(ncn, 0).reshape(ncn, ncn, ncn, 3))
+    assert np.array_equal(o.force_c(0), d["force_c_halo"])
+    o.coarse_max_dt_and_velocity(a_mid, dt)
+    assert o.step_out().dt_c_acc == d["dt_c_acc"]
+    assert np.array_equal(o.get_particles(0)[0], d["xv_kicked"])
+    o.delete_particles()
+    x, q = o.get_particles(0)
+    assert np.array_equal(x, d["xv_final"]) and np.array_equal(q, d["pid_final"])

@@ -120,8 +120,9 @@ def test_tile_force_vs_oracle(PM):
     assert mg == pytest.approx(mo, rel=1e-5)
 
 
-def test_coarse_mesh_vs_oracle(PM):
-    p = cfg1()
+@pytest.mark.parametrize("coarse_ngp", [False, True])
+def test_coarse_mesh_vs_oracle(PM, coarse_ngp):
+    p = cfg1(coarse_ngp=coarse_ngp)
     g, o = both(PM, p)
     xv = clustered_particles(30000, 64.0, seed=9)
     g.upload_particles(xv)
@@ -175,6 +176,8 @@ CASES = {
     "p3m_intra_clustered": (dict(ngp=True, ppint=True), "clustered", "pp"),
     "p3m_ext_clustered": (dict(ngp=True, ppint=True, pp_ext=True), "clustered", "pp ext"),
     "p3m_ext_uniform": (dict(ngp=True, ppint=True, pp_ext=True), "uniform", "pp ext"),
+    "pm_coarse_ngp_clustered": (dict(ngp=True, coarse_ngp=True), "clustered", ""),          # -DCOARSE_NGP
+    "p3m_coarse_ngp_cic_clustered": (dict(ngp=False, coarse_ngp=True), "clustered", ""),
 }
 
 

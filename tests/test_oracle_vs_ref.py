@@ -40,8 +40,10 @@ def make_input(n, box, seed):
     return xv, pid
 
 
-@pytest.mark.skipif(not ref_lib.available("cfg1_1rank"), reason="oracle/_ref not built")
-def test_single_rank_stages_bitwise():
+@pytest.mark.parametrize("cfg,kw", [("cfg1_1rank", {}), ("cfg1_cngp", dict(coarse_ngp=True))])
+def test_single_rank_stages_bitwise(cfg, kw):
+    if not ref_lib.available(cfg):
+        pytest.skip("oracle/_ref/%s not built" % cfg)
     # the reference keeps its state in process-global COMMON blocks: run it in a child process
     code = r"""
 import sys, numpy as np
@@ -49,17 +51,17 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 from ref_lib import Ref
 from ref_stage_run import run_stages
 d = np.load(sys.argv[1])
-ref = Ref('cfg1_1rank')
+ref = Ref(%r)
 res = run_stages(ref, d['xv_0'], d['pid_0'], tuple(float(v) for v in d['scal']), [tuple(t) for t in d['tiles']])
 np.savez(sys.argv[2], **res)
-""" % (HERE, os.path.dirname(HERE))
+""" % (HERE, os.path.dirname(HERE), cfg)
     xv, pid = make_input(6000, 64.0, 4242)
     with tempfile.TemporaryDirectory() as td:
         np.savez(os.path.join(td, "in.npz"), xv_0=xv, pid_0=pid, scal=np.asarray(SCAL, np.float32), tiles=np.asarray(TILES, np.int32))
         subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")],
                               stdout=subprocess.DEVNULL, preexec_fn=_big_stack, env=CHILD_ENV)
         ref = dict(np.load(os.path.join(td, "out.npz")))
-    compare_with_oracle(cfg1(), [(xv, pid)], [ref])
+    compare_with_oracle(cfg1(**kw), [(xv, pid)], [ref])
 
 
 def compare_with_oracle(p, parts, refs, pids_travel=True):
