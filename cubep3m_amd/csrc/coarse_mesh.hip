@@ -19,7 +19,11 @@ struct CGeo { int nb, E, Nn, ms, ncn, nc, cngp; };   // cngp: -DCOARSE_NGP (whol
 // (LDS float atomics cost ~2.5 clocks per lane on this part: a scatter into an LDS tile spent 80 % of its time
 // in ds_add_f32, and a gather per output cell re-reads cell_end 1.5 times.)
 // The chain window hoc(0:ncn+1) of coarse_mass.f90:85-87 is implied: i1 in [0,ncn] <=> x in [-ms/2, Nn+ms/2).
-#define CROWS 4   // fine rows whose range / first record loads are in flight together
+#ifndef CM_FLY
+#define CM_FLY 4
+#endif
+#define CM_CAP 16   // listed record indices per lane (k_coarse_moments<0>)
+template <int CROWS>   // 0: listed walk; else fine rows whose range / first record loads are in flight together
 __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ mom, CGeo G,
                                                        float mass_p, float *__restrict__ rho_c, const int *__restrict__ crow, int crow_w) {
   const int m1 = G.ncn + 1;
@@ -53,10 +57,42 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
     }
   };
   const int nrow = G.ms * G.ms;
-  for (int r0 = 0; r0 < nrow; r0 += CROWS) {
-    int p0[CROWS], p1[CROWS];
+  if (CROWS == 0) {
+    // Listed: a lane's records come from ms^2 short ranges (half a record each at the reference's density).  Walking them
+    // row by row makes the wavefront run `add` once per row and again for every extra record any lane has in that row --
+    // several times the work of its busiest lane (PMC: 58 % VALU-busy at 34 % active lanes).  Instead the row loop only
+    // lists the record indices in LDS (coalesced table loads, no arithmetic), and the lanes then take their records four at
+    // a time, loads first: the wavefront runs `add` about as often as its busiest lane has records, with four loads in
+    // flight per lane.  A full list is worked off before the row loop goes on, so the order of the sums never changes.
+    extern __shared__ int lst[];                         // [CM_CAP][256]
+    int cnt = 0;
+    auto drain = [&]() {
+      for (int k = 0; k < cnt; k += CM_FLY) {
+        float4 q[CM_FLY];
 #pragma unroll
-    for (int u = 0; u < CROWS; u++) {
+        for (int u = 0; u < CM_FLY; u++) { q[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (k + u < cnt) q[u] = spos[lst[(k + u) * 256 + threadIdx.x]]; }
+#pragma unroll
+        for (int u = 0; u < CM_FLY; u++) if (k + u < cnt) add(q[u]);
+      }
+      cnt = 0;
+    };
+    for (int r = 0; r < nrow; r++) {
+      const int zz = r / G.ms, yy = r - zz * G.ms;
+      int a0, a1;
+      if (crow) { const int *row = crow + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * crow_w + ci; a0 = row[0]; a1 = row[1]; }
+      else { const int *row = cs + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * G.E + x0; a0 = row[0]; a1 = row[G.ms]; }
+      for (int sidx = a0; sidx < a1; sidx++) {
+        if (cnt == CM_CAP) drain();
+        lst[cnt * 256 + threadIdx.x] = sidx; cnt++;
+      }
+    }
+    drain();
+  } else
+  for (int r0 = 0; r0 < nrow; r0 += (CROWS ? CROWS : 1)) {
+    constexpr int CR = CROWS ? CROWS : 1;
+    int p0[CR], p1[CR];
+#pragma unroll
+    for (int u = 0; u < CR; u++) {
       const int r = r0 + u, zz = r / G.ms, yy = r - zz * G.ms;
       p0[u] = 0; p1[u] = 0;
       if (r < nrow) {
@@ -64,11 +100,11 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
         else { const int *row = cs + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * G.E + x0; p0[u] = row[0]; p1[u] = row[G.ms]; }
       }
     }
-    float4 first[CROWS];
+    float4 first[CR];
 #pragma unroll
-    for (int u = 0; u < CROWS; u++) { first[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (p1[u] > p0[u]) first[u] = spos[p0[u]]; }
+    for (int u = 0; u < CR; u++) { first[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (p1[u] > p0[u]) first[u] = spos[p0[u]]; }
 #pragma unroll
-    for (int u = 0; u < CROWS; u++) {
+    for (int u = 0; u < CR; u++) {
       if (p1[u] > p0[u]) add(first[u]);
       for (int s = p0[u] + 1; s < p1[u]; s++) add(spos[s]);
     }
@@ -104,8 +140,12 @@ int coarse_deposit(p3m_ctx *c, float mass_p) {
   if (g.ms / 2 > g.nb) { p3m_set_error("coarse_deposit: mesh_scale/2 > nf_buf"); return P3M_EINVAL; }
   const int64_t m1 = g.ncn + 1, tot = m1 * m1 * m1, n3 = (int64_t)g.ncn * g.ncn * g.ncn;
   HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));
-  hipLaunchKernelGGL(k_coarse_moments, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G,
-                     mass_p, c->rho_c, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w);
+  static const int crows = getenv("P3M_CROWS") ? atoi(getenv("P3M_CROWS")) : 0;   // 0: listed walk (default); 1..16: row by row, that many rows in flight
+  const int *crow = c->cells_compact ? (const int *)c->crow : (const int *)nullptr;
+#define LAUNCH_CM(N) hipLaunchKernelGGL(k_coarse_moments<N>, dim3((unsigned)cdiv(tot, 256)), dim3(256), (N) ? 0 : sizeof(int) * CM_CAP * 256, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G, \
+                                        mass_p, c->rho_c, crow, c->crow_w)
+  if (crows >= 16) LAUNCH_CM(16); else if (crows >= 8) LAUNCH_CM(8); else if (crows >= 4) LAUNCH_CM(4); else if (crows >= 2) LAUNCH_CM(2); else if (crows >= 1) LAUNCH_CM(1); else LAUNCH_CM(0);
+#undef LAUNCH_CM
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_coarse_collect, dim3((unsigned)std::min<int64_t>(1024, cdiv(n3, 256))), dim3(256), 0, c->stream, (const float *)c->cmom, c->rho_c, g.ncn, c->d_sums + 1 * P3M_SUM_SPAN);
   HIP_TRY(hipGetLastError());
