@@ -27,6 +27,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# this pool's host driver supports dmabuf IPC only: without it RCCL between processes fails in hipIpcGetMemHandle
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from cubep3m_amd.kernels import default_tables  # noqa: E402
 from cubep3m_amd.params import Params  # noqa: E402
