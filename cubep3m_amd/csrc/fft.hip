@@ -610,6 +610,24 @@ __global__ __launch_bounds__(TB) void k_fft_lines3(LinesArgs a, Factors fac, con
 // 16 per Stockham stage plus the staging copy; one exchange buffer of n*16 complex, so two workgroups share a CU.
 // LDS element (k1, b, col) sits at ((k1*R2P + b)*16 + col), R2P = R2|1: the four line groups of a wave then fall in
 // different bank halves on the stage-2 read, and the stage-1 write is contiguous.
+// Stage-1 epilogue of the two-register-stage kernels: element k1 times W^(g*k1) into the exchange buffer.  The twiddle comes
+// from the LDS table; read in the statement that uses it, every ds_read is followed by a wait a handful of instructions later
+// (the kernels sit at their VGPR limit, so the compiler does not hoist them).  Here the reads run TWD elements ahead.
+#ifndef P3M_TWD
+#define P3M_TWD 2
+#endif
+template <int R, int STRIDE> __device__ __forceinline__ void store_twiddled(c32 *px, const c32 (&v)[R], const c32 *tw, int gq) {
+  c32 w[P3M_TWD];
+#pragma unroll
+  for (int d = 0; d < P3M_TWD; d++) if (1 + d < R) w[d] = tw[__mul24(gq, 1 + d)];
+  px[0] = v[0];
+#pragma unroll
+  for (int k1 = 1; k1 < R; k1++) {
+    const c32 wk = w[(k1 - 1) % P3M_TWD];
+    if (k1 + P3M_TWD < R) w[(k1 - 1) % P3M_TWD] = tw[__mul24(gq, k1 + P3M_TWD)];
+    px[k1 * STRIDE] = vmul(v[k1], wk);
+  }
+}
 template <int R1, int R2> struct L2Cfg {
   static constexpr int n = R1 * R2, R2P = R2 | 1, S1 = R2 * BXC, S2 = R1 * BXC, TB = ((S1 > S2 ? S1 : S2) + 63) / 64 * 64;
   static constexpr size_t lds = sizeof(float2) * ((size_t)R1 * R2P * BXC + n);
@@ -649,8 +667,7 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_pe
       dft<R1>(v);
       c32 *px = X + g * BXC + col;
       int gq = g; asm volatile("" : "+v"(gq));   // opaque: keeps the R1 twiddle offsets from being hoisted out of the loop into live registers
-#pragma unroll
-      for (int k1 = 0; k1 < R1; k1++) px[k1 * (R2P * BXC)] = k1 ? vmul(v[k1], tw[__mul24(gq, k1)]) : v[0];
+      store_twiddled<R1, R2P * BXC>(px, v, tw, gq);
     }
     __syncthreads();
     if (s2) {
@@ -732,8 +749,7 @@ __global__ __launch_bounds__((L3Cfg<R1, R2>::TB)) void k_fft_lines3r(LinesArgs a
       dft<R1>(v);
       c32 *px = X0 + g * BXC + col;
       int gq = g; asm volatile("" : "+v"(gq));   // opaque: keeps the R1 twiddle offsets from being hoisted out of the loop into live registers
-#pragma unroll
-      for (int k1 = 0; k1 < R1; k1++) px[k1 * (R2P * BXC)] = k1 ? vmul(v[k1], tw[__mul24(gq, k1)]) : v[0];
+      store_twiddled<R1, R2P * BXC>(px, v, tw, gq);
     }
     __syncthreads();
     // forward, stage 2 (role B): rho-hat g + R1*k2 into registers
@@ -757,8 +773,7 @@ __global__ __launch_bounds__((L3Cfg<R1, R2>::TB)) void k_fft_lines3r(LinesArgs a
         dft<R2>(t);
         c32 *px = Xw + g * BXC + col;
         int gq = g; asm volatile("" : "+v"(gq));
-#pragma unroll
-        for (int k1 = 0; k1 < R2; k1++) px[k1 * (R1P * BXC)] = k1 ? vmul(t[k1], tw[__mul24(gq, k1)]) : t[0];
+        store_twiddled<R2, R1P * BXC>(px, t, tw, gq);
       }
       __syncthreads();
       if (comp < 2) fetch_k(w, comp + 1, rB);
