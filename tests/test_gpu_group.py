@@ -41,6 +41,7 @@ def run_both(p, xv, pid, scal, force_rccl=False, steps=1):
     ("clustered", dict(ngp=True, ppint=True, pp_ext=True), True),
     ("clustered", dict(ngp=True, ppint=True, pp_ext=True, lrckcorr=True, pencil=True), False),
     ("uniform", dict(ngp=False, pencil=True), True),
+    ("clustered", dict(ngp=True, coarse_ngp=True), False),          # -DCOARSE_NGP across rank boundaries (force halo cells)
 ])
 def test_eight_logical_ranks_match_oracle(kind, kw, force_rccl):
     p = cfg1(nodes_dim=2, **kw)
