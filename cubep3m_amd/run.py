@@ -34,10 +34,14 @@ def main(argv=None):
     ap.add_argument("--pp-ext", action="store_true")
     ap.add_argument("--cic", action="store_true", help="CIC instead of NGP on the fine mesh")
     ap.add_argument("--binary", action="store_true", help="-DBINARY file layout")
+    ap.add_argument("--lrckcorr", action="store_true", help="-DLRCKCORR coarse kernel correction")
+    ap.add_argument("--coarse-ngp", action="store_true", help="-DCOARSE_NGP coarse deposit and gather")
+    ap.add_argument("--pencil", action="store_true", help="coarse FFT in 2-D pencils (the p3dfft build) instead of slabs; nodes_dim > 1")
     ap.add_argument("--max-nts", type=int, default=4000)
     a = ap.parse_args(argv)
 
-    p = Params(nodes_dim=a.nodes_dim, tiles_node_dim=a.tiles, nf_tile=a.nf_tile, ngp=not a.cic, ppint=a.ppint, pp_ext=a.pp_ext)
+    p = Params(nodes_dim=a.nodes_dim, tiles_node_dim=a.tiles, nf_tile=a.nf_tile, ngp=not a.cic, ppint=a.ppint, pp_ext=a.pp_ext,
+               lrckcorr=a.lrckcorr, coarse_ngp=a.coarse_ngp, pencil=a.pencil and a.nodes_dim > 1)
     g = ParticleMeshGroup(p, 0, 1)
     npart = 0
     for i, r in enumerate(g.local_ranks):
