@@ -3,7 +3,7 @@
 //   link_list.f90 + particle_pass.f90 (single rank: periodic self exchange) -> k_pass_axis
 //   link_list's chaining mesh hoc/ll (and llf, hoc_fine/ll_fine) -> sort by extended fine cell:
 //     k_row_hist / exclusive scan / k_row_scatter (by x-row), k_row_sort (inside each row)
-//   delete_particles.f90 + move_grid_back.f90 -> k_flag_physical / scan / k_compact
+//   delete_particles.f90 + move_grid_back.f90 -> k_count_physical / scan of the block counts / k_compact
 // Records are SoA float4 pos, float4 vel, int64 pid.  Everything here is HBM-bound streaming
 // (the row histogram / scatter aggregate their atomics per block in LDS).
 #include "p3m_internal.h"
@@ -651,13 +651,44 @@ int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, c
 // ------------------------------------------------------------------ delete_particles.f90:17-47 (+ move_grid_back.f90:17-24)
 // move_grid_back (xv -= shake_offset) runs BEFORE delete_particles (particle_mesh_threaded.f90:716-720),
 // so the range test is applied to the shifted-back positions.
-__global__ __launch_bounds__(PT) void k_flag_physical(const float4 *__restrict__ spos, int n, float Nn, int *__restrict__ flags,
-                                                      float mx, float my, float mz) {
-  const int i = blockIdx.x * PT + threadIdx.x;
-  if (i >= n) return;
-  float4 p = spos[i];
+// Survivors of delete_particles, counted per block of PT consecutive sorted records (SORT_RPT such blocks per workgroup,
+// the chunking of k_compact_drift_hist).  The exclusive scan of these counts gives every block its first destination;
+// the rank of a record inside its block is a ballot away (block_rank), so no per-record flag / offset array is written,
+// scanned or read (it used to be 4 B written + scanned + read per record).
+__device__ __forceinline__ bool survives(float4 p, float Nn, float mx, float my, float mz) {
   p.x -= mx; p.y -= my; p.z -= mz;
-  flags[i] = (p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn) ? 1 : 0;
+  return p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn;
+}
+__global__ __launch_bounds__(PT) void k_count_physical(const float4 *__restrict__ spos, int n, float Nn, int *__restrict__ cnt, float mx, float my, float mz) {
+  __shared__ int wc[SORT_RPT][PT / 64];
+  float4 pl[SORT_RPT];
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    pl[u] = make_float4(-1.f, -1.f, -1.f, 0.f);
+    if (i < n) pl[u] = spos[i];
+  }
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && survives(pl[u], Nn, mx, my, mz));
+    if ((threadIdx.x & 63) == 0) wc[u][threadIdx.x >> 6] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < SORT_RPT) {
+    const int blk = blockIdx.x * SORT_RPT + threadIdx.x;
+    if ((int64_t)blk * PT < n) { int t = 0; for (int w = 0; w < PT / 64; w++) t += wc[threadIdx.x][w]; cnt[blk] = t; }
+  }
+}
+// destination of a surviving record: first destination of its block + survivors before it in the block (every thread calls)
+__device__ __forceinline__ int block_rank(bool keep, int *wcnt) {   // wcnt: PT/64 ints of LDS, not in use by anybody else until the next barrier
+  const unsigned long long m = __ballot(keep);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wcnt[wv] = __popcll(m);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wv; w++) base += wcnt[w];
+  return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 // DRIFT: the next step's update_position (update_position.f90:68-76) rides on the copy, applied to the very value
 // k_compact alone would have stored
@@ -665,12 +696,14 @@ template <bool DRIFT>
 __global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos, const float4 *__restrict__ svel, const int64_t *__restrict__ spid,
                                                 const int *__restrict__ offs, int n, float Nn, float4 *__restrict__ pos, float4 *__restrict__ vel,
                                                 int64_t *__restrict__ pid, float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off) {
+  __shared__ int wcnt[PT / 64];
   const int i = blockIdx.x * PT + threadIdx.x;
-  if (i >= n) return;
-  float4 p = spos[i];
+  float4 p = make_float4(-1.f, -1.f, -1.f, 0.f);
+  if (i < n) p = spos[i];
+  const bool keep = i < n && survives(p, Nn, mx, my, mz);
+  const int o = offs[blockIdx.x] + block_rank(keep, wcnt);   // offs: first destination of every block of PT records
+  if (!keep) return;
   p.x -= mx; p.y -= my; p.z -= mz;
-  if (!(p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn)) return;
-  const int o = offs[i];
   const float4 v = svel[i];
   if (DRIFT) {
     if (use_off) { p.x = p.x + v.x * hs + ox; p.y = p.y + v.y * hs + oy; p.z = p.z + v.z * hs + oz; }  // :71
@@ -688,8 +721,8 @@ __global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restr
                                                            int64_t *__restrict__ pid, float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off,
                                                            float nb, int E, int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt) {
   __shared__ int key[SORT_HB], val[SORT_HB];
+  __shared__ int wc[SORT_RPT][PT / 64];
   for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
-  __syncthreads();
   float4 pl[SORT_RPT];
 #pragma unroll
   for (int u = 0; u < SORT_RPT; u++) {   // all position loads first
@@ -697,14 +730,25 @@ __global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restr
     pl[u] = make_float4(-1.f, -1.f, -1.f, 0.f);
     if (i < n) pl[u] = spos[i];
   }
+  int rk[SORT_RPT];   // survivors before this record in its wavefront; the wavefronts' totals meet in LDS
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < SORT_RPT; u++) {
+    const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && survives(pl[u], Nn, mx, my, mz));
+    rk[u] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wc[u][wv] = __popcll(m);
+  }
+  __syncthreads();
 #pragma unroll
   for (int u = 0; u < SORT_RPT; u++) {
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
     float4 p = pl[u];
-    p.x -= mx; p.y -= my; p.z -= mz;
     int row = -1;
-    if (i < n && p.x >= 0.0f && p.x < Nn && p.y >= 0.0f && p.y < Nn && p.z >= 0.0f && p.z < Nn) {   // delete_particles.f90:17-47
-      const int o = offs[i];
+    if (i < n && survives(p, Nn, mx, my, mz)) {   // delete_particles.f90:17-47
+      p.x -= mx; p.y -= my; p.z -= mz;
+      int o = offs[blockIdx.x * SORT_RPT + u] + rk[u];   // offs: first destination of every block of PT records
+      for (int w = 0; w < wv; w++) o += wc[u][w];
       const float4 v = svel[i];
       if (use_off) { p.x = p.x + v.x * hs + ox; p.y = p.y + v.y * hs + oy; p.z = p.z + v.z * hs + oz; }  // update_position.f90:71
       else { p.x = p.x + v.x * hs; p.y = p.y + v.y * hs; p.z = p.z + v.z * hs; }                           // :73
@@ -731,10 +775,11 @@ int particles_finalize_enqueue(p3m_ctx *c, const float *move_back) {
   if (n == 0) { c->np_local = 0; return P3M_OK; }
   float mx = 0, my = 0, mz = 0;
   if (move_back) { mx = move_back[0]; my = move_back[1]; mz = move_back[2]; }
-  hipLaunchKernelGGL(k_flag_physical, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, n, (float)c->g.Nn, c->flags, mx, my, mz);
+  const int nblk = cdiv(n, PT);   // c->flags: survivors per block of PT sorted records, then (scanned) every block's first destination
+  hipLaunchKernelGGL(k_count_physical, dim3(cdiv(nblk, SORT_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, n, (float)c->g.Nn, c->flags, mx, my, mz);
   HIP_TRY(hipGetLastError());
-  P3M_TRY(exclusive_scan_i32(c, c->flags, n));
-  HIP_TRY(hipMemcpyAsync(c->h_counters, c->flags + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  P3M_TRY(exclusive_scan_i32(c, c->flags, nblk));
+  HIP_TRY(hipMemcpyAsync(c->h_counters, c->flags + nblk, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->pend_mb[0] = mx; c->pend_mb[1] = my; c->pend_mb[2] = mz;
   return P3M_OK;
 }
