@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 template <bool COARSE>
 __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, TileGeo G,
                                                       int Nn, int ms, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
-                                                      float *__restrict__ fmax_out, const float *__restrict__ fc, int ncn, const int *__restrict__ crow, int crow_w) {
+                                                      float *__restrict__ fmax_out, const float *__restrict__ fc, int ncn, const int *__restrict__ crow, int crow_w,
+                                                      int *__restrict__ cnt256) {   // cnt256: survivors per block of 256 sorted records, counted on the way (or nullptr)
   extern __shared__ float frow[];   // [3][fbp]
   const int fb = G.fb, fbp = G.fbp, lo = G.nb - 2, lane = threadIdx.x;
   const int jj = blockIdx.x % fb, kk = (blockIdx.x / fb) % fb, tile = blockIdx.x / (fb * fb);
@@ -367,6 +368,16 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
     if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) continue;  // chains of hoc(1..ncn) only (:234-236)
     // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
     if (((int)floorf(p.x / (float)ms)) / nct != tx || ((int)floorf(p.y / (float)ms)) / nct != ty || ((int)floorf(p.z / (float)ms)) / nct != tz) continue;
+    if (cnt256) {
+      // every physical record passes here exactly once (in its owner tile): they are the survivors of delete_particles.
+      // The lanes hold consecutive sorted indices, i.e. at most two blocks of 256: one atomic per block and wavefront
+      const int blk = s >> 8;
+      const unsigned long long act = __ballot(1);
+      const int first = __shfl(blk, __ffsll((long long)act) - 1, 64);
+      const unsigned long long m1 = __ballot(blk == first);
+      if (lane == __ffsll((long long)m1) - 1) atomicAdd(&cnt256[first], __popcll(m1));
+      if (blk != first) { const unsigned long long m2 = __ballot(1); if (lane == __ffsll((long long)m2) - 1) atomicAdd(&cnt256[blk], __popcll(m2)); }
+    }
     const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
     const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
     float fx, fy, fz;
@@ -418,14 +429,24 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
   if (!(c->p.flags & P3M_FLAG_NGP)) { P3M_TRY(fine_force_max(c)); return fine_kick(c, a_mid, dt); }
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
+  // the kick visits every physical record once: it counts them per block of 256 sorted records for delete_particles
+  // (particles_finalize_enqueue), which then needs no pass of its own over the positions -- unless the grid moves back first
+  static const bool nocount = getenv("P3M_SEPARATE_COUNT") && getenv("P3M_SEPARATE_COUNT")[0] == '1';
+  int *cnt256 = nullptr;
+  c->cnt_from_kick = 0;
+  if (!nocount && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK) && c->np_all > 0) {
+    cnt256 = c->flags;
+    HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
+    c->cnt_from_kick = c->np_all;
+  }
   if (c->coarse_first)
     hipLaunchKernelGGL(k_fine_kick_rows<true>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
                        (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
-                       (const float *)c->force_c, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w);
+                       (const float *)c->force_c, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w, cnt256);
   else
     hipLaunchKernelGGL(k_fine_kick_rows<false>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
                        (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
-                       (const float *)nullptr, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w);
+                       (const float *)nullptr, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w, cnt256);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

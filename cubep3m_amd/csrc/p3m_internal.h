@@ -92,6 +92,7 @@ struct p3m_ctx {
   bool pending_compact = false; int pend_n = 0; float pend_mb[3] = {0, 0, 0};   // deferred ghost removal (particles.hip)
   hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;   // single-rank whole steps: the coarse force forms on stream2 underneath the fine-mesh force sweep
   int sort_ncur = 0;           // records handed to the sort queued by particles_sort_enqueue
+  int cnt_from_kick = 0;       // records the NGP kick counted into c->flags per block of 256 (survivors of delete_particles without move_grid_back); 0: not counted
   bool hist_done = false;      // the x-row counts of the next sort were accumulated while the arrival arrays were written (particles.hip)
   bool finalize_queued = false; // particles_finalize_enqueue ran, particles_finalize_finish has not
   bool lazy_counters = false;  // whole steps: the sort's deleted count has not been read yet, np_all is its upper bound (the tail is padded)

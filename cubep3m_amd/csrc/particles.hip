@@ -776,7 +776,9 @@ int particles_finalize_enqueue(p3m_ctx *c, const float *move_back) {
   float mx = 0, my = 0, mz = 0;
   if (move_back) { mx = move_back[0]; my = move_back[1]; mz = move_back[2]; }
   const int nblk = cdiv(n, PT);   // c->flags: survivors per block of PT sorted records, then (scanned) every block's first destination
-  hipLaunchKernelGGL(k_count_physical, dim3(cdiv(nblk, SORT_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, n, (float)c->g.Nn, c->flags, mx, my, mz);
+  const bool counted = c->cnt_from_kick == n && mx == 0.f && my == 0.f && mz == 0.f;   // the NGP kick of this step counted them on its way (fine_max_and_kick)
+  c->cnt_from_kick = 0;
+  if (!counted) hipLaunchKernelGGL(k_count_physical, dim3(cdiv(nblk, SORT_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, n, (float)c->g.Nn, c->flags, mx, my, mz);
   HIP_TRY(hipGetLastError());
   P3M_TRY(exclusive_scan_i32(c, c->flags, nblk));
   HIP_TRY(hipMemcpyAsync(c->h_counters, c->flags + nblk, sizeof(int), hipMemcpyDeviceToHost, c->stream));
