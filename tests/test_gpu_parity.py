@@ -666,7 +666,8 @@ def test_report_force_superposition_on_the_hip_path(PM):
 # ---------------------------------------------------------------------------------- BASELINE configs 2 and 5 at full size
 def test_config2_pm_only_full_size_properties(PM):
     """BASELINE config 2: 256^3 fine mesh / 128^3 particles, PM only (NGP), 2^3 tiles of 176 (the tile size every cfg2
-    bench line runs): size-independent properties of a whole step, and the kick against the oracle on a sample."""
+    bench line runs): size-independent properties of a whole step.  (The kick, the dt limits and the particle set of this
+    configuration against the oracle at full size: tests/test_gpu_baseline_sizes.py.)"""
     p = Params(tiles_node_dim=2, nf_tile=176, ngp=True, density_buffer=1.5)
     n = 128 ** 3
     xv = grid_jitter_particles(128, 256.0, seed=778, sigma=0.4)
