@@ -33,10 +33,14 @@
 #define BXC 16
 // half lengths h = n/2 = R1*R2 with two-register-stage x kernels (k_fft_x_fwd2, k_fft_x_inv2)
 #define P3M_X2_SIZES(X) X(32, 8, 4) X(40, 8, 5) X(48, 8, 6) X(56, 8, 7) X(64, 8, 8) X(80, 10, 8) X(88, 11, 8) X(96, 12, 8) X(104, 13, 8) X(112, 14, 8) \
-  X(128, 16, 8) X(152, 19, 8) X(160, 16, 10) X(176, 16, 11) X(192, 16, 12) X(224, 16, 14) X(256, 16, 16) X(280, 20, 14) X(304, 19, 16)
+  X(128, 16, 8) X(152, 19, 8) X(160, 16, 10) X(176, 16, 11) X(192, 16, 12) X(224, 16, 14) X(256, 16, 16) X(280, 20, 14) X(304, 19, 16) \
+  X(320, 20, 16) X(352, 22, 16) X(384, 24, 16) X(416, 26, 16) X(448, 28, 16) X(512, 32, 16)
 // line lengths n = R1*R2 with a two-register-stage y/z kernel (k_fft_lines2, k_fft_lines3r); anything else runs the LDS Stockham kernels
 #define P3M_LINES2_SIZES(X) X(64, 8, 8) X(80, 10, 8) X(96, 12, 8) X(112, 14, 8) X(128, 16, 8) X(160, 16, 10) X(176, 16, 11) X(192, 16, 12) X(208, 16, 13) X(224, 16, 14) \
-  X(256, 16, 16) X(304, 19, 16) X(320, 20, 16) X(352, 22, 16) X(384, 24, 16) X(448, 28, 16) X(512, 32, 16) X(560, 28, 20) X(608, 32, 19)
+  X(256, 16, 16) X(304, 19, 16) X(320, 20, 16) X(352, 22, 16) X(384, 24, 16) X(448, 28, 16) X(512, 32, 16) X(560, 28, 20) X(608, 32, 19) \
+  X(640, 32, 20) X(704, 32, 22) X(768, 32, 24) X(832, 32, 26) X(896, 32, 28) X(1024, 32, 32)
+// Lines longer than P3M_STOCKHAM_MAX no longer fit a 16-column bundle twice into the 160 KiB LDS: they exist with register stages only
+#define P3M_STOCKHAM_MAX 608
 
 __device__ __forceinline__ int64_t bundle_off(int64_t b, int n, int nchunk, int o, int chunk) {
   return (((b * n + o) * nchunk + chunk) * (int64_t)n) * BXC;
@@ -47,7 +51,7 @@ __device__ __forceinline__ int64_t bundle_off2(int64_t b, int planes, int line, 
 }
 
 // P3M_FFT_STOCKHAM=1 in the environment forces the LDS Stockham kernels for every size (A/B measurements)
-static bool lines2_off() { static const bool off = getenv("P3M_FFT_STOCKHAM") && getenv("P3M_FFT_STOCKHAM")[0] == '1'; return off; }
+static bool lines2_off(int n) { static const bool off = getenv("P3M_FFT_STOCKHAM") && getenv("P3M_FFT_STOCKHAM")[0] == '1'; return off && n <= P3M_STOCKHAM_MAX; }
 
 // ------------------------------------------------------------------ x pass, forward (r2c): ROWS -> LY
 // RB consecutive rows per batch (a power of two, compile-time, so that all LDS index arithmetic is shifts
@@ -333,9 +337,11 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ sr
 // columns of real elements 2j, 2j+1, j = k1 + R1*k2, as 8-byte pairs at compile-time offsets.  A wave holds RPW whole
 // rows (Q = max(R1,R2) lanes each); exchange element (row, k1, b) sits at (row*R1 + k1)*R2P + b, R2P odd.  The next
 // batch's gather is in flight during both stages.
-template <int R1, int R2>
+// BOX = false: every row of `rows_total` LY rows (rpp rows per plane) as a real row of 2*px floats at box + row*2*px (the
+// coarse mesh, the probes): fb = n, lo = 0, the pad floats n .. 2*px-1 are written as zeros.
+template <int R1, int R2, bool BOX = true>
 __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ src, int n, int px, int rows_total, const float2 *__restrict__ tw_g,
-                                                    float inv_scale, float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride) {
+                                                    float inv_scale, float *__restrict__ box, int fb, int lo, int ntile, int64_t box_comp_stride, int rpp) {
   using C = X2Cfg<R1, R2>;
   constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P, NLD = C::NLD;
   extern __shared__ float2 lds[];
@@ -348,13 +354,19 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
   const bool act = rw < C::RPW, s1 = act && q < R2, s2 = act && q < R1;
   const int nbatch = (rows_total + RB - 1) / RB;
   const float rscale = 1.0f / inv_scale;
-  const int64_t cstride = (int64_t)n * BXC;
+  const int64_t cstride = (int64_t)(BOX ? n : rpp) * BXC;
   c32 twq[R1];   // W_h^{q*k1}
 #pragma unroll
   for (int k1 = 0; k1 < R1; k1++) twq[k1] = reinterpret_cast<const c32 *>(tw_g)[s1 ? 2 * q * k1 : 0];
   auto tables = [&](int w, int buf) {
     const int64_t srow = (int64_t)w * RB + threadIdx.x;
     if ((int)threadIdx.x < RB && srow < rows_total) {
+      if (!BOX) {
+        const unsigned bz = (unsigned)srow / (unsigned)rpp;
+        src_row[buf][threadIdx.x] = (((int64_t)bz * nchunk) * rpp + ((unsigned)srow - bz * rpp)) * BXC;
+        dst_off[buf][threadIdx.x] = srow * (int64_t)(2 * px);
+        return;
+      }
       const unsigned s32 = (unsigned)srow, t2 = s32 / (unsigned)fb, bb = t2 / (unsigned)fb;
       const int jj = (int)(s32 - t2 * fb), kk = (int)(t2 - bb * fb);
       const int comp = (int)(bb / (unsigned)ntile), tl = (int)(bb - comp * ntile);
@@ -422,7 +434,10 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
       dft<R2>(u);
       const int x0 = 2 * q - lo;   // box column of real element 2j for k2 = 0; lo is even
       float *pd = box + dst_off[buf][r] + x0;
-      if (fb == fbp) {
+      if (!BOX) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) *reinterpret_cast<c32 *>(pd + 2 * R1 * k2) = (c32){u[k2].x * rscale, -u[k2].y * rscale};
+      } else if (fb == fbp) {
 #pragma unroll
         for (int k2 = 0; k2 < R2; k2++)
           if ((unsigned)(x0 + 2 * R1 * k2) < (unsigned)fb) __builtin_nontemporal_store((c32){u[k2].x * rscale, -u[k2].y * rscale}, reinterpret_cast<c32 *>(pd + 2 * R1 * k2));
@@ -437,6 +452,13 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
             *reinterpret_cast<float2 *>(pd + 2 * R1 * k2) = o2;
           }
         }
+      }
+    }
+    if (!BOX) {   // pad floats n .. 2*px-1 of every row
+      const int npad = px - h;
+      for (int e = threadIdx.x; e < nrows * npad; e += C::TB) {
+        const int rr = e / npad;
+        *reinterpret_cast<c32 *>(box + dst_off[buf][rr] + 2 * (h + (e - rr * npad))) = (c32){0.f, 0.f};
       }
     }
   }
@@ -631,9 +653,14 @@ template <int R, int STRIDE> __device__ __forceinline__ void store_twiddled(c32 
 template <int R1, int R2> struct L2Cfg {
   static constexpr int n = R1 * R2, R2P = R2 | 1, S1 = R2 * BXC, S2 = R1 * BXC, TB = ((S1 > S2 ? S1 : S2) + 63) / 64 * 64;
   static constexpr size_t lds = sizeof(float2) * ((size_t)R1 * R2P * BXC + n);
+  // wavefronts per SIMD the LDS lets in, capped at 4 (128 VGPRs); the long lines (one workgroup per CU) get the whole file
+  static constexpr int wgs = (int)((size_t)160 * 1024 / lds), wv = ((TB / 64) * (wgs < 1 ? 1 : wgs) + 3) / 4, WPE = wv > 4 ? 4 : (wv < 1 ? 1 : wv);
 };
-template <int R1, int R2, bool INV, bool TR>
-__global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft_lines2(LinesArgs a, const float2 *__restrict__ tw_g) {
+// NC = 2 (INV, TR): one component, K at a.kern.  NC = 1 (INV, TR): the k-space multiply of particle_mesh_threaded.f90:183-192 on the way in, one force component after the other
+// from the same bundle of rho-hat (re-read per component: the workgroup holds K_c and ONE component at a time, so two
+// workgroups still share a CU); component c goes to dst + c*dst_comp_stride.
+template <int R1, int R2, bool INV, bool TR, int NC = 0>
+__global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_per_eu(L2Cfg<R1, R2>::WPE, L2Cfg<R1, R2>::WPE))) void k_fft_lines2(LinesArgs a, const float2 *__restrict__ tw_g) {
   using C = L2Cfg<R1, R2>;
   constexpr int n = C::n, R2P = C::R2P;
   extern __shared__ float2 lds[];
@@ -645,8 +672,9 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_pe
   auto locate = [&](int bid, int &o, int &chunk, int64_t &b) {
     chunk = bid % a.nchunk; const int rest = bid / a.nchunk; o = a.olo + rest % a.ocount; b = rest / a.ocount;
   };
+  static_assert(NC == 0 || (INV && TR), "the fused multiply belongs to the transposing inverse z pass");
   c32 v[R1];
-  auto fetch = [&](int w, bool on) {   // defines v on every path: a stale v would stay live through the whole loop body
+  auto fetch = [&](int w, int comp, bool on) {   // defines v on every path: a stale v would stay live through the whole loop body
 #pragma unroll
     for (int m = 0; m < R1; m++) v[m] = (c32){0.f, 0.f};
     if (!on) return;
@@ -654,11 +682,20 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_pe
     const c32 *src = reinterpret_cast<const c32 *>(a.src + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk)) + g * BXC + col;
 #pragma unroll
     for (int m = 0; m < R1; m++) v[m] = TR ? src[m * (R2 * BXC)] : __builtin_nontemporal_load(src + m * (R2 * BXC));   // in place, read once and written once: past the caches
+    if (NC != 0) {
+      const float *k = a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk) + g * BXC + col;
+      float K[R1];
+#pragma unroll
+      for (int m = 0; m < R1; m++) K[m] = k[m * (R2 * BXC)];
+#pragma unroll
+      for (int m = 0; m < R1; m++) v[m] = (c32){-v[m].y * K[m], v[m].x * K[m]};   // i K rho-hat; the conj of the inverse follows below
+    }
   };
   int w = blockIdx.x;
   __syncthreads();
-  for (; w < nwork; w += gridDim.x) {
-    fetch(w, s1);
+  for (; w < nwork; w += gridDim.x)
+  for (int comp = 0; comp < (NC == 1 ? 3 : 1); comp++) {
+    fetch(w, comp, s1);
     if (s1) {
       if (INV) {
 #pragma unroll
@@ -681,6 +718,7 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_pe
       if (!TR) { d0 = reinterpret_cast<c32 *>(a.dst + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk)) + col; rstride = BXC; }
       else { d0 = reinterpret_cast<c32 *>(a.dst + bundle_off2(b, a.dst_planes, a.dst_line, a.nchunk, 0, chunk)) + o * BXC + col; rstride = (int64_t)a.nchunk * a.dst_line * BXC; }
       d0 += g * rstride;
+      if (NC != 0) d0 += comp * a.dst_comp_stride;
       int r0 = g - a.slo; asm volatile("" : "+v"(r0));        // likewise the R2 row-range predicates
       asm volatile("" : "+s"(rstride));                        // and row offsets
 #pragma unroll
@@ -827,7 +865,16 @@ static bool factorize(int n, int *nfac, int *fac) {
 
 int fft_plan_create(FftPlan *pl, int n) {
   if (n < 4 || (n & 3)) { p3m_set_error("fft: n=%d must be a multiple of 4", n); return P3M_EINVAL; }
-  if (n > 608) { p3m_set_error("fft: n=%d > 608: a 16-column bundle no longer fits the 160 KiB LDS", n); return P3M_EINVAL; }
+  if (n > P3M_STOCKHAM_MAX) {   // longer lines run the register-stage kernels only: both the line length and its half need an instance
+    bool l2 = false, x2 = false;
+#define X(N, A, B) if (n == N) l2 = true;
+    P3M_LINES2_SIZES(X)
+#undef X
+#define X(H, A, B) if (n == 2 * H) x2 = true;
+    P3M_X2_SIZES(X)
+#undef X
+    if (!l2 || !x2) { p3m_set_error("fft: n=%d > %d has no register-stage instance (640, 704, 768, 832, 896, 1024)", n, P3M_STOCKHAM_MAX); return P3M_EINVAL; }
+  }
   pl->n = n;
   pl->px = ((n / 2 + 1) + 15) / 16 * 16;
   if (!factorize(n, &pl->nfac_full, pl->fac_full) || !factorize(n / 2, &pl->nfac_half, pl->fac_half)) {
@@ -913,7 +960,7 @@ template <int R1, int R2> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, 
 // rpp: rows per plane of the LY output; 0 = pl.n (whole planes).  A pencil decomposition hands in planes of fewer rows.
 int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp) {
   if (rpp <= 0) rpp = pl.n;
-  if (!lines2_off()) {
+  if (!lines2_off(pl.n)) {
 #define X(H, A, B) if (pl.n == 2 * H) return x_fwd2_impl<A, B>(c, pl, src, dst, rows, rpp);
     P3M_X2_SIZES(X)
 #undef X
@@ -951,30 +998,35 @@ static int x_inv_rb(p3m_ctx *c, const FftPlan &pl, const float *src, float *out,
     default: return x_inv_impl<RSET, 64>(c, pl, src, out, batch, mode, box, fb, lo, ntile, bcs, rpp);
   }
 }
-template <int R1, int R2> static int x_inv2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, int batch, float *box, int fb, int lo, int ntile, int64_t bcs) {
+template <int R1, int R2, bool BOX> static int x_inv2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, int64_t rows, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp) {
   using C = X2Cfg<R1, R2>;
   const int n = pl.n;
-  const int64_t rows = (int64_t)batch * fb * fb;
   if (rows > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)rows); return P3M_EINVAL; }
   const float scale = (float)n * (float)n * (float)n;
-  P3M_TRY((set_lds(k_fft_x_inv2<R1, R2>, C::lds)));
+  P3M_TRY((set_lds(k_fft_x_inv2<R1, R2, BOX>, C::lds)));
   static int occ = 0;
   if (occ == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_inv2<R1, R2>), C::TB, C::lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_inv2<R1, R2, BOX>), C::TB, C::lds));
     if (occ < 1) occ = 1;
   }
   const int64_t nbatch = cdiv(rows, C::RB);
   const int64_t g = (int64_t)256 * occ;
-  hipLaunchKernelGGL((k_fft_x_inv2<R1, R2>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, reinterpret_cast<const float2 *>(src), n,
-                     pl.px, (int)rows, pl.d_tw, scale, box, fb, lo, ntile, bcs);
+  hipLaunchKernelGGL((k_fft_x_inv2<R1, R2, BOX>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, reinterpret_cast<const float2 *>(src), n,
+                     pl.px, (int)rows, pl.d_tw, scale, box, fb, lo, ntile, bcs, rpp);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
 // src in LY; mode 0 writes real ROWS to out, mode 1 the force box; rpp (mode 0): rows per plane of the LY input, 0 = pl.n
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp) {
   if (rpp <= 0) rpp = pl.n;
-  if (mode == 1 && (lo & 1) == 0 && !lines2_off()) {
-#define X(H, A, B) if (pl.n == 2 * H) return x_inv2_impl<A, B>(c, pl, src, batch, box, fb, lo, ntile, bcs);
+  if (mode == 1 && (lo & 1) == 0 && !lines2_off(pl.n)) {
+#define X(H, A, B) if (pl.n == 2 * H) return x_inv2_impl<A, B, true>(c, pl, src, (int64_t)batch * fb * fb, box, fb, lo, ntile, bcs, rpp);
+    P3M_X2_SIZES(X)
+#undef X
+  }
+  if (mode == 0 && !lines2_off(pl.n)) {   // `batch` counts ROWS when negative (distributed slabs), whole n^2 arrays otherwise
+    const int64_t rows = batch < 0 ? -(int64_t)batch : (int64_t)batch * pl.n * pl.n;
+#define X(H, A, B) if (pl.n == 2 * H) return x_inv2_impl<A, B, false>(c, pl, src, rows, out, pl.n, 0, 1, 0, rpp);
     P3M_X2_SIZES(X)
 #undef X
   }
@@ -1031,7 +1083,7 @@ template <bool FWD> static int launch_lines3_t(p3m_ctx *c, const FftPlan &pl, co
 #undef L3
 }
 static bool lines2_has(int n) {
-  if (lines2_off()) return false;
+  if (lines2_off(n)) return false;
 #define X(N, A, B) if (n == N) return true;
   P3M_LINES2_SIZES(X)
 #undef X
@@ -1053,34 +1105,54 @@ template <int R1, int R2> static int lines3r_impl(p3m_ctx *c, const FftPlan &pl,
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
+template <int R1, int R2, bool INV, bool TR, int NC> static int lines2_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch);
+// P3M_Z_UNFUSED=1: the forward z pass and the multiply + inverse z pass as two launches of the one-buffer kernel even where the
+// fused kernel fits (A/B measurements; lines longer than 608 always run this way)
+static bool z_unfused() { static const bool on = getenv("P3M_Z_UNFUSED") && getenv("P3M_Z_UNFUSED")[0] == '1'; return on; }
+template <bool INV, bool TR, int NC> static int launch_lines(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch);
 static int launch_lines3(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch, bool fwd = false) {
-  if (fwd && lines2_has(pl.n)) {
+  if (lines2_has(pl.n)) {
+    if (fwd && !z_unfused()) {
 #define X(N, A, B) if (pl.n == N) { if constexpr (L3Cfg<A, B>::lds <= 160 * 1024) return lines3r_impl<A, B>(c, pl, a, batch); }   // two exchange buffers must fit the LDS
+      P3M_LINES2_SIZES(X)
+#undef X
+    }
+    if (fwd) {   // forward z in place, then the multiply + inverse z from rho-hat
+      LinesArgs f = a;
+      f.dst = const_cast<float2 *>(a.src); f.kern = nullptr; f.slo = 0; f.scount = pl.n; f.dst_planes = a.src_planes; f.dst_line = pl.n;
+      P3M_TRY((launch_lines<false, false, 0>(c, pl, f, batch)));
+    }
+#define X(N, A, B) if (pl.n == N) return lines2_impl<A, B, true, true, 1>(c, pl, a, batch);
     P3M_LINES2_SIZES(X)
 #undef X
   }
   return fwd ? launch_lines3_t<true>(c, pl, a, batch) : launch_lines3_t<false>(c, pl, a, batch);
 }
-template <int R1, int R2, bool INV, bool TR> static int lines2_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
+template <int R1, int R2, bool INV, bool TR, int NC> static int lines2_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
   using C = L2Cfg<R1, R2>;
   a.n = pl.n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
-  P3M_TRY((set_lds(k_fft_lines2<R1, R2, INV, TR>, C::lds)));
+  P3M_TRY((set_lds(k_fft_lines2<R1, R2, INV, TR, NC>, C::lds)));
   static int occ = 0;
   if (occ == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines2<R1, R2, INV, TR>), C::TB, C::lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines2<R1, R2, INV, TR, NC>), C::TB, C::lds));
     if (occ < 1) occ = 1;
   }
   int grid = 256 * occ;
   if (grid > a.nbundles) grid = a.nbundles;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_fft_lines2<R1, R2, INV, TR>), dim3((unsigned)grid), dim3(C::TB), C::lds, c->stream, a, pl.d_tw);
+  hipLaunchKernelGGL((k_fft_lines2<R1, R2, INV, TR, NC>), dim3((unsigned)grid), dim3(C::TB), C::lds, c->stream, a, pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
 template <bool INV, bool TR, int NC> static int launch_lines(p3m_ctx *c, const FftPlan &pl, const LinesArgs &a, int batch) {
   const int rs = rset_of(pl.nfac_full, pl.fac_full);
+  if constexpr (NC == 1) if (lines2_has(pl.n)) {   // single-component multiply (fft3d_inverse with a kernel)
+#define X(N, A, B) if (pl.n == N) return lines2_impl<A, B, INV, TR, 2>(c, pl, a, batch);
+    P3M_LINES2_SIZES(X)
+#undef X
+  }
   if constexpr (NC == 0) if (lines2_has(pl.n)) {
-#define X(N, A, B) if (pl.n == N) return lines2_impl<A, B, INV, TR>(c, pl, a, batch);
+#define X(N, A, B) if (pl.n == N) return lines2_impl<A, B, INV, TR, 0>(c, pl, a, batch);
     P3M_LINES2_SIZES(X)
 #undef X
   }
@@ -1178,6 +1250,16 @@ int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float
     case 3: return fft_inverse3_box_z(c, pl, data, work, kern, batch, fb, lo, true);   // as the step runs it: forward z pass fused in (data: rho after x,y)
     case 4: return fft_inverse3_box_y(c, pl, work, batch, fb, lo);
     case 5: return fft_x_inverse(c, pl, work, nullptr, 3 * batch, 1, box, fb, lo, batch, bcs, 0);
+    case 6: {   // the multiply + inverse z pass on its own (one exchange buffer, rho-hat re-read per component): the second half of the un-fused z pair
+      LinesArgs z = full_args(pl, work, data);
+      z.kern = kern; z.kern_comp_stride = (int64_t)pl.n * pl.n * pl.px; z.dst_comp_stride = (int64_t)batch * pl.n * pl.n * pl.px;
+      z.slo = lo; z.scount = fb;
+#define X(N, A, B) if (pl.n == N) return lines2_impl<A, B, true, true, 1>(c, pl, z, batch);
+      P3M_LINES2_SIZES(X)
+#undef X
+      p3m_set_error("fft_single_pass: no register-stage kernel for n=%d", pl.n);
+      return P3M_EINVAL;
+    }
   }
   p3m_set_error("fft_single_pass: bad selector %d", which);
   return P3M_EINVAL;

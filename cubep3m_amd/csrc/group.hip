@@ -775,15 +775,18 @@ static int coarse_force_dist(p3m_group *G) {
 
 // ================================================================== public group API
 extern "C" int p3m_hip_group_set_kernel_tables(p3m_group *G, const float *fine_table, const float *coarse_table) {
-  if (!G || !fine_table || !coarse_table) return P3M_EINVAL;
+  const bool coarse_only = G && (G->base.flags & P3M_FLAG_COARSE_ONLY);
+  if (!G || (!fine_table && !coarse_only) || !coarse_table) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(G->device));
   if (G->nodes == 1) return p3m_hip_set_kernel_tables(G->ctx[0], fine_table, coarse_table);
-  // kern_f is identical on every rank: build once, copy
-  P3M_TRY(build_fine_kernel(G->ctx[0], fine_table));
-  const Geometry &g = G->ctx[0]->g;
-  for (size_t i = 1; i < G->ctx.size(); i++) {
-    HIP_TRY(hipMemcpyAsync(G->ctx[i]->kern_f, G->ctx[0]->kern_f, sizeof(float) * 3 * g.nf * g.nf * g.px, hipMemcpyDeviceToDevice, G->stream));
-    G->ctx[i]->have_kf = true;
+  if (!coarse_only) {
+    // kern_f is identical on every rank: build once, copy
+    P3M_TRY(build_fine_kernel(G->ctx[0], fine_table));
+    const Geometry &g = G->ctx[0]->g;
+    for (size_t i = 1; i < G->ctx.size(); i++) {
+      HIP_TRY(hipMemcpyAsync(G->ctx[i]->kern_f, G->ctx[0]->kern_f, sizeof(float) * 3 * g.nf * g.nf * g.px, hipMemcpyDeviceToDevice, G->stream));
+      G->ctx[i]->have_kf = true;
+    }
   }
   P3M_TRY(build_coarse_kernel_dist(G, coarse_table));
   G->have_k = true;
@@ -858,6 +861,7 @@ extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, 
   if (!G) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(G->device));
   if (G->nodes == 1) return p3m_hip_particle_mesh(G->ctx[0], a_mid, dt, dt_old, mass_p, offset, move_back, out);
+  if (G->base.flags & P3M_FLAG_COARSE_ONLY) { p3m_set_error("particle_mesh on a P3M_FLAG_COARSE_ONLY group (it holds the coarse mesh only)"); return P3M_ESTATE; }
   for (p3m_ctx *c : G->ctx) if (!c->have_kf || !c->have_kc) { p3m_set_error("particle_mesh before the Green's functions were set"); return P3M_ESTATE; }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
   P3M_TRY(ghost_pass(G));                                                                           // :61-63
@@ -963,6 +967,74 @@ extern "C" int p3m_hip_group_probe_coarse(p3m_group *G, float mass_p, int32_t i,
   return P3M_OK;
 }
 
+
+// ------------------------------------------------------------------ the distributed coarse transform on its own
+static int need_dist(p3m_group *G, int32_t i) {
+  if (!G || i < 0 || i >= (int)G->ctx.size()) return P3M_EINVAL;
+  if (G->nodes == 1) { p3m_set_error("the distributed coarse transform needs a multi-rank group (nodes_dim > 1)"); return P3M_EINVAL; }
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_set_coarse_density(p3m_group *G, int32_t i, const float *rho_c) {
+  P3M_TRY(need_dist(G, i));
+  if (!rho_c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  const Geometry &g = G->ctx[0]->g;
+  HIP_TRY(hipMemcpyAsync(G->ctx[i]->rho_c, rho_c, sizeof(float) * (size_t)g.ncn * g.ncn * g.ncn, hipMemcpyHostToDevice, G->stream));
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_coarse_transform(p3m_group *G, int32_t what, int32_t reps, float *ms) {
+  P3M_TRY(need_dist(G, 0));
+  if (what < 0 || what > 1 || reps < 0) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  if (what == 1) for (p3m_ctx *c : G->ctx) if (!c->have_kc) { p3m_set_error("coarse force before the coarse kernel was set"); return P3M_ESTATE; }
+  auto once = [&]() -> int {
+    if (what == 0) return dist_forward(G, [&](int li) { return G->ctx[li]->rho_c; });
+    for (p3m_ctx *c : G->ctx) HIP_TRY(hipMemsetAsync(c->d_red + 2 * P3M_RED_SPAN, 0, P3M_RED_SPAN * sizeof(float), G->stream));
+    return coarse_force_dist(G);
+  };
+  P3M_TRY(once());
+  if (reps > 0) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int r = hipEventRecord(e0, G->stream) == hipSuccess ? P3M_OK : P3M_EDEVICE;
+    for (int k = 0; k < reps && r == P3M_OK; k++) r = once();
+    if (r == P3M_OK && (hipEventRecord(e1, G->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) r = P3M_EDEVICE;
+    float t = 0.f;
+    if (r == P3M_OK && hipEventElapsedTime(&t, e0, e1) != hipSuccess) r = P3M_EDEVICE;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    P3M_TRY(r);
+    if (ms) *ms = t / (float)reps;
+  }
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_get_coarse_hat(p3m_group *G, int32_t i, float *hat, int64_t nfloats) {
+  P3M_TRY(need_dist(G, i));
+  const Geometry &g = G->ctx[0]->g;
+  const int64_t want = (int64_t)G->s * G->ncl * g.nc * 16 * 2;
+  if (!hat || nfloats != want) { p3m_set_error("get_coarse_hat: the local rho-hat holds %lld floats ([s=%d][ncl=%d][nc=%d][16] complex)", (long long)want, G->s, G->ncl, g.nc); return P3M_EINVAL; }
+  HIP_TRY(hipSetDevice(G->device));
+  HIP_TRY(hipMemcpyAsync(hat, G->cd[i].lz, sizeof(float) * (size_t)want, hipMemcpyDeviceToHost, G->stream));
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_get_coarse_force(p3m_group *G, int32_t i, float *force_c) {
+  P3M_TRY(need_dist(G, i));
+  if (!force_c) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  const Geometry &g = G->ctx[0]->g;
+  const size_t fcs = (size_t)(g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2);
+  std::vector<float> tmp(3 * fcs);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), G->ctx[i]->force_c, sizeof(float) * 3 * fcs, hipMemcpyDeviceToHost, G->stream));
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  for (int comp = 0; comp < 3; comp++) for (size_t k = 0; k < fcs; k++) force_c[k * 3 + comp] = tmp[comp * fcs + k];
+  return P3M_OK;
+}
+extern "C" int64_t p3m_hip_group_coarse_exchange_bytes(const p3m_group *G) {
+  if (!G || G->nodes == 1) return 0;
+  return (int64_t)G->s * G->ncl * G->s * 16 * (int64_t)sizeof(float2);
+}
 
 extern "C" int32_t p3m_hip_coarse_fft_schedule(int32_t nodes_dim, uint32_t flags, int32_t rank, int32_t which, int32_t j, int32_t *peer, int32_t *index) {
   if (nodes_dim < 1 || !peer || !index) return P3M_EINVAL;

@@ -43,7 +43,8 @@ static int fill_geometry(const p3m_params *p, Geometry *g) {
   g->hx = g->nf / 2 + 1; g->fb = g->pt + 3;
   g->fbp = (g->fb + 3) / 4 * 4;
   g->px = (g->hx + 15) / 16 * 16; g->pxc = ((g->nc / 2 + 1) + 15) / 16 * 16;
-  if ((int64_t)g->E * g->E * g->E > 2000000000LL) { p3m_set_error("extended fine domain %d^3 exceeds int32 cell indices", g->E); return P3M_EINVAL; }
+  const bool coarse_only = (p->flags & P3M_FLAG_COARSE_ONLY) != 0;   // no particle store, no fine mesh: their int32 limits do not apply
+  if (!coarse_only && (int64_t)g->E * g->E * g->E > 2000000000LL) { p3m_set_error("extended fine domain %d^3 exceeds int32 cell indices", g->E); return P3M_EINVAL; }
   const int nd = g->nodes_dim, rk = p->rank;
   if (rk < 0 || rk >= g->nodes) { p3m_set_error("rank %d out of range", rk); return P3M_EINVAL; }
   g->cart[0] = rk / (nd * nd); g->cart[1] = (rk / nd) % nd; g->cart[2] = rk % nd;  // mpi_initialization.f90:60-64
@@ -55,7 +56,7 @@ static int fill_geometry(const p3m_params *p, Geometry *g) {
   // cubepm.par:170-172
   const double Nn = g->Nn, nb = g->nb;
   const double inner = (double)((g->Nn / 2) * (int64_t)(g->Nn / 2)) * (g->Nn / 2) + (8.0 * nb * nb * nb + 6.0 * nb * Nn * Nn + 12.0 * nb * nb * Nn) / 8.0;
-  g->max_np = (int64_t)((double)p->density_buffer * inner);
+  g->max_np = coarse_only ? 0 : (int64_t)((double)p->density_buffer * inner);
   if (g->max_np > 2000000000LL) { p3m_set_error("max_np exceeds int32"); return P3M_EINVAL; }
   return P3M_OK;
 }
@@ -83,6 +84,9 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   }
   c->cap = g.max_np;
 #define A(x) do { int _r = (x); if (_r) return fail(_r); } while (0)
+  const bool coarse_only = (params->flags & P3M_FLAG_COARSE_ONLY) != 0;
+  if (coarse_only && g.nodes == 1) { p3m_set_error("P3M_FLAG_COARSE_ONLY is for multi-rank groups"); return fail(P3M_EINVAL); }
+  if (!coarse_only) {
   A(dalloc(&c->pos, c->cap)); A(dalloc(&c->vel, c->cap)); A(dalloc(&c->pid, c->cap));
   A(dalloc(&c->spos, c->cap)); A(dalloc(&c->svel, c->cap)); A(dalloc(&c->spid, c->cap));
   A(dalloc(&c->tpos, c->cap)); A(dalloc(&c->tidx, c->cap));
@@ -109,9 +113,10 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   A(dalloc(&c->kern_f, (size_t)3 * g.nf * g.nf * g.px));
   if (hipMemset(c->kern_f, 0, (size_t)3 * g.nf * g.nf * g.px * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
   A(fft_plan_create(&c->plan_f, g.nf));
+  A(dalloc(&c->cmom, (size_t)8 * (g.ncn + 1) * (g.ncn + 1) * (g.ncn + 1)));
+  }   // !coarse_only
   // coarse mesh
   A(dalloc(&c->rho_c, (size_t)g.ncn * g.ncn * g.ncn));
-  A(dalloc(&c->cmom, (size_t)8 * (g.ncn + 1) * (g.ncn + 1) * (g.ncn + 1)));
   A(dalloc(&c->force_c, (size_t)3 * (g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2)));
   if (g.nodes == 1) {
     const size_t Sc = (size_t)g.nc * g.nc * (2 * g.pxc);

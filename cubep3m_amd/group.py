@@ -211,6 +211,42 @@ class ParticleMeshGroup:
         _lib.check(self.L.p3m_hip_group_projection(self.h, mass_p, *(m.ctypes.data_as(C.c_void_p) for m in maps), C.byref(tot)))
         return maps[0], maps[1], maps[2], tot.value
 
+    # -- the distributed coarse transform on its own (any multi-rank group; Params(coarse_only=True) holds nothing else) -----
+    def set_coarse_density(self, i, rho_c):
+        n = self.params.nc_node_dim
+        rho_c = np.ascontiguousarray(rho_c, np.float32)
+        assert rho_c.shape == (n, n, n)
+        _lib.check(self.L.p3m_hip_group_set_coarse_density(self.h, i, rho_c))
+
+    def coarse_transform(self, what, reps=0):
+        """what = "forward": the distributed r2c transform of every rank's rho_c; "force": coarse_force.f90 (forward, multiply,
+        three inverse transforms, force halo).  Returns the average ms per run over `reps` timed runs (None for reps = 0)."""
+        ms = C.c_float()
+        _lib.check(self.L.p3m_hip_group_coarse_transform(self.h, {"forward": 0, "force": 1}[what], reps, C.byref(ms)))
+        return ms.value if reps > 0 else None
+
+    def coarse_hat(self, i):
+        """rho-hat of local rank i as complex64 [local ky][kz][kx] (kx up to the padded row pitch; slabs: ky = rank*nc_slab + local ky)."""
+        p = self.params
+        px = ((p.nc_dim // 2 + 1) + 15) // 16 * 16
+        if p.pencil:
+            px = (px + 16 * p.nodes_dim - 1) // (16 * p.nodes_dim) * (16 * p.nodes_dim)
+        s = p.nc_node_dim // p.nodes_dim if p.pencil else p.nc_slab
+        ncl = px // 16 // (p.nodes_dim if p.pencil else 1)
+        raw = np.empty((s, ncl, p.nc_dim, 16), np.complex64)
+        _lib.check(self.L.p3m_hip_group_get_coarse_hat(self.h, i, raw.ctypes.data_as(C.c_void_p), raw.size * 2))
+        return raw.transpose(0, 2, 1, 3).reshape(s, p.nc_dim, ncl * 16)
+
+    def coarse_force(self, i):
+        n = self.params.nc_node_dim + 2
+        f = np.empty((n, n, n, 3), np.float32)
+        _lib.check(self.L.p3m_hip_group_get_coarse_force(self.h, i, f.ctypes.data_as(C.c_void_p)))
+        return f
+
+    @property
+    def coarse_exchange_bytes(self):
+        return int(self.L.p3m_hip_group_coarse_exchange_bytes(self.h))
+
     def coarse(self, mass_p, i, want_force=True):
         p = self.params
         rho = np.empty((p.nc_node_dim,) * 3, np.float32)

@@ -15,6 +15,7 @@ FLAG_LRCKCORR = 1 << 3
 FLAG_MOVE_GRID_BACK = 1 << 4
 FLAG_PENCIL = 1 << 5
 FLAG_COARSE_NGP = 1 << 6
+FLAG_COARSE_ONLY = 1 << 7
 
 P3M_OK, P3M_EINVAL, P3M_ENOMEM, P3M_ECAPACITY, P3M_EDEVICE, P3M_ESTATE, P3M_ECOMM = 0, -1, -2, -3, -4, -5, -6
 
@@ -83,6 +84,7 @@ class Params:
     lrckcorr: bool = False
     move_grid_back: bool = False
     coarse_ngp: bool = False   # -DCOARSE_NGP: whole-weight coarse deposit and gather on cell i2 (coarse_cic_mass.f90:21-24)
+    coarse_only: bool = False   # groups: every rank holds its coarse mesh only (stand-alone distributed coarse transform)
     pencil: bool = False   # coarse FFT in 2-D pencils (p3dfft_coarse.f90) instead of slabs (fftw3ds.f90); multi-rank groups only
     rsoft: float = 0.1
     pp_bias: float = 1.0
@@ -138,6 +140,7 @@ class Params:
             | (FLAG_MOVE_GRID_BACK if self.move_grid_back else 0)
             | (FLAG_PENCIL if self.pencil else 0)
             | (FLAG_COARSE_NGP if self.coarse_ngp else 0)
+            | (FLAG_COARSE_ONLY if self.coarse_only else 0)
         )
 
     def validate(self):

@@ -185,7 +185,7 @@ class ParticleMesh:
         _lib.check(self.L.p3m_hip_time_pp(self.h, a_mid, dt, mass_p, reps, C.byref(a), C.byref(b), C.byref(na), C.byref(nb)))
         return a.value, b.value, na.value, nb.value
 
-    FFT_PASSES = ("x_fwd", "y_fwd", "z_fwd", "z_inv_fused", "y_inv", "x_inv_extract")
+    FFT_PASSES = ("x_fwd", "y_fwd", "z_fwd", "z_inv_fused", "y_inv", "x_inv_extract", "z_inv_multiply")
 
     def time_fft_pass(self, which, reps=20):
         """Average ms per launch of one FFT pass kernel over the tile batch (HIP events on the library stream)."""

@@ -55,6 +55,11 @@ extern "C" {
                                          dim_y = nodes_dim, dim_z = nodes_dim^2 (cubepm.par:210-215).  Needs
                                          nc_node_dim % nodes_dim == 0 instead of nc_dim % nodes_dim^3 == 0; groups only */
 
+#define P3M_FLAG_COARSE_ONLY (1u << 7) /* groups only: every logical rank holds its coarse mesh and nothing else (no particle
+                                         store, no fine mesh): the stand-alone distributed coarse transform, e.g. a literal
+                                         1024^3 slab FFT (fftw3ds.f90:103-183 at nc_dim = 1024, cubepm.par:196-197).  Only
+                                         the p3m_hip_group_*coarse* entry points and the kernel tables work on such a group */
+
 /* ---- error codes -------------------------------------------------------------------- */
 #define P3M_OK            0
 #define P3M_EINVAL       -1  /* bad parameter / unsupported size                         */
@@ -202,8 +207,9 @@ int p3m_hip_time_fine_sweep(p3m_ctx *ctx, float mass_p, int32_t reps, float *ms_
 /* One pass kernel of the fine-mesh FFT over the whole tile batch, launched `reps` times between
    HIP events on the library's stream; returns the average milliseconds per launch.
    which: 0 x-forward (r2c rows), 1 y-forward lines, 2 z-forward lines, 3 z-inverse lines fused with
-   the i*K multiply, 4 y-inverse lines, 5 x-inverse (c2r rows) + force-box extraction.  *batch returns
-   the number of tiles one launch processed. */
+   the i*K multiply, 4 y-inverse lines, 5 x-inverse (c2r rows) + force-box extraction, 6 the multiply +
+   inverse z pass on its own (the second launch of the un-fused z pair that tiles longer than 608 cells and
+   P3M_Z_UNFUSED=1 run instead of 3: 2 then 6).  *batch returns the number of tiles one launch processed. */
 int p3m_hip_time_fft_pass(p3m_ctx *ctx, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch);
 /* Benchmark hook for the two PP kernels (particle_mesh_threaded.f90:324-361 and :378-624) on the sorted records with ghosts
    (call p3m_hip_link_list_and_pass first; velocities are kicked `reps`+1 times): average ms per launch and the number of
@@ -292,6 +298,22 @@ int p3m_hip_group_update_position(p3m_group *g, float dt, float dt_old, const fl
 int p3m_hip_group_particle_mesh(p3m_group *g, float a_mid, float dt, float dt_old, float mass_p,
                                 const float *offset, const float *move_back, p3m_step_out *out);
 int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho_c, float *force_c);
+/* The distributed coarse transform on its own (coarse_force.f90:18-90 through fftw3ds.f90:4-183 / p3dfft_coarse.f90), on any
+ * group and in particular on a P3M_FLAG_COARSE_ONLY one (the literal 1024^3 slab FFT of BASELINE config 4):
+ *   set_coarse_density  rho_c of local rank i from the host, float[ncn][ncn][ncn] (what coarse_mass leaves in rho_c)
+ *   coarse_transform    what = 0: the forward transform (cube -> x-lines, x and y passes, all-to-all, z pass: rho-hat of the
+ *                       own ky slab); what = 1: coarse_force -- forward transform, i K_c multiply, three inverse transforms,
+ *                       slab -> cube, force halo (coarse_force_buffer.f90), maximum.  Runs once untimed, then `reps` times
+ *                       between HIP events on the group's stream: *ms = average milliseconds per run (reps = 0: once, no timing)
+ *   get_coarse_hat      rho-hat of local rank i as the device holds it: float2[s][ncl][nc][16] = (local ky, kx chunk, kz, kx
+ *                       within the chunk); slabs: ky = rank*nc_slab + local ky, ncl = all chunks of (nc/2+1 rounded up to 16)/16
+ *   get_coarse_force    force_c(3, 0:ncn+1, 0:ncn+1, 0:ncn+1) of local rank i, component fastest (as p3m_hip_group_probe_coarse)
+ *   coarse_exchange_bytes  bytes one rank sends to ONE peer in the y<->z transpose of one transform (SURVEY 8d "per-link bytes") */
+int p3m_hip_group_set_coarse_density(p3m_group *g, int32_t i, const float *rho_c);
+int p3m_hip_group_coarse_transform(p3m_group *g, int32_t what, int32_t reps, float *ms);
+int p3m_hip_group_get_coarse_hat(p3m_group *g, int32_t i, float *hat, int64_t nfloats);
+int p3m_hip_group_get_coarse_force(p3m_group *g, int32_t i, float *force_c);
+int64_t p3m_hip_group_coarse_exchange_bytes(const p3m_group *g);
 /* projection.f90 for every logical rank of this process: ghost pass, sort, CIC projection, ghost removal (the sequence of
  * cubepm.f90:193-228); the maps receive the sum over THIS process's ranks, rho_tot the sum over all ranks (:34-35); a host
  * running several processes adds the maps up (the reference's mpi_reduce, :41-54). */

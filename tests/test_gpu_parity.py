@@ -32,7 +32,7 @@ def both(PM, p):
 
 
 # ---------------------------------------------------------------------------------- FFT
-@pytest.mark.parametrize("n", [8, 16, 20, 28, 40, 44, 52, 64, 68, 76, 80, 96, 112, 128, 160, 176, 192, 208, 224, 256, 304, 320, 512])
+@pytest.mark.parametrize("n", [8, 16, 20, 28, 40, 44, 52, 64, 68, 76, 80, 96, 112, 128, 160, 176, 192, 208, 224, 256, 304, 320, 512, 640, 704])
 def test_fft_forward_and_inverse_vs_oracle(PM, n):
     g = PM(cfg1(), set_kernels=False)
     rng = np.random.default_rng(n)
@@ -538,7 +538,7 @@ def test_bench_sized_tile_force_and_fft_vs_oracle(PM):
     assert np.abs(back[:, :, :n] - rho[:, :, :n]).max() < 1e-4 and np.all(back[:, :, n:] == 0)
 
 
-@pytest.mark.parametrize("n", [64, 80, 96, 112, 128, 160, 176, 192, 208, 224, 256, 304, 320, 352, 384, 448, 608])   # (512: its coarse mesh, 116 = 4 * 29, has no radix)
+@pytest.mark.parametrize("n", [64, 80, 96, 112, 128, 160, 176, 192, 208, 224, 256, 304, 320, 352, 384, 448, 608, 768, 832])   # (512: its coarse mesh, 116 = 4 * 29, has no radix; likewise 640, 704, 896, 1024)
 def test_tile_force_at_the_register_fft_sizes(PM, n):
     """Every tile size with two-register-stage FFT kernels (fft.hip, P3M_LINES2_SIZES / P3M_X2_SIZES) through the whole fine
     force: forward x and y passes, fused z pass, pruned inverse y and x passes, force box -- against the oracle."""
@@ -557,10 +557,39 @@ def test_tile_force_at_the_register_fft_sizes(PM, n):
     assert mg == pytest.approx(mo, rel=1e-5)
 
 
-@pytest.mark.parametrize("switch", ["P3M_FFT_STOCKHAM", "P3M_SEPARATE_COARSE_KICK"])
+@pytest.mark.parametrize("n", [768, 832, 896, 1024])
+def test_long_lines_forward_transform_vs_numpy(PM, n):
+    """Line lengths beyond 608 (register-stage kernels only: 640 ... 1024 = 32 x 32, the literal 1024^3 coarse mesh of BASELINE
+    config 4, fftw3ds.f90:103-183) on a sparse random field: the forward transform against numpy's float64 rfftn on a sub-block
+    of the spectrum (all ky, kz for the first 24 kx), and the round trip."""
+    g = PM(cfg1(), set_kernels=False)
+    rng = np.random.default_rng(n)
+    a = np.zeros((n, n, n + 2), np.float32)
+    a[:, :, :n] = (rng.random((n, n, n), dtype=np.float32) < 0.05).astype(np.float32) * 8.0
+    hat = g.fft3d(a, n, +1)
+    kx = 24
+    sub = np.empty((n, n, kx), np.complex128)
+    for z0 in range(0, n, 64):                                   # the x transform in slabs: the float64 copy of the whole field is 8.6 GB at 1024
+        sub[z0:z0 + 64] = np.fft.rfft(a[z0:z0 + 64, :, :n].astype(np.float64), axis=2)[:, :, :kx]
+    sub = np.fft.fftn(sub, axes=(0, 1))
+    got = hat[:, :, 0:2 * kx:2] + 1j * hat[:, :, 1:2 * kx:2]
+    assert np.abs(got - sub).max() / np.abs(sub).max() < 2e-6
+    top = hat[:, :, n - 8:n + 2]                                 # the last columns up to the Nyquist one
+    ref = np.empty((n, n, 5), np.complex128)
+    for z0 in range(0, n, 64):
+        ref[z0:z0 + 64] = np.fft.rfft(a[z0:z0 + 64, :, :n].astype(np.float64), axis=2)[:, :, n // 2 - 4:]
+    ref = np.fft.fftn(ref, axes=(0, 1))
+    assert np.abs((top[:, :, 0::2] + 1j * top[:, :, 1::2]) - ref).max() / np.abs(ref).max() < 2e-6
+    del sub, ref, got
+    back = g.fft3d(hat, n, -1)
+    assert np.abs(back[:, :, :n] - a[:, :, :n]).max() < 1e-4 and np.all(back[:, :, n:] == 0)
+
+
+@pytest.mark.parametrize("switch", ["P3M_FFT_STOCKHAM", "P3M_SEPARATE_COARSE_KICK", "P3M_Z_UNFUSED"])
 def test_fallback_paths_stay_at_parity(switch):
-    """The run-time switches select the LDS Stockham FFT kernels for every size, and the coarse kick in its own pass: both
-    are the paths other tile sizes / PP runs take, so they are held to the same parity tests (in a child process: the
+    """The run-time switches select the LDS Stockham FFT kernels for every size, the coarse kick in its own pass, and the
+    un-fused z pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run: all
+    are paths other tile sizes / PP runs take, so they are held to the same parity tests (in a child process: the
     switches are read once per process)."""
     import os
     import subprocess
