@@ -58,6 +58,11 @@ CONFIGS = {
     "cfg4_pp": dict(params=dict(nodes_dim=2, tiles_node_dim=1, nf_tile=560, ngp=True, ppint=True, pp_ext=True, density_buffer=1.3), nside_rank=256,
                     workload="1024^3 fine mesh / 512^3 particles, PM+PP+PP_EXT (NGP), 2x2x2 logical ranks, nf_tile=560 (one tile per rank), "
                              "256^3 coarse mesh with slab FFT + all-to-all transpose"),
+    # configs[3] with the CIC mass assignment / interpolation on the fine mesh (fine_cic_mass.f90:13-43, particle_mesh_threaded.f90:289-316):
+    # the reference built without -DNGP
+    "cfg4_cic": dict(params=dict(nodes_dim=2, tiles_node_dim=1, nf_tile=560, ngp=False, density_buffer=1.3), nside_rank=256,
+                     workload="1024^3 fine mesh / 512^3 particles, PM-only (CIC fine mesh), 2x2x2 logical ranks, nf_tile=560 (one tile per rank), "
+                              "256^3 coarse mesh with slab FFT + all-to-all transpose"),
     # configs[3]'s problem as ONE rank of 2^3 tiles (what a single-GPU user of the reference would build: nodes_dim = 1)
     "cfg4_1rank": dict(params=dict(nodes_dim=1, tiles_node_dim=2, nf_tile=560, ngp=True, density_buffer=1.3), nside_rank=512,
                        workload="1024^3 fine mesh / 512^3 particles, PM-only (NGP), one rank of 2^3 tiles of nf_tile=560, 256^3 coarse mesh"),
@@ -172,16 +177,138 @@ def cpu_baseline(scal):
                       % (steps, p.nf_tile, p.tiles_node_dim, ntile, threads, cores, el)}
 
 
+def open_group(p, torch, dist, rank, world, ddev, uid, require_rccl, dist_backend):
+    """The group of logical ranks this process drives, connected by RCCL when there is more than one process.  If the RCCL
+    communicator cannot be set up (agreed on by all ranks) the run exits non-zero -- unless --allow-host-transport was
+    given: then the same exchanges go through the host-callback transport over a gloo group and the line is marked."""
+    from cubep3m_amd.group import ParticleMeshGroup
+
+    if world == 1:
+        return ParticleMeshGroup(p, rank, world, set_kernels=False), "none"
+    from cubep3m_amd.group import torch_transport
+    from cubep3m_amd.lib import P3MError
+
+    ok, grp = 1, None
+    try:
+        grp = ParticleMeshGroup(p, rank, world, unique_id=uid, set_kernels=False)
+    except P3MError as e:
+        ok = 0
+        print("rank %d: RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
+    flag = torch.tensor([ok], device=ddev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return grp, "rccl"
+    if require_rccl:
+        raise SystemExit("RCCL transport unavailable (a multi-GPU line needs it; --allow-host-transport falls back to gloo)")
+    if grp is not None:
+        grp.close()
+    gloo = dist.new_group(backend="gloo") if dist_backend == "nccl" else None
+    return ParticleMeshGroup(p, rank, world, set_kernels=False, transport=torch_transport(dist, gloo)), "host callbacks over gloo (RCCL unavailable)"
+
+
+def comm_audit(grp, dist, rank, world):
+    """Per-rank record of the device and the RCCL communicator this process really uses (printed to stderr by every rank,
+    gathered into the JSON line by rank 0): device UUID, ncclCommCount, ncclCommUserRank."""
+    info = dict(grp.comm_info(), rank=rank, logical_ranks=list(grp.local_ranks))
+    print("bench rank %d: device %d uuid %s ncclCommCount %d ncclCommUserRank %d logical ranks %s"
+          % (rank, info["device"], info["uuid"], info["comm_count"], info["comm_rank"], info["logical_ranks"]), file=sys.stderr, flush=True)
+    if world == 1:
+        return [info]
+    allinfo = [None] * world
+    dist.all_gather_object(allinfo, info)
+    return allinfo
+
+
+def slab_leg(args, torch, dist, rank, world, local_dev, ddev, require_rccl):
+    """--config slab1024: BASELINE configs[3] read literally (SURVEY section 8, config note (ii)) -- a 1024^3 real coarse field,
+    slab-decomposed over the eight logical ranks of the 2x2x2 decomposition (nc_slab = 128, fftw3ds.f90:103-183), one forward
+    and three inverse transforms per step (coarse_force.f90:18-90).  A "step" is one coarse_force on device-resident density:
+    cube -> slab redistribution, forward x / y passes, all-to-all transpose, z pass, multiply, three inverse transforms with
+    their transposes, slab -> cube, force halo."""
+    from cubep3m_amd.group import rccl_unique_id
+
+    p = Params(nodes_dim=2, tiles_node_dim=4, nf_tile=560, coarse_only=True, cores=1, lrckcorr=True, device=local_dev)
+    assert p.nc_dim == 1024 and p.nc_slab == 128
+    uid = None
+    if world > 1:
+        t = torch.zeros(128, dtype=torch.uint8, device=ddev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        uid = bytes(t.cpu().numpy().tobytes())
+    grp, transport = open_group(p, torch, dist, rank, world, ddev, uid, require_rccl, args.dist_backend)
+    _, coarse = default_tables()
+    grp.set_kernel_tables(None, coarse)
+    audit = comm_audit(grp, dist, rank, world)
+    n = p.nc_node_dim
+    for i, r in enumerate(grp.local_ranks):     # a sparse random density (1/8 particle per fine cell = 8 per coarse cell on average)
+        rng = np.random.default_rng(4000 + r)
+        grp.set_coarse_density(i, rng.poisson(8.0, (n, n, n)).astype(np.float32) * 8.0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        grp.coarse_transform("force")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        grp.coarse_transform("force")           # ends with a stream synchronisation
+    sync()
+    el = time.perf_counter() - t0
+    ms_fwd = grp.coarse_transform("forward", reps=5)
+    ms_force = grp.coarse_transform("force", reps=5)
+    if dist is not None:
+        tt = torch.tensor([el, ms_fwd, ms_force], dtype=torch.float64, device=ddev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el, ms_fwd, ms_force = (float(v) for v in tt.tolist())
+    if rank == 0:
+        nc = p.nc_dim
+        ms_step = 1e3 * el / args.steps
+        slab_bytes = 4.0 * (nc + 2) * nc * p.nc_slab                  # one rank's slab, SURVEY 8a row a15
+        alg = 10.5 * slab_bytes * p.nodes                             # SURVEY 8d "coarse FFT 10.5 x 4(nc+2) nc nc_slab" per rank
+        per_peer = grp.coarse_exchange_bytes
+        res = {"metric": "coarse_slab_fft_transforms_per_sec", "value": 4.0 * args.steps / el, "unit": "1024^3 transforms/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "transport_fallback": transport.startswith("host callbacks"),
+               "config": {"workload": "literal 1024^3 real coarse field, slab-decomposed over 2x2x2 = 8 logical ranks (nc_slab = 128): one forward + "
+                                      "three inverse transforms with the K_c multiply, cube<->slab redistribution and force halo (coarse_force.f90)",
+                          "name": "slab1024", "logical_ranks": p.nodes, "ranks_per_gpu": p.nodes // world, "transport": transport},
+               "ms_per_transform": ms_step / 4.0,
+               "events": {"forward_ms": ms_fwd, "coarse_force_ms": ms_force, "three_inverse_ms": ms_force - ms_fwd},
+               "roofline": {"bound": "hbm" if world == 1 else "xgmi", "kernel": "coarse_force (1 forward + 3 inverse 1024^3 transforms, all passes and exchanges)",
+                            "achieved": alg / (ms_force * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                            "frac": alg / (ms_force * 1e-3) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes": alg},
+               "all_to_all": {"bytes_per_peer_per_transpose": per_peer, "peers": p.nodes - 1, "transposes_per_step": 4,
+                              "bytes_per_rank_per_step": 4 * per_peer * (p.nodes - 1),
+                              "note": "each rank sends nc_slab x (nc/2+1 padded to 16) x nc_slab complex to every other rank per transform "
+                                      "(SURVEY 8d: 67 MB per link at G = 8); between ranks of one GPU these are device copies"},
+               "ranks": audit}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+    grp.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS) + ["slab1024"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the non-headline legs of the default run (PM+PP step at the headline's size, PP kernel rates)")
-    ap.add_argument("--require-rccl", action="store_true",
-                    help="multi-GPU runs: exit non-zero instead of falling back to the host-callback transport when RCCL cannot be set up")
+    ap.add_argument("--require-rccl", action="store_true", help="(default for --gpus > 1; kept for old command lines)")
+    ap.add_argument("--allow-host-transport", action="store_true",
+                    help="multi-GPU runs: fall back to the host-callback transport over gloo when RCCL cannot be set up, instead of "
+                         "exiting non-zero (such a line says nothing about xGMI and is marked transport_fallback)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the host side (gloo: debugging on fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -208,6 +335,19 @@ def main():
 
     from cubep3m_amd.group import ParticleMeshGroup, rccl_unique_id
 
+    require_rccl = world > 1 and not args.allow_host_transport and args.dist_backend == "nccl"
+    if world > 1:
+        # a multi-GPU line must come from `world` DIFFERENT devices: gather every rank's device UUID
+        props = torch.cuda.get_device_properties(local_dev)
+        my = "%s/%d" % (getattr(props, "uuid", None) or "dev", local_dev)
+        ids = [None] * world
+        dist.all_gather_object(ids, my)
+        if len(set(ids)) < world and args.dist_backend != "gloo":
+            raise SystemExit("bench.py --gpus %d sees only %d distinct device(s) %s: one process per GPU is required "
+                             "(--dist-backend gloo runs several ranks on one device for debugging)" % (world, len(set(ids)), sorted(set(ids))))
+    if args.config == "slab1024":
+        return slab_leg(args, torch, dist, rank, world, local_dev, ddev, require_rccl)
+
     cfg = CONFIGS[args.config]
     p = Params(**cfg["params"])
     p.device = local_dev
@@ -222,32 +362,9 @@ def main():
         uid = bytes(t.cpu().numpy().tobytes())
 
     fine, coarse = default_tables()
-    transport = "rccl" if world > 1 else "none"
-    if world > 1:
-        # RCCL inside the library; if its communicator cannot be set up on this node (agreed on by all ranks), the same
-        # exchanges go through the host-callback transport over a gloo group instead of failing the run
-        from cubep3m_amd.group import torch_transport
-        from cubep3m_amd.lib import P3MError
-
-        ok, grp = 1, None
-        try:
-            grp = ParticleMeshGroup(p, rank, world, unique_id=uid, set_kernels=False)
-        except P3MError as e:
-            ok = 0
-            print("rank %d: RCCL transport unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], device=ddev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if args.require_rccl:
-                raise SystemExit("RCCL transport unavailable and --require-rccl given")
-            if grp is not None:
-                grp.close()
-            gloo = dist.new_group(backend="gloo") if args.dist_backend == "nccl" else None
-            grp = ParticleMeshGroup(p, rank, world, set_kernels=False, transport=torch_transport(dist, gloo))
-            transport = "host callbacks over gloo (RCCL unavailable)"
-        grp.set_kernel_tables(fine, coarse)
-    else:
-        grp = ParticleMeshGroup(p, rank, world, fine, coarse)
+    grp, transport = open_group(p, torch, dist, rank, world, ddev, uid, require_rccl, args.dist_backend)
+    grp.set_kernel_tables(fine, coarse)
+    audit = comm_audit(grp, dist, rank, world)
     box = float(p.nf_physical_node_dim)
     nside = cfg["nside_rank"]
     mass_p = float((p.nf_physical_node_dim / nside) ** 3)  # fine cells per particle = 8
@@ -350,6 +467,7 @@ def main():
                        "ranks_per_gpu": p.nodes // world, "tiles_per_rank": ntile, "nf_tile": p.nf_tile, "transport": transport,
                        "flags": {"ngp": p.ngp, "ppint": p.ppint, "pp_ext": p.pp_ext}},
             "roofline": roofline,
+            "ranks": audit,
         }
         if world == 1 and args.config == "cfg4" and not args.no_extra:
             # non-headline legs (rank 0, one GPU): the same 512^3-particle problem with PPINT + PP_EXT on, and the two
@@ -390,6 +508,7 @@ def main():
                 xv[:, 3:] = np.random.default_rng(99 + r).normal(0, 0.05, (len(xv), 3)).astype(np.float32)
                 return xv
 
+            res["cic"] = side_leg("cfg4_cic", uniform_ic, "synthetic uniform (the headline's particles)")
             res["pm_pp"] = side_leg("cfg4_pp", uniform_ic, "synthetic uniform (the headline's particles)")
             # the same two step types on a clustered particle set: dense cells, unequal rows, heavy pair lists
             cdata = "synthetic clustered: 30 % of the particles in Gaussian blobs of ~205 particles, sigma 0.6 cells (SURVEY Appendix C's recipe at its density)"

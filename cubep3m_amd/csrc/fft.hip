@@ -477,8 +477,14 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
 struct LinesArgs {
   float2 *dst; const float2 *src; const float *kern;
   int64_t kern_comp_stride, dst_comp_stride;
+  int64_t kern_batch_stride;   // floats between the kernel tables of consecutive batch entries: 0 where all tiles share kern_f, one slab where every logical rank of a distributed transform has its own ky range
   int n, nchunk, olo, ocount, slo, scount, nbundles;
   int src_planes, dst_planes, dst_line;
+  // seg > 0 (register-stage kernels, !TR): the source line arrives in n/seg segments of `seg` elements, one from each peer of an
+  // all-to-all -- element idx of bundle (o, chunk) of batch entry b sits at
+  //   b*src_planes*nchunk*n*16 + (idx/seg)*(src_planes*nchunk*seg*16) + ((o*nchunk + chunk)*seg + idx%seg)*16
+  // (the receive buffer [peer][plane][chunk][seg][16] as it is): the pass reads it in place of a separate permutation kernel
+  int seg; unsigned seg_magic;
 };
 // Each workgroup walks a grid-stride list of work items and is software-pipelined: the next
 // item's global loads are issued into registers (LUX 16-byte loads per lane) before the butterflies
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(TB) void k_fft_lines(LinesArgs a, Factors fac, cons
 #pragma unroll
     for (int u = 0; u < LUX; u++) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); if ((int)threadIdx.x + u * T < ne) v[u] = src4[(int)threadIdx.x + u * T]; }
     if (NC != 0) {
-      const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk));
+      const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + b * a.kern_batch_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk));
 #pragma unroll
       for (int u = 0; u < LUX; u++) { K[u] = make_float2(0.f, 0.f); if ((int)threadIdx.x + u * T < ne) K[u] = k2[(int)threadIdx.x + u * T]; }
     }
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(TB) void k_fft_lines3(LinesArgs a, Factors fac, con
   };
   auto fetch_k = [&](int bid, int comp) {
     int o, chunk; int64_t b; locate(bid, o, chunk, b);
-    const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk));
+    const float2 *k2 = reinterpret_cast<const float2 *>(a.kern + comp * a.kern_comp_stride + b * a.kern_batch_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk));
 #pragma unroll
     for (int u = 0; u < LUX; u++) { K[u] = make_float2(0.f, 0.f); if ((int)threadIdx.x + u * T < ne) K[u] = k2[(int)threadIdx.x + u * T]; }
   };
@@ -679,11 +685,22 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_pe
     for (int m = 0; m < R1; m++) v[m] = (c32){0.f, 0.f};
     if (!on) return;
     int o, chunk; int64_t b; locate(w, o, chunk, b);
+    if (!TR && a.seg > 0) {   // segmented source (see LinesArgs): 32-bit offsets inside one batch entry
+      const c32 *base = reinterpret_cast<const c32 *>(a.src) + b * ((int64_t)a.src_planes * a.nchunk * n * BXC) + (unsigned)((o - a.olo) * a.nchunk + chunk) * (unsigned)a.seg * BXC + col;
+      const unsigned sst = (unsigned)a.src_planes * a.nchunk * a.seg * BXC;
+      fdiv_t ds; ds.m = a.seg_magic; ds.d = a.seg;
+#pragma unroll
+      for (int m = 0; m < R1; m++) {
+        const int idx = R2 * m + g, t = fdiv(idx, ds);
+        v[m] = __builtin_nontemporal_load(base + ((unsigned)t * sst + (unsigned)(idx - t * a.seg) * BXC));
+      }
+      return;
+    }
     const c32 *src = reinterpret_cast<const c32 *>(a.src + bundle_off2(b, a.src_planes, n, a.nchunk, o, chunk)) + g * BXC + col;
 #pragma unroll
     for (int m = 0; m < R1; m++) v[m] = TR ? src[m * (R2 * BXC)] : __builtin_nontemporal_load(src + m * (R2 * BXC));   // in place, read once and written once: past the caches
     if (NC != 0) {
-      const float *k = a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk) + g * BXC + col;
+      const float *k = a.kern + comp * a.kern_comp_stride + b * a.kern_batch_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk) + g * BXC + col;
       float K[R1];
 #pragma unroll
       for (int m = 0; m < R1; m++) K[m] = k[m * (R2 * BXC)];
@@ -773,7 +790,7 @@ __global__ __launch_bounds__((L3Cfg<R1, R2>::TB)) void k_fft_lines3r(LinesArgs a
     for (int m = 0; m < R2; m++) K[m] = 0.f;
     if (!on) return;
     int o, chunk; int64_t b; locate(w, o, chunk, b);
-    const float *k = a.kern + comp * a.kern_comp_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk) + g * BXC + col;
+    const float *k = a.kern + comp * a.kern_comp_stride + b * a.kern_batch_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk) + g * BXC + col;
 #pragma unroll
     for (int m = 0; m < R2; m++) K[m] = k[m * (R1 * BXC)];
   };
@@ -1268,25 +1285,30 @@ int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float
 // ------------------------------------------------------------------ entry points for the distributed (slab) transforms, group.hip
 // planes: bundle planes held locally (nc_slab); the transposing passes write the all-to-all send layout
 // [line element][chunk][plane][16] directly.
-int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes) {
+// batch: logical ranks laid out one after the other (src and dst batch strides are one rank's slab)
+int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes, int batch) {
   LinesArgs a = full_args(pl, send, ly);
   a.ocount = planes; a.src_planes = planes; a.dst_planes = pl.n; a.dst_line = planes;
-  return launch_lines<false, true, 0>(c, pl, a, 1);
+  return launch_lines<false, true, 0>(c, pl, a, batch);
 }
-int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, float *lz, int planes) {
-  LinesArgs a = full_args(pl, lz, lz);
+// seg > 0: src is the all-to-all receive buffer, n/seg segments per line (LinesArgs::seg); register-stage kernels only (fft_has_segmented)
+bool fft_has_segmented(const FftPlan &pl) { return lines2_has(pl.n); }
+int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, const float *src, float *lz, int planes, int seg, int batch) {
+  LinesArgs a = full_args(pl, lz, src);
   a.ocount = planes; a.src_planes = planes;
-  return launch_lines<false, false, 0>(c, pl, a, 1);
+  if (seg > 0) { if (!lines2_has(pl.n) || pl.n % seg) return P3M_EINVAL; a.seg = seg; a.seg_magic = fdiv_magic(seg); }
+  return launch_lines<false, false, 0>(c, pl, a, batch);
 }
 int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3, const float *kern3, int planes, int64_t kern_comp_stride,
-                    int64_t send_comp_stride) {
+                    int64_t send_comp_stride, int batch, int64_t kern_batch_stride) {
   LinesArgs a = full_args(pl, send3, lz);
   a.ocount = planes; a.src_planes = planes; a.dst_planes = pl.n; a.dst_line = planes;
-  a.kern = kern3; a.kern_comp_stride = kern_comp_stride; a.dst_comp_stride = send_comp_stride;
-  return launch_lines3(c, pl, a, 1);
+  a.kern = kern3; a.kern_comp_stride = kern_comp_stride; a.dst_comp_stride = send_comp_stride; a.kern_batch_stride = kern_batch_stride;
+  return launch_lines3(c, pl, a, batch);
 }
-int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, float *ly3, int planes, int batch) {
-  LinesArgs a = full_args(pl, ly3, ly3);
+int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, const float *src, float *ly3, int planes, int batch, int seg) {
+  LinesArgs a = full_args(pl, ly3, src);
   a.ocount = planes; a.src_planes = planes;
+  if (seg > 0) { if (!lines2_has(pl.n) || pl.n % seg) return P3M_EINVAL; a.seg = seg; a.seg_magic = fdiv_magic(seg); }
   return launch_lines<true, false, 0>(c, pl, a, batch);
 }

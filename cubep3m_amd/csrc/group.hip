@@ -19,14 +19,16 @@
 #include <cmath>
 #include <cstring>
 #include <rccl/rccl.h>
+#include "fft_core.h"
 
 int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp = 0);
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp = 0);
-int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes);
-int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, float *lz, int planes);
+int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes, int batch = 1);
+int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, const float *src, float *lz, int planes, int seg, int batch = 1);
+bool fft_has_segmented(const FftPlan &pl);
 int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3, const float *kern3, int planes, int64_t kern_comp_stride,
-                    int64_t send_comp_stride);
-int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, float *ly3, int planes, int batch);
+                    int64_t send_comp_stride, int batch = 1, int64_t kern_batch_stride = 0);
+int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, const float *src, float *ly3, int planes, int batch, int seg);
 
 #define NCCL_TRY(expr)                                                                             \
   do {                                                                                             \
@@ -34,6 +36,7 @@ int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, float *ly3, int planes, int ba
     if (_r != ncclSuccess) { p3m_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); return P3M_ECOMM; } \
   } while (0)
 
+#define P3M_MAX_LOCAL 64        // local ranks one batched launch can address (per-rank pointers in kernel arguments)
 struct CoarseDist {            // per local logical rank; slabs: nxb = nd^2, rpp = nc, ncl = nchunk; pencils: nxb = nd, rpp = ncn, ncl = nchunk/nd
   float *blocks_in = nullptr;  // [nxb][s][ncn][ncn]       cube -> slab / pencil arrivals
   float *rows = nullptr;       // [3][s][rpp][2*px]        real rows of the local planes
@@ -59,6 +62,13 @@ struct p3m_group {
   hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;
   std::vector<p3m_ctx *> ctx; std::vector<int> lrank, owner, lidx;
   std::vector<CoarseDist> cd;
+  // The coarse arrays of all local ranks are slices of group-wide allocations.  `batched` (slabs whose line length has
+  // register-stage FFT kernels): laid out [component][local rank][...], so that every stage of the distributed transform is ONE
+  // launch over all local ranks (the rank is the batch index of the FFT kernels) instead of one per rank; otherwise (pencils,
+  // Stockham sizes) [local rank][component][...] and the per-rank loops.  cstride: floats between two components of one rank.
+  bool batched = false; size_t cstride = 0, rstride = 0;   // rstride: the same for the real rows
+  float *a_blocks_in = nullptr, *a_rows = nullptr, *a_ly = nullptr, *a_send = nullptr, *a_recv = nullptr, *a_lz = nullptr, *a_kern = nullptr,
+        *a_blocks_out = nullptr, *a_blocks_back = nullptr, *a_rho_c = nullptr, *a_force_c = nullptr, *a_halo = nullptr;
   ncclComm_t comm = nullptr; bool force_nccl = false;
   p3m_transport tr{}; bool have_tr = false;
   char *h_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};   // pinned send / receive staging of the host transport
@@ -192,13 +202,16 @@ extern "C" void p3m_hip_group_destroy(p3m_group *G) {
   if (!G) return;
   (void)hipSetDevice(G->device);
   if (G->stream) (void)hipStreamSynchronize(G->stream);
-  for (CoarseDist &d : G->cd) {
-    gfree(d.blocks_in); gfree(d.rows); gfree(d.ly); gfree(d.send); gfree(d.recv); gfree(d.lz); gfree(d.kern);
-    gfree(d.blocks_out); gfree(d.blocks_back);
-    for (int i = 0; i < 2; i++) { gfree(d.halo_s[i]); gfree(d.halo_r[i]); }
-    gfree(d.sb); gfree(d.rb); gfree(d.d_cnt);
+  for (CoarseDist &d : G->cd) { gfree(d.sb); gfree(d.rb); gfree(d.d_cnt); }
+  gfree(G->a_blocks_in); gfree(G->a_rows); gfree(G->a_ly); gfree(G->a_send); gfree(G->a_recv); gfree(G->a_lz); gfree(G->a_kern);
+  gfree(G->a_blocks_out); gfree(G->a_blocks_back); gfree(G->a_halo);
+  for (p3m_ctx *c : G->ctx) {
+    if (!c) continue;
+    if (G->a_rho_c) c->rho_c = nullptr;       // slices of the group's arrays
+    if (G->a_force_c) c->force_c = nullptr;
+    c->stream = nullptr; p3m_hip_destroy(c);
   }
-  for (p3m_ctx *c : G->ctx) { if (c) { c->stream = nullptr; p3m_hip_destroy(c); } }
+  gfree(G->a_rho_c); gfree(G->a_force_c);
   if (G->comm) (void)ncclCommDestroy(G->comm);
   gfree(G->d_red4); gfree(G->d_sum3);
   if (G->h_cnt) (void)hipHostFree(G->h_cnt);
@@ -288,20 +301,33 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     const size_t NB = (size_t)G->s * G->ncl * g.nc * 16 * 2;             // floats of one component's complex slab / pencil
     const size_t nrows = (size_t)3 * G->s * G->rpp * 2 * G->plan_c.px;
     const size_t blk = (size_t)G->s * g.ncn * g.ncn;
-    G->cd.resize(G->ctx.size());
-    for (CoarseDist &d : G->cd) {
+    const size_t nl = G->ctx.size();
+    G->cd.resize(nl);
+    G->batched = !G->pencil && fft_has_segmented(G->plan_c) && g.ncn % 4 == 0 && nl <= P3M_MAX_LOCAL && (uint64_t)3 * nl * G->s * G->rpp * G->rpp < 0xffffffffull &&
+                 !(getenv("P3M_COARSE_PER_RANK") && getenv("P3M_COARSE_PER_RANK")[0] == '1');   // the switch: A/B runs and tests of the per-rank path
+    const size_t face = (size_t)3 * (g.ncn + 2) * (g.ncn + 2), fcs = (size_t)(g.ncn + 2) * (g.ncn + 2) * (g.ncn + 2), n3 = (size_t)g.ncn * g.ncn * g.ncn;
 #define A(x) do { int _r = (x); if (_r) return fail(_r); } while (0)
-      A(galloc(&d.blocks_in, (size_t)G->nxb * blk)); A(galloc(&d.rows, nrows));
-      A(galloc(&d.ly, 3 * NB)); A(galloc(&d.send, 3 * NB)); A(galloc(&d.recv, 3 * NB)); A(galloc(&d.lz, NB)); A(galloc(&d.kern, 3 * NB / 2));
-      A(galloc(&d.blocks_out, (size_t)G->nxb * 3 * blk)); A(galloc(&d.blocks_back, (size_t)G->nxb * 3 * blk));
-      for (int i = 0; i < 2; i++) {
-        A(galloc(&d.halo_s[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2))); A(galloc(&d.halo_r[i], (size_t)3 * (g.ncn + 2) * (g.ncn + 2)));
-      }
+    A(galloc(&G->a_blocks_in, nl * G->nxb * blk)); A(galloc(&G->a_rows, nl * nrows));
+    A(galloc(&G->a_ly, nl * 3 * NB)); A(galloc(&G->a_send, nl * 3 * NB)); A(galloc(&G->a_recv, nl * 3 * NB)); A(galloc(&G->a_lz, nl * NB)); A(galloc(&G->a_kern, nl * 3 * NB / 2));
+    A(galloc(&G->a_blocks_out, nl * G->nxb * 3 * blk)); A(galloc(&G->a_blocks_back, nl * G->nxb * 3 * blk));
+    A(galloc(&G->a_halo, nl * 4 * face)); A(galloc(&G->a_rho_c, nl * n3)); A(galloc(&G->a_force_c, nl * 3 * fcs));
+    if (hipMemset(G->a_rows, 0, sizeof(float) * nl * nrows) != hipSuccess) return fail(P3M_EDEVICE);
+    G->cstride = G->batched ? nl * NB : NB; G->rstride = G->batched ? nl * (nrows / 3) : nrows / 3;
+    for (size_t i = 0; i < nl; i++) {
+      CoarseDist &d = G->cd[i];
+      const size_t ro = G->batched ? i : 3 * i;   // first component of rank i, in slabs
+      d.blocks_in = G->a_blocks_in + i * G->nxb * blk; d.rows = G->a_rows + ro * (nrows / 3);
+      d.ly = G->a_ly + ro * NB; d.send = G->a_send + ro * NB; d.recv = G->a_recv + ro * NB; d.lz = G->a_lz + i * NB; d.kern = G->a_kern + ro * (NB / 2);
+      d.blocks_out = G->a_blocks_out + i * G->nxb * 3 * blk; d.blocks_back = G->a_blocks_back + i * G->nxb * 3 * blk;
+      for (int k = 0; k < 2; k++) { d.halo_s[k] = G->a_halo + (i * 4 + k) * face; d.halo_r[k] = G->a_halo + (i * 4 + 2 + k) * face; }
       A(galloc(&d.sb, (size_t)G->seg_total)); A(galloc(&d.rb, (size_t)G->seg_total));
       A(galloc(&d.d_cnt, 128));
-#undef A
-      if (hipMemset(d.rows, 0, sizeof(float) * nrows) != hipSuccess) return fail(P3M_EDEVICE);
+      // rho_c and force_c of the contexts become slices too (uniform strides for the batched launches)
+      p3m_ctx *c = G->ctx[i];
+      (void)hipFree(c->rho_c); (void)hipFree(c->force_c);
+      c->rho_c = G->a_rho_c + i * n3; c->force_c = G->a_force_c + i * 3 * fcs;
     }
+#undef A
   }
   if (galloc(&G->d_red4, 8) || galloc(&G->d_sum3, 4)) return fail(P3M_ENOMEM);
   if (hipHostMalloc(reinterpret_cast<void **>(&G->h_cnt), sizeof(int) * 128 * G->ctx.size()) != hipSuccess) return fail(P3M_ENOMEM);
@@ -327,6 +353,20 @@ extern "C" int p3m_hip_group_comm_init_rccl(p3m_group *G, const void *unique_id_
   ncclUniqueId id; memcpy(&id, unique_id_128, sizeof(id));
   NCCL_TRY(ncclCommInitRank(&G->comm, G->nprocs, id, G->proc));
   G->force_nccl = force_for_local_peers != 0;
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_comm_info(p3m_group *G, int32_t *comm_count, int32_t *comm_rank, int32_t *device, char *uuid_hex33) {
+  if (!G) return P3M_EINVAL;
+  int cnt = -1, rk = -1;
+  if (G->comm) { NCCL_TRY(ncclCommCount(G->comm, &cnt)); NCCL_TRY(ncclCommUserRank(G->comm, &rk)); }
+  if (comm_count) *comm_count = cnt;
+  if (comm_rank) *comm_rank = rk;
+  if (device) *device = G->device;
+  if (uuid_hex33) {
+    hipUUID u; memset(&u, 0, sizeof(u));
+    HIP_TRY(hipDeviceGetUuid(&u, G->device));
+    for (int i = 0; i < 16; i++) snprintf(uuid_hex33 + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+  }
   return P3M_OK;
 }
 extern "C" int p3m_hip_group_set_transport(p3m_group *G, const p3m_transport *t) {
@@ -569,6 +609,94 @@ __global__ __launch_bounds__(256) void k_lrck_slab(float *__restrict__ kern, con
   kern[idx] = kern[idx] * (wc / uncorr[idx]);
 }
 
+// ------------------------------------------------------------------ batched layout kernels (G->batched: slabs, ncn % 4 == 0)
+// One launch serves every local rank; a wavefront moves whole rows with 16-byte accesses and does the index arithmetic once per
+// row (the per-element kernels above spend a chain of 64-bit divisions on every float: 1.8 ms for a 1.6 GB array).
+struct RowGeom { int nl, s, nc, ncn, nd, rpp, rp; unsigned m_rpp, m_s, m_ncn; };
+// blocks_in [rank][(j*nd+i)][zl][yy][xx] -> rows [rank][zl][y][x] (component 0 of the rows array), pad columns zero
+__global__ __launch_bounds__(256) void k_blocks_to_rows_b(const float *__restrict__ blocks, float *__restrict__ rows, RowGeom q) {
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= (unsigned)q.nl * q.s * q.rpp) return;
+  fdiv_t d_rpp{q.m_rpp, q.rpp}, d_s{q.m_s, q.s}, d_ncn{q.m_ncn, q.ncn};
+  const unsigned plane = fdiv(row, d_rpp), y = row - plane * q.rpp, rank = fdiv(plane, d_s), zl = plane - rank * q.s;
+  const unsigned j = fdiv(y, d_ncn), yy = y - j * q.ncn;
+  const int64_t blk = (int64_t)q.s * q.ncn * q.ncn;
+  float4 *dst = reinterpret_cast<float4 *>(rows + (int64_t)row * q.rp);
+  for (int x4 = lane; x4 < q.rp / 4; x4 += 64) {
+    const int x = 4 * x4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < q.nc) {
+      const unsigned i = fdiv(x, d_ncn);
+      v = *reinterpret_cast<const float4 *>(blocks + ((int64_t)rank * q.nd * q.nd + (j * q.nd + i)) * blk + ((int64_t)zl * q.ncn + yy) * q.ncn + (x - i * q.ncn));
+    }
+    dst[x4] = v;
+  }
+}
+// rows [comp][rank][zl][y][x] -> blocks_out [rank][(j*nd+i)][comp][zl][yy][xx]; one wavefront per (comp, rank, zl, y) row
+__global__ __launch_bounds__(256) void k_rows_to_blocks_b(const float *__restrict__ rows, float *__restrict__ blocks, RowGeom q) {
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= 3u * q.nl * q.s * q.rpp) return;
+  fdiv_t d_rpp{q.m_rpp, q.rpp}, d_s{q.m_s, q.s}, d_ncn{q.m_ncn, q.ncn};
+  const unsigned plane = fdiv(row, d_rpp), y = row - plane * q.rpp, pr = fdiv(plane, d_s), zl = plane - pr * q.s;   // pr = comp*nl + rank
+  const unsigned comp = pr / (unsigned)q.nl, rank = pr - comp * q.nl;
+  const unsigned j = fdiv(y, d_ncn), yy = y - j * q.ncn;
+  const int64_t blk = (int64_t)q.s * q.ncn * q.ncn;
+  const float4 *src = reinterpret_cast<const float4 *>(rows + (int64_t)row * q.rp);
+  for (int x4 = lane; x4 < q.nc / 4; x4 += 64) {
+    const int x = 4 * x4; const unsigned i = fdiv(x, d_ncn);
+    *reinterpret_cast<float4 *>(blocks + (((int64_t)rank * q.nd * q.nd + (j * q.nd + i)) * 3 + comp) * blk + ((int64_t)zl * q.ncn + yy) * q.ncn + (x - i * q.ncn)) = src[x4];
+  }
+}
+// blocks_back [rank][qz][comp][zl][yy][xx] -> force_c [rank][comp][1+qz*s+zl][1+yy][1+xx], and max |F| over the interior
+// (coarse_max_dt.f90:24-31) on the way: one wavefront per (rank, qz, zl, yy) takes the three component rows
+struct RankPtrs { float *p[P3M_MAX_LOCAL]; };
+__global__ __launch_bounds__(256) void k_blocks_to_force_b(const float *__restrict__ blocks, float *__restrict__ fc, int nl, int nq, int s, int ncn, unsigned m_ncn,
+                                                           unsigned m_s, RankPtrs red) {
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const unsigned nrow = (unsigned)nl * nq * s * ncn;
+  float mx = 0.f; unsigned rank = 0;
+  if (row < nrow) {
+    fdiv_t d_ncn{m_ncn, ncn}, d_s{m_s, s};
+    const unsigned t = fdiv(row, d_ncn), yy = row - t * ncn, t2 = fdiv(t, d_s), zl = t - t2 * s, qz = t2 % (unsigned)nq;
+    rank = t2 / (unsigned)nq;
+    const int m = ncn + 2; const int64_t fcs = (int64_t)m * m * m, blk = (int64_t)s * ncn * ncn;
+    const float *b0 = blocks + (((int64_t)rank * nq + qz) * 3) * blk + ((int64_t)zl * ncn + yy) * ncn;
+    float *f0 = fc + (int64_t)rank * 3 * fcs + ((int64_t)(1 + qz * s + zl) * m + (1 + yy)) * m + 1;
+    for (int x4 = lane; x4 < ncn / 4; x4 += 64) {
+      const float4 a = reinterpret_cast<const float4 *>(b0)[x4], b = reinterpret_cast<const float4 *>(b0 + blk)[x4], c = reinterpret_cast<const float4 *>(b0 + 2 * blk)[x4];
+      float *pa = f0 + 4 * x4;
+      pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
+      pa[fcs] = b.x; pa[fcs + 1] = b.y; pa[fcs + 2] = b.z; pa[fcs + 3] = b.w;
+      pa[2 * fcs] = c.x; pa[2 * fcs + 1] = c.y; pa[2 * fcs + 2] = c.z; pa[2 * fcs + 3] = c.w;
+      mx = fmaxf(fmaxf(mx, sqrtf(a.x * a.x + b.x * b.x + c.x * c.x)), sqrtf(a.y * a.y + b.y * b.y + c.y * c.y));
+      mx = fmaxf(fmaxf(mx, sqrtf(a.z * a.z + b.z * b.z + c.z * c.z)), sqrtf(a.w * a.w + b.w * b.w + c.w * c.w));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+  if (lane == 0 && row < nrow) atomicMax(reinterpret_cast<unsigned int *>(red.p[rank]) + p3m_slot() * 16, __float_as_uint(mx));
+}
+// coarse_force_buffer.f90 for all local ranks: blockIdx.y = rank*2 + side; halo [rank][4][face]: slots 0,1 = send to -axis / +axis, 2,3 = received
+__global__ __launch_bounds__(256) void k_halo_pack_b(const float *__restrict__ fc, float *__restrict__ halo, int ncn, int axis) {
+  const int m = ncn + 2; const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)3 * m * m) return;
+  const int rank = blockIdx.y >> 1, side = blockIdx.y & 1, pl = side ? ncn : 1;
+  const int a = (int)(idx % m), b = (int)((idx / m) % m), comp = (int)(idx / ((int64_t)m * m));
+  int i, j, k;
+  if (axis == 0) { i = pl; j = a; k = b; } else if (axis == 1) { i = a; j = pl; k = b; } else { i = a; j = b; k = pl; }
+  const int64_t fcs = (int64_t)m * m * m, face = (int64_t)3 * m * m;
+  halo[((int64_t)rank * 4 + side) * face + idx] = fc[(int64_t)rank * 3 * fcs + (int64_t)comp * fcs + ((int64_t)k * m + j) * m + i];
+}
+__global__ __launch_bounds__(256) void k_halo_unpack_b(float *__restrict__ fc, const float *__restrict__ halo, int ncn, int axis) {
+  const int m = ncn + 2; const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)3 * m * m) return;
+  const int rank = blockIdx.y >> 1, side = blockIdx.y & 1, pl = side ? 0 : ncn + 1;   // slot 2 (from the + neighbour's plane 1) fills ncn+1, slot 3 fills 0
+  const int a = (int)(idx % m), b = (int)((idx / m) % m), comp = (int)(idx / ((int64_t)m * m));
+  int i, j, k;
+  if (axis == 0) { i = pl; j = a; k = b; } else if (axis == 1) { i = a; j = pl; k = b; } else { i = a; j = b; k = pl; }
+  const int64_t fcs = (int64_t)m * m * m, face = (int64_t)3 * m * m;
+  fc[(int64_t)rank * 3 * fcs + (int64_t)comp * fcs + ((int64_t)k * m + j) * m + i] = halo[((int64_t)rank * 4 + 2 + side) * face + idx];
+}
+
 // ---- who exchanges with whom in the transposes of the coarse transform (rank = c1*nd^2 + c2*nd + c3, x <-> c3, z <-> c1)
 // cube <-> x-lines.  Slabs (pack_slab, fftw3ds.f90:24-52): z-slice q of r's cube goes to the q-th rank of the own z-layer.
 // Pencils (pack_pencils, p3dfft_coarse.f90:69-127 with pen_neighbor_to / pen_neighbor_fm of mpi_initialization_p3dfft.f90:48-51):
@@ -607,6 +735,12 @@ static int group_exchange(p3m_group *G, int count, size_t bytes, P peer, I index
   return do_exchange(G, m);
 }
 
+static RowGeom row_geom(const p3m_group *G) {
+  const Geometry &g = G->ctx[0]->g;
+  RowGeom q; q.nl = (int)G->ctx.size(); q.s = G->s; q.nc = g.nc; q.ncn = g.ncn; q.nd = G->nd; q.rpp = G->rpp; q.rp = 2 * G->plan_c.px;
+  q.m_rpp = fdiv_magic(q.rpp); q.m_s = fdiv_magic(q.s); q.m_ncn = fdiv_magic(q.ncn);
+  return q;
+}
 // forward distributed transform of every rank's cube `cube_of(i)` (ncn^3 floats) into d.lz: rho-hat of the own ky slab and
 // (pencils) the own kx chunks, all kz
 template <typename F> static int dist_forward(p3m_group *G, F cube_of) {
@@ -616,6 +750,17 @@ template <typename F> static int dist_forward(p3m_group *G, F cube_of) {
   // cube -> x-lines
   P3M_TRY(group_exchange(G, G->nxb, blk * sizeof(float), [&](int r, int q) { return xl_peer(G, r, q); }, [&](int r) { return xl_index(G, r); },
                          [&](int li) { return (const char *)cube_of(li); }, [&](int li) { return (char *)G->cd[li].blocks_in; }));
+  if (G->batched) {   // every stage once, over all local ranks
+    p3m_ctx *c0 = G->ctx[0];
+    const RowGeom q = row_geom(G);
+    hipLaunchKernelGGL(k_blocks_to_rows_b, dim3(cdiv((int64_t)nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_blocks_in, G->a_rows, q);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(fft_x_forward_rows(c0, G->plan_c, G->a_rows, G->a_ly, (int64_t)nl * s * rpp, rpp));
+    P3M_TRY(fft_slab_y_fwd(c0, G->plan_c, G->a_ly, G->a_send, s, nl));
+    P3M_TRY(group_exchange(G, yz_count(G), (size_t)s * ncl * s * 16 * sizeof(float2), [&](int r, int j) { return yz_peer(G, r, j); },
+                           [&](int r) { return yz_index(G, r); }, [&](int li) { return (const char *)G->cd[li].send; }, [&](int li) { return (char *)G->cd[li].recv; }));
+    return fft_slab_z_fwd(c0, G->plan_l, G->a_recv, G->a_lz, s, s, nl);   // reads the arrivals where they lie
+  }
   const size_t NBc = (size_t)s * ncl * nc * 16;   // complex elements of one component's slab / pencil
   const size_t xyb = (size_t)s * ncl * ncn * 16 * sizeof(float2);   // pencils: one block of the x<->y transpose
   for (int i = 0; i < nl; i++) {
@@ -642,10 +787,11 @@ template <typename F> static int dist_forward(p3m_group *G, F cube_of) {
                          [&](int r) { return yz_index(G, r); }, [&](int li) { return (const char *)G->cd[li].send; }, [&](int li) { return (char *)G->cd[li].recv; }));
   for (int i = 0; i < nl; i++) {
     p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
+    if (fft_has_segmented(G->plan_l)) { P3M_TRY(fft_slab_z_fwd(c, G->plan_l, d.recv, d.lz, s, s)); continue; }   // the z pass reads the arrivals where they lie
     hipLaunchKernelGGL(k_a2a_permute, dim3(cdiv((int64_t)NBc, 256)), dim3(256), 0, G->stream, reinterpret_cast<const float2 *>(d.recv),
                        reinterpret_cast<float2 *>(d.lz), s, ncl, nc, 1);
     HIP_TRY(hipGetLastError());
-    P3M_TRY(fft_slab_z_fwd(c, G->plan_l, d.lz, s));                                   // LZ in place: rho-hat(ky slab, all kz)
+    P3M_TRY(fft_slab_z_fwd(c, G->plan_l, d.lz, d.lz, s, 0));                          // LZ in place: rho-hat(ky slab, all kz)
   }
   return P3M_OK;
 }
@@ -669,7 +815,7 @@ static int build_coarse_kernel_dist(p3m_group *G, const float *table4_host) {
       }
       P3M_TRY(dist_forward(G, [&](int li) { return G->ctx[li]->rho_c; }));
       for (int i = 0; i < nl; i++) {
-        float *dst = pass == 0 ? unc[i] : G->cd[i].kern + (size_t)comp * NBc;
+        float *dst = pass == 0 ? unc[i] : G->cd[i].kern + (size_t)comp * (G->cstride / 2);
         hipLaunchKernelGGL(k_take_imag_g, dim3(cdiv(NBc, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].lz, dst, NBc);
         if (pass == 1 && lr)
           hipLaunchKernelGGL(k_lrck_slab, dim3(cdiv(NBc, 256)), dim3(256), 0, G->stream, dst, (const float *)unc[i], nc, s, nchunk, yz_index(G, G->lrank[i]) * s,
@@ -691,22 +837,34 @@ static int coarse_force_dist(p3m_group *G) {
   const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, ncl = G->ncl, rpp = G->rpp;
   const size_t NBc = (size_t)s * ncl * nc * 16, blk = (size_t)s * ncn * ncn;
   P3M_TRY(dist_forward(G, [&](int li) { return G->ctx[li]->rho_c; }));                  // coarse_force.f90:18
-  for (int i = 0; i < nl; i++)                                                           // :37-50 x3, fused multiply
+  const int64_t ccs = (int64_t)(G->cstride / 2);                                         // complex elements between two components of a rank
+  if (G->batched) P3M_TRY(fft_slab_z_inv3(G->ctx[0], G->plan_l, G->a_lz, G->a_send, G->a_kern, s, ccs, ccs, nl, (int64_t)NBc));
+  else for (int i = 0; i < nl; i++)                                                      // :37-50 x3, fused multiply
     P3M_TRY(fft_slab_z_inv3(G->ctx[i], G->plan_l, G->cd[i].lz, G->cd[i].send, G->cd[i].kern, s, (int64_t)NBc, (int64_t)NBc));
   const size_t ab = (size_t)s * ncl * s * 16 * sizeof(float2);
   std::vector<XMsg> m2;                                                                  // transpose back, 3 components in one exchange
   for (int comp = 0; comp < 3; comp++) {
-    const size_t co = (size_t)comp * NBc * sizeof(float2);
+    const size_t co = (size_t)comp * ccs * sizeof(float2);
     group_msgs(G, m2, yz_count(G), ab, [&](int r, int j) { return yz_peer(G, r, j); }, [&](int r) { return yz_index(G, r); },
                [&](int li) { return (const char *)G->cd[li].send + co; }, [&](int li) { return (char *)G->cd[li].recv + co; });
   }
   P3M_TRY(do_exchange(G, m2));
+  if (G->batched) {
+    p3m_ctx *c0 = G->ctx[0];
+    P3M_TRY(fft_slab_y_inv(c0, G->plan_l, G->a_recv, G->a_ly, s, 3 * nl, s));
+    P3M_TRY(fft_x_inverse(c0, G->plan_c, G->a_ly, G->a_rows, -(3 * nl * s * rpp), 0, nullptr, 0, 0, 1, 0, rpp));
+    hipLaunchKernelGGL(k_rows_to_blocks_b, dim3(cdiv((int64_t)3 * nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_rows, G->a_blocks_out, row_geom(G));
+    HIP_TRY(hipGetLastError());
+  } else
   for (int i = 0; i < nl; i++) {
     p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
-    hipLaunchKernelGGL(k_a2a_permute, dim3(cdiv((int64_t)3 * NBc, 256)), dim3(256), 0, G->stream, reinterpret_cast<const float2 *>(d.recv),
-                       reinterpret_cast<float2 *>(d.ly), s, ncl, nc, 3);
-    HIP_TRY(hipGetLastError());
-    P3M_TRY(fft_slab_y_inv(c, G->plan_l, d.ly, s, 3));
+    if (fft_has_segmented(G->plan_l)) P3M_TRY(fft_slab_y_inv(c, G->plan_l, d.recv, d.ly, s, 3, s));
+    else {
+      hipLaunchKernelGGL(k_a2a_permute, dim3(cdiv((int64_t)3 * NBc, 256)), dim3(256), 0, G->stream, reinterpret_cast<const float2 *>(d.recv),
+                         reinterpret_cast<float2 *>(d.ly), s, ncl, nc, 3);
+      HIP_TRY(hipGetLastError());
+      P3M_TRY(fft_slab_y_inv(c, G->plan_l, d.ly, d.ly, s, 3, 0));
+    }
     if (G->pencil) P3M_TRY(permute5(G->stream, d.ly, d.send, {3 * s, ncl, nd, ncn, 1},  // [comp,zl][cl][iy'][yl] -> [iy'][comp,zl][cl][yl]
                                     {(int64_t)ncl * ncn, ncn, (int64_t)3 * s * ncl * ncn, 1, 0}));
   }
@@ -716,6 +874,7 @@ static int coarse_force_dist(p3m_group *G) {
     for (int i = 0; i < nl; i++)                                                         // [iy][comp,zl][cl][yl] -> LY [comp,zl][chunk = iy*ncl + cl][yl]
       P3M_TRY(permute5(G->stream, G->cd[i].recv, G->cd[i].ly, {nd, 3 * s, ncl, ncn, 1}, {(int64_t)ncl * ncn, (int64_t)G->nchunk * ncn, ncn, 1, 0}));
   }
+  if (!G->batched)
   for (int i = 0; i < nl; i++) {
     p3m_ctx *c = G->ctx[i]; CoarseDist &d = G->cd[i];
     P3M_TRY(fft_x_inverse(c, G->plan_c, d.ly, d.rows, -(3 * s * rpp), 0, nullptr, 0, 0, 1, 0, rpp));   // incl. /nc^3 (fftw3ds.f90:161, p3dfft_coarse.f90:57)
@@ -735,6 +894,13 @@ static int coarse_force_dist(p3m_group *G) {
     P3M_TRY(do_exchange(G, m3));
   }
   const int m = ncn + 2; const size_t face = (size_t)3 * m * m;
+  if (G->batched) {   // the maximum (coarse_max_dt.f90) rides on this copy
+    RankPtrs red;
+    for (int i = 0; i < nl; i++) red.p[i] = G->ctx[i]->d_red + 2 * P3M_RED_SPAN;
+    hipLaunchKernelGGL(k_blocks_to_force_b, dim3(cdiv((int64_t)nl * G->nxb * s * ncn, 4)), dim3(256), 0, G->stream, (const float *)G->a_blocks_back, G->a_force_c, nl, G->nxb, s,
+                       ncn, fdiv_magic(ncn), fdiv_magic(s), red);
+    HIP_TRY(hipGetLastError());
+  } else
   for (int i = 0; i < nl; i++) {
     const int64_t tot = (int64_t)G->nxb * 3 * blk;
     hipLaunchKernelGGL(k_blocks_to_force, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].blocks_back, G->ctx[i]->force_c, s, ncn, G->nxb);
@@ -742,6 +908,8 @@ static int coarse_force_dist(p3m_group *G) {
   }
   // one-cell halo: x, then y (carrying the x halo), then z (coarse_force_buffer.f90:19-63)
   for (int axis = 0; axis < 3; axis++) {
+    if (G->batched) hipLaunchKernelGGL(k_halo_pack_b, dim3(cdiv((int64_t)face, 256), 2 * nl), dim3(256), 0, G->stream, (const float *)G->a_force_c, G->a_halo, ncn, axis);
+    else
     for (int i = 0; i < nl; i++) {
       hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[0], ncn, axis, 1);    // to -axis
       hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[1], ncn, axis, ncn);  // to +axis
@@ -759,12 +927,15 @@ static int coarse_force_dist(p3m_group *G) {
       hm.push_back({r, rpl, li >= 0 ? (const void *)G->cd[li].halo_s[1] : nullptr, lp >= 0 ? (void *)G->cd[lp].halo_r[1] : nullptr, face * sizeof(float)});  // plane ncn -> their 0
     }
     P3M_TRY(do_exchange(G, hm));
+    if (G->batched) hipLaunchKernelGGL(k_halo_unpack_b, dim3(cdiv((int64_t)face, 256), 2 * nl), dim3(256), 0, G->stream, G->a_force_c, (const float *)G->a_halo, ncn, axis);
+    else
     for (int i = 0; i < nl; i++) {
       hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[0], ncn, axis, ncn + 1);
       hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[1], ncn, axis, 0);
     }
     HIP_TRY(hipGetLastError());
   }
+  if (!G->batched)
   for (int i = 0; i < nl; i++) {
     hipLaunchKernelGGL(k_gmax_interior, dim3(std::min<int64_t>(1024, cdiv((int64_t)ncn * ncn * ncn, 256))), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, ncn,
                        G->ctx[i]->d_red + 2 * P3M_RED_SPAN);

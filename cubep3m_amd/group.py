@@ -138,6 +138,13 @@ class ParticleMeshGroup:
         _lib.check(self.L.p3m_hip_group_set_kernel_tables(self.h, np.ascontiguousarray(fine_table, np.float32),
                                                           np.ascontiguousarray(coarse_table, np.float32)))
 
+    def comm_info(self):
+        """{"comm_count", "comm_rank"} of the RCCL communicator (-1: none), the HIP device ordinal and its UUID."""
+        cnt, rk, dev = C.c_int32(), C.c_int32(), C.c_int32()
+        uuid = C.create_string_buffer(33)
+        _lib.check(self.L.p3m_hip_group_comm_info(self.h, C.byref(cnt), C.byref(rk), C.byref(dev), uuid))
+        return {"comm_count": cnt.value, "comm_rank": rk.value, "device": dev.value, "uuid": uuid.value.decode()}
+
     def coarse_power(self, mass_p, box):
         """coarse_power.f90 on the coarse density of the last particle_mesh step: (nc_dim, 2) rows (k, Delta^2(k))."""
         ps = np.zeros((self.params.nc_dim, 2), np.float32)

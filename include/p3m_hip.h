@@ -309,6 +309,10 @@ int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho
  *                       within the chunk); slabs: ky = rank*nc_slab + local ky, ncl = all chunks of (nc/2+1 rounded up to 16)/16
  *   get_coarse_force    force_c(3, 0:ncn+1, 0:ncn+1, 0:ncn+1) of local rank i, component fastest (as p3m_hip_group_probe_coarse)
  *   coarse_exchange_bytes  bytes one rank sends to ONE peer in the y<->z transpose of one transform (SURVEY 8d "per-link bytes") */
+/* Who this process is in the group's RCCL communicator and which device it drives: comm_count / comm_rank from
+ * ncclCommCount / ncclCommUserRank (both -1 when no communicator was set up), the HIP device ordinal, and the device's UUID
+ * as 32 hex digits + NUL (uuid_hex33).  bench.py prints these per rank so that a multi-GPU line can be audited. */
+int p3m_hip_group_comm_info(p3m_group *g, int32_t *comm_count, int32_t *comm_rank, int32_t *device, char *uuid_hex33);
 int p3m_hip_group_set_coarse_density(p3m_group *g, int32_t i, const float *rho_c);
 int p3m_hip_group_coarse_transform(p3m_group *g, int32_t what, int32_t reps, float *ms);
 int p3m_hip_group_get_coarse_hat(p3m_group *g, int32_t i, float *hat, int64_t nfloats);
