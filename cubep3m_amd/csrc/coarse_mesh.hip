@@ -206,7 +206,7 @@ int coarse_force(p3m_ctx *c) {
 }
 
 // coarse_velocity.f90:137-179: CIC gather of force_c (with halo) at x/ms - 0.5, particles of hoc(1..ncn)
-__global__ __launch_bounds__(256) void k_coarse_kick(const float4 *__restrict__ spos, float4 *__restrict__ svel, int n, CGeo G,
+__global__ __launch_bounds__(256) void k_coarse_kick(const float4 *__restrict__ spos, float4 *__restrict__ vel, int n, CGeo G,
                                                      const float *__restrict__ fc, float a_mid, float dt) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void k_coarse_kick(const float4 *__restrict__ 
   float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
   if (G.cngp) { dx1 = dy1 = dz1 = 0.0f; dx2 = dy2 = dz2 = 1.0f; }                           // :146-149
   const int m = G.ncn + 2; const int64_t cs = (int64_t)m * m * m;
-  float4 v = svel[s];
+  const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
+  float4 v = vel[vi];
 #pragma unroll
   for (int cz = 0; cz < 2; cz++)
 #pragma unroll
@@ -231,14 +232,14 @@ __global__ __launch_bounds__(256) void k_coarse_kick(const float4 *__restrict__ 
         const int64_t o = ((int64_t)(k1 + cz) * m + (j1 + cy)) * m + (i1 + cx);
         v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + cs] * dV; v.z = v.z + fc[o + 2 * cs] * dV;
       }
-  svel[s] = v;
+  vel[vi] = v;
 }
 
 int coarse_kick(p3m_ctx *c, float a_mid, float dt) {
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
   CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc, (c->p.flags & P3M_FLAG_COARSE_NGP) ? 1 : 0};
-  hipLaunchKernelGGL(k_coarse_kick, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G,
+  hipLaunchKernelGGL(k_coarse_kick, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G,
                      (const float *)c->force_c, a_mid, dt);
   HIP_TRY(hipGetLastError());
   return P3M_OK;

@@ -287,7 +287,7 @@ int fine_force_max(p3m_ctx *c) {
 
 // ------------------------------------------------------------------ :227-319 gather + kick of the physical particles
 template <bool NGP>
-__global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ spos, float4 *__restrict__ svel, int n, TileGeo G, int Nn, int ms,
+__global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ spos, float4 *__restrict__ vel, int n, TileGeo G, int Nn, int ms,
                                                    const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
   const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
   const int tile = (tz * G.T + ty) * G.T + tx;
   const float *f0 = fbox + (int64_t)tile * fb * fb * G.fbp;
-  float4 v = svel[s];
+  const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
+  float4 v = vel[vi];
   if (NGP) {
     const int64_t o = ((int64_t)k1 * fb + j1) * G.fbp + i1;
     v.x = v.x + f0[o] * a_mid * P3M_G_F * dt;                                                         // :265-266
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
           v.x = v.x + f0[o] * dVc; v.y = v.y + f0[o + comp_stride] * dVc; v.z = v.z + f0[o + 2 * comp_stride] * dVc;
         }
   }
-  svel[s] = v;
+  vel[vi] = v;
 }
 
 // NGP: max |F|^2 (:208-223) and the kick (:244-270) in ONE pass over the force box.  One wavefront per box row
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 // corner terms) follows the fine kick of a record in registers -- PM-only runs, where nothing else touches the
 // velocities between the two kicks, so the sums are the ones two separate passes would form.
 template <bool COARSE>
-__global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, TileGeo G,
+__global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G,
                                                       int Nn, int ms, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
                                                       float *__restrict__ fmax_out, const float *__restrict__ fc, int ncn, const int *__restrict__ crow, int crow_w,
                                                       int *__restrict__ cnt256) {   // cnt256: survivors per block of 256 sorted records, counted on the way (or nullptr)
@@ -345,6 +346,14 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
   int tx, ty, tz; tile_xyz(tile, G.T, tx, ty, tz);
   const float *f0 = fbox + (int64_t)tile * fb * fb * fbp;
   const int64_t ro = ((int64_t)kk * fb + jj) * fbp;
+  // tile-local cell l <-> extended cell l + t*pt; the box row (jj,kk) is the local cell row (jj+lo, kk+lo).  The chain row range ->
+  // record -> velocity (reached through the arrival index in the record's fourth lane) is three dependent round trips: it is
+  // started here, for the first 64 records of the row (a row holds ~70), so that it runs underneath the loads of the box row
+  int p0, p1;
+  if (crow) { const int *t = crow + ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * crow_w + ncn + 2 + 2 * tx; p0 = t[0]; p1 = t[1]; }   // compact table
+  else { const int64_t row = ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * G.E + tx * G.pt + lo; p0 = cs[row]; p1 = cs[row + fb]; }
+  float4 pf = make_float4(-1.f, -1.f, -1.f, 0.f), vf = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p0 + lane < p1) { pf = spos[p0 + lane]; vf = vel[rec_index(pf)]; }
   float m = 0.f;
   for (int q = lane; q < (fbp >> 2); q += 64) {
     const float4 a = *reinterpret_cast<const float4 *>(f0 + ro + 4 * q), b = *reinterpret_cast<const float4 *>(f0 + ro + comp_stride + 4 * q),
@@ -356,15 +365,12 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
   if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out) + p3m_slot() * 16, __float_as_uint(m));
   __syncthreads();
-  // tile-local cell l <-> extended cell l + t*pt; the box row (jj,kk) is the local cell row (jj+lo, kk+lo)
-  int p0, p1;
-  if (crow) { const int *t = crow + ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * crow_w + ncn + 2 + 2 * tx; p0 = t[0]; p1 = t[1]; }   // compact table
-  else { const int64_t row = ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * G.E + tx * G.pt + lo; p0 = cs[row]; p1 = cs[row + fb]; }
   const float fNn = (float)Nn;
   const int nct = G.pt / ms;
   const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
   for (int s = p0 + lane; s < p1; s += 64) {
-    const float4 p = spos[s];
+    const bool first = s < p0 + 64;   // uniform over the wavefront
+    const float4 p = first ? pf : spos[s];
     if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) continue;  // chains of hoc(1..ncn) only (:234-236)
     // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
     if (((int)floorf(p.x / (float)ms)) / nct != tx || ((int)floorf(p.y / (float)ms)) / nct != ty || ((int)floorf(p.z / (float)ms)) / nct != tz) continue;
@@ -383,7 +389,8 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
     float fx, fy, fz;
     if (j1 == jj && k1 == kk) { fx = frow[i1]; fy = frow[fbp + i1]; fz = frow[2 * fbp + i1]; }
     else { const int64_t o = ((int64_t)k1 * fb + j1) * fbp + i1; fx = f0[o]; fy = f0[o + comp_stride]; fz = f0[o + 2 * comp_stride]; }
-    float4 v = svel[s];
+    const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
+    float4 v = first ? vf : vel[vi];
     v.x = v.x + fx * a_mid * P3M_G_F * dt;                                                             // :265-266
     v.y = v.y + fy * a_mid * P3M_G_F * dt;
     v.z = v.z + fz * a_mid * P3M_G_F * dt;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
             v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
           }
     }
-    svel[s] = v;
+    vel[vi] = v;
   }
 }
 
@@ -415,10 +422,10 @@ int fine_kick(p3m_ctx *c, float a_mid, float dt) {
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   if (c->p.flags & P3M_FLAG_NGP)
-    hipLaunchKernelGGL(k_fine_kick<true>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G, g.Nn,
+    hipLaunchKernelGGL(k_fine_kick<true>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
                        g.ms, (const float *)c->fbox, cs, a_mid, dt);
   else
-    hipLaunchKernelGGL(k_fine_kick<false>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, c->np_all, G, g.Nn,
+    hipLaunchKernelGGL(k_fine_kick<false>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
                        g.ms, (const float *)c->fbox, cs, a_mid, dt);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
@@ -441,11 +448,11 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
   }
   if (c->coarse_first)
     hipLaunchKernelGGL(k_fine_kick_rows<true>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
-                       (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
+                       (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
                        (const float *)c->force_c, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w, cnt256);
   else
     hipLaunchKernelGGL(k_fine_kick_rows<false>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
-                       (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
+                       (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
                        (const float *)nullptr, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w, cnt256);
   HIP_TRY(hipGetLastError());
   return P3M_OK;

@@ -87,9 +87,8 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   const bool coarse_only = (params->flags & P3M_FLAG_COARSE_ONLY) != 0;
   if (coarse_only && g.nodes == 1) { p3m_set_error("P3M_FLAG_COARSE_ONLY is for multi-rank groups"); return fail(P3M_EINVAL); }
   if (!coarse_only) {
-  A(dalloc(&c->pos, c->cap)); A(dalloc(&c->vel, c->cap)); A(dalloc(&c->pid, c->cap));
-  A(dalloc(&c->spos, c->cap)); A(dalloc(&c->svel, c->cap)); A(dalloc(&c->spid, c->cap));
-  A(dalloc(&c->tpos, c->cap)); A(dalloc(&c->tidx, c->cap));
+  A(dalloc(&c->pos, c->cap)); A(dalloc(&c->vel, c->cap)); A(dalloc(&c->vel_alt, c->cap)); A(dalloc(&c->pid_home, c->cap));
+  A(dalloc(&c->spos, c->cap)); A(dalloc(&c->tpos, c->cap));
   A(dalloc(&c->flags, c->cap + 8)); A(dalloc(&c->cand, c->cap));
   const int64_t ncell = (int64_t)g.E * g.E * g.E;
   int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // every entry of [0, ncell] is rewritten by each sort; the pads stay zero
@@ -141,8 +140,8 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  dfree(c->pos); dfree(c->vel); dfree(c->pid); dfree(c->spos); dfree(c->svel); dfree(c->spid);
-  dfree(c->tpos); dfree(c->tidx); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
+  dfree(c->pos); dfree(c->vel); dfree(c->vel_alt); dfree(c->pid_home); dfree(c->spos);
+  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);
@@ -237,14 +236,18 @@ __global__ __launch_bounds__(256) void k_unpack_xv(const float *__restrict__ xv6
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float *r = xv6 + (int64_t)i * 6;
-  pos[i] = make_float4(r[0], r[1], r[2], 0.f); vel[i] = make_float4(r[3], r[4], r[5], 0.f);
+  pos[i] = make_float4(r[0], r[1], r[2], 0.f); vel[i] = with_index(r[3], r[4], r[5], i);   // PID slot = upload index
 }
 __global__ __launch_bounds__(256) void k_pack_xv(const float4 *__restrict__ pos, const float4 *__restrict__ vel, float *__restrict__ xv6, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float4 p = pos[i], v = vel[i];
+  const float4 p = pos[i]; const float4 v = vel[i];
   float *r = xv6 + (int64_t)i * 6;
   r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = v.x; r[4] = v.y; r[5] = v.z;
+}
+__global__ __launch_bounds__(256) void k_gather_pid(const float4 *__restrict__ vel, const int64_t *__restrict__ pid_home, int64_t *__restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = pid_home[rec_index(vel[i])];
 }
 __global__ __launch_bounds__(256) void k_iota_pid(int64_t *pid, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -255,16 +258,14 @@ extern "C" int p3m_hip_upload_particles(p3m_ctx *c, const float *xv6, const int6
   if (!c || np_local < 0 || (np_local > 0 && !xv6)) return P3M_EINVAL;
   if (np_local > c->cap) { p3m_set_error("np_local %d exceeds max_np %lld", np_local, (long long)c->cap); return P3M_ECAPACITY; }
   HIP_TRY(hipSetDevice(c->device));
-  c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false;
+  c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false; c->cnt_from_kick = 0; c->n_home = 0;
   if (np_local == 0) return P3M_OK;
-  float *stage = reinterpret_cast<float *>(c->spos);  // 16 B/record of scratch >= ... 24 B/record needs svel too
-  // spos and svel are separate allocations: stage through a temporary instead
   float *tmp = nullptr; P3M_TRY(dalloc(&tmp, (size_t)np_local * 6));
-  (void)stage;
   HIP_TRY(hipMemcpyAsync(tmp, xv6, sizeof(float) * 6 * (size_t)np_local, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_unpack_xv, dim3(cdiv(np_local, 256)), dim3(256), 0, c->stream, (const float *)tmp, c->pos, c->vel, np_local);
-  if (pid) HIP_TRY(hipMemcpyAsync(c->pid, pid, sizeof(int64_t) * (size_t)np_local, hipMemcpyHostToDevice, c->stream));
-  else hipLaunchKernelGGL(k_iota_pid, dim3(cdiv(np_local, 256)), dim3(256), 0, c->stream, c->pid, np_local);
+  if (pid) HIP_TRY(hipMemcpyAsync(c->pid_home, pid, sizeof(int64_t) * (size_t)np_local, hipMemcpyHostToDevice, c->stream));
+  else hipLaunchKernelGGL(k_iota_pid, dim3(cdiv(np_local, 256)), dim3(256), 0, c->stream, c->pid_home, np_local);
+  c->n_home = np_local;
   HIP_TRY(hipStreamSynchronize(c->stream));
   dfree(tmp);
   return P3M_OK;
@@ -284,7 +285,12 @@ extern "C" int p3m_hip_download_particles(p3m_ctx *c, float *xv6, int64_t *pid, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     dfree(tmp);
   }
-  if (pid) { HIP_TRY(hipMemcpyAsync(pid, c->pid, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+  if (pid) {   // PIDs live in pid_home; the records carry their slot (p3m_internal.h)
+    int64_t *tmp = nullptr; P3M_TRY(dalloc(&tmp, (size_t)n));
+    hipLaunchKernelGGL(k_gather_pid, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4 *)c->vel, (const int64_t *)c->pid_home, tmp, n);
+    HIP_TRY(hipMemcpyAsync(pid, tmp, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream));
+    dfree(tmp);
+  }
   return P3M_OK;
 }
 

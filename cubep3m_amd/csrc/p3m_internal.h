@@ -35,6 +35,11 @@ void p3m_set_error(const char *fmt, ...);
 __device__ __forceinline__ int p3m_slot() { return (int)((blockIdx.x + 13u * blockIdx.y + 31u * blockIdx.z) & (P3M_NSLOT - 1)); }
 #endif
 
+#ifdef __HIPCC__
+__device__ __forceinline__ int rec_index(const float4 &p) { return __float_as_int(p.w); }
+__device__ __forceinline__ float4 with_index(float x, float y, float z, int i) { return make_float4(x, y, z, __int_as_float(i)); }
+#endif
+
 // ------------------------------------------------------------------ FFT plan (fft.hip)
 struct FftPlan {
   int n = 0;               // real transform length per axis
@@ -70,8 +75,21 @@ struct p3m_ctx {
   int64_t cap = 0;        // capacity in records (physical + ghosts)
   int np_local = 0;       // physical particles
   int np_all = 0;         // after the ghost pass
-  float4 *pos = nullptr, *vel = nullptr; int64_t *pid = nullptr;       // unsorted (arrival order)
-  float4 *spos = nullptr, *svel = nullptr; int64_t *spid = nullptr;    // sorted by extended fine cell
+  // Records (round 3): only the POSITIONS are sorted.  Velocity and PID stay where they are and are reached through an index
+  // carried in the fourth lane of the records (integer bits; never touched by arithmetic):
+  //   pos[i]   arrival order   {x, y, z, -}
+  //   vel[i]   arrival order   {vx, vy, vz, slot}  slot = index of the record's PID in pid_home (the kicks gather / scatter these
+  //                            16-byte records through spos[s].w; 12-byte velocity records were measured slower: a gather of
+  //                            records that straddle cache lines costs more than the 4 bytes it saves)
+  //   tpos[j]  row-bucketed    {x, y, z, i}        i = arrival index        (intermediate of the sort)
+  //   spos[s]  cell-sorted     {x, y, z, i}
+  //   pid_home[slot]           written at upload and when a migrant arrives, read at download and when a migrant leaves
+  // delete_particles (the compaction, deferred into the next drift) writes the next arrival arrays into the buffers the sort's
+  // intermediate used (pos <-> tpos, vel <-> vel_alt swap roles).  A step moves 16 B per record through the two sort
+  // passes instead of 16 + 16 + 8 + 4.
+  float4 *pos = nullptr; float4 *vel = nullptr, *vel_alt = nullptr;
+  int64_t *pid_home = nullptr; int n_home = 0;   // slots in use (upper bound: departed records leave holes; repacked when full)
+  float4 *spos = nullptr;      // sorted by extended fine cell
   int *cell_end = nullptr;     // [E^3+1] inclusive prefix of per-cell counts, shifted by one: start(c)=cell_end[c], end(c)=cell_end[c+1]
   int *row_end = nullptr;      // [E^2+1] the same for whole x-rows of cells (first level of the sort)
   // PM-only NGP whole steps need cell offsets at few places only: per x-row the ncn+2 starts at stride mesh_scale the
@@ -79,7 +97,7 @@ struct p3m_ctx {
   // writes this compact table instead of the 4 E^3 bytes of cell_end (cells_compact == true); anything else that reads
   // cell_end calls particles_full_cells first, which rebuilds it from the sorted records.
   int *crow = nullptr; int crow_w = 0; bool cells_compact = false;
-  float4 *tpos = nullptr; int *tidx = nullptr;    // row-bucketed intermediate of the sort: position and arrival index
+  float4 *tpos = nullptr;      // row-bucketed intermediate of the sort: position and arrival index
   int *scan_tmp = nullptr; size_t scan_tmp_n = 0;
   int *flags = nullptr;        // [cap] compaction flags / offsets
   unsigned char *cflag = nullptr; // [(E/ms)^3] coarse cells holding a record whose tile-local cell differs from floor(x)

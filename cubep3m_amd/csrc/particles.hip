@@ -4,7 +4,8 @@
 //   link_list's chaining mesh hoc/ll (and llf, hoc_fine/ll_fine) -> sort by extended fine cell:
 //     k_row_hist / exclusive scan / k_row_scatter (by x-row), k_row_sort (inside each row)
 //   delete_particles.f90 + move_grid_back.f90 -> k_count_physical / scan of the block counts / k_compact
-// Records are SoA float4 pos, float4 vel, int64 pid.  Everything here is HBM-bound streaming
+// Records: float4 positions whose fourth lane carries an index (p3m_internal.h), 12-byte velocities in arrival order, PIDs at
+// rest in pid_home.  Everything here is HBM-bound streaming
 // (the row histogram / scatter aggregate their atomics per block in LDS).
 #include "p3m_internal.h"
 #include <stdlib.h>
@@ -131,8 +132,9 @@ __device__ __forceinline__ void flag_displaced(const float4 &p, float nb, int E,
   if (displaced) { const int Ec = E / ms, cb = (int)nb / ms; cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] = 1; }
 }
 template <bool HIST>   // HIST: the images' x-rows are counted on the way (rs; the originals were counted by k_compact_drift_hist)
-__global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, float4 *__restrict__ vel, int64_t *__restrict__ pid, int n_cur,
-                                                    int cap, float Nn, float nb, int *__restrict__ counter, int *__restrict__ overflow, int E, int *__restrict__ rs) {
+__global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, float4 *__restrict__ vel, int n_cur,
+                                                    int cap, float Nn, float nb, int *__restrict__ counter, int *__restrict__ overflow, int E, int *__restrict__ rs,
+                                                    unsigned char *__restrict__ cflag, int ms, int pt) {   // cflag: see flag_displaced (PPINT runs)
   __shared__ int wsum[PT / 64];
   __shared__ int base_sh;
   __shared__ int key[HIST ? SORT_HB : 1], val[HIST ? SORT_HB : 1];
@@ -161,14 +163,18 @@ __global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, fl
   __syncthreads();
   if (cnt != 0) {
     int s = n_cur + base_sh + off + inc - cnt;
-    const float4 v = vel[i]; const int64_t id = pid[i];
+    const float4 v = vel[i];
     for (int c = 0; c < nz; c++)
       for (int b = 0; b < ny; b++)
         for (int a = 0; a < nx; a++) {
           if ((a | b | c) == 0) continue;
           if (s < cap) {
-            pos[s] = make_float4(ox[a], oy[b], oz[c], p.w); vel[s] = v; pid[s] = id;
-            if (HIST) hist_row_one(key, val, rs, ((int)floorf(oz[c]) + (int)nb) * E + (int)floorf(oy[b]) + (int)nb);   // images lie inside [-nb, Nn+nb)
+            pos[s] = make_float4(ox[a], oy[b], oz[c], 0.f); vel[s] = v;   // v.w: the image keeps the PID slot of its original (same rank)
+            if (HIST) {
+              hist_row_one(key, val, rs, ((int)floorf(oz[c]) + (int)nb) * E + (int)floorf(oy[b]) + (int)nb);   // images lie inside [-nb, Nn+nb)
+              // the image of a record that drifted out of [0, Nn) is the physical one: the flag k_row_hist would have set for it
+              if (cflag && ox[a] >= 0.f && ox[a] < Nn && oy[b] >= 0.f && oy[b] < Nn && oz[c] >= 0.f && oz[c] < Nn) flag_displaced(make_float4(ox[a], oy[b], oz[c], 0.f), nb, E, ms, pt, cflag);
+            }
           } else *overflow = 1;
           s++;
         }
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos,
 
 // rs[r+1] holds start(r) on entry and end(r) = start(r+1) on exit
 __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ pos, int n, float Nn, float nb, int E, int *__restrict__ rs,
-                                                    float4 *__restrict__ tpos, int *__restrict__ tidx) {
+                                                    float4 *__restrict__ tpos) {
   __shared__ int key[SORT_HB], val[SORT_HB];
   for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
   __syncthreads();
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
     if (ent[u] == -1) continue;
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
     const int s = ent[u] >= 0 ? val[ent[u]] + rank[u] : rank[u];
-    tpos[s] = p[u]; tidx[s] = i;   // velocity and PID stay where they are: k_row_sort fetches them by index
+    tpos[s] = with_index(p[u].x, p[u].y, p[u].z, i);   // velocity and PID stay where they are: the record carries its arrival index
   }
 }
 
@@ -262,28 +268,20 @@ struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, r
 // compact cell table (p3m_internal.h, crow): entry ci < ncn+2 = start of cell ms*ci - ms/2 + nb (what k_coarse_moments reads),
 // entries ncn+2 + 2*tx, +1 = start of cells tx*pt + lo and tx*pt + lo + fb (the force-box row of tile column tx)
 struct RowCompact { int *crow; int w, ncn, ms, T, pt, lo, fb; };   // crow == nullptr: write the full cell_end row
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ tidx, const float4 *__restrict__ vel,
-                                                 const int64_t *__restrict__ pid, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
-                                                 float4 *__restrict__ spos, float4 *__restrict__ svel, int64_t *__restrict__ spid,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
+                                                 float4 *__restrict__ spos,
                                                  int *__restrict__ cand, int *__restrict__ ncand, int cand_cap, RowDep dep, RowCompact cc) {
   extern __shared__ int bins[];
   const int row = blockIdx.x, lane = threadIdx.x;
   const int r0 = rs[row], r1 = rs[row + 1];
   // the first 128 records of the row (a row holds ~70 at the reference's density) live in registers from here on: their
-  // positions feed both the histogram and the scatter, and their velocity / PID gathers are issued as soon as the
-  // arrival indices land, so that they complete under the histogram, the scan and the cell_end / density row stores
+  // positions feed both the histogram and the scatter.  Only positions move: the fourth lane carries the arrival index
+  // through which the kicks and the compaction reach velocity and PID (p3m_internal.h)
   constexpr int RR = 2;
-  float4 rp[RR], rv[RR]; int64_t rid[RR]; bool rin[RR];
+  float4 rp[RR]; bool rin[RR];
 #pragma unroll
   for (int u = 0; u < RR; u++) { const int i = r0 + u * 64 + lane; rin[u] = i < r1; rp[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (rin[u]) rp[u] = tpos[i]; }
-  {
-    int rsrc[RR];
-#pragma unroll
-    for (int u = 0; u < RR; u++) { rsrc[u] = 0; if (rin[u]) rsrc[u] = tidx[r0 + u * 64 + lane]; }
-    for (int j = lane; j < E; j += 64) bins[j] = 0;
-#pragma unroll
-    for (int u = 0; u < RR; u++) { rv[u] = make_float4(0.f, 0.f, 0.f, 0.f); rid[u] = 0; if (rin[u]) { rv[u] = vel[rsrc[u]]; rid[u] = pid[rsrc[u]]; } }
-  }
+  for (int j = lane; j < E; j += 64) bins[j] = 0;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < RR; u++) if (rin[u]) atomicAdd(&bins[(int)floorf(rp[u].x) + (int)nb], 1);
@@ -347,17 +345,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   // records with a coordinate within 2^-10 below a cell face: only these can be moved into the next
   // cell by the rounding of xv + offset_tile (fine_mesh.hip, count-based NGP deposit fix-up)
   const float thr = 1.0f - 0.0009765625f;
-  auto place = [&](const float4 &p, const float4 &v, int64_t id) {
+  auto place = [&](const float4 &p) {
     const int s = atomicAdd(&bins[(int)floorf(p.x) + (int)nb], 1);
-    spos[s] = p; svel[s] = v; spid[s] = id;
+    spos[s] = p;
     if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
       const int k = atomicAdd(ncand, 1);
       if (k < cand_cap) cand[k] = s;
     }
   };
 #pragma unroll
-  for (int u = 0; u < RR; u++) if (rin[u]) place(rp[u], rv[u], rid[u]);
-  for (int i = r0 + RR * 64 + lane; i < r1; i += 64) { const int src = tidx[i]; place(tpos[i], vel[src], pid[src]); }
+  for (int u = 0; u < RR; u++) if (rin[u]) place(rp[u]);
+  for (int i = r0 + RR * 64 + lane; i < r1; i += 64) place(tpos[i]);
 }
 
 // cell_end from the sorted records (after a sort that wrote only the compact table): one wavefront per row, as k_row_sort
@@ -400,11 +398,11 @@ int particles_pass_self(p3m_ctx *c) {
   int n_cur = c->np_local;
   if (n_cur > 0) {
     if (c->hist_done)
-      hipLaunchKernelGGL(k_make_images<true>, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
-                         (float)g.nb, cnt, cnt + 3, g.E, c->row_end);
+      hipLaunchKernelGGL(k_make_images<true>, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, n_cur, (int)c->cap, (float)g.Nn,
+                         (float)g.nb, cnt, cnt + 3, g.E, c->row_end, (c->p.flags & P3M_FLAG_PPINT) ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
     else
-      hipLaunchKernelGGL(k_make_images<false>, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, c->pid, n_cur, (int)c->cap, (float)g.Nn,
-                         (float)g.nb, cnt, cnt + 3, g.E, c->row_end);
+      hipLaunchKernelGGL(k_make_images<false>, dim3(cdiv(n_cur, PT)), dim3(PT), 0, c->stream, c->pos, c->vel, n_cur, (int)c->cap, (float)g.Nn,
+                         (float)g.nb, cnt, cnt + 3, g.E, c->row_end, (unsigned char *)nullptr, g.ms, g.pt);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -434,6 +432,7 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   const int nblk = cdiv(n_cur, PT * SORT_RPT);
   const bool counted = c->hist_done;   // the rows were counted by the kernels that wrote the arrival arrays (k_compact_drift_hist, ...)
   c->hist_done = false;
+  c->cnt_from_kick = 0;                // spos is rewritten: per-block survivor counts of an earlier kick are stale
   if (!counted) {
     HIP_TRY(hipMemsetAsync(cnt + 4, 0, 2 * sizeof(int), c->stream));
     HIP_TRY(hipMemsetAsync(c->row_end - 3, 0, (size_t)(nrows + 8) * sizeof(int), c->stream));
@@ -447,7 +446,7 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   P3M_TRY(exclusive_scan_i32(c, c->row_end + 1, nrows));
   if (n_cur > 0) {
     hipLaunchKernelGGL(k_row_scatter, dim3(nblk), dim3(PT), 0, c->stream, (const float4 *)c->pos, n_cur, (float)g.Nn, (float)g.nb, g.E, c->row_end,
-                       c->tpos, c->tidx);
+                       c->tpos);
     HIP_TRY(hipGetLastError());
   }
   RowDep dep{nullptr, nullptr, 0.f, g.T, g.nf, g.pt, 2 * g.px};
@@ -460,8 +459,8 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   RowCompact cc{nullptr, c->crow_w, g.ncn, g.ms, g.T, g.pt, g.nb - 2, g.fb};
   c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT)) && !full_always;
   if (c->cells_compact) cc.crow = c->crow;
-  hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos, (const int *)c->tidx,
-                     (const float4 *)c->vel, (const int64_t *)c->pid, (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->svel, c->spid, c->cand, cnt + 5,
+  hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos,
+                     (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->cand, cnt + 5,
                      (int)c->cap, dep, cc);
   HIP_TRY(hipGetLastError());
   // records that left the chaining mesh were dropped (link_list.f90:26-53): the sorted arrays hold n_cur - deleted records.
@@ -530,7 +529,7 @@ __device__ __forceinline__ int axis_shift(float x, float Nn, float nb, float *im
   *img = x; return 0;
 }
 constexpr int GP_RPT = 8;   // records per thread: <= 52 reservation atomics per 2048 records
-__global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid,
+__global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid_home,
                                                    int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts, int all_full) {
   __shared__ int lc[GSLOTS], base[GSLOTS];
   if (threadIdx.x < GSLOTS) lc[threadIdx.x] = 0;
@@ -586,7 +585,7 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
       const int s = base[k] + rk[r][t - 1];
       if (s >= S.cap[k]) continue;
       if (k & 1) {   // migrant: the whole record
-        const float4 v = vel[i]; const int64_t id = pid[i];
+        const float4 v = vel[i]; const int64_t id = pid_home[rec_index(v)];
         float4 *o = sbuf + (int64_t)S.off[k] + 2 * (int64_t)s;
         img.w = v.x;
         o[0] = img; o[1] = make_float4(v.y, v.z, __int_as_float((int)(id & 0xffffffffLL)), __int_as_float((int)(id >> 32)));
@@ -595,10 +594,11 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
   }
 }
 // appends the received segments: blockIdx.y = slot - 2; dst[k] = first record index of that segment in pos/vel/pid
-struct GhostIn { int off[GSLOTS]; int cnt[GSLOTS]; int dst[GSLOTS]; };
+struct GhostIn { int off[GSLOTS]; int cnt[GSLOTS]; int dst[GSLOTS]; int slot0[GSLOTS]; };   // slot0: first pid_home slot of a migrant segment
 template <bool HIST>   // HIST: the arrivals' x-rows are counted on the way (see hist_row)
 __global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ rbuf, GhostIn T, float4 *__restrict__ pos, float4 *__restrict__ vel,
-                                                     int64_t *__restrict__ pid, float Nn, float nb, int E, int *__restrict__ rs) {
+                                                     int64_t *__restrict__ pid_home, float Nn, float nb, int E, int *__restrict__ rs,
+                                                     unsigned char *__restrict__ cflag, int ms, int pt) {   // cflag: see flag_displaced (PPINT runs)
   __shared__ int key[HIST ? SORT_HB : 1], val[HIST ? SORT_HB : 1];
   if (HIST) { for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; } __syncthreads(); }
   const int k = blockIdx.y + 2, n = T.cnt[k];
@@ -612,14 +612,18 @@ __global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ 
         const float4 r0 = r[0], r1 = r[1];
         const int o = T.dst[k] + i;
         q = make_float4(r0.x, r0.y, r0.z, 0.f);
-        pos[o] = q; vel[o] = make_float4(r0.w, r1.x, r1.y, 0.f);
-        pid[o] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
+        pos[o] = q; vel[o] = with_index(r0.w, r1.x, r1.y, T.slot0[k] + i);   // a migrant settles here: its PID gets a slot of this rank's pid_home
+        pid_home[T.slot0[k] + i] = (int64_t)(unsigned int)__float_as_int(r1.z) | ((int64_t)__float_as_int(r1.w) << 32);
       } else {
         // ghosts: the velocity / PID slots stay unwritten -- nothing reads them before delete_particles drops the record
         q = rbuf[(int64_t)T.off[k] + i];
         pos[T.dst[k] + i] = q;
       }
-      if (HIST && in_hoc_range(q, -nb, Nn + nb)) row = ((int)floorf(q.z) + (int)nb) * E + (int)floorf(q.y) + (int)nb;
+      if (HIST && in_hoc_range(q, -nb, Nn + nb)) {
+        row = ((int)floorf(q.z) + (int)nb) * E + (int)floorf(q.y) + (int)nb;
+        // a migrant is physical here: the flag k_row_hist would have set for it (only the fused histogram skips that kernel)
+        if (cflag && q.x >= 0.f && q.x < Nn && q.y >= 0.f && q.y < Nn && q.z >= 0.f && q.z < Nn) flag_displaced(q, nb, E, ms, pt, cflag);
+      }
     }
     if (HIST) hist_row(key, val, rs, row);
   }
@@ -629,21 +633,49 @@ int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int
   P3M_TRY(particles_resolve(c));
   if (c->np_local == 0) return P3M_OK;
   GhostSegs S; for (int k = 0; k < GSLOTS; k++) { S.off[k] = seg_off[k]; S.cap[k] = seg_cap[k]; }
-  hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, PT * GP_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid,
+  hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, PT * GP_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid_home,
                      c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
+// pid_home is full of holes (records that left this rank keep their slot): the physical records take slots 0..np_local-1 again
+__global__ __launch_bounds__(PT) void k_pid_repack(float4 *__restrict__ vel, const int64_t *__restrict__ pid_home, int64_t *__restrict__ tmp, int n) {
+  const int i = blockIdx.x * PT + threadIdx.x;
+  if (i >= n) return;
+  float4 v = vel[i];
+  tmp[i] = pid_home[rec_index(v)];
+  v.w = __int_as_float(i);
+  vel[i] = v;
+}
+static int pid_repack(p3m_ctx *c) {
+  const int n = c->np_local;
+  if (n > 0) {
+    int64_t *tmp = reinterpret_cast<int64_t *>(c->spos);   // free between the compaction and the sort (16 B per record of room)
+    hipLaunchKernelGGL(k_pid_repack, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, c->vel, (const int64_t *)c->pid_home, tmp, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->pid_home, tmp, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+  }
+  c->n_home = n;
+  return P3M_OK;
+}
 int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base) {
-  GhostIn T; int mx = 0, run = base;
-  for (int k = 0; k < GSLOTS; k++) { T.off[k] = seg_off[k]; T.cnt[k] = k >= 2 ? cnt[k] : 0; T.dst[k] = run; run += T.cnt[k]; mx = std::max(mx, T.cnt[k]); }
+  GhostIn T; int mx = 0, run = base; int64_t nmig = 0;
+  for (int k = 2; k < GSLOTS; k += 1) if (k & 1) nmig += cnt[k];
+  if ((int64_t)c->n_home + nmig > c->cap) P3M_TRY(pid_repack(c));   // cap >= np_local + arrivals was checked by the caller
+  int slot = c->n_home;
+  for (int k = 0; k < GSLOTS; k++) {
+    T.off[k] = seg_off[k]; T.cnt[k] = k >= 2 ? cnt[k] : 0; T.dst[k] = run; run += T.cnt[k]; mx = std::max(mx, T.cnt[k]);
+    T.slot0[k] = slot; if (k & 1) slot += T.cnt[k];
+  }
   if (mx == 0) return P3M_OK;
+  c->n_home = slot;
+  unsigned char *cflag = (c->p.flags & P3M_FLAG_PPINT) ? c->cflag : nullptr;
   if (c->hist_done)
-    hipLaunchKernelGGL(k_ghost_unpack<true>, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid, (float)c->g.Nn,
-                       (float)c->g.nb, c->g.E, c->row_end);
+    hipLaunchKernelGGL(k_ghost_unpack<true>, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid_home, (float)c->g.Nn,
+                       (float)c->g.nb, c->g.E, c->row_end, cflag, c->g.ms, c->g.pt);
   else
-    hipLaunchKernelGGL(k_ghost_unpack<false>, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid, (float)c->g.Nn,
-                       (float)c->g.nb, c->g.E, c->row_end);
+    hipLaunchKernelGGL(k_ghost_unpack<false>, dim3(std::min(1024, cdiv(mx, PT)), GSLOTS - 2), dim3(PT), 0, c->stream, rbuf, T, c->pos, c->vel, c->pid_home, (float)c->g.Nn,
+                       (float)c->g.nb, c->g.E, c->row_end, cflag, c->g.ms, c->g.pt);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -692,10 +724,11 @@ __device__ __forceinline__ int block_rank(bool keep, int *wcnt) {   // wcnt: PT/
 }
 // DRIFT: the next step's update_position (update_position.f90:68-76) rides on the copy, applied to the very value
 // k_compact alone would have stored
+// vel_old: the arrival-order velocities of the step that ends here (read through the index in spos[s].w); pos / vel: the next arrival arrays
 template <bool DRIFT>
-__global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos, const float4 *__restrict__ svel, const int64_t *__restrict__ spid,
+__global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos, const float4 *__restrict__ vel_old,
                                                 const int *__restrict__ offs, int n, float Nn, float4 *__restrict__ pos, float4 *__restrict__ vel,
-                                                int64_t *__restrict__ pid, float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off) {
+                                                float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off) {
   __shared__ int wcnt[PT / 64];
   const int i = blockIdx.x * PT + threadIdx.x;
   float4 p = make_float4(-1.f, -1.f, -1.f, 0.f);
@@ -704,21 +737,22 @@ __global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos,
   const int o = offs[blockIdx.x] + block_rank(keep, wcnt);   // offs: first destination of every block of PT records
   if (!keep) return;
   p.x -= mx; p.y -= my; p.z -= mz;
-  const float4 v = svel[i];
+  const int src = rec_index(p);
+  const float4 v = vel_old[src];   // its fourth lane is the PID slot: it travels with the velocity
   if (DRIFT) {
     if (use_off) { p.x = p.x + v.x * hs + ox; p.y = p.y + v.y * hs + oy; p.z = p.z + v.z * hs + oz; }  // :71
     else { p.x = p.x + v.x * hs; p.y = p.y + v.y * hs; p.z = p.z + v.z * hs; }                           // :73
   }
-  pos[o] = p; vel[o] = v; pid[o] = spid[i];
+  pos[o] = p; vel[o] = v;
 }
 
 // k_compact<true> with the row histogram of the sort that follows (k_row_hist) counted on the way: SORT_RPT records per
 // thread like k_row_hist, so that a block's 2048 consecutive (cell-sorted) records hit a few dozen rows of the LDS table.
 // Records that the drift carries out of the chaining mesh are counted as deleted (link_list.f90:26-53), coarse cells with a
 // displaced record are flagged (see k_row_hist).
-__global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restrict__ spos, const float4 *__restrict__ svel, const int64_t *__restrict__ spid,
+__global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restrict__ spos, const float4 *__restrict__ vel_old,
                                                            const int *__restrict__ offs, int n, float Nn, float4 *__restrict__ pos, float4 *__restrict__ vel,
-                                                           int64_t *__restrict__ pid, float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off,
+                                                           float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off,
                                                            float nb, int E, int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt) {
   __shared__ int key[SORT_HB], val[SORT_HB];
   __shared__ int wc[SORT_RPT][PT / 64];
@@ -749,10 +783,11 @@ __global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restr
       p.x -= mx; p.y -= my; p.z -= mz;
       int o = offs[blockIdx.x * SORT_RPT + u] + rk[u];   // offs: first destination of every block of PT records
       for (int w = 0; w < wv; w++) o += wc[u][w];
-      const float4 v = svel[i];
+      const int src = rec_index(p);
+      const float4 v = vel_old[src];   // its fourth lane is the PID slot: it travels with the velocity
       if (use_off) { p.x = p.x + v.x * hs + ox; p.y = p.y + v.y * hs + oy; p.z = p.z + v.z * hs + oz; }  // update_position.f90:71
       else { p.x = p.x + v.x * hs; p.y = p.y + v.y * hs; p.z = p.z + v.z * hs; }                           // :73
-      pos[o] = p; vel[o] = v; pid[o] = spid[i];
+      pos[o] = p; vel[o] = v;
       if (in_hoc_range(p, -nb, Nn + nb)) {
         row = ((int)floorf(p.z) + (int)nb) * E + (int)floorf(p.y) + (int)nb;
         if (cflag && p.x >= 0.f && p.x < Nn && p.y >= 0.f && p.y < Nn && p.z >= 0.f && p.z < Nn) flag_displaced(p, nb, E, ms, pt, cflag);
@@ -825,19 +860,21 @@ int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const floa
     // the sort follows: count its x-rows here and in the kernels that append the ghosts (c->hist_done)
     P3M_TRY(particles_hist_begin(c));
     const Geometry &g = c->g;
-    hipLaunchKernelGGL(k_compact_drift_hist, dim3(cdiv(n, PT * SORT_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel, (const int64_t *)c->spid,
-                       (const int *)c->flags, n, (float)g.Nn, c->pos, c->vel, c->pid, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
+    hipLaunchKernelGGL(k_compact_drift_hist, dim3(cdiv(n, PT * SORT_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->vel,
+                       (const int *)c->flags, n, (float)g.Nn, c->tpos, c->vel_alt, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
                        offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0, (float)g.nb, g.E, c->row_end, c->d_counters + 4,
                        (c->p.flags & P3M_FLAG_PPINT) ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
     c->hist_done = true;
   } else if (drift)
-    hipLaunchKernelGGL(k_compact<true>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel, (const int64_t *)c->spid,
-                       (const int *)c->flags, n, (float)c->g.Nn, c->pos, c->vel, c->pid, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
+    hipLaunchKernelGGL(k_compact<true>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->vel,
+                       (const int *)c->flags, n, (float)c->g.Nn, c->tpos, c->vel_alt, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
                        offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0);
   else
-    hipLaunchKernelGGL(k_compact<false>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->svel, (const int64_t *)c->spid,
-                       (const int *)c->flags, n, (float)c->g.Nn, c->pos, c->vel, c->pid, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], 0.f, 0.f, 0.f, 0.f, 0);
+    hipLaunchKernelGGL(k_compact<false>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->vel,
+                       (const int *)c->flags, n, (float)c->g.Nn, c->tpos, c->vel_alt, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], 0.f, 0.f, 0.f, 0.f, 0);
   HIP_TRY(hipGetLastError());
+  // the new arrival arrays were written into the buffers of the sort's intermediate; the old ones take over that role
+  std::swap(c->pos, c->tpos); std::swap(c->vel, c->vel_alt);
   return P3M_OK;
 }
 int particles_resolve(p3m_ctx *c) { return particles_compact(c, false, 0.f, 0.f, nullptr); }

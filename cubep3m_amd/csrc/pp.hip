@@ -53,7 +53,7 @@ __device__ __forceinline__ void ref_bucket(const float4 &p, const PPGeo &G, int 
 // (v_readlane) per partner, each lane keeping the partners of its own cell -- instead of every lane streaming its whole
 // cell from global memory.  Same partner order per lane (ascending sorted index) as the per-lane loop.
 #define PP_INTRA_DENSE 12
-__global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs,
+__global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs,
                                                   const unsigned char *__restrict__ cflag, int n, PPGeo G, float mass_p, float a_mid, float dt,
                                                   float *__restrict__ fmax_out, float r2_soft) {
   const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
@@ -158,9 +158,9 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     (void)nct;
   }
   if (phys) {
-    float4 v = svel[s];
+    const int vi = __float_as_int(spos[s].w); float4 v = vel[vi];   // the velocity stays in arrival order (p3m_internal.h)
     v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
-    svel[s] = v;
+    vel[vi] = v;
     mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356
   }
   for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_down(mag, o, 64));
@@ -173,7 +173,7 @@ int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   const Geometry &g = c->g;
   if (c->np_all == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
-  hipLaunchKernelGGL(k_pp_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end,
+  hipLaunchKernelGGL(k_pp_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end,
                      (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1 * P3M_RED_SPAN, first_r2_with_root_above(G.rsoft));
   HIP_TRY(hipGetLastError());
   return P3M_OK;
@@ -186,7 +186,7 @@ int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
 // omission of the pairs inside the top pp_range planes), so the
 // per-tile maxval(|pp_ext_force_accum|) (:617) is reproduced including the partial sums of records
 // in the rim.  Only records whose cell is in the physical tile are kicked (:576-590).
-__global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G,
+__global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G,
                                                float mass_p, float a_mid, float dt, float *__restrict__ tile_max) {
   const int e = G.pt + 2 * G.ppr;
   const int ry = blockIdx.x % e, rz = (blockIdx.x / e) % e, tile = blockIdx.x / (e * e);
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
       }
     const bool phys = (cx >= lox + G.ppr && cx < lox + G.ppr + G.pt && ry >= G.ppr && ry < G.ppr + G.pt && rz >= G.ppr && rz < G.ppr + G.pt);
     if (phys) {                                                                   // :576-582
-      float4 v = svel[s];
+      const int vi = __float_as_int(spos[s].w); float4 v = vel[vi];   // the velocity stays in arrival order (p3m_internal.h)
       v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
-      svel[s] = v;
+      vel[vi] = v;
     }
     mymax = fmaxf(mymax, sqrtf(ax * ax + ay * ay + az * az));                     // :617
   }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
 #define PB_Z 4
 #define PPT_CAP 2048    // staged records per block
 #define PP_LPH 2        // lanes per home record
-__global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G,
+__global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G,
                                                       float mass_p, float a_mid, float dt, float *__restrict__ tile_max, int bx_cells, int nbx, int nby,
                                                       float r2_soft, float r2_taper) {
   extern __shared__ int lds_i[];
@@ -392,9 +392,9 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
       const int ry = cy - loy, rz = cz - loz;
       const bool phys = (cx >= lox + ppr && cx < lox + ppr + G.pt && ry >= ppr && ry < ppr + G.pt && rz >= ppr && rz < ppr + G.pt);
       if (phys) {                                                                   // :576-582
-        float4 v = svel[s];
+        const int vi = __float_as_int(spos[s].w); float4 v = vel[vi];   // the velocity stays in arrival order (p3m_internal.h)
         v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
-        svel[s] = v;
+        vel[vi] = v;
       }
       mymax = fmaxf(mymax, sqrtf(ax * ax + ay * ay + az * az));                     // :617
     }
@@ -463,7 +463,7 @@ __device__ __forceinline__ void pp_ext_eval(const float4 &p, float ox, float oy,
   }
 }
 template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
-__global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos, float4 *__restrict__ svel, const int *__restrict__ cs, PPGeo G, PPForce F,
+__global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
                                                 float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
                                                 const int *__restrict__ task_group, int ngroups, int ngy, int nxb, int xbw, int ntask_cap, int *__restrict__ counter) {
   __shared__ int list[PP_LCAP][64];
@@ -612,9 +612,9 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
         const int ry = cy - loy;
         const bool phys = (cx >= lox + ppr && cx < lox + ppr + G.pt && ry >= ppr && ry < ppr + G.pt && rz >= ppr && rz < ppr + G.pt);
         if (phys) {                                                                   // :576-582
-          float4 v = svel[s];
+          const int vi = __float_as_int(spos[s].w); float4 v = vel[vi];   // the velocity stays in arrival order (p3m_internal.h)
           v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
-          svel[s] = v;
+          vel[vi] = v;
         }
         mag = sqrtf(ax * ax + ay * ay + az * az);                                     // :617
       }
@@ -675,10 +675,10 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     static const int wpc = getenv("P3M_PP_WPC") ? atoi(getenv("P3M_PP_WPC")) : 15;          // resident wavefronts per CU (10.4 KB of LDS each)
     static const bool unr = getenv("P3M_PP_UNROLL") && getenv("P3M_PP_UNROLL")[0] == '1';    // compile-time reach: all 25 windows loaded up front (116 VGPRs)
     if (g.pp_range == 2 && unr)
-      hipLaunchKernelGGL(k_pp_ext2<2>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, F, a_mid, dt,
+      hipLaunchKernelGGL(k_pp_ext2<2>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
                          c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, nxb, xbw, ntask_cap, c->pp_counter);
     else
-      hipLaunchKernelGGL(k_pp_ext2<0>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, F, a_mid, dt,
+      hipLaunchKernelGGL(k_pp_ext2<0>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
                          c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, nxb, xbw, ntask_cap, c->pp_counter);
     HIP_TRY(hipGetLastError());
     return P3M_OK;
@@ -694,13 +694,13 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     const size_t lds = sizeof(int) * (4 * HR + PB_Y * PB_Z + 1 + ((HR * wseg + 3) & ~3) + 4) + sizeof(float4) * PPT_CAP;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pp_ext_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned blocks = (unsigned)((int64_t)g.ntiles * nbx * nby * nby);
-    hipLaunchKernelGGL(k_pp_ext_tiled, dim3(blocks), dim3(256), lds, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, mass_p, a_mid,
+    hipLaunchKernelGGL(k_pp_ext_tiled, dim3(blocks), dim3(256), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, mass_p, a_mid,
                        dt, c->d_tile_ext, bx_cells, nbx, nby, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f)));
     HIP_TRY(hipGetLastError());
     return P3M_OK;
   }
   const unsigned blocks = (unsigned)((int64_t)g.ntiles * e * e);
-  hipLaunchKernelGGL(k_pp_ext, dim3(blocks), dim3(64), 0, c->stream, (const float4 *)c->spos, c->svel, (const int *)c->cell_end, G, mass_p, a_mid,
+  hipLaunchKernelGGL(k_pp_ext, dim3(blocks), dim3(64), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, mass_p, a_mid,
                      dt, c->d_tile_ext);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
