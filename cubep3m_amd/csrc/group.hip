@@ -77,7 +77,7 @@ struct p3m_group {
   // transform then splits the kx chunks over the nd ranks that hold the same z planes (x<->y transpose) and ky over the nd^2
   // ranks that hold the same chunks (y<->z transpose).  plan_l: plan_c with the row pitch of the local chunks (shares the twiddles)
   bool pencil = false; int ncl = 0, rpp = 0, nxb = 0; FftPlan plan_l;
-  int seg_off[54] = {0}, seg_cap[54] = {0}; int64_t seg_total = 0;   // segments by slot (2m ghosts, 2m+1 migrants), offsets in float4 units
+  int64_t seg_off[54] = {0}; int seg_cap[54] = {0}; int64_t seg_total = 0;   // segments by slot (2m ghosts, 2m+1 migrants), offsets in float4 units
   int *h_cnt = nullptr;        // pinned [nlocal*4]
   int *d_gather = nullptr, *h_gather = nullptr, *h_hdr = nullptr;   // ghost pass: [nodes][64] counts of every rank (device, pinned), [nlocal] pinned headers
   float *d_red4 = nullptr; double *d_sum3 = nullptr; float *h_red4 = nullptr; double *h_sum3 = nullptr;
@@ -289,10 +289,10 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
         // migrants: records that left the rank through this face / edge / corner in one step -- or, with -DMOVE_GRID_BACK
         // (ghosts can turn physical when the grid moves back), every image
         const int64_t capm = nz == 0 ? 0 : ((base->flags & P3M_FLAG_MOVE_GRID_BACK) ? cap : cap / 4 + (f0 < 1.0 ? 16 : 4096));
-        G->seg_off[2 * m] = (int)run; G->seg_cap[2 * m] = (int)cap; run += cap;                 // ghosts: one float4 each
-        G->seg_off[2 * m + 1] = (int)run; G->seg_cap[2 * m + 1] = (int)capm; run += 2 * capm;   // migrants: two
+        G->seg_off[2 * m] = run; G->seg_cap[2 * m] = (int)cap; run += cap;                 // ghosts: one float4 each
+        G->seg_off[2 * m + 1] = run; G->seg_cap[2 * m + 1] = (int)capm; run += 2 * capm;   // migrants: two
       }
-      if (run > 0x3fffffff) return fail(P3M_ECAPACITY);
+      if (run > ((int64_t)1 << 36)) { p3m_set_error("ghost segments of %lld records exceed the exchange buffer limit", (long long)run); return fail(P3M_ECAPACITY); }
       G->seg_total = run;
     }
     if (galloc(&G->d_gather, (size_t)64 * nodes) != P3M_OK) return fail(P3M_ENOMEM);
@@ -389,7 +389,7 @@ static int shift_neighbour(const p3m_group *G, int r, int m) {
 // segment layout from the capacities: slot k = 2m (ghosts, one float4 each) or 2m+1 (migrants, two)
 static int64_t layout_segments(p3m_group *G) {
   int64_t run = 0;
-  for (int k = 0; k < 54; k++) { G->seg_off[k] = (int)run; run += (int64_t)G->seg_cap[k] * ((k & 1) ? 2 : 1); }
+  for (int k = 0; k < 54; k++) { G->seg_off[k] = run; run += (int64_t)G->seg_cap[k] * ((k & 1) ? 2 : 1); }
   return run;
 }
 static int ghost_pass(p3m_group *G) {
@@ -444,7 +444,7 @@ static int ghost_pass(p3m_group *G) {
     for (int k = 2; k < 54; k++)
       if (need[k] > G->seg_cap[k]) G->seg_cap[k] = (int)std::min<int64_t>(cap, (int64_t)need[k] + need[k] / 4 + 1024);
     const int64_t run = layout_segments(G);
-    if (run > 0x3fffffff) { p3m_set_error("ghost segments of %lld records exceed the exchange buffer limit", (long long)run); return P3M_ECAPACITY; }
+    if (run > ((int64_t)1 << 36)) { p3m_set_error("ghost segments of %lld records exceed the exchange buffer limit", (long long)run); return P3M_ECAPACITY; }
     G->seg_total = run;
     HIP_TRY(hipStreamSynchronize(G->stream));
     for (int i = 0; i < nl; i++) {
@@ -963,6 +963,59 @@ extern "C" int p3m_hip_group_set_kernel_tables(p3m_group *G, const float *fine_t
   G->have_k = true;
   return P3M_OK;
 }
+// kern_c z-slabs of the reference (kern_c(3, nc/2+1, nc, nc_slab), kernel_checkpoint.f90) -> every rank's ky slab in the bundle layout:
+// recv [q][comp][kyl][kzl][px] (q: the rank whose z-slab the block came from) -> kern [comp][kyl][chunk][q*s + kzl][16]
+__global__ __launch_bounds__(256) void k_kern_scatter(const float *__restrict__ recv, float *__restrict__ kern, int nodes, int s, int px, int nc, int64_t kcs) {
+  const int64_t per = (int64_t)3 * s * s * px, idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= per * nodes) return;
+  const int q = (int)(idx / per); int64_t r = idx - q * per;
+  const int x = (int)(r % px); r /= px; const int kzl = (int)(r % s); r /= s; const int kyl = (int)(r % s); const int comp = (int)(r / s);
+  kern[comp * kcs + (((int64_t)kyl * (px / 16) + x / 16) * nc + (q * s + kzl)) * 16 + x % 16] = recv[idx];
+}
+int kernels_set_fine_raw(p3m_ctx *c, const float *kern_f);   // p3m_api.hip
+extern "C" int p3m_hip_group_set_kernels_raw(p3m_group *G, const float *kern_f, const float *const *kern_c_slabs) {
+  if (!G || !kern_f || !kern_c_slabs) return P3M_EINVAL;
+  HIP_TRY(hipSetDevice(G->device));
+  if (G->nodes == 1) return p3m_hip_set_kernels_raw(G->ctx[0], kern_f, kern_c_slabs[0]);
+  if (G->pencil) { p3m_set_error("set_kernels_raw: kern_c z-slabs do not map onto the pencil decomposition (build the kernels from the tables)"); return P3M_EINVAL; }
+  if (!(G->base.flags & P3M_FLAG_COARSE_ONLY)) {
+    P3M_TRY(kernels_set_fine_raw(G->ctx[0], kern_f));
+    const Geometry &g0 = G->ctx[0]->g;
+    for (size_t i = 1; i < G->ctx.size(); i++) {
+      HIP_TRY(hipMemcpyAsync(G->ctx[i]->kern_f, G->ctx[0]->kern_f, sizeof(float) * 3 * g0.nf * g0.nf * g0.px, hipMemcpyDeviceToDevice, G->stream));
+      G->ctx[i]->have_kf = true;
+    }
+  }
+  const Geometry &g = G->ctx[0]->g;
+  const int nl = (int)G->ctx.size(), s = G->s, nc = g.nc, hx = nc / 2 + 1, px = G->plan_c.px;
+  const size_t blkf = (size_t)3 * s * s * px;                        // floats of one (source slab, destination slab) block
+  if ((size_t)G->nodes * blkf > 3 * (size_t)s * G->ncl * nc * 16 * 2) { p3m_set_error("set_kernels_raw: staging too small"); return P3M_EINVAL; }
+  std::vector<float> host((size_t)G->nodes * blkf);
+  for (int i = 0; i < nl; i++) {
+    const float *slab = kern_c_slabs[i];
+    if (!slab) return P3M_EINVAL;
+    std::fill(host.begin(), host.end(), 0.f);
+    for (int t = 0; t < G->nodes; t++)
+      for (int comp = 0; comp < 3; comp++) for (int kyl = 0; kyl < s; kyl++) for (int kzl = 0; kzl < s; kzl++) {
+        float *dst = host.data() + (size_t)t * blkf + (((size_t)comp * s + kyl) * s + kzl) * px;
+        const float *src = slab + (((size_t)kzl * nc + (size_t)(t * s + kyl)) * hx) * 3 + comp;   // kern_c(comp, kx, ky, kz local), component fastest
+        for (int x = 0; x < hx; x++) dst[x] = src[(size_t)x * 3];
+      }
+    HIP_TRY(hipMemcpyAsync(G->cd[i].send, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice, G->stream));
+    HIP_TRY(hipStreamSynchronize(G->stream));
+  }
+  P3M_TRY(group_exchange(G, G->nodes, blkf * sizeof(float), [&](int r, int j) { (void)r; return j; }, [&](int r) { return r; },
+                         [&](int li) { return (const char *)G->cd[li].send; }, [&](int li) { return (char *)G->cd[li].recv; }));
+  for (int i = 0; i < nl; i++) {
+    hipLaunchKernelGGL(k_kern_scatter, dim3(cdiv((int64_t)G->nodes * blkf, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].recv, G->cd[i].kern, G->nodes, s, px, nc,
+                       (int64_t)(G->cstride / 2));
+    HIP_TRY(hipGetLastError());
+    G->ctx[i]->have_kc = true;
+  }
+  HIP_TRY(hipStreamSynchronize(G->stream));
+  G->have_k = true;
+  return P3M_OK;
+}
 extern "C" int p3m_hip_group_upload_particles(p3m_group *G, int32_t i, const float *xv6, const int64_t *pid, int32_t np) {
   if (!G || i < 0 || i >= (int)G->ctx.size()) return P3M_EINVAL;
   return p3m_hip_upload_particles(G->ctx[i], xv6, pid, np);
@@ -1027,9 +1080,18 @@ extern "C" int p3m_hip_group_update_position(p3m_group *G, float dt, float dt_ol
 }
 
 // subroutine particle_mesh on every local rank (particle_mesh_threaded.f90:2-726)
+static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float dt_old, float mass_p, const float *offset, const float *move_back, p3m_step_out *out);
 extern "C" int p3m_hip_group_particle_mesh(p3m_group *G, float a_mid, float dt, float dt_old, float mass_p, const float *offset,
                                            const float *move_back, p3m_step_out *out) {
   if (!G) return P3M_EINVAL;
+  const int r = group_particle_mesh_step(G, a_mid, dt, dt_old, mass_p, offset, move_back, out);
+  if (r != P3M_OK && r != P3M_ESTATE && G->nodes > 1) {   // e.g. P3M_ECAPACITY in the ghost pass: images may already be counted into the row histogram
+    for (p3m_ctx *c : G->ctx) particles_reset_after_error(c);
+    if (G->stream2) (void)hipStreamSynchronize(G->stream2);
+  }
+  return r;
+}
+static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float dt_old, float mass_p, const float *offset, const float *move_back, p3m_step_out *out) {
   HIP_TRY(hipSetDevice(G->device));
   if (G->nodes == 1) return p3m_hip_particle_mesh(G->ctx[0], a_mid, dt, dt_old, mass_p, offset, move_back, out);
   if (G->base.flags & P3M_FLAG_COARSE_ONLY) { p3m_set_error("particle_mesh on a P3M_FLAG_COARSE_ONLY group (it holds the coarse mesh only)"); return P3M_ESTATE; }
@@ -1099,7 +1161,8 @@ extern "C" int p3m_hip_group_projection(p3m_group *G, float mass_p, float *pxy, 
     for (p3m_ctx *c : G->ctx) { double t = 0.0; P3M_TRY(projection_rank(c, mass_p, d, d + n2, d + 2 * n2, &t)); tot += t; }
     for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize(c, nullptr));
     if (G->nodes > 1 && G->nprocs > 1) {
-      if (G->have_tr) { if (G->tr.allreduce_sum_f64(G->tr.user, &tot, 1)) return P3M_ECOMM; }
+      if (!G->comm && G->have_tr) { if (G->tr.allreduce_sum_f64(G->tr.user, &tot, 1)) return P3M_ECOMM; }
+      else if (!G->comm) { p3m_set_error("group reduction between processes needs RCCL or a host transport"); return P3M_ECOMM; }
       else {
         HIP_TRY(hipMemcpyAsync(G->d_sum3, &tot, sizeof(double), hipMemcpyHostToDevice, G->stream));
         NCCL_TRY(ncclAllReduce(G->d_sum3, G->d_sum3, 1, ncclDouble, ncclSum, G->comm, G->stream));
@@ -1248,10 +1311,12 @@ extern "C" int p3m_hip_group_coarse_power(p3m_group *G, float mass_p, float box,
       c->stream = keep;
       P3M_TRY(r);
     }
-    if (G->nprocs > 1 && G->comm && !G->have_tr) NCCL_TRY(ncclAllReduce(d_ps, d_ps, 2 * nb, ncclDouble, ncclSum, G->comm, G->stream));
+    // the same choice as reduce_step_out and do_exchange: RCCL when there is a communicator, the host transport otherwise
+    const bool use_tr = G->nprocs > 1 && !G->comm && G->have_tr;
+    if (G->nprocs > 1 && G->comm) NCCL_TRY(ncclAllReduce(d_ps, d_ps, 2 * nb, ncclDouble, ncclSum, G->comm, G->stream));
     HIP_TRY(hipMemcpyAsync(acc.data(), d_ps, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, G->stream));
     HIP_TRY(hipStreamSynchronize(G->stream));
-    if (G->nprocs > 1 && G->have_tr) { if (G->tr.allreduce_sum_f64(G->tr.user, acc.data(), 2 * nb)) { p3m_set_error("host transport: all-reduce callback failed"); return P3M_ECOMM; } }
+    if (use_tr) { if (G->tr.allreduce_sum_f64(G->tr.user, acc.data(), 2 * nb)) { p3m_set_error("host transport: all-reduce callback failed"); return P3M_ECOMM; } }
     else if (G->nprocs > 1 && !G->comm) { p3m_set_error("group reduction between processes needs RCCL or a host transport"); return P3M_ECOMM; }
     return P3M_OK;
   };

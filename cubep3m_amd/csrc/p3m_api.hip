@@ -204,9 +204,19 @@ static void kern_from_device(const float *planes, float *aos, int n, int hx, int
     aos[((((size_t)z * n + y) * hx) + x) * 3 + comp] = planes[comp * plane + lz_index(n, px, x, y, z)];
 }
 
+// kern_f in the reference's layout -> this context's device planes (also used by p3m_hip_group_set_kernels_raw)
+int kernels_set_fine_raw(p3m_ctx *c, const float *kern_f) {
+  const Geometry &g = c->g;
+  const size_t nf = (size_t)g.nf * g.nf * g.px;
+  std::vector<float> tmp(3 * nf);
+  kern_to_device(kern_f, tmp.data(), g.nf, g.hx, g.px);
+  HIP_TRY(hipMemcpy(c->kern_f, tmp.data(), sizeof(float) * 3 * nf, hipMemcpyHostToDevice));
+  c->have_kf = true;
+  return P3M_OK;
+}
 extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const float *kern_c) {
   if (!c || !kern_f || !kern_c) return P3M_EINVAL;
-  if (c->g.nodes != 1) { p3m_set_error("set_kernels_raw: single-rank contexts only"); return P3M_EINVAL; }
+  if (c->g.nodes != 1) { p3m_set_error("set_kernels_raw: single-rank contexts only (groups: p3m_hip_group_set_kernels_raw)"); return P3M_EINVAL; }
   HIP_TRY(hipSetDevice(c->device));
   const Geometry &g = c->g;
   const size_t nf = (size_t)g.nf * g.nf * g.px, ncx = (size_t)g.nc * g.nc * g.pxc;
@@ -309,7 +319,9 @@ extern "C" int p3m_hip_update_position(p3m_ctx *c, float dt, float dt_old, const
 extern "C" int p3m_hip_link_list_and_pass(p3m_ctx *c) {
   if (!c) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
-  return particles_pass_and_sort(c);
+  const int r = particles_pass_and_sort(c);
+  if (r != P3M_OK) particles_reset_after_error(c);   // e.g. P3M_ECAPACITY after the images were counted into the row histogram
+  return r;
 }
 
 static int fine_sweep(p3m_ctx *c, float mass_p) {
@@ -447,9 +459,22 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
   return P3M_OK;
 }
 
+// after an error in the middle of a step: nothing that was queued for "later" may be trusted by the next call -- the next sort
+// counts its rows itself (k_row_hist), no survivor counts, no deferred counters, no half-finished ghost removal
+void particles_reset_after_error(p3m_ctx *c) {
+  c->hist_done = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+}
+static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, float mass_p, const float *offset, const float *move_back, p3m_step_out *out);
 extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt_old, float mass_p, const float *offset,
                                      const float *move_back, p3m_step_out *out) {
   if (!c) return P3M_EINVAL;
+  const int r = particle_mesh_step(c, a_mid, dt, dt_old, mass_p, offset, move_back, out);
+  if (r != P3M_OK && r != P3M_ESTATE && r != P3M_ECOMM && r != P3M_EINVAL) particles_reset_after_error(c);   // the three leave before the first state change
+  return r;
+}
+static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, float mass_p, const float *offset, const float *move_back, p3m_step_out *out) {
   P3M_TRY(need_kernels(c));
   // every parameter / state check comes before the first state change (the drift)
   if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }

@@ -170,14 +170,15 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass);   // the device half
 int particles_sort_finish(p3m_ctx *c, bool wait);             // ... and the host half (wait: one stream sync for the exact counters; else deferred)
 void particles_collect_counters(p3m_ctx *c);                  // deferred counters, after the step's synchronisation
 int particles_full_cells(p3m_ctx *c);   // cell_end valid again after a sort that wrote the compact table only
-int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts);
-int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base);
+int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int64_t *seg_off, const int *seg_cap, int *d_counts);
+int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int64_t *seg_off, const int *cnt, int base);
 int particles_finalize(p3m_ctx *c, const float *move_back);
 int particles_finalize_enqueue(p3m_ctx *c, const float *move_back);
 int particles_finalize_finish(p3m_ctx *c, bool wait);
 int particles_preload();
 int scan_reserve(p3m_ctx *c, int64_t n_max);   // scan.hip
 int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset);
+void particles_reset_after_error(p3m_ctx *c);   // p3m_api.hip: consistent state after a step that failed half-way
 int particles_resolve(p3m_ctx *c);   // finish a deferred ghost removal before the arrival arrays are read
 
 // ---- fine_mesh.hip

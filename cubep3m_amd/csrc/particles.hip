@@ -518,7 +518,7 @@ int particles_pass_and_sort(p3m_ctx *c) {
 // rank's volume: its image is PHYSICAL at the destination and survives there) travels with everything:
 // {x,y,z,vx | vy,vz,pid}.  Coordinates are final in both.
 #define GSLOTS 54
-struct GhostSegs { int off[GSLOTS]; int cap[GSLOTS]; };   // float4 offset / record capacity of each slot's segment in the send and receive buffers
+struct GhostSegs { int64_t off[GSLOTS]; int cap[GSLOTS]; };   // float4 offset / record capacity of each slot's segment in the send and receive buffers
 // the (at most one, since Nn >= 2 nb) shift of a coordinate: 0 none, 1 image at the + neighbour, 2 at the - neighbour
 __device__ __forceinline__ int axis_shift(float x, float Nn, float nb, float *img) {
   if (x >= Nn - nb) { *img = fmaxf(x - Nn, -nb); return 1; }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
   }
 }
 // appends the received segments: blockIdx.y = slot - 2; dst[k] = first record index of that segment in pos/vel/pid
-struct GhostIn { int off[GSLOTS]; int cnt[GSLOTS]; int dst[GSLOTS]; int slot0[GSLOTS]; };   // slot0: first pid_home slot of a migrant segment
+struct GhostIn { int64_t off[GSLOTS]; int cnt[GSLOTS]; int dst[GSLOTS]; int slot0[GSLOTS]; };   // slot0: first pid_home slot of a migrant segment
 template <bool HIST>   // HIST: the arrivals' x-rows are counted on the way (see hist_row)
 __global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ rbuf, GhostIn T, float4 *__restrict__ pos, float4 *__restrict__ vel,
                                                      int64_t *__restrict__ pid_home, float Nn, float nb, int E, int *__restrict__ rs,
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(PT) void k_ghost_unpack(const float4 *__restrict__ 
   }
   if (HIST) { __syncthreads(); hist_flush(key, val, rs); }
 }
-int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int *seg_off, const int *seg_cap, int *d_counts) {
+int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int64_t *seg_off, const int *seg_cap, int *d_counts) {
   P3M_TRY(particles_resolve(c));
   if (c->np_local == 0) return P3M_OK;
   GhostSegs S; for (int k = 0; k < GSLOTS; k++) { S.off[k] = seg_off[k]; S.cap[k] = seg_cap[k]; }
@@ -658,7 +658,7 @@ static int pid_repack(p3m_ctx *c) {
   c->n_home = n;
   return P3M_OK;
 }
-int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int *seg_off, const int *cnt, int base) {
+int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int64_t *seg_off, const int *cnt, int base) {
   GhostIn T; int mx = 0, run = base; int64_t nmig = 0;
   for (int k = 2; k < GSLOTS; k += 1) if (k & 1) nmig += cnt[k];
   if ((int64_t)c->n_home + nmig > c->cap) P3M_TRY(pid_repack(c));   // cap >= np_local + arrivals was checked by the caller

@@ -659,12 +659,11 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
     const int64_t ngroups_max = (int64_t)g.ntiles * e * ngy * ((e + 3) / 4);
     if (ngroups_max > 0x3fffffff) { p3m_set_error("extended PP: too many row groups"); return P3M_EINVAL; }
-    if (!c->pp_plan) {
-      HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
-      HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)(mult * (c->cap / 64 + 1) + ngroups_max + 64)));   // any patch width
-      HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
-      P3M_TRY(scan_reserve(c, ngroups_max + 8));
-    }
+    // each buffer under its own check: a failed allocation must not leave the others looking ready
+    if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
+    if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)(mult * (c->cap / 64 + 1) + ngroups_max + 64)));   // any patch width
+    if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
+    P3M_TRY(scan_reserve(c, ngroups_max + 8));
     HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
     hipLaunchKernelGGL(k_pp_plan, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, ngy, nxb, xbw, ngroups, c->pp_plan);
     HIP_TRY(hipGetLastError());
@@ -762,27 +761,36 @@ extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, 
   const Geometry &g = c->g;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   unsigned long long *d_cnt = nullptr, h_cnt[2] = {0, 0};
-  HIP_TRY(hipMalloc(&d_cnt, 2 * sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
-  if (c->np_all > 0) {
-    hipLaunchKernelGGL(k_pp_count_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->np_all, G, d_cnt);
-    const int e = g.pt + 2 * g.pp_range;
-    if (g.pp_range > 0)
-      hipLaunchKernelGGL(k_pp_count_ext, dim3((unsigned)((int64_t)g.ntiles * e * e)), dim3(64), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, G, d_cnt + 1);
-  }
-  HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, c->stream));
-  hipEvent_t e0, e1, e2;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
-  P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); P3M_TRY(pp_extended(c, a_mid, dt, mass_p));   // warm-up
-  HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < reps; i++) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
-  HIP_TRY(hipEventRecord(e1, c->stream));
-  for (int i = 0; i < reps; i++) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
-  HIP_TRY(hipEventRecord(e2, c->stream));
-  HIP_TRY(hipEventSynchronize(e2));
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   float a = 0.f, b = 0.f;
-  HIP_TRY(hipEventElapsedTime(&a, e0, e1)); HIP_TRY(hipEventElapsedTime(&b, e1, e2));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipFree(d_cnt);
+  auto body = [&]() -> int {   // every early return leaves through the clean-up below
+    HIP_TRY(hipMalloc(&d_cnt, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
+    if (c->np_all > 0) {
+      hipLaunchKernelGGL(k_pp_count_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->np_all, G, d_cnt);
+      const int e = g.pt + 2 * g.pp_range;
+      if (g.pp_range > 0)
+        hipLaunchKernelGGL(k_pp_count_ext, dim3((unsigned)((int64_t)g.ntiles * e * e)), dim3(64), 0, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, G, d_cnt + 1);
+    }
+    HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+    P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); P3M_TRY(pp_extended(c, a_mid, dt, mass_p));   // warm-up
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; i++) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    for (int i = 0; i < reps; i++) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
+    HIP_TRY(hipEventRecord(e2, c->stream));
+    HIP_TRY(hipEventSynchronize(e2));
+    HIP_TRY(hipEventElapsedTime(&a, e0, e1)); HIP_TRY(hipEventElapsedTime(&b, e1, e2));
+    return P3M_OK;
+  };
+  const int rc = body();
+  if (rc != P3M_OK) (void)hipStreamSynchronize(c->stream);   // h_cnt lives on this frame
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e2) (void)hipEventDestroy(e2);
+  if (d_cnt) (void)hipFree(d_cnt);
+  P3M_TRY(rc);
   *ms_intra = a / reps; *ms_ext = b / reps; *evals_intra = (int64_t)h_cnt[0]; *evals_ext = (int64_t)h_cnt[1];
   return P3M_OK;
 }

@@ -91,14 +91,23 @@ extern "C" int p3m_hip_timestep(const p3m_time_params *P, uint32_t flags, p3m_ti
     S->da = da_1 + da_2;
     S->a_mid = S->a + (S->da / 2);                      // :168
     S->tau = S->tau + dt; S->t = S->t + dt; S->a = S->a + S->da;   // :193-195
-  } else {                                              // :197-216 (pair_infall / pairwise_ic / shake_test_ic runs are not built)
+  } else {                                              // :197-216
     S->a = 1.0f; S->a_mid = S->a; S->da = 0.0f;
-    float dt = fminf(1.0f, dt_f_acc);
-    if (ppint) dt = fminf(dt, dt_pp_acc);
-    if (ppext) dt = fminf(dt, dt_pp_ext_acc);
-    dt = fminf(dt, dt_c_acc);
+    float dt;
+    if (ppint && P->pair_infall) {                      // :204-206: min(0.05/sqrt(G*mass_p/cur_sep**2), dt_f_acc, dt_pp_acc, dt_c_acc)
+      dt = fminf(0.05f / sqrtf(P3M_G_F * P->mass_p / (P->cur_sep * P->cur_sep)), dt_f_acc);
+      dt = fminf(dt, dt_pp_acc);
+      dt = fminf(dt, dt_c_acc);
+    } else {                                            // :208-214
+      dt = fminf(1.0f, dt_f_acc);
+      if (ppint) dt = fminf(dt, dt_pp_acc);
+      if (ppext) dt = fminf(dt, dt_pp_ext_acc);
+      dt = fminf(dt, dt_c_acc);
+    }
+    if (P->pairwise_ic) dt = 1.0f;                      // :210
+    if (P->shake_test_ic) dt = 1.0f;                    // :211
     S->dt = dt;
-    S->t = S->t + dt;
+    S->t = S->t + dt;                                   // :212
   }
   return P3M_OK;
 }

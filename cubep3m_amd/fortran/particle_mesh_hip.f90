@@ -6,13 +6,15 @@
 !! The host keeps cubep3m's decomposition, time-step loop, RNG, I/O; this file is a thin
 !! ISO_C_BINDING shim over include/p3m_hip.h.  Single-rank builds (nodes_dim = 1); multi-rank hosts
 !! additionally hand the library a transport (include/p3m_hip.h, p3m_transport).
-!! RESIDENT PARTICLES: between output steps the host never reads xv (cubepm.f90:103-236 only touches it through
-!! particle_mesh, and on checkpoint / projection / halofind steps through update_position, checkpoint, link_list, ...), so
-!! the particles stay on the device: they are uploaded when the host's copy is the newer one (first call, and the call after
-!! an output step, where cubepm.f90:175-176 drifted xv on the host) and downloaded only when the host is about to read them
-!! (checkpoint_step .or. projection_step .or. halofind_step .or. final_step, COMMON /lvar/; or the loop's other exits, nts ==
-!! max_nts and a > 1, cubepm.f90:235).  np_local follows the device every step.  P3M_HIP_RESIDENT=0 in the environment
-!! restores the copy-in / copy-out of every step (hosts with other readers of xv).
+!! RESIDENT PARTICLES (opt-in, P3M_HIP_RESIDENT=1): between output steps the main loop of cubepm.f90 (:103-236) never reads xv
+!! except through particle_mesh, and on checkpoint / projection / halofind steps through update_position, checkpoint,
+!! link_list, ...; with the switch on, the particles stay on the device: they are uploaded when the host's copy is the newer one
+!! (first call, and the call after an output step, where cubepm.f90:175-176 drifted xv on the host) and downloaded only when
+!! the flags in COMMON /lvar/ say the host reads them next (checkpoint_step .or. projection_step .or. halofind_step .or.
+!! final_step; or the loop's other exits, nts == max_nts and a > 1, cubepm.f90:235).  np_local follows the device every step.
+!! The DEFAULT is the copy-in / copy-out of every step, because not every reader of xv announces itself in COMMON:
+!! cubepm_kill.f90 decides `kill_step` AFTER particle_mesh returns (a local of its main program) and then writes xv through
+!! checkpoint_kill; a -DMHD host reads xv in its gas coupling.  Such hosts must leave the switch off.
 !! Compile with the reference's own flags, e.g.
 !!   flang -cpp -ffree-form -I<source_threads> -DNGP -DPPINT -DPP_EXT -DDISP_MESH -c particle_mesh_hip.f90
 subroutine particle_mesh
@@ -75,7 +77,7 @@ subroutine particle_mesh
 
   type(c_ptr), save :: ctx = c_null_ptr
   logical, save :: device_current = .false.   ! the device holds the particles the host's xv describes
-  logical, save :: resident = .true.
+  logical, save :: resident = .false.   ! opt-in: P3M_HIP_RESIDENT=1
   logical :: host_reads
   character(len=8) :: envv
   integer :: envl
@@ -113,7 +115,7 @@ subroutine particle_mesh
     ierr_c = p3m_hip_create(par, ctx)
     if (ierr_c /= 0) stop 'p3m_hip_create failed'
     call get_environment_variable('P3M_HIP_RESIDENT', envv, envl)
-    if (envl > 0) resident = (envv(1:1) /= '0')
+    if (envl > 0) resident = (envv(1:1) == '1')
     ! the same tables fine_kernel / coarse_kernel read (kernel_initialization.f90:15,344)
     open(unit=18, file=kernel_path//'wfxyzf.3.ascii', status='old', iostat=fstat)
     if (fstat /= 0) stop 'error opening fine mesh kernel'

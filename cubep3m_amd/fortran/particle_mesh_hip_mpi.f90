@@ -5,7 +5,7 @@
 !! host-transport callbacks of include/p3m_hip.h, implemented below with the MPI calls the host already has.
 !! (A host that links RCCL instead calls p3m_hip_group_comm_init_rccl with an id broadcast by MPI_Bcast and needs none
 !! of the callbacks.)  Particles stay resident on the device between output steps exactly as in particle_mesh_hip.f90 (see
-!! there); P3M_HIP_RESIDENT=0 restores the per-step copies.  Link instead of particle_mesh_threaded.o, with -lp3m_hip.  Compile like the reference:
+!! there: opt-in, P3M_HIP_RESIDENT=1; the default copies the particles in and out every step).  Link instead of particle_mesh_threaded.o, with -lp3m_hip.  Compile like the reference:
 !!   mpif90 -cpp -ffree-form -I<source_threads> -DNGP -DPPINT -DPP_EXT -DDISP_MESH -c particle_mesh_hip_mpi.f90
 module p3m_mpi_transport
   use iso_c_binding
@@ -128,7 +128,7 @@ subroutine particle_mesh
 
   type(c_ptr), save :: grp = c_null_ptr
   logical, save :: device_current = .false.   ! the device holds the particles the host's xv describes
-  logical, save :: resident = .true.
+  logical, save :: resident = .false.   ! opt-in: P3M_HIP_RESIDENT=1
   logical :: host_reads
   character(len=8) :: envv
   integer :: envl
@@ -171,7 +171,7 @@ subroutine particle_mesh
     ierr_c = p3m_hip_group_create(par, int(rank, c_int32_t), int(nodes, c_int32_t), grp)   ! process `rank` of `nodes`: one logical rank each
     if (ierr_c /= 0) stop 'p3m_hip_group_create failed'
     call get_environment_variable('P3M_HIP_RESIDENT', envv, envl)
-    if (envl > 0) resident = (envv(1:1) /= '0')
+    if (envl > 0) resident = (envv(1:1) == '1')
     tr%user = c_null_ptr
     tr%exchange = c_funloc(p3m_exchange)
     tr%allreduce_max_f32 = c_funloc(p3m_allreduce_max_f32)

@@ -138,6 +138,15 @@ class ParticleMeshGroup:
         _lib.check(self.L.p3m_hip_group_set_kernel_tables(self.h, np.ascontiguousarray(fine_table, np.float32),
                                                           np.ascontiguousarray(coarse_table, np.float32)))
 
+    def set_kernels_raw(self, kern_f, kern_c_slabs):
+        """kern_f (nf, nf, nf/2+1, 3) and, per LOCAL rank, its z-slab of kern_c (nc_slab, nc, nc/2+1, 3) -- the reference's arrays
+        (component fastest); collective over the processes of the group."""
+        kf = np.ascontiguousarray(kern_f, np.float32)
+        slabs = [np.ascontiguousarray(k, np.float32) for k in kern_c_slabs]
+        assert len(slabs) == self.nlocal
+        arr = (C.c_void_p * self.nlocal)(*[k.ctypes.data for k in slabs])
+        _lib.check(self.L.p3m_hip_group_set_kernels_raw(self.h, kf, arr))
+
     def comm_info(self):
         """{"comm_count", "comm_rank"} of the RCCL communicator (-1: none), the HIP device ordinal and its UUID."""
         cnt, rk, dev = C.c_int32(), C.c_int32(), C.c_int32()

@@ -31,7 +31,7 @@ EXPORTS = [
     "p3m_hip_group_ctx", "p3m_hip_group_set_kernel_tables", "p3m_hip_group_upload_particles", "p3m_hip_group_download_particles",
     "p3m_hip_group_particle_mesh", "p3m_hip_group_update_position", "p3m_hip_group_probe_coarse",
     "p3m_hip_group_set_coarse_density", "p3m_hip_group_coarse_transform", "p3m_hip_group_get_coarse_hat", "p3m_hip_group_get_coarse_force",
-    "p3m_hip_group_coarse_exchange_bytes", "p3m_hip_group_comm_info",
+    "p3m_hip_group_coarse_exchange_bytes", "p3m_hip_group_comm_info", "p3m_hip_group_set_kernels_raw",
     "p3m_hip_projection", "p3m_hip_group_projection", "p3m_hip_coarse_power", "p3m_hip_group_coarse_power", "p3m_hip_coarse_fft_schedule", "p3m_hip_write_power", "p3m_hip_write_projection", "p3m_hip_read_projection",
 ]
 
@@ -116,6 +116,7 @@ def load():
     L.p3m_hip_group_update_position.argtypes = [vp, f32, f32, vp]
     L.p3m_hip_group_probe_coarse.argtypes = [vp, f32, i32, vp, vp]
     L.p3m_hip_group_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p]
+    L.p3m_hip_group_set_kernels_raw.argtypes = [vp, f32p, C.POINTER(vp)]
     L.p3m_hip_group_set_coarse_density.argtypes = [vp, i32, f32p]
     L.p3m_hip_group_coarse_transform.argtypes = [vp, i32, i32, C.POINTER(f32)]
     L.p3m_hip_group_get_coarse_hat.argtypes = [vp, i32, vp, C.c_int64]

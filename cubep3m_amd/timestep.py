@@ -23,7 +23,8 @@ class P3MTimeParams(C.Structure):
     _fields_ = [("cosmo", C.c_int32), ("restrict_da", C.c_int32), ("omega_m", C.c_float), ("omega_l", C.c_float), ("wde", C.c_float),
                 ("dt_scale", C.c_float), ("dt_max", C.c_float), ("ra_max", C.c_float), ("da_max", C.c_float),
                 ("num_checkpoints", C.c_int32), ("num_projections", C.c_int32), ("num_halofinds", C.c_int32),
-                ("a_checkpoint", C.c_float * MAX_INPUT), ("a_projection", C.c_float * MAX_INPUT), ("a_halofind", C.c_float * MAX_INPUT)]
+                ("a_checkpoint", C.c_float * MAX_INPUT), ("a_projection", C.c_float * MAX_INPUT), ("a_halofind", C.c_float * MAX_INPUT),
+                ("pairwise_ic", C.c_int32), ("pair_infall", C.c_int32), ("shake_test_ic", C.c_int32), ("cur_sep", C.c_float), ("mass_p", C.c_float)]
 
 
 class P3MTimeState(C.Structure):
@@ -49,6 +50,12 @@ class TimeParams:
     a_projection: list = field(default_factory=list)
     a_halofind: list = field(default_factory=list)
     pad: float = 100.0       # value of the list entries past the end (see include/p3m_hip.h)
+    # the non-cosmological test runs of timestep.f90:197-216 (cubepm.par:61-68)
+    pairwise_ic: bool = False
+    pair_infall: bool = False
+    shake_test_ic: bool = False
+    cur_sep: float = 1.0
+    mass_p: float = 1.0
 
     def to_c(self) -> P3MTimeParams:
         c = P3MTimeParams(int(self.cosmo), int(self.restrict_da), self.omega_m, self.omega_l, self.wde, self.dt_scale, self.dt_max, self.ra_max,
@@ -60,6 +67,8 @@ class TimeParams:
             arr = getattr(c, name)
             for i in range(MAX_INPUT):
                 arr[i] = lst[i] if i < len(lst) else self.pad
+        c.pairwise_ic, c.pair_infall, c.shake_test_ic = int(self.pairwise_ic), int(self.pair_infall), int(self.shake_test_ic)
+        c.cur_sep, c.mass_p = self.cur_sep, self.mass_p
         return c
 
 

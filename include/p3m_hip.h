@@ -233,6 +233,11 @@ typedef struct p3m_time_params {
   /* scale factors of the output steps; timestep.f90 reads entry cur_* even past num_* (the
      reference leaves zeros there): callers pad with a value > 1                                    */
   float a_checkpoint[P3M_MAX_INPUT], a_projection[P3M_MAX_INPUT], a_halofind[P3M_MAX_INPUT];
+  /* the non-cosmological test runs (cosmo = 0, timestep.f90:197-216; cubepm.par:61-68): pairwise_ic / shake_test_ic force
+     dt = 1 (:210-211); pair_infall (with P3M_FLAG_PPINT) limits dt by 0.05 / sqrt(G mass_p / cur_sep^2) and leaves the
+     extended-PP limit out (:204-206); cur_sep is what report_pair.f90:49 measured last, the host keeps it current        */
+  int32_t pairwise_ic, pair_infall, shake_test_ic;
+  float cur_sep, mass_p;
 } p3m_time_params;
 typedef struct p3m_time_state {   /* the COMMON variables timestep.f90 reads and writes (cubepm.fh:19-29) */
   int32_t nts;
@@ -298,6 +303,11 @@ int p3m_hip_group_update_position(p3m_group *g, float dt, float dt_old, const fl
 int p3m_hip_group_particle_mesh(p3m_group *g, float a_mid, float dt, float dt_old, float mass_p,
                                 const float *offset, const float *move_back, p3m_step_out *out);
 int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho_c, float *force_c);
+/* Green's functions a multi-rank host already holds (kernel_checkpoint.f90 / a restart): kern_f as for p3m_hip_set_kernels_raw
+ * (identical on every rank), and kern_c_slabs[i] = the z-slab kern_c(3, nc_dim/2+1, nc_dim, nc_slab) of local rank i in the
+ * reference's layout (cubep3m.fh:56; kz = rank*nc_slab + local index).  The library keeps k space in transposed order (every rank
+ * owns a ky slab), so the slabs are redistributed once through the group's transport.  Slab decomposition only. */
+int p3m_hip_group_set_kernels_raw(p3m_group *g, const float *kern_f, const float *const *kern_c_slabs);
 /* The distributed coarse transform on its own (coarse_force.f90:18-90 through fftw3ds.f90:4-183 / p3dfft_coarse.f90), on any
  * group and in particular on a P3M_FLAG_COARSE_ONLY one (the literal 1024^3 slab FFT of BASELINE config 4):
  *   set_coarse_density  rho_c of local rank i from the host, float[ncn][ncn][ncn] (what coarse_mass leaves in rho_c)

@@ -1210,12 +1210,21 @@ void orc_timestep(const p3m_time_params *P, unsigned flags, p3m_time_state *S, f
   if (S->nts != 1) S->dt_old = S->dt;                              /* :21 */
   if (!P->cosmo) {                                                 /* :197-216 */
     S->a = 1.0f; S->a_mid = S->a; S->da = 0.0f;
-    dt = 1.0f;
-    if (dt_f_acc < dt) dt = dt_f_acc;
-    if ((flags & P3M_FLAG_PPINT) && dt_pp_acc < dt) dt = dt_pp_acc;
-    if ((flags & P3M_FLAG_PPINT) && (flags & P3M_FLAG_PP_EXT) && dt_pp_ext_acc < dt) dt = dt_pp_ext_acc;
-    if (dt_c_acc < dt) dt = dt_c_acc;
-    S->dt = dt; S->t += dt;
+    if ((flags & P3M_FLAG_PPINT) && P->pair_infall) {              /* :204-206 */
+      dt = 0.05f / sqrtf(G_F * P->mass_p / (P->cur_sep * P->cur_sep));
+      if (dt_f_acc < dt) dt = dt_f_acc;
+      if (dt_pp_acc < dt) dt = dt_pp_acc;
+      if (dt_c_acc < dt) dt = dt_c_acc;
+    } else {                                                       /* :208-214 */
+      dt = 1.0f;
+      if (dt_f_acc < dt) dt = dt_f_acc;
+      if ((flags & P3M_FLAG_PPINT) && dt_pp_acc < dt) dt = dt_pp_acc;
+      if ((flags & P3M_FLAG_PPINT) && (flags & P3M_FLAG_PP_EXT) && dt_pp_ext_acc < dt) dt = dt_pp_ext_acc;
+      if (dt_c_acc < dt) dt = dt_c_acc;
+    }
+    if (P->pairwise_ic) dt = 1.0f;                                 /* :210 */
+    if (P->shake_test_ic) dt = 1.0f;                               /* :211 */
+    S->dt = dt; S->t += dt;                                        /* :212 */
     return;
   }
   dt_e = P->dt_max;                                                /* :59 */

@@ -494,3 +494,98 @@ def test_per_rank_coarse_path_stays_at_parity():
                        env=dict(os.environ, P3M_COARSE_PER_RANK="1"), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_group_takes_the_kernels_a_host_already_holds():
+    """p3m_hip_group_set_kernels_raw: kern_f and every rank's z-slab of kern_c in the reference's layout (what kernel_checkpoint.f90
+    writes) instead of the two ascii tables -- redistributed once into the transposed k-space order; the step then matches the
+    oracle like the table-built group does."""
+    from cubep3m_amd.group import ParticleMeshGroup
+
+    p = cfg1(nodes_dim=2, ngp=True, ppint=True, pp_ext=True, lrckcorr=True)
+    xv, pid = global_ic("clustered", 60000, float(p.nf_physical_dim), 42)
+    o = ol.Oracle(p)
+    o.set_kernel_tables(FINE_TABLE, COARSE_TABLE)
+    kf, kc = o.kern_f(), o.kern_c()                       # (nf, nf, nf/2+1, 3), (nc, nc, nc/2+1, 3) = [kz][ky][kx][comp]
+    s = p.nc_slab
+    g = ParticleMeshGroup(p, 0, 1, set_kernels=False)
+    g.set_kernels_raw(kf, [kc[r * s:(r + 1) * s] for r in g.local_ranks])
+    parts = g.scatter_global(xv, pid)
+    for r in range(8):
+        o.set_particles(r, *parts[r])
+    og, oo = g.particle_mesh(0.01, 0.3, 0.3, 8.0), o.particle_mesh(0.01, 0.3, 0.3, 8.0)
+    for name in ("dt_f_acc", "dt_c_acc", "dt_pp_acc", "dt_pp_ext_acc"):
+        assert getattr(og, name) == pytest.approx(getattr(oo, name), rel=1e-5), name
+    v0 = dict(zip(pid.tolist(), xv[:, 3:]))
+    num = den = 0.0
+    for i, r in enumerate(g.local_ranks):
+        xg, pg = by_pid(*g.download_particles(i))
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po)
+        vin = np.stack([v0[q] for q in pg.tolist()])
+        num += ((xg[:, 3:].astype(np.float64) - xo[:, 3:].astype(np.float64)) ** 2).sum()
+        den += ((xo[:, 3:].astype(np.float64) - vin) ** 2).sum()
+    assert np.sqrt(num / den) <= 1e-5
+
+
+def test_five_steps_with_every_exchange_on_rccl_and_the_second_stream():
+    """One RCCL communicator serves two streams: the ghost pass and the all-reduces on the main stream, the coarse transform's
+    exchanges on the second one (underneath the fine-mesh sweeps).  Five steps with every exchange forced through
+    ncclSend/ncclRecv (P3M_ONE_STREAM unset), particles crossing rank boundaries, against the oracle."""
+    import os
+
+    assert os.environ.get("P3M_ONE_STREAM", "0") != "1"
+    p = cfg1(nodes_dim=2, ngp=True, ppint=True, pp_ext=True)
+    xv, pid = global_ic("clustered", 60000, float(p.nf_physical_dim), 123)
+    g, o, og, oo = run_both(p, xv, pid, (0.01, 0.3, 0.3, 8.0), force_rccl=True, steps=5)
+    info = g.comm_info()
+    assert info["comm_count"] == 1 and info["comm_rank"] == 0 and len(info["uuid"]) == 32
+    assert og.np_total == oo.np_total == len(xv) and og.np_ghost == oo.np_ghost
+    for name in ("dt_f_acc", "dt_c_acc", "dt_pp_acc", "dt_pp_ext_acc"):
+        assert getattr(og, name) == pytest.approx(getattr(oo, name), rel=3e-5), name
+    v0 = dict(zip(pid.tolist(), xv[:, 3:]))
+    num = den = 0.0
+    for i, r in enumerate(g.local_ranks):
+        xg, pg = by_pid(*g.download_particles(i))
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
+        assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 2e-4
+        vin = np.stack([v0[q] for q in pg.tolist()])
+        num += ((xg[:, 3:].astype(np.float64) - xo[:, 3:].astype(np.float64)) ** 2).sum()
+        den += ((xo[:, 3:].astype(np.float64) - vin) ** 2).sum()
+    assert np.sqrt(num / den) <= 3e-5
+
+
+def test_one_rank_per_gpu_share_of_config5_fits_the_device():
+    """ranks_per_gpu = 1 at BASELINE config 5's size: ONE logical rank of the 2x2x2 decomposition (1024^3 fine cells, 2^3 tiles
+    of 560, room for 1.3 x 512^3 particles, PPINT + PP_EXT) as process 0 of 8 -- its coarse slab buffers are those of a
+    512^3 mesh in 8 slabs (nc_slab = 64), its ghost segments are opened to the reference's max_buf (2.2 max_np floats per
+    direction, cubepm.par:174: a face holds 0.37 max_np records).  Everything is allocated at creation; it has to fit the
+    288 GB of one MI355X with room to spare."""
+    import os
+
+    import torch
+
+    from cubep3m_amd.group import ParticleMeshGroup
+    from cubep3m_amd.params import Params
+
+    p = Params(nodes_dim=2, tiles_node_dim=2, nf_tile=560, ngp=True, ppint=True, pp_ext=True, density_buffer=1.3, cores=8)
+    assert p.nc_dim == 512 and p.nc_slab == 64
+    torch.cuda.synchronize()
+    free0, total = torch.cuda.mem_get_info()
+    old = os.environ.get("P3M_GHOST_SEG_FACTOR")
+    os.environ["P3M_GHOST_SEG_FACTOR"] = "%.3f" % (2.2 / 6.0 * p.nf_physical_node_dim / p.nf_buf)
+    try:
+        g = ParticleMeshGroup(p, 0, 8, set_kernels=False)
+    finally:
+        if old is None:
+            del os.environ["P3M_GHOST_SEG_FACTOR"]
+        else:
+            os.environ["P3M_GHOST_SEG_FACTOR"] = old
+    assert g.nlocal == 1 and g.local_ranks == [0]
+    free1, _ = torch.cuda.mem_get_info()
+    used = free0 - free1
+    g.close()
+    assert total >= 280e9                              # an MI355X
+    assert 40e9 < used < 0.6 * total, used              # measured: see DESIGN (Multi-GPU)
+    print("config-5 share, one rank per GPU: %.1f GB of %.1f GB" % (used / 1e9, total / 1e9))

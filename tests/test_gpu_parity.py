@@ -84,6 +84,33 @@ def test_fine_deposit_vs_oracle(PM, ngp):
             assert float(rg.sum(dtype=np.float64)) == pytest.approx(float(ro.sum(dtype=np.float64)), rel=1e-7)
 
 
+def test_ngp_density_of_a_heavy_blob_is_bit_exact(PM):
+    """The count-based NGP deposit (rho = mass_p added count times, from the sort's histogram or from cell_end) with hundreds of
+    particles per cell and the face fix-up on such cells: 5000 particles inside two cells' reach, some of them half an ulp
+    below a face -- every cell of the tile, bit for bit, through the phase-level deposit and after a whole step."""
+    p = cfg1(ngp=True, density_buffer=3.0)
+    g, o = both(PM, p)
+    rng = np.random.default_rng(255)
+    xv = uniform_particles(9000, 64.0, seed=19)
+    xv[:5000, :3] = np.clip(np.float32(20.2) + rng.normal(0, 0.6, (5000, 3)).astype(np.float32), 0.01, 63.99)
+    xv[:400, 0] = np.nextafter(np.float32(21.0), np.float32(0))         # xv + offset rounds these into the next cell (:139)
+    xv[400:800, 1] = np.nextafter(np.float32(20.0), np.float32(0))
+    g.upload_particles(xv)
+    o.set_particles(0, xv)
+    g.link_list_and_pass()
+    o.link_list()
+    assert o.particle_pass() == 0
+    ro = o.tile_density(0, (0, 0, 0), 8.0)
+    assert ro.max() >= 255 * 8.0
+    assert np.array_equal(g.tile_density((0, 0, 0), 8.0), ro)
+    g.delete_particles()
+    out = g.particle_mesh(0.5, 0.0, 0.0, 8.0)                         # whole step: the sort writes the counts
+    oo = ol.Oracle(p); oo.set_kernel_tables(FINE_TABLE, COARSE_TABLE); oo.set_particles(0, xv)
+    ref = oo.particle_mesh(0.5, 0.0, 0.0, 8.0)
+    assert out.sum_rho_f == ref.sum_rho_f and out.dt_f_acc == pytest.approx(ref.dt_f_acc, rel=DT_TOL)
+    assert np.array_equal(g.tile_density((0, 0, 0), 8.0), ro)
+
+
 def test_phase_level_calls_after_a_whole_step_rebuild_the_cell_offsets(PM):
     """PM-only NGP whole steps write the compact per-row cell table instead of cell_end (particles.hip); a phase-level
     deposit or projection afterwards must see the full offsets again (particles_full_cells): the NGP density of the
@@ -597,7 +624,7 @@ def test_fallback_paths_stay_at_parity(switch):
 
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "test_tile_force_vs_oracle or config1_kick_parity or register_fft_sizes and 176 or test_fft_forward and 176 or two_steps_with_drift"],
+                        "test_tile_force_vs_oracle or config1_kick_parity or register_fft_sizes and 176 or test_fft_forward and 176 or two_steps_with_drift or fine_deposit_vs or heavy_blob"],
                        env=dict(os.environ, **{switch: "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
@@ -621,6 +648,8 @@ def test_report_pair_two_particle_force_on_the_hip_path(PM, r):
     timestep.f90:200-217): F_sim = v/dt/mass_p against Newton's F = -G r/r^3 -- through the HIP path, held to the
     ORACLE's value of the same quantities (the reference's mesh force scatters by 5-20 % at 3-16 cells; parity means the
     same scatter, SURVEY 'Pair-force envelope'), and to the closed form where the reference itself is Newtonian."""
+    from cubep3m_amd.timestep import Simulation, TimeParams, new_state
+
     p = cfg1(ngp=True, ppint=True, pp_ext=True)
     mass, a_mid, dt = 10000.0, 1.0, 1.0
     G = 1.0 / 6.0 / 3.141592654
@@ -629,7 +658,11 @@ def test_report_pair_two_particle_force_on_the_hip_path(PM, r):
         g, o = both(PM, p)
         g.upload_particles(xv)
         o.set_particles(0, xv)
-        g.particle_mesh(a_mid, dt, 0.0, mass)
+        # the harness's own time loop: cosmo = .false., pairwise_ic = .true. -> timestep chooses a = a_mid = 1, dt = 1
+        # (timestep.f90:197-211), dt_old = 0 on the first step
+        sim = Simulation(g, TimeParams(cosmo=False, pairwise_ic=True, mass_p=mass), new_state(1.0), mass_p=mass)
+        sim.step()
+        assert (sim.st.a_mid, sim.st.dt, sim.st.dt_old, sim.st.nts) == (1.0, 1.0, 0.0, 1)
         o.particle_mesh(a_mid, dt, 0.0, mass)
         xg, _ = by_pid(*g.download_particles())
         xo, _ = by_pid(*o.get_particles(0))
