@@ -625,6 +625,269 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
   }
 }
 
+
+// ------------------------------------------------------------------ extended PP, version 3: the partner region of a patch through LDS
+// k_pp_ext2 at the reference's density is bound by cache-line traffic: every home record reads 50 cell offsets and ~15 partner
+// records straight from global memory, 44 cache lines per load instruction -- ~200 KB of lines per 64 home records through an
+// L2 that hits 44 % of the time.  Here a task is up to PP3_NT home records of a 3-D PATCH (PP3_HZ planes x PP3_HY rows x xbw
+// cells, 7/8 of PP3_NT home records at the mean density) worked by PP3_NT / 64 wavefronts, and everything its homes can reach -- the
+// (HZ+2r) x (HY+2r) partner rows clipped to the patch's x range +-r -- is brought into LDS ONCE per task by row-wise coalesced
+// loads: the cell offsets of every partner row (one load instruction per row, kept as 16-bit offsets from the row's first
+// record) and the partner records themselves (a flat copy over the concatenated row segments).  A home lane then finds its
+// (2r+1)^2 row windows in the LDS offsets, lists the partners' LDS indices (lanes with few partners) or walks the windows
+// directly (dense cells), and reads the partners from LDS: a partner record is fetched from HBM once per ~3 home records it
+// serves instead of once per home record, the offsets once per patch.  Regions with more records than the staging area holds
+// (blobs) are worked off in batches of PP3_PCAP records of the concatenated row segments; a row segment of more than 65 534
+// records sends the task down a plain per-lane path over global memory.  The partner order per home record (rows in z, y
+// order, ascending sorted index) is that of k_pp_ext.
+#define PP3_HZ 4
+#define PP3_HY 16
+#define PP3_NT 256
+#define PP3_PCAP 704
+#define PP3_LCAP 28
+__global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PPGeo G, int npy, int npx, int xbw, int ngroups, int *__restrict__ plan) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const int e = G.pt + 2 * G.ppr, npz = (e + PP3_HZ - 1) / PP3_HZ;
+  const int xb = g % npx, gy = (g / npx) % npy, gz = (g / (npx * npy)) % npz, tile = g / (npx * npy * npz);
+  const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+  const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
+  const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);
+  int count = 0;
+  for (int j = 0; j < PP3_HZ * PP3_HY; j++) {
+    const int rz = gz * PP3_HZ + j / PP3_HY, ry = gy * PP3_HY + j % PP3_HY;
+    if (rz < e && ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count += cs[rb + hx1] - cs[rb + hx0]; }
+  }
+  plan[g] = (count + PP3_NT - 1) / PP3_NT;
+}
+__global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
+                                                    float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
+                                                    const int *__restrict__ task_group, int ngroups, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
+                                                    int Wp, int NRmax) {   // Wp: entries per row of the offset table (xbw + 2r + 1 rounded up to even); NRmax: partner rows
+  extern __shared__ int sm[];
+  constexpr int NH = PP3_HZ * PP3_HY, NW = PP3_NT / 64;
+  float4 *prec = reinterpret_cast<float4 *>(sm);                              // [PP3_PCAP]  staged partner records (16-byte aligned: first)
+  unsigned short *list = reinterpret_cast<unsigned short *>(prec + PP3_PCAP); // [NW][PP3_LCAP][64]
+  unsigned short *offs = list + NW * PP3_LCAP * 64;                           // [NRmax][Wp]  records of partner row r before cell X0 + i
+  int *rowg = reinterpret_cast<int *>(offs + (size_t)NRmax * Wp);             // [NRmax]      sorted index of the row segment's first record
+  int *cum = rowg + NRmax;                          // [NRmax + 1]  records of the rows before r in the concatenated partner sequence
+  int *rstart = cum + NRmax + 1, *roff = rstart + NH;   // home rows: first record, exclusive prefix of the home counts ([NH + 1])
+  int *misc = roff + NH + 1;                        // [0] task, [1] fat flag, [2..5] wave maxima
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned short *mylist = list + wv * PP3_LCAP * 64;
+  const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E, npz = (e + PP3_HZ - 1) / PP3_HZ;
+  const int ntask = min(plan[ngroups], ntask_cap);
+  const int per = (ntask + PP_NSEG - 1) / PP_NSEG;
+  int seg = blockIdx.x % PP_NSEG;
+  // thread 0 draws the NEXT task (counter, task -> group, group -> first task: three dependent round trips) while the
+  // workgroup works on the current one; nxt_* are its registers, misc[] hands them to the others
+  int nxt_t = 0, nxt_g = 0, nxt_sub = 0;
+  auto draw = [&]() {   // thread 0 only: a task of segment `seg`, or t >= send when it has run dry
+    const int sbeg = min(seg * per, ntask), send = min(sbeg + per, ntask);
+    int tf = __hip_atomic_load(counter + 32 * seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tf < send - sbeg) tf = atomicAdd(counter + 32 * seg, 1);
+    nxt_t = sbeg + tf;
+    if (nxt_t < send) { nxt_g = task_group[nxt_t]; nxt_sub = nxt_t - plan[nxt_g]; }
+  };
+  if (tid == 0) draw();
+  for (int tried = 0; tried < PP_NSEG;) {
+    const int send = min(min(seg * per, ntask) + per, ntask);
+    __syncthreads();                                  // the previous task's readers of the LDS tables (and of misc) are done
+    if (tid == 0) { misc[0] = nxt_t; misc[1] = 0; misc[6] = nxt_g; misc[7] = nxt_sub; }
+    __syncthreads();
+    const int t = misc[0];
+    if (t >= send) { seg = (seg + 1) % PP_NSEG; tried++; if (tid == 0) draw(); continue; }
+    tried = 0;
+    const int g = misc[6], sub = misc[7];
+    if (tid == 0) draw();                             // in flight during this task
+    const int xb = g % npx, gy = (g / npx) % npy, gz = (g / (npx * npy)) % npz, tile = g / (npx * npy * npz);
+    const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+    const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
+    const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);           // home cells [hx0, hx1)
+    const int hz0 = loz + gz * PP3_HZ, hy0 = loy + gy * PP3_HY;
+    // the partner region: rows [Z0, Z1] x [Y0, Y1], cells [X0, X1]
+    const int Z0 = max(hz0 - ppr, loz), Z1 = min(hz0 + PP3_HZ - 1 + ppr, loz + e - 1);
+    const int Y0 = max(hy0 - ppr, loy), Y1 = min(hy0 + PP3_HY - 1 + ppr, loy + e - 1);
+    const int X0 = max(hx0 - ppr, lox), X1 = min(hx1 - 1 + ppr, lox + e - 1);
+    const int NRY = Y1 - Y0 + 1, NR = (Z1 - Z0 + 1) * NRY, W = X1 - X0 + 2;
+    // home rows of the patch (wavefront 0), cell offsets of every partner row (one coalesced load per row, all wavefronts)
+    int hcnt = 0, hst = 0;
+    if (tid < NH) {
+      const int rz = gz * PP3_HZ + tid / PP3_HY, ry = gy * PP3_HY + tid % PP3_HY;
+      if (rz < e && ry < e) { const int64_t rb = ((int64_t)(loz + rz) * E + (loy + ry)) * E; hst = cs[rb + hx0]; hcnt = cs[rb + hx1] - hst; }
+    }
+    constexpr int RCH = 20;
+    for (int rc = wv; rc < NR; rc += NW * RCH) {      // RCH rows of this wavefront at a time: their loads are in flight together
+      int o[RCH];
+#pragma unroll
+      for (int u = 0; u < RCH; u++) {
+        const int r = rc + u * NW;
+        o[u] = 0;
+        if (r < NR && lane < W) { const int zz = Z0 + r / NRY, yy = Y0 + r % NRY; o[u] = cs[((int64_t)zz * E + yy) * E + X0 + lane]; }
+      }
+#pragma unroll
+      for (int u = 0; u < RCH; u++) {
+        const int r = rc + u * NW;
+        if (r >= NR) break;
+        const int first = __shfl(o[u], 0, 64), d = o[u] - first;
+        if (lane < W) offs[r * Wp + lane] = (unsigned short)min(d, 65535);
+        if (lane == W - 1) { if (d > 65534) misc[1] = 1; }
+        if (lane == 0) rowg[r] = first;
+      }
+    }
+    if (wv == 0) {
+      int hinc = hcnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(hinc, o, 64); if (lane >= o) hinc += u; }
+      const int total = __shfl(hinc, NH - 1, 64);
+      if (lane < NH) { rstart[lane] = hst; roff[lane] = hinc - hcnt; }
+      if (lane == 0) roff[NH] = total;
+    }
+    __syncthreads();
+    const int total = roff[NH];
+    const bool fat = misc[1] != 0;                    // uniform
+    // concatenated partner sequence: cum[r] = records of rows < r
+    if (wv == 0) {
+      int carry = 0;
+      for (int r0 = 0; r0 < NR; r0 += 64) {
+        const int r = r0 + lane;
+        const int cnt = r < NR ? (int)offs[r * Wp + W - 1] : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        if (r < NR) cum[r] = carry + inc - cnt;
+        carry += __shfl(inc, 63, 64);
+      }
+      if (lane == 0) cum[NR] = carry;
+    }
+    // this thread's home record
+    const int h = sub * PP3_NT + tid;
+    const bool valid = h < total;
+    int j = 0;
+    { int lo = 0, hi = NH; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= h) lo = mid; else hi = mid; } j = lo; }
+    const int s = valid ? rstart[j] + (h - roff[j]) : 0;
+    const float4 p = valid ? spos[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cx = valid ? (int)floorf(p.x) + G.nb : hx0;                       // :412
+    const int cz = hz0 + (valid ? j / PP3_HY : 0), cy = hy0 + (valid ? j % PP3_HY : 0);
+    int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);
+    // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): see k_pp_ext
+    if (cz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
+    const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1);
+    const int x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
+    const bool phys = valid && (cx >= lox + ppr && cx < lox + ppr + G.pt && cy - loy >= ppr && cy - loy < ppr + G.pt && cz - loz >= ppr && cz - loz < ppr + G.pt);
+    const int vi = rec_index(p);                      // the velocity stays in arrival order (p3m_internal.h); fetched now, needed after the sums
+    float4 vrec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (phys) vrec = vel[vi];
+    __syncthreads();
+    const int Ptot = cum[NR];                         // uniform
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (fat) {
+      // a row segment holds more records than a 16-bit offset counts: windows and partners straight from global memory
+      if (valid)
+        for (int zz = z0; zz <= z1; zz++)
+          for (int yy = y0; yy <= y1; yy++) {
+            const int64_t rb = ((int64_t)zz * E + yy) * E;
+            const int a = cs[rb + x0], b = cs[rb + x1 + 1];
+            int s0 = 0, s1 = 0;
+            if (zz == cz && yy == cy) { s0 = cs[rb + cx]; s1 = cs[rb + cx + 1]; }    // own cell is excluded (:515-516)
+            for (int q = a; q < b; q++) {
+              if (q >= s0 && q < s1) { q = s1 - 1; continue; }
+              const float4 o = spos[q];
+              pp_ext_eval(p, o.x, o.y, o.z, F, ax, ay, az);
+            }
+          }
+    } else {
+      // own cell, excluded (:515-516), as positions of the concatenated sequence
+      int own0 = 0, own1 = 0;
+      if (valid) {
+        const int r = (cz - Z0) * NRY + (cy - Y0);
+        own0 = cum[r] + offs[r * Wp + (cx - X0)]; own1 = cum[r] + offs[r * Wp + (cx - X0) + 1];
+      }
+      for (int b0 = 0; b0 < max(Ptot, 1); b0 += PP3_PCAP) {   // batches of the concatenated partner sequence (one, unless a blob sits here)
+        const int b1 = min(b0 + PP3_PCAP, Ptot);
+        if (b0 > 0) __syncthreads();                  // the previous batch's readers are done
+        {                                             // flat copy: v -> (row, index) by bisection over cum; the loads of a thread's records are in flight together
+          constexpr int NV = (PP3_PCAP + PP3_NT - 1) / PP3_NT;
+          float4 q[NV];
+#pragma unroll
+          for (int u = 0; u < NV; u++) {
+            const int v = b0 + tid + u * PP3_NT;
+            q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < b1) {
+              int lo = 0, hi = NR;
+              while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cum[mid] <= v) lo = mid; else hi = mid; }
+              q[u] = spos[rowg[lo] + (v - cum[lo])];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < NV; u++) { const int v = b0 + tid + u * PP3_NT; if (v < b1) prec[v - b0] = q[u]; }
+        }
+        __syncthreads();
+        // pass 1: list the LDS indices of this lane's partners inside the batch.  A window holds 0.6 partners on average: the
+        // first three of every window are appended by predicated stores (no loop whose trip count is the wavefront's maximum),
+        // a rare tail loop takes the rest
+        int n = 0;
+        if (valid) {
+          for (int zz = z0; zz <= z1; zz++)
+            for (int yy = y0; yy <= y1; yy++) {
+              const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r] - b0;
+              int va = cr + (int)offs[r * Wp + (x0 - X0)], vb = cr + (int)offs[r * Wp + (x1 + 1 - X0)];   // positions in the batch
+              va = max(va, 0); vb = min(vb, b1 - b0);
+              const bool ownrow = (zz == cz && yy == cy);
+              // the own cell [o0, o1) splits the own row's window in two (:515-516)
+              const int o0 = ownrow ? min(max(own0 - b0, va), vb) : vb, o1 = ownrow ? min(max(own1 - b0, va), vb) : vb;
+#pragma unroll
+              for (int half = 0; half < 2; half++) {
+                const int a = half == 0 ? va : o1, b = half == 0 ? o0 : vb;
+                if (half == 1 && !ownrow) break;
+                const int cnt = b - a;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                  if (k < cnt) { if (n < PP3_LCAP) mylist[n * 64 + lane] = (unsigned short)(a + k); n++; }
+                for (int v = a + 3; v < b; v++) { if (n < PP3_LCAP) mylist[n * 64 + lane] = (unsigned short)v; n++; }
+              }
+            }
+        }
+        const bool listed = n <= PP3_LCAP;
+        const int nl = listed ? n : 0;
+        const int nmax = wave_max_i(nl);
+        for (int k = 0; k < nmax; k += 4) {           // four partners in flight at a time
+          float4 o[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { o[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (k + u < nl) o[u] = prec[mylist[(k + u) * 64 + lane]]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (k + u < nl) pp_ext_eval(p, o[u].x, o[u].y, o[u].z, F, ax, ay, az);
+        }
+        // dense lanes and multi-batch regions: walk the windows, partners from the staged batch
+        if (valid && !listed) {
+          for (int zz = z0; zz <= z1; zz++)
+            for (int yy = y0; yy <= y1; yy++) {
+              const int r = (zz - Z0) * NRY + (yy - Y0);
+              const int va = max(cum[r] + (int)offs[r * Wp + (x0 - X0)], b0), vb = min(cum[r] + (int)offs[r * Wp + (x1 + 1 - X0)], b1);
+              for (int v = va; v < vb; v++) {
+                if (v >= own0 && v < own1) { v = own1 - 1; continue; }
+                const float4 o = prec[v - b0];
+                pp_ext_eval(p, o.x, o.y, o.z, F, ax, ay, az);
+              }
+            }
+        }
+      }
+    }
+    float mag = 0.f;
+    if (valid) {
+      if (phys) {                                                                   // :576-582
+        float4 v = vrec;
+        v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
+        vel[vi] = v;
+      }
+      mag = sqrtf(ax * ax + ay * ay + az * az);                                     // :617
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
+    if (lane == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(mag));
+  }
+}
+
 // the smallest float r2 with sqrtf(r2) > t (sqrtf is correctly rounded and monotone): "rmag > t" becomes "r2 >= this"
 static float first_r2_with_root_above(float t) {
   float r2 = t * t;
@@ -640,6 +903,45 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   const int e = g.pt + 2 * g.pp_range;
   static const bool v1 = getenv("P3M_PP_EXT_V1") && getenv("P3M_PP_EXT_V1")[0] == '1';   // A/B switch: the LDS-tiled kernel of round 1
+  // P3M_PP_EXT_V3=1: the LDS-staged kernel (k_pp_ext3).  Measured on a 560 tile against k_pp_ext2 (ms per launch, uniform /
+  // blobs of 205 / blobs of 13 000): 4.0 / 10.7 / 534 against 4.1 / 10.1 / 715 -- thirteen times fewer cache lines, but as many
+  // instruction slots: it only wins where cells are heavy, so the gather kernel stays the default
+  static const bool v3 = getenv("P3M_PP_EXT_V3") && getenv("P3M_PP_EXT_V3")[0] == '1';
+  if (!v1 && v3) {
+    // patches of PP3_HZ x PP3_HY rows x xbw cells holding 7/8 of PP3_NT home records at the mean density (one task)
+    static const int xbw_env = getenv("P3M_PP_XBW") ? atoi(getenv("P3M_PP_XBW")) : 0;
+    const double rho_mean = (double)c->np_all / ((double)g.E * g.E * g.E);
+    int xbw = xbw_env > 0 ? xbw_env : (int)std::lround((0.875 * PP3_NT) / std::max(1e-9, rho_mean * PP3_HZ * PP3_HY));
+    xbw = std::max(4, std::min(std::min(xbw, e), 64 - 2 * g.pp_range - 1));      // one load instruction per partner row
+    const int npx = (e + xbw - 1) / xbw, npy = (e + PP3_HY - 1) / PP3_HY, npz = (e + PP3_HZ - 1) / PP3_HZ;
+    const int64_t ngroups64 = (int64_t)g.ntiles * npz * npy * npx;
+    const int64_t mult1 = std::min<int64_t>(g.T, 2 + (2 * g.pp_range) / g.pt), mult = mult1 * mult1 * mult1;
+    const int64_t ngroups_max = (int64_t)g.ntiles * npz * npy * ((e + 3) / 4);
+    const int64_t ntask_cap64 = mult * (c->cap / PP3_NT + 1) + ngroups_max + 64;
+    if (ngroups_max > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many patches"); return P3M_EINVAL; }
+    const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
+    if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
+    if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)ntask_cap64));
+    if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
+    P3M_TRY(scan_reserve(c, ngroups_max + 8));
+    HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
+    hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
+    hipLaunchKernelGGL(k_pp_fill, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, c->pp_task_group, ntask_cap);
+    HIP_TRY(hipGetLastError());
+    PPForce F{mass_p, G.pp_bias, 1.0f / G.pp_bias, 1.0f / G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f))};
+    const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
+    const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * ((size_t)(PP3_NT / 64) * PP3_LCAP * 64 + (size_t)NRmax * Wp) +
+                       sizeof(int) * ((size_t)2 * NRmax + 1 + 2 * PP3_HZ * PP3_HY + 1 + 8);   // 8: misc
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pp_ext3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const int wpc3 = getenv("P3M_PP_WPC") ? atoi(getenv("P3M_PP_WPC")) : 0;
+    int wpc = wpc3 > 0 ? wpc3 : (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));   // resident workgroups per CU by LDS
+    hipLaunchKernelGGL(k_pp_ext3, dim3(256 * wpc), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
+                       c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter, Wp, NRmax);
+    HIP_TRY(hipGetLastError());
+    return P3M_OK;
+  }
   if (!v1) {
     // a group is a patch of PP_RG rows x xbw cells holding ~192 records (three tasks) at the mean density.  Measured on a 560
     // tile (ms per launch, uniform / 30 % of the particles in blobs of 205): whole rows 3.85 / 13.1, 96 cells 4.02 / 9.9,

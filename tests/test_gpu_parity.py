@@ -612,11 +612,11 @@ def test_long_lines_forward_transform_vs_numpy(PM, n):
     assert np.abs(back[:, :, :n] - a[:, :, :n]).max() < 1e-4 and np.all(back[:, :, n:] == 0)
 
 
-@pytest.mark.parametrize("switch", ["P3M_FFT_STOCKHAM", "P3M_SEPARATE_COARSE_KICK", "P3M_Z_UNFUSED"])
+@pytest.mark.parametrize("switch", ["P3M_FFT_STOCKHAM", "P3M_SEPARATE_COARSE_KICK", "P3M_Z_UNFUSED", "P3M_PP_EXT_V3"])
 def test_fallback_paths_stay_at_parity(switch):
     """The run-time switches select the LDS Stockham FFT kernels for every size, the coarse kick in its own pass, and the
-    un-fused z pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run: all
-    are paths other tile sizes / PP runs take, so they are held to the same parity tests (in a child process: the
+    un-fused z pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run, the
+    LDS-staged extended-PP kernel (k_pp_ext3, the faster one where cells are heavy): all are paths other tile sizes / PP runs take, so they are held to the same parity tests (in a child process: the
     switches are read once per process)."""
     import os
     import subprocess
@@ -624,7 +624,7 @@ def test_fallback_paths_stay_at_parity(switch):
 
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "test_tile_force_vs_oracle or config1_kick_parity or register_fft_sizes and 176 or test_fft_forward and 176 or two_steps_with_drift or fine_deposit_vs or heavy_blob"],
+                        "test_tile_force_vs_oracle or config1_kick_parity or register_fft_sizes and 176 or test_fft_forward and 176 or two_steps_with_drift or fine_deposit_vs or heavy_blob or dense_blob or other_tilings"],
                        env=dict(os.environ, **{switch: "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
