@@ -136,10 +136,15 @@ def pp_leg():
 
 
 def cpu_baseline(scal):
-    """The CPU oracle (tests/oracle_lib.py: a C port of the reference path, OpenMP over fine tiles like the reference's
-    `!$omp do`) on a bounded sample: a 256^3-cell sub-volume (BASELINE configs[1]: 128^3 particles of the same uniform
-    density), full particle_mesh steps, on ALL host cores of this box: 2^3 tiles of 176 when the box has <= 8 cores,
-    4^3 tiles of 112 (64 work items) otherwise.  Checker-side code, used here only as the reported baseline."""
+    """The CPU oracle (tests/oracle_lib.py: a C port of the reference path with the reference's own OpenMP regions -- the
+    tile loop of particle_mesh_threaded.f90:84, coarse_mass.f90:83, coarse_velocity.f90:137, update_position.f90:68,
+    coarse_force.f90:37-86; link_list, particle_pass and delete_particles are serial there and here) on a bounded sample: a
+    256^3-cell sub-volume (BASELINE configs[1]: 128^3 particles of the same uniform density), full particle_mesh steps, 4^3
+    tiles of 112 (64 work items; 2^3 tiles of 176 on boxes with <= 8 cores).  The thread count is swept (8, 16, 32, 64, bounded
+    by the box) with the phases timed one by one; the best count is reported.  Checker-side code, used here only as the
+    reported baseline."""
+    import ctypes
+
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
@@ -152,29 +157,56 @@ def cpu_baseline(scal):
     p = Params(**CONFIGS[key]["params"])
     ntile = p.tiles_node_dim ** 3
     fine, coarse = default_tables()
-    threads = max(1, min(cores_avail, ntile))
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    xv = make_particles(128, 256.0)
-    o = ol.Oracle(p)
-    o.set_kernel_tables(fine, coarse)
-    o.set_particles(0, xv)
-    a_mid, dt, dt_old, mass_p = scal
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        o.particle_mesh(a_mid, dt, dt_old, mass_p)
-        steps += 1
-        if time.perf_counter() - t0 > 15.0 or steps >= 12:
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(cores_avail, 64)))
+    omp = None
+    for name in ("libgomp.so.1", "libomp.so", "libomp.so.5"):
+        try:
+            omp = ctypes.CDLL(name)
             break
-    el = time.perf_counter() - t0
-    return {"value": len(xv) * steps / el, "unit": "particle-updates/s", "cores": threads, "kind": "port",
-            "host_cpus": cores, "host_cpus_usable": cores_avail,
-            "sample": "%d full particle_mesh step(s) of a 256^3-cell / 128^3-particle sub-volume (same density, nf_tile=%d, %d^3 tiles = %d work "
-                      "items) on the CPU oracle (C port of the reference path, OpenMP over fine tiles as the reference does) with %d threads "
-                      "on a box with %d CPUs, %.1f s.  Context (survey-time probe of the reference Fortran itself, amdflang + MKL FFT shim, "
-                      "dev container, 4 OpenMP threads, same 256^3/128^3 problem, BASELINE.md section 2): 1.65e6 particle-updates/s PM-only, "
-                      "0.96e6 with PP + extended PP; the reference's own 2007 log (8 cores, 128^3 particles, PM+PP): 8.8e4"
-                      % (steps, p.nf_tile, p.tiles_node_dim, ntile, threads, cores, el)}
+        except OSError:
+            continue
+    xv = make_particles(128, 256.0)
+    a_mid, dt, dt_old, mass_p = scal
+    phases = ("update_position", "link_list", "particle_pass", "fine_mesh", "coarse_mesh", "delete_particles")
+    sweep = {}
+    t_all = time.perf_counter()
+    for threads in sorted({t for t in (8, 16, 32, 64) if t <= cores_avail} or {max(1, cores_avail)}):
+        if omp is not None:
+            omp.omp_set_num_threads(threads)
+        o = ol.Oracle(p)
+        o.set_kernel_tables(fine, coarse)
+        o.set_particles(0, xv)
+        o.particle_mesh(a_mid, dt, dt_old, mass_p)          # warm-up step (first touch of the tile work spaces)
+        split = dict.fromkeys(phases, 0.0)
+        steps = 0
+        t0 = time.perf_counter()
+        while steps < 2 and (steps == 0 or time.perf_counter() - t_all < 25.0):
+            for name, call in (("update_position", lambda: o.update_position(dt, dt_old)), ("link_list", o.link_list),
+                               ("particle_pass", o.particle_pass), ("fine_mesh", lambda: o.fine_mesh(a_mid, dt, mass_p)),
+                               ("coarse_mesh", lambda: o.coarse_mesh(a_mid, dt, mass_p)), ("delete_particles", o.delete_particles)):
+                t1 = time.perf_counter()
+                call()
+                split[name] += time.perf_counter() - t1
+            steps += 1
+        el = time.perf_counter() - t0
+        o.close()
+        sweep[threads] = {"particle_updates_per_s": len(xv) * steps / el, "s_per_step": el / steps,
+                          "phase_s_per_step": {k: v / steps for k, v in split.items()}}
+        if time.perf_counter() - t_all > 25.0:
+            break
+    best = max(sweep, key=lambda t: sweep[t]["particle_updates_per_s"])
+    el_all = time.perf_counter() - t_all
+    return {"value": sweep[best]["particle_updates_per_s"], "unit": "particle-updates/s", "cores": best, "kind": "port",
+            "host_cpus": cores, "host_cpus_usable": cores_avail, "thread_sweep": sweep,
+            "sample": "full particle_mesh steps of a 256^3-cell / 128^3-particle sub-volume (same density, nf_tile=%d, %d^3 tiles = %d work items) "
+                      "on the CPU oracle (C port of the reference path with the reference's OpenMP regions; link_list, particle_pass, "
+                      "delete_particles serial as in the reference), swept over %s threads with one warm-up and up to two timed steps each "
+                      "on a box with %d CPUs, %.1f s in all; best: %d threads, %.2f s per step (%s).  Context (survey-time probe of the "
+                      "reference Fortran itself, amdflang + MKL FFT shim, dev container, 4 OpenMP threads, same 256^3/128^3 problem, "
+                      "BASELINE.md section 2): 1.65e6 particle-updates/s PM-only, 0.96e6 with PP + extended PP; the reference's own 2007 log "
+                      "(8 cores, 128^3 particles, PM+PP): 8.8e4"
+                      % (p.nf_tile, p.tiles_node_dim, ntile, sorted(sweep), cores, el_all, best, sweep[best]["s_per_step"],
+                         ", ".join("%s %.3f" % (k, v) for k, v in sweep[best]["phase_s_per_step"].items()))}
 
 
 def open_group(p, torch, dist, rank, world, ddev, uid, require_rccl, dist_backend):

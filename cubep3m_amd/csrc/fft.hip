@@ -485,6 +485,10 @@ struct LinesArgs {
   //   b*src_planes*nchunk*n*16 + (idx/seg)*(src_planes*nchunk*seg*16) + ((o*nchunk + chunk)*seg + idx%seg)*16
   // (the receive buffer [peer][plane][chunk][seg][16] as it is): the pass reads it in place of a separate permutation kernel
   int seg; unsigned seg_magic;
+  // direct_s > 0 (register-stage kernels, TR): every logical rank of the transpose lives in this process and is a batch entry --
+  // line element idx of batch entry b belongs to peer idx / direct_s, and is stored straight into THAT peer's receive block
+  // (where the all-to-all would have copied it): the normal address plus (peer - b) * direct_delta elements
+  int direct_s; unsigned direct_magic; int64_t direct_delta;
 };
 // Each workgroup walks a grid-stride list of work items and is software-pipelined: the next
 // item's global loads are issued into registers (LUX 16-byte loads per lane) before the butterflies
@@ -738,6 +742,16 @@ __global__ __launch_bounds__((L2Cfg<R1, R2>::TB)) __attribute__((amdgpu_waves_pe
       if (NC != 0) d0 += comp * a.dst_comp_stride;
       int r0 = g - a.slo; asm volatile("" : "+v"(r0));        // likewise the R2 row-range predicates
       asm volatile("" : "+s"(rstride));                        // and row offsets
+      if (TR && a.direct_s > 0) {                              // the transposing store lands in the peers' receive blocks
+        fdiv_t dd; dd.m = a.direct_magic; dd.d = a.direct_s;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) {
+          c32 r = u[k2];
+          if (INV) r.y = -r.y;
+          const int idx = g + R1 * k2, peer = fdiv(idx, dd);
+          if ((unsigned)(r0 + R1 * k2) < (unsigned)a.scount) d0[(int64_t)(R1 * k2) * rstride + (int64_t)(peer - (int)b) * a.direct_delta] = r;
+        }
+      } else
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++) {
         c32 r = u[k2];
@@ -1286,9 +1300,15 @@ int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float
 // planes: bundle planes held locally (nc_slab); the transposing passes write the all-to-all send layout
 // [line element][chunk][plane][16] directly.
 // batch: logical ranks laid out one after the other (src and dst batch strides are one rank's slab)
-int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes, int batch) {
+// direct: the batch entries are ALL the ranks of the transpose (batch * planes == n): store into the peers' receive blocks of `send`
+int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes, int batch, bool direct) {
   LinesArgs a = full_args(pl, send, ly);
   a.ocount = planes; a.src_planes = planes; a.dst_planes = pl.n; a.dst_line = planes;
+  if (direct) {
+    if (!lines2_has(pl.n) || batch * planes != pl.n) return P3M_EINVAL;
+    const int64_t rstride = (int64_t)(pl.px / BXC) * planes * BXC;
+    a.direct_s = planes; a.direct_magic = fdiv_magic(planes); a.direct_delta = (int64_t)pl.n * rstride - (int64_t)planes * rstride;
+  }
   return launch_lines<false, true, 0>(c, pl, a, batch);
 }
 // seg > 0: src is the all-to-all receive buffer, n/seg segments per line (LinesArgs::seg); register-stage kernels only (fft_has_segmented)
@@ -1300,10 +1320,15 @@ int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, const float *src, float *lz, i
   return launch_lines<false, false, 0>(c, pl, a, batch);
 }
 int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3, const float *kern3, int planes, int64_t kern_comp_stride,
-                    int64_t send_comp_stride, int batch, int64_t kern_batch_stride) {
+                    int64_t send_comp_stride, int batch, int64_t kern_batch_stride, bool direct) {
   LinesArgs a = full_args(pl, send3, lz);
   a.ocount = planes; a.src_planes = planes; a.dst_planes = pl.n; a.dst_line = planes;
   a.kern = kern3; a.kern_comp_stride = kern_comp_stride; a.dst_comp_stride = send_comp_stride; a.kern_batch_stride = kern_batch_stride;
+  if (direct) {   // see fft_slab_y_fwd
+    if (!lines2_has(pl.n) || batch * planes != pl.n) return P3M_EINVAL;
+    const int64_t rstride = (int64_t)(pl.px / BXC) * planes * BXC;
+    a.direct_s = planes; a.direct_magic = fdiv_magic(planes); a.direct_delta = (int64_t)pl.n * rstride - (int64_t)planes * rstride;
+  }
   return launch_lines3(c, pl, a, batch);
 }
 int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, const float *src, float *ly3, int planes, int batch, int seg) {

@@ -23,11 +23,11 @@
 
 int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp = 0);
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp = 0);
-int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes, int batch = 1);
+int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes, int batch = 1, bool direct = false);
 int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, const float *src, float *lz, int planes, int seg, int batch = 1);
 bool fft_has_segmented(const FftPlan &pl);
 int fft_slab_z_inv3(p3m_ctx *c, const FftPlan &pl, const float *lz, float *send3, const float *kern3, int planes, int64_t kern_comp_stride,
-                    int64_t send_comp_stride, int batch = 1, int64_t kern_batch_stride = 0);
+                    int64_t send_comp_stride, int batch = 1, int64_t kern_batch_stride = 0, bool direct = false);
 int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, const float *src, float *ly3, int planes, int batch, int seg);
 
 #define NCCL_TRY(expr)                                                                             \
@@ -67,6 +67,11 @@ struct p3m_group {
   // launch over all local ranks (the rank is the batch index of the FFT kernels) instead of one per rank; otherwise (pencils,
   // Stockham sizes) [local rank][component][...] and the per-rank loops.  cstride: floats between two components of one rank.
   bool batched = false; size_t cstride = 0, rstride = 0;   // rstride: the same for the real rows
+  // direct (batched, ONE process holding every rank, no forced RCCL): the three redistributions of the transform are no
+  // exchanges at all -- the x pass gathers its rows from the ranks' cubes, the transposing y / z passes store into the peers'
+  // receive blocks, the inverse x pass's rows go straight into the owners' force_c (70 GB of device-to-device copies per
+  // coarse_force at nc = 1024 otherwise).  P3M_COARSE_COPY=1 keeps the message path (what several processes run).
+  bool direct = false;
   float *a_blocks_in = nullptr, *a_rows = nullptr, *a_ly = nullptr, *a_send = nullptr, *a_recv = nullptr, *a_lz = nullptr, *a_kern = nullptr,
         *a_blocks_out = nullptr, *a_blocks_back = nullptr, *a_rho_c = nullptr, *a_force_c = nullptr, *a_halo = nullptr;
   ncclComm_t comm = nullptr; bool force_nccl = false;
@@ -312,6 +317,7 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     A(galloc(&G->a_blocks_out, nl * G->nxb * 3 * blk)); A(galloc(&G->a_blocks_back, nl * G->nxb * 3 * blk));
     A(galloc(&G->a_halo, nl * 4 * face)); A(galloc(&G->a_rho_c, nl * n3)); A(galloc(&G->a_force_c, nl * 3 * fcs));
     if (hipMemset(G->a_rows, 0, sizeof(float) * nl * nrows) != hipSuccess) return fail(P3M_EDEVICE);
+    G->direct = G->batched && nprocs == 1 && !(getenv("P3M_COARSE_COPY") && getenv("P3M_COARSE_COPY")[0] == '1');
     G->cstride = G->batched ? nl * NB : NB; G->rstride = G->batched ? nl * (nrows / 3) : nrows / 3;
     for (size_t i = 0; i < nl; i++) {
       CoarseDist &d = G->cd[i];
@@ -353,6 +359,7 @@ extern "C" int p3m_hip_group_comm_init_rccl(p3m_group *G, const void *unique_id_
   ncclUniqueId id; memcpy(&id, unique_id_128, sizeof(id));
   NCCL_TRY(ncclCommInitRank(&G->comm, G->nprocs, id, G->proc));
   G->force_nccl = force_for_local_peers != 0;
+  if (G->force_nccl) G->direct = false;   // every exchange through RCCL: keep the message path
   return P3M_OK;
 }
 extern "C" int p3m_hip_group_comm_info(p3m_group *G, int32_t *comm_count, int32_t *comm_rank, int32_t *device, char *uuid_hex33) {
@@ -632,6 +639,27 @@ __global__ __launch_bounds__(256) void k_blocks_to_rows_b(const float *__restric
     dst[x4] = v;
   }
 }
+// the same from the ranks' cubes themselves (G->direct): block (j*nd+i) of rank r is z-slice r % nd^2 of the cube of rank
+// layer(r) + j*nd + i (pack_slab, fftw3ds.f90:24-52)
+__global__ __launch_bounds__(256) void k_cubes_to_rows_b(const float *__restrict__ cubes, float *__restrict__ rows, RowGeom q) {
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= (unsigned)q.nl * q.s * q.rpp) return;
+  fdiv_t d_rpp{q.m_rpp, q.rpp}, d_s{q.m_s, q.s}, d_ncn{q.m_ncn, q.ncn};
+  const unsigned plane = fdiv(row, d_rpp), y = row - plane * q.rpp, rank = fdiv(plane, d_s), zl = plane - rank * q.s;
+  const unsigned j = fdiv(y, d_ncn), yy = y - j * q.ncn;
+  const unsigned nd2 = q.nd * q.nd, layer = rank / nd2, qz = rank - layer * nd2;
+  const int64_t n3 = (int64_t)q.ncn * q.ncn * q.ncn;
+  float4 *dst = reinterpret_cast<float4 *>(rows + (int64_t)row * q.rp);
+  for (int x4 = lane; x4 < q.rp / 4; x4 += 64) {
+    const int x = 4 * x4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < q.nc) {
+      const unsigned i = fdiv(x, d_ncn);
+      v = *reinterpret_cast<const float4 *>(cubes + (int64_t)(layer * nd2 + j * q.nd + i) * n3 + ((int64_t)(qz * q.s + zl) * q.ncn + yy) * q.ncn + (x - i * q.ncn));
+    }
+    dst[x4] = v;
+  }
+}
 // rows [comp][rank][zl][y][x] -> blocks_out [rank][(j*nd+i)][comp][zl][yy][xx]; one wavefront per (comp, rank, zl, y) row
 __global__ __launch_bounds__(256) void k_rows_to_blocks_b(const float *__restrict__ rows, float *__restrict__ blocks, RowGeom q) {
   const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -674,6 +702,36 @@ __global__ __launch_bounds__(256) void k_blocks_to_force_b(const float *__restri
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
   if (lane == 0 && row < nrow) atomicMax(reinterpret_cast<unsigned int *>(red.p[rank]) + p3m_slot() * 16, __float_as_uint(mx));
+}
+// G->direct: rows [comp][rank][zl][y][x] -> force_c of the OWNERS, and max |F| on the way (unpack_slab, fftw3ds.f90:69-99 +
+// coarse_max_dt.f90:24-31): row (rank r, zl, y) holds, for i < nd, cells of the cube of rank layer(r) + (y/ncn)*nd + i, in its
+// plane (r % nd^2)*s + zl.  One wavefront takes the three component rows.
+__global__ __launch_bounds__(256) void k_rows_to_force_b(const float *__restrict__ rows, float *__restrict__ fc, RowGeom q, int64_t rstride, RankPtrs red) {
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= (unsigned)q.nl * q.s * q.rpp) return;
+  fdiv_t d_rpp{q.m_rpp, q.rpp}, d_s{q.m_s, q.s}, d_ncn{q.m_ncn, q.ncn};
+  const unsigned plane = fdiv(row, d_rpp), y = row - plane * q.rpp, rank = fdiv(plane, d_s), zl = plane - rank * q.s;
+  const unsigned j = fdiv(y, d_ncn), yy = y - j * q.ncn;
+  const unsigned nd2 = q.nd * q.nd, layer = rank / nd2, qz = rank - layer * nd2;
+  const int m = q.ncn + 2; const int64_t fcs = (int64_t)m * m * m;
+  const float *r0 = rows + (int64_t)row * q.rp;
+  for (unsigned i = 0; i < (unsigned)q.nd; i++) {              // the nd owners along x
+    const unsigned owner = layer * nd2 + j * q.nd + i;
+    float *f0 = fc + (int64_t)owner * 3 * fcs + ((int64_t)(1 + qz * q.s + zl) * m + (1 + yy)) * m + 1;
+    float mx = 0.f;
+    for (int x4 = lane; x4 < q.ncn / 4; x4 += 64) {
+      const float4 a = reinterpret_cast<const float4 *>(r0 + i * q.ncn)[x4], b = reinterpret_cast<const float4 *>(r0 + rstride + i * q.ncn)[x4],
+                   c = reinterpret_cast<const float4 *>(r0 + 2 * rstride + i * q.ncn)[x4];
+      float *pa = f0 + 4 * x4;
+      pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
+      pa[fcs] = b.x; pa[fcs + 1] = b.y; pa[fcs + 2] = b.z; pa[fcs + 3] = b.w;
+      pa[2 * fcs] = c.x; pa[2 * fcs + 1] = c.y; pa[2 * fcs + 2] = c.z; pa[2 * fcs + 3] = c.w;
+      mx = fmaxf(fmaxf(mx, sqrtf(a.x * a.x + b.x * b.x + c.x * c.x)), sqrtf(a.y * a.y + b.y * b.y + c.y * c.y));
+      mx = fmaxf(fmaxf(mx, sqrtf(a.z * a.z + b.z * b.z + c.z * c.z)), sqrtf(a.w * a.w + b.w * b.w + c.w * c.w));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int *>(red.p[owner]) + p3m_slot() * 16, __float_as_uint(mx));
+  }
 }
 // coarse_force_buffer.f90 for all local ranks: blockIdx.y = rank*2 + side; halo [rank][4][face]: slots 0,1 = send to -axis / +axis, 2,3 = received
 __global__ __launch_bounds__(256) void k_halo_pack_b(const float *__restrict__ fc, float *__restrict__ halo, int ncn, int axis) {
@@ -747,6 +805,14 @@ template <typename F> static int dist_forward(p3m_group *G, F cube_of) {
   const Geometry &g = G->ctx[0]->g;
   const int nl = (int)G->ctx.size(), nd = G->nd, s = G->s, nc = g.nc, ncn = g.ncn, rp = 2 * G->plan_c.px, ncl = G->ncl, rpp = G->rpp;
   const size_t blk = (size_t)s * ncn * ncn;
+  if (G->direct && cube_of(0) == G->a_rho_c) {   // no exchanges: gather from the cubes, store into the peers' receive blocks
+    p3m_ctx *c0 = G->ctx[0];
+    hipLaunchKernelGGL(k_cubes_to_rows_b, dim3(cdiv((int64_t)nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_rho_c, G->a_rows, row_geom(G));
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(fft_x_forward_rows(c0, G->plan_c, G->a_rows, G->a_ly, (int64_t)nl * s * rpp, rpp));
+    P3M_TRY(fft_slab_y_fwd(c0, G->plan_c, G->a_ly, G->a_recv, s, nl, true));
+    return fft_slab_z_fwd(c0, G->plan_l, G->a_recv, G->a_lz, s, s, nl);
+  }
   // cube -> x-lines
   P3M_TRY(group_exchange(G, G->nxb, blk * sizeof(float), [&](int r, int q) { return xl_peer(G, r, q); }, [&](int r) { return xl_index(G, r); },
                          [&](int li) { return (const char *)cube_of(li); }, [&](int li) { return (char *)G->cd[li].blocks_in; }));
@@ -831,6 +897,42 @@ static int build_coarse_kernel_dist(p3m_group *G, const float *table4_host) {
   return P3M_OK;
 }
 
+// coarse_force_buffer.f90 for all local ranks
+static int coarse_force_halo(p3m_group *G) {
+  const Geometry &g = G->ctx[0]->g;
+  const int nl = (int)G->ctx.size(), nd = G->nd, ncn = g.ncn;
+  const int m = ncn + 2; const size_t face = (size_t)3 * m * m;
+  // one-cell halo: x, then y (carrying the x halo), then z (coarse_force_buffer.f90:19-63)
+  for (int axis = 0; axis < 3; axis++) {
+    if (G->batched) hipLaunchKernelGGL(k_halo_pack_b, dim3(cdiv((int64_t)face, 256), 2 * nl), dim3(256), 0, G->stream, (const float *)G->a_force_c, G->a_halo, ncn, axis);
+    else
+    for (int i = 0; i < nl; i++) {
+      hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[0], ncn, axis, 1);    // to -axis
+      hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[1], ncn, axis, ncn);  // to +axis
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<XMsg> hm;
+    for (int r = 0; r < G->nodes; r++) {
+      const int c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
+      int cp[3] = {c1, c2, c3}, cmn[3] = {c1, c2, c3};
+      const int dim = 2 - axis;
+      cp[dim] = (cp[dim] + 1) % nd; cmn[dim] = (cmn[dim] - 1 + nd) % nd;
+      const int rpl = cp[0] * nd * nd + cp[1] * nd + cp[2], rmn = cmn[0] * nd * nd + cmn[1] * nd + cmn[2];
+      const int li = G->lidx[r], lp = G->lidx[rpl], lm = G->lidx[rmn];
+      hm.push_back({r, rmn, li >= 0 ? (const void *)G->cd[li].halo_s[0] : nullptr, lm >= 0 ? (void *)G->cd[lm].halo_r[0] : nullptr, face * sizeof(float)});  // plane 1 -> their ncn+1
+      hm.push_back({r, rpl, li >= 0 ? (const void *)G->cd[li].halo_s[1] : nullptr, lp >= 0 ? (void *)G->cd[lp].halo_r[1] : nullptr, face * sizeof(float)});  // plane ncn -> their 0
+    }
+    P3M_TRY(do_exchange(G, hm));
+    if (G->batched) hipLaunchKernelGGL(k_halo_unpack_b, dim3(cdiv((int64_t)face, 256), 2 * nl), dim3(256), 0, G->stream, G->a_force_c, (const float *)G->a_halo, ncn, axis);
+    else
+    for (int i = 0; i < nl; i++) {
+      hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[0], ncn, axis, ncn + 1);
+      hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[1], ncn, axis, 0);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  return P3M_OK;
+}
 // coarse_force.f90 + coarse_force_buffer.f90 + coarse_max_dt.f90 for all local ranks
 static int coarse_force_dist(p3m_group *G) {
   const Geometry &g = G->ctx[0]->g;
@@ -838,6 +940,17 @@ static int coarse_force_dist(p3m_group *G) {
   const size_t NBc = (size_t)s * ncl * nc * 16, blk = (size_t)s * ncn * ncn;
   P3M_TRY(dist_forward(G, [&](int li) { return G->ctx[li]->rho_c; }));                  // coarse_force.f90:18
   const int64_t ccs = (int64_t)(G->cstride / 2);                                         // complex elements between two components of a rank
+  if (G->direct) {   // no exchanges (see p3m_group::direct)
+    p3m_ctx *c0 = G->ctx[0];
+    P3M_TRY(fft_slab_z_inv3(c0, G->plan_l, G->a_lz, G->a_recv, G->a_kern, s, ccs, ccs, nl, (int64_t)NBc, true));
+    P3M_TRY(fft_slab_y_inv(c0, G->plan_l, G->a_recv, G->a_ly, s, 3 * nl, s));
+    P3M_TRY(fft_x_inverse(c0, G->plan_c, G->a_ly, G->a_rows, -(3 * nl * s * rpp), 0, nullptr, 0, 0, 1, 0, rpp));
+    RankPtrs red;
+    for (int i = 0; i < nl; i++) red.p[i] = G->ctx[i]->d_red + 2 * P3M_RED_SPAN;
+    hipLaunchKernelGGL(k_rows_to_force_b, dim3(cdiv((int64_t)nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_rows, G->a_force_c, row_geom(G), (int64_t)G->rstride, red);
+    HIP_TRY(hipGetLastError());
+    return coarse_force_halo(G);
+  }
   if (G->batched) P3M_TRY(fft_slab_z_inv3(G->ctx[0], G->plan_l, G->a_lz, G->a_send, G->a_kern, s, ccs, ccs, nl, (int64_t)NBc));
   else for (int i = 0; i < nl; i++)                                                      // :37-50 x3, fused multiply
     P3M_TRY(fft_slab_z_inv3(G->ctx[i], G->plan_l, G->cd[i].lz, G->cd[i].send, G->cd[i].kern, s, (int64_t)NBc, (int64_t)NBc));
@@ -893,7 +1006,6 @@ static int coarse_force_dist(p3m_group *G) {
       }
     P3M_TRY(do_exchange(G, m3));
   }
-  const int m = ncn + 2; const size_t face = (size_t)3 * m * m;
   if (G->batched) {   // the maximum (coarse_max_dt.f90) rides on this copy
     RankPtrs red;
     for (int i = 0; i < nl; i++) red.p[i] = G->ctx[i]->d_red + 2 * P3M_RED_SPAN;
@@ -906,35 +1018,7 @@ static int coarse_force_dist(p3m_group *G) {
     hipLaunchKernelGGL(k_blocks_to_force, dim3(cdiv(tot, 256)), dim3(256), 0, G->stream, (const float *)G->cd[i].blocks_back, G->ctx[i]->force_c, s, ncn, G->nxb);
     HIP_TRY(hipGetLastError());
   }
-  // one-cell halo: x, then y (carrying the x halo), then z (coarse_force_buffer.f90:19-63)
-  for (int axis = 0; axis < 3; axis++) {
-    if (G->batched) hipLaunchKernelGGL(k_halo_pack_b, dim3(cdiv((int64_t)face, 256), 2 * nl), dim3(256), 0, G->stream, (const float *)G->a_force_c, G->a_halo, ncn, axis);
-    else
-    for (int i = 0; i < nl; i++) {
-      hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[0], ncn, axis, 1);    // to -axis
-      hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, G->cd[i].halo_s[1], ncn, axis, ncn);  // to +axis
-    }
-    HIP_TRY(hipGetLastError());
-    std::vector<XMsg> hm;
-    for (int r = 0; r < G->nodes; r++) {
-      const int c1 = r / (nd * nd), c2 = (r / nd) % nd, c3 = r % nd;
-      int cp[3] = {c1, c2, c3}, cmn[3] = {c1, c2, c3};
-      const int dim = 2 - axis;
-      cp[dim] = (cp[dim] + 1) % nd; cmn[dim] = (cmn[dim] - 1 + nd) % nd;
-      const int rpl = cp[0] * nd * nd + cp[1] * nd + cp[2], rmn = cmn[0] * nd * nd + cmn[1] * nd + cmn[2];
-      const int li = G->lidx[r], lp = G->lidx[rpl], lm = G->lidx[rmn];
-      hm.push_back({r, rmn, li >= 0 ? (const void *)G->cd[li].halo_s[0] : nullptr, lm >= 0 ? (void *)G->cd[lm].halo_r[0] : nullptr, face * sizeof(float)});  // plane 1 -> their ncn+1
-      hm.push_back({r, rpl, li >= 0 ? (const void *)G->cd[li].halo_s[1] : nullptr, lp >= 0 ? (void *)G->cd[lp].halo_r[1] : nullptr, face * sizeof(float)});  // plane ncn -> their 0
-    }
-    P3M_TRY(do_exchange(G, hm));
-    if (G->batched) hipLaunchKernelGGL(k_halo_unpack_b, dim3(cdiv((int64_t)face, 256), 2 * nl), dim3(256), 0, G->stream, G->a_force_c, (const float *)G->a_halo, ncn, axis);
-    else
-    for (int i = 0; i < nl; i++) {
-      hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[0], ncn, axis, ncn + 1);
-      hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((int64_t)face, 256)), dim3(256), 0, G->stream, G->ctx[i]->force_c, (const float *)G->cd[i].halo_r[1], ncn, axis, 0);
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  P3M_TRY(coarse_force_halo(G));
   if (!G->batched)
   for (int i = 0; i < nl; i++) {
     hipLaunchKernelGGL(k_gmax_interior, dim3(std::min<int64_t>(1024, cdiv((int64_t)ncn * ncn * ncn, 256))), dim3(256), 0, G->stream, (const float *)G->ctx[i]->force_c, ncn,

@@ -426,6 +426,7 @@ void orc_coarse_kernel(orc_ctx *c, const float *table4 /* [k][j][i][3] rows of w
 void orc_update_position(orc_ctx *c, float dt, float dt_old, const float *offset) {
   for (int rk = 0; rk < c->nodes; rk++) {
     orc_rank *R = &c->r[rk];
+#pragma omp parallel for schedule(static)                                 /* update_position.f90:68 */
     for (int i = 1; i <= R->np_local; i++) for (int d = 1; d <= 3; d++) {
       if (offset) XV(R, d, i) = XV(R, d, i) + XV(R, d + 3, i) * 0.5f * (dt + dt_old) + offset[d - 1]; /* :71 */
       else XV(R, d, i) = XV(R, d, i) + XV(R, d + 3, i) * 0.5f * (dt + dt_old);                       /* :73 */
@@ -934,6 +935,7 @@ void orc_coarse_density(orc_ctx *c, float mass_p) {
     orc_rank *R = &c->r[rk];
     memset(R->rho_c, 0, sizeof(float) * (size_t)ncn * ncn * ncn);         /* coarse_mass.f90:23 */
     for (int k0 = 0; k0 <= ms - 1; k0++)                                  /* :82 */
+#pragma omp parallel for schedule(dynamic)                                /* :83: planes mesh_scale apart deposit into disjoint cells */
       for (int k = k0; k <= ncn + 1; k += ms) for (int j = 0; j <= ncn + 1; j++) for (int i = 0; i <= ncn + 1; i++) {
         int pp = HOC(c, R, i, j, k);
         int boundary = (i <= 1 || i >= ncn || j <= 1 || j >= ncn || k <= 1 || k >= ncn);  /* :88-90 */
@@ -976,6 +978,7 @@ void orc_coarse_force(orc_ctx *c) {
   orc_fft3d(slab, nc, +1);                                                /* coarse_force.f90:18 */
   memcpy(cr, slab, sizeof(float) * S);                                    /* :20 */
   for (int cc = 1; cc <= 3; cc++) {
+#pragma omp parallel for schedule(static)                                 /* coarse_force.f90:37,56,75 */
     for (int k = 1; k <= nc; k++) for (int j = 1; j <= nc; j++) for (int i = 1; i <= hx; i++) {
       int ii = 2 * i, im = ii - 1;
       float kc = c->kern_c[(((size_t)(k - 1) * nc + (j - 1)) * hx + (i - 1)) * 3 + (cc - 1)];
@@ -983,6 +986,7 @@ void orc_coarse_force(orc_ctx *c) {
       SL(slab, ii, j, k) = SL(cr, im, j, k) * kc;                         /* :44 */
     }
     orc_fft3d(slab, nc, -1);                                              /* :50 incl. /nc^3 (fftw3ds.f90:161) */
+#pragma omp parallel for schedule(static)
     for (int k = 1; k <= nc; k++) for (int j = 1; j <= nc; j++) for (int i = 1; i <= nc; i++)
       fg[(((size_t)(k - 1) * nc + (j - 1)) * nc + (i - 1)) * 3 + (cc - 1)] = SL(slab, i, j, k);
   }
@@ -1084,6 +1088,7 @@ void orc_coarse_max_dt_and_velocity(orc_ctx *c, float a_mid, float dt) {
   c->dt_c_acc = sqrtf((float)ms / (gmax * a_mid * G_F));                  /* coarse_max_dt.f90:36 */
   for (int rk = 0; rk < c->nodes; rk++) {
     orc_rank *R = &c->r[rk];
+#pragma omp parallel for schedule(dynamic)                                /* coarse_velocity.f90:137: every particle is in one chain */
     for (int k = 1; k <= ncn; k++) for (int j = 1; j <= ncn; j++) for (int i = 1; i <= ncn; i++) {
       int pp = HOC(c, R, i, j, k);
       while (pp != 0) {

@@ -479,10 +479,13 @@ def test_capacity_overflow_in_the_ghost_pass_is_one_error_for_the_whole_group():
     assert e.value.code == -3 and "max_np" in str(e.value)
 
 
-def test_per_rank_coarse_path_stays_at_parity():
+@pytest.mark.parametrize("switch", ["P3M_COARSE_PER_RANK", "P3M_COARSE_COPY"])
+def test_per_rank_coarse_path_stays_at_parity(switch):
     """P3M_COARSE_PER_RANK=1 runs the distributed coarse transform rank by rank (the path of pencil decompositions and of mesh
-    sizes without register-stage FFT kernels) where the default batches every stage over the local ranks: held to the same
-    tests, in a child process (the switch is read when the group is created)."""
+    sizes without register-stage FFT kernels) where the default batches every stage over the local ranks; P3M_COARSE_COPY=1
+    keeps the batched stages but moves the three redistributions as messages (what several processes run) where a single
+    process gathers / stores them in place: both held to the same tests, in a child process (the switches are read when the
+    group is created)."""
     import os
     import subprocess
     import sys
@@ -491,7 +494,7 @@ def test_per_rank_coarse_path_stays_at_parity():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_group.py"), os.path.join(here, "test_gpu_baseline_sizes.py"),
                         os.path.join(here, "test_gpu_slab1024.py"), "-q", "-x", "-m", "gpu", "-k",
                         "distributed_coarse_mesh or eight_logical_ranks_match_oracle or nc256"],
-                       env=dict(os.environ, P3M_COARSE_PER_RANK="1"), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
+                       env=dict(os.environ, **{switch: "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 
