@@ -58,22 +58,44 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
         const int js = j + dj; if (js < wlo || js >= whi) continue;
         const int64_t rb = ((int64_t)(tz * pt + ks) * E + (ty * pt + js)) * E + tx * pt;
         const int p0 = cs[rb + wlo], p1 = cs[rb + whi];
-        for (int s = p0 + threadIdx.x; s < p1; s += 64) {
-          const float4 p = spos[s];
-          const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                   // :139
-          const int i1 = (int)floorf(x), j1 = (int)floorf(y), k1 = (int)floorf(z);                     // 0-based (:143 minus 1)
-          if (NGP) {
+        if (NGP) {
+          for (int s = p0 + threadIdx.x; s < p1; s += 64) {
+            const float4 p = spos[s];
+            const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                 // :139
+            const int i1 = (int)floorf(x), j1 = (int)floorf(y), k1 = (int)floorf(z);                   // 0-based (:143 minus 1)
             if (j1 == j && k1 == k) atomicAdd(&row[i1], mass_p);                                         // :148
-          } else {
-            // fine_cic_mass.f90:17-43 / fine_cic_mass_buffer.f90:25-53 (clipped to 1..nf)
+          }
+        } else {
+          // CIC, fine_cic_mass.f90:17-43 / fine_cic_mass_buffer.f90:25-53 (clipped to 1..nf).  ds_add_f32 costs ~2.6 clocks per
+          // lane on this part (tools/ldsbench.hip: 0.2 T updates/s against 1.16 T/s for a read-add-write), so the scatter avoids
+          // it: the 64 records of a chunk come from ONE sorted cell row, their cells ascend, equal cells are neighbours.  The
+          // first lane of every run of equal cells updates the row buffer with a plain read-add-write -- no two of them touch the
+          // same word -- and the (rare) other lanes of a run follow with atomics; the lower and the upper cell of the records are
+          // two such rounds, and the LDS operations of a wavefront complete in order.  A chunk whose cells do not ascend (xv +
+          // offset rounded a record into the next cell ahead of a neighbour of its own cell) takes the atomics for everybody.
+          for (int s0 = p0; s0 < p1; s0 += 64) {   // uniform trip count: the rounds below are wavefront operations
+            const int s = s0 + (int)threadIdx.x;
+            const bool live = s < p1;
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) p = spos[s];
+            const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                 // :139
+            const int i1 = live ? (int)floorf(x) : 0x3fffffff, j1 = (int)floorf(y), k1 = (int)floorf(z);   // 0-based (:143 minus 1)
             const float dx1 = (float)(i1 + 1) - x, dy1 = (float)(j1 + 1) - y, dz1 = (float)(k1 + 1) - z;
             const float dx2 = 1.f - dx1, dy2 = 1.f - dy1, dz2 = 1.f - dz1;
-            float wy, wz;
-            if (j1 == j) wy = dy1; else if (j1 + 1 == j) wy = dy2; else continue;
-            if (k1 == k) wz = dz1; else if (k1 + 1 == k) wz = dz2; else continue;
+            float wy = 0.f, wz = 0.f; bool use = live;
+            if (j1 == j) wy = dy1; else if (j1 + 1 == j) wy = dy2; else use = false;
+            if (k1 == k) wz = dz1; else if (k1 + 1 == k) wz = dz2; else use = false;
             const float mx1 = mass_p * dx1, mx2 = mass_p * dx2;                                          // :23-24
-            atomicAdd(&row[i1], mx1 * wy * wz);
-            if (i1 + 1 < nf) atomicAdd(&row[i1 + 1], mx2 * wy * wz);
+            const float w1 = mx1 * wy * wz, w2 = mx2 * wy * wz;
+            const int prev = __shfl_up(i1, 1, 64);
+            const bool first = threadIdx.x == 0 || prev != i1;          // first lane of a run of equal cells
+            const bool ascending = __ballot(threadIdx.x != 0 && prev > i1) == 0ull;
+            const bool plain = ascending && first;
+            if (use && plain) { const float v = row[i1]; row[i1] = v + w1; }
+            if (use && !plain) atomicAdd(&row[i1], w1);
+            if (use && i1 + 1 < nf) {
+              if (plain) { const float v = row[i1 + 1]; row[i1 + 1] = v + w2; } else atomicAdd(&row[i1 + 1], w2);
+            }
           }
         }
       }
@@ -286,14 +308,23 @@ int fine_force_max(p3m_ctx *c) {
 }
 
 // ------------------------------------------------------------------ :227-319 gather + kick of the physical particles
-template <bool NGP>
+// COARSE: the coarse-mesh kick (coarse_velocity.f90:137-179, same arithmetic and order as k_coarse_kick) follows the fine kick of
+// a record in registers -- PM-only whole steps, where nothing else touches the velocities between the two kicks.  cnt256: the
+// survivors of delete_particles (the physical records) per block of 256 sorted records = per workgroup, counted on the way.
+template <bool NGP, bool COARSE = false>
 __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ spos, float4 *__restrict__ vel, int n, TileGeo G, int Nn, int ms,
-                                                   const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt) {
+                                                   const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
+                                                   const float *__restrict__ fc, int ncn, int *__restrict__ cnt256) {
   const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= n) return;
-  const float4 p = spos[s];
+  float4 p = make_float4(-1.f, -1.f, -1.f, 0.f);
+  if (s < n) p = spos[s];
   const float fNn = (float)Nn;
-  if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) return;  // chains of hoc(1..ncn) only (:234-236)
+  const bool physical = p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;   // chains of hoc(1..ncn) only (:234-236)
+  if (cnt256) {
+    const unsigned long long m = __ballot(physical);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt256[blockIdx.x], __popcll(m));
+  }
+  if (!physical) return;
   const int nct = G.pt / ms;
   // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
   const int tx = ((int)floorf(p.x / (float)ms)) / nct, ty = ((int)floorf(p.y / (float)ms)) / nct, tz = ((int)floorf(p.z / (float)ms)) / nct;
@@ -322,6 +353,24 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
           const float dVc = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
           const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * G.fbp + (i1 + cx);
           v.x = v.x + f0[o] * dVc; v.y = v.y + f0[o + comp_stride] * dVc; v.z = v.z + f0[o + 2 * comp_stride] * dVc;
+        }
+  }
+  if (COARSE) {
+    const float inv = 1.0f / (float)ms;
+    const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
+    const int ci = (int)floorf(cx_) + 1, cj = (int)floorf(cy_) + 1, ck = (int)floorf(cz_) + 1;
+    const float ex1 = (float)ci - cx_, ey1 = (float)cj - cy_, ez1 = (float)ck - cz_;
+    const float ex2 = 1.0f - ex1, ey2 = 1.0f - ey1, ez2 = 1.0f - ez1;
+    const int m = ncn + 2; const int64_t ccs = (int64_t)m * m * m;
+#pragma unroll
+    for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+      for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+        for (int cx = 0; cx < 2; cx++) {                                                              // :153-168
+          const float dV = a_mid * P3M_G_F * dt * (cx ? ex2 : ex1) * (cy ? ey2 : ey1) * (cz ? ez2 : ez1);
+          const int64_t o = ((int64_t)(ck + cz) * m + (cj + cy)) * m + (ci + cx);
+          v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
         }
   }
   vel[vi] = v;
@@ -421,12 +470,26 @@ int fine_kick(p3m_ctx *c, float a_mid, float dt) {
   if (c->np_all == 0) return P3M_OK;
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
+  // the kick visits every record once: it counts the physical ones per block of 256 sorted records for delete_particles
+  // (particles_finalize_enqueue) -- unless the grid moves back before the deletion
+  static const bool nocount = getenv("P3M_SEPARATE_COUNT") && getenv("P3M_SEPARATE_COUNT")[0] == '1';
+  int *cnt256 = nullptr;
+  c->cnt_from_kick = 0;
+  if (!nocount && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK)) {
+    cnt256 = c->flags;
+    HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
+    c->cnt_from_kick = c->np_all;
+  }
+  const float *fc = nullptr;
   if (c->p.flags & P3M_FLAG_NGP)
-    hipLaunchKernelGGL(k_fine_kick<true>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
-                       g.ms, (const float *)c->fbox, cs, a_mid, dt);
+    hipLaunchKernelGGL((k_fine_kick<true, false>), dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
+                       g.ms, (const float *)c->fbox, cs, a_mid, dt, fc, g.ncn, cnt256);
+  else if (c->coarse_first)
+    hipLaunchKernelGGL((k_fine_kick<false, true>), dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
+                       g.ms, (const float *)c->fbox, cs, a_mid, dt, (const float *)c->force_c, g.ncn, cnt256);
   else
-    hipLaunchKernelGGL(k_fine_kick<false>, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
-                       g.ms, (const float *)c->fbox, cs, a_mid, dt);
+    hipLaunchKernelGGL((k_fine_kick<false, false>), dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
+                       g.ms, (const float *)c->fbox, cs, a_mid, dt, fc, g.ncn, cnt256);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }

@@ -352,7 +352,8 @@ void reductions_fold(p3m_ctx *c) {
 // whole-step calls only: the fine kick can carry the coarse kick when no PP kick sits between them in the reference's order
 bool coarse_kick_rides_on_fine(const p3m_ctx *c) {
   static const bool off = getenv("P3M_SEPARATE_COARSE_KICK") && getenv("P3M_SEPARATE_COARSE_KICK")[0] == '1';
-  return !off && (c->p.flags & P3M_FLAG_NGP) && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT | P3M_FLAG_COARSE_NGP));   // -DCOARSE_NGP: k_coarse_kick has the switch
+  // NGP: k_fine_kick_rows<true>; CIC fine mesh (PPINT needs NGP; PP_EXT kicks in between): k_fine_kick<false, true>
+  return !off && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT | P3M_FLAG_COARSE_NGP));   // -DCOARSE_NGP: k_coarse_kick has the switch
 }
 
 // the two halves of the fine mesh step: density + force of every tile (positions only), then everything that moves velocities
