@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_coarse_max(const float *__restrict__ fc
     mx = fmaxf(mx, sqrtf(a * a + b * b + d * d));
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out) + p3m_slot() * 16, __float_as_uint(mx));
+  if ((threadIdx.x & 63) == 0) p3m_atomic_max_nonneg(out + p3m_slot() * 16, mx);
 }
 
 int coarse_force(p3m_ctx *c) {

@@ -152,34 +152,51 @@ __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, 
     if (threadIdx.x == 0 && s != 0.f) atomicAdd(sum_interior + p3m_slot() * 8, (double)s);
   }
 }
-// candidates: sorted indices of records within 2^-10 below a cell face in some coordinate (k_row_sort)
-__global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, const int *__restrict__ cand, const int *__restrict__ ncand_dev, int cand_cap,
-                                                   float *__restrict__ rho, int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
-  // the candidate count stays on the device (written by k_row_sort of this step): no host round trip between sort and deposit
-  const int ncand = min(*ncand_dev, cand_cap);
+// candidates: sorted indices of records within 2^-10 below a cell face in some coordinate, in P3M_CAND_SLOTS lists (k_row_sort;
+// blockIdx.y = list).  ALL: a list overflowed (cand_cnt[16 * slots] != 0): every sorted record is looked at instead (blockIdx.y = 0
+// only; the list kernel then leaves everything to this one)
+__device__ __forceinline__ void ngp_fixup_record(const float4 &p, float *__restrict__ rho, int tile0, int tl, const TileGeo &G, float mass_p, double *__restrict__ sum_interior) {
   const int nf = G.nf, pt = G.pt, nb = G.nb;
+  int t3[3]; tile_xyz(tile0 + tl, G.T, t3[0], t3[1], t3[2]);
+  const float xs[3] = {p.x, p.y, p.z};
+  int gl[3], rr[3]; bool member = true, moved = false;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    gl[d] = (int)floorf(xs[d]) + nb - t3[d] * pt;                       // cell the count-based deposit used
+    member = member && gl[d] >= 4 && gl[d] < nf - 4;                     // chain window (:120-121)
+    rr[d] = (int)floorf(xs[d] + (float)(-t3[d] * pt + nb));             // the reference's cell (:134,:139,:143)
+    moved = moved || (rr[d] != gl[d]);
+  }
+  if (!member || !moved) return;
+  float *base = rho + (int64_t)tl * nf * nf * G.rp;
+  atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0]], -mass_p);
+  atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0]], mass_p);
+  if (sum_interior) {
+    const bool ig = gl[0] >= nb && gl[0] < nf - nb && gl[1] >= nb && gl[1] < nf - nb && gl[2] >= nb && gl[2] < nf - nb;
+    const bool ir = rr[0] >= nb && rr[0] < nf - nb && rr[1] >= nb && rr[1] < nf - nb && rr[2] >= nb && rr[2] < nf - nb;
+    if (ig != ir) atomicAdd(sum_interior, ir ? (double)mass_p : -(double)mass_p);
+  }
+}
+template <bool ALL>
+__global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, int nrec, const int *__restrict__ cand, const int *__restrict__ cand_cnt, int cand_seg,
+                                                   float *__restrict__ rho, int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
+  // the candidate counts stay on the device (written by k_row_sort of this step): no host round trip between sort and deposit
+  const bool overflow = cand_cnt[16 * P3M_CAND_SLOTS] != 0;
+  if (ALL != overflow) return;
+  if (ALL) {
+    const float thr = 1.0f - 0.0009765625f;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nrec * ntile; id += (int64_t)gridDim.x * 256) {
+      const int tl = (int)(id / nrec); const int s = (int)(id - (int64_t)tl * nrec);
+      const float4 p = spos[s];
+      if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) ngp_fixup_record(p, rho, tile0, tl, G, mass_p, sum_interior);
+    }
+    return;
+  }
+  const int slot = blockIdx.y, ncand = min(cand_cnt[slot * 16], cand_seg);
+  const int *list = cand + (int64_t)slot * cand_seg;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)ncand * ntile; id += (int64_t)gridDim.x * 256) {
     const int tl = (int)(id / ncand); const int ci = (int)(id - (int64_t)tl * ncand);
-    const float4 p = spos[cand[ci]];
-    int t3[3]; tile_xyz(tile0 + tl, G.T, t3[0], t3[1], t3[2]);
-    const float xs[3] = {p.x, p.y, p.z};
-    int gl[3], rr[3]; bool member = true, moved = false;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      gl[d] = (int)floorf(xs[d]) + nb - t3[d] * pt;                       // cell the count-based deposit used
-      member = member && gl[d] >= 4 && gl[d] < nf - 4;                     // chain window (:120-121)
-      rr[d] = (int)floorf(xs[d] + (float)(-t3[d] * pt + nb));             // the reference's cell (:134,:139,:143)
-      moved = moved || (rr[d] != gl[d]);
-    }
-    if (!member || !moved) continue;
-    float *base = rho + (int64_t)tl * nf * nf * G.rp;
-    atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0]], -mass_p);
-    atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0]], mass_p);
-    if (sum_interior) {
-      const bool ig = gl[0] >= nb && gl[0] < nf - nb && gl[1] >= nb && gl[1] < nf - nb && gl[2] >= nb && gl[2] < nf - nb;
-      const bool ir = rr[0] >= nb && rr[0] < nf - nb && rr[1] >= nb && rr[1] < nf - nb && rr[2] >= nb && rr[2] < nf - nb;
-      if (ig != ir) atomicAdd(sum_interior, ir ? (double)mass_p : -(double)mass_p);
-    }
+    ngp_fixup_record(spos[list[ci]], rho, tile0, tl, G, mass_p, sum_interior);
   }
 }
 
@@ -194,10 +211,12 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
     HIP_TRY(hipGetLastError());
     if (c->np_all > 0) {
-      // records within 2^-10 below a cell face: ~0.3 % of the records; the grid is sized for that share, the loop covers any count
-      const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256) * ntile;
-      hipLaunchKernelGGL(k_ngp_fixup, dim3((unsigned)std::min<int64_t>(4096, cdiv(guess, 256))), dim3(256), 0, c->stream, (const float4 *)c->spos, (const int *)c->cand,
-                         (const int *)(c->d_counters + 5), (int)std::min<int64_t>(c->cap, 0x7fffffff), c->rho, tile0, ntile, G, mass_p, c->d_sums);
+      // records within 2^-10 below a cell face: ~0.3 % of the records; the grids are sized for that share, the loops cover any count
+      const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256 / P3M_CAND_SLOTS) * ntile;
+      hipLaunchKernelGGL(k_ngp_fixup<false>, dim3((unsigned)std::min<int64_t>(256, cdiv(guess, 256)), P3M_CAND_SLOTS), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,
+                         (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums);
+      hipLaunchKernelGGL(k_ngp_fixup<true>, dim3(2048), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,   // leaves at once unless a list overflowed
+                         (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums);
       HIP_TRY(hipGetLastError());
     }
     return P3M_OK;
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(256) void k_force_max(const float *__restrict__ fbo
     m = fmaxf(m, f);
   }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out) + p3m_slot() * 16, __float_as_uint(m));    // m >= 0
+  if ((threadIdx.x & 63) == 0) p3m_atomic_max_nonneg(out + p3m_slot() * 16, m);    // m >= 0
 }
 int fine_force_max(p3m_ctx *c) {
   const Geometry &g = c->g;
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
                        fmaxf(a.z * a.z + b.z * b.z + d.z * d.z, a.w * a.w + b.w * b.w + d.w * d.w)));
   }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-  if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out) + p3m_slot() * 16, __float_as_uint(m));
+  if (lane == 0 && m > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, m);
   __syncthreads();
   const float fNn = (float)Nn;
   const int nct = G.pt / ms;

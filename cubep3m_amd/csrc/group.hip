@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void k_gmax_interior(const float *__restrict__
     mx = fmaxf(mx, sqrtf(a * a + b * b + d * d));                        // coarse_max_dt.f90:24-31
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(out) + p3m_slot() * 16, __float_as_uint(mx));
+  if ((threadIdx.x & 63) == 0) p3m_atomic_max_nonneg(out + p3m_slot() * 16, mx);
 }
 // real-space coarse kernel on this rank's cube, global coordinates (kernel_initialization.f90:293-336, :366-457)
 __global__ __launch_bounds__(256) void k_ck_cube(float *__restrict__ cube, const float *__restrict__ table, int ncn, int nc, int ox, int oy, int oz, int ms,
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void k_blocks_to_force_b(const float *__restri
     }
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
-  if (lane == 0 && row < nrow) atomicMax(reinterpret_cast<unsigned int *>(red.p[rank]) + p3m_slot() * 16, __float_as_uint(mx));
+  if (lane == 0 && row < nrow) p3m_atomic_max_nonneg(red.p[rank] + p3m_slot() * 16, mx);
 }
 // G->direct: rows [comp][rank][zl][y][x] -> force_c of the OWNERS, and max |F| on the way (unpack_slab, fftw3ds.f90:69-99 +
 // coarse_max_dt.f90:24-31): row (rank r, zl, y) holds, for i < nd, cells of the cube of rank layer(r) + (y/ncn)*nd + i, in its
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void k_rows_to_force_b(const float *__restrict
       mx = fmaxf(fmaxf(mx, sqrtf(a.z * a.z + b.z * b.z + c.z * c.z)), sqrtf(a.w * a.w + b.w * b.w + c.w * c.w));
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned int *>(red.p[owner]) + p3m_slot() * 16, __float_as_uint(mx));
+    if (lane == 0) p3m_atomic_max_nonneg(red.p[owner] + p3m_slot() * 16, mx);
   }
 }
 // coarse_force_buffer.f90 for all local ranks: blockIdx.y = rank*2 + side; halo [rank][4][face]: slots 0,1 = send to -axis / +axis, 2,3 = received

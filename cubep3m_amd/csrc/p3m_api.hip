@@ -89,7 +89,10 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   if (!coarse_only) {
   A(dalloc(&c->pos, c->cap)); A(dalloc(&c->vel, c->cap)); A(dalloc(&c->vel_alt, c->cap)); A(dalloc(&c->pid_home, c->cap));
   A(dalloc(&c->spos, c->cap)); A(dalloc(&c->tpos, c->cap));
-  A(dalloc(&c->flags, c->cap + 8)); A(dalloc(&c->cand, c->cap));
+  A(dalloc(&c->flags, c->cap + 8));
+  c->cand_seg = (int)std::max<int64_t>(1024, c->cap / 16);   // a list holds 4x its share of ALL records; beyond that the fix-up scans everything
+  if (getenv("P3M_CAND_SEG")) c->cand_seg = std::max(1, atoi(getenv("P3M_CAND_SEG")));   // tests of the overflow path
+  A(dalloc(&c->cand, (size_t)c->cand_seg * P3M_CAND_SLOTS)); A(dalloc(&c->cand_cnt, 16 * P3M_CAND_SLOTS + 16));
   const int64_t ncell = (int64_t)g.E * g.E * g.E;
   int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // every entry of [0, ncell] is rewritten by each sort; the pads stay zero
   if (hipMemset(raw, 0, (size_t)(ncell + 16) * sizeof(int)) != hipSuccess) return fail(P3M_EDEVICE);
@@ -141,7 +144,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->vel_alt); dfree(c->pid_home); dfree(c->spos);
-  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
+  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);

@@ -28,10 +28,18 @@ void p3m_set_error(const char *fmt, ...);
     if (_r != P3M_OK) return _r; \
   } while (0)
 
+#define P3M_CAND_SLOTS 64
 #define P3M_NSLOT 64
 #define P3M_SUM_SPAN (P3M_NSLOT * 8)    // doubles per reduced sum
 #define P3M_RED_SPAN (P3M_NSLOT * 16)   // floats per reduced maximum
 #ifdef __HIPCC__
+// Running maximum of non-negative floats (their bit patterns order like unsigned integers).  The atomic is only issued when the
+// value beats what a plain look at the word shows: atomics on ONE address serialise at ~12 ns each on this part, and a kernel
+// cannot retire before its atomics have -- 270 000 wavefronts each posting their maximum to one word are 3.2 ms, however little
+// the wavefronts compute (that was the extended-PP kernel at uniform density).  A stale look only costs a superfluous atomic.
+__device__ __forceinline__ void p3m_atomic_max_nonneg(float *addr, float v) {
+  if (v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
 __device__ __forceinline__ int p3m_slot() { return (int)((blockIdx.x + 13u * blockIdx.y + 31u * blockIdx.z) & (P3M_NSLOT - 1)); }
 #endif
 
@@ -101,7 +109,11 @@ struct p3m_ctx {
   int *scan_tmp = nullptr; size_t scan_tmp_n = 0;
   int *flags = nullptr;        // [cap] compaction flags / offsets
   unsigned char *cflag = nullptr; // [(E/ms)^3] coarse cells holding a record whose tile-local cell differs from floor(x)
-  int *cand = nullptr; int ncand = 0; // [cap] sorted indices of records within 2^-10 below a cell face
+  // sorted indices of the records within 2^-10 below a cell face (the only ones xv + offset_tile can round into the next cell):
+  // P3M_CAND_SLOTS lists of cand_seg entries each, filled by k_row_sort (list = row mod slots); their lengths sit on cache lines
+  // of their own in cand_cnt[slot * 16] -- appending to ONE list cost k_row_sort half its run time (66 000 atomics on one
+  // address serialise at ~12 ns each); cand_cnt[16 * slots] is set when a list overflowed: the fix-up then scans every record
+  int *cand = nullptr; int *cand_cnt = nullptr; int cand_seg = 0;
   int *pp_plan = nullptr, *pp_task_group = nullptr, *pp_counter = nullptr;   // extended PP (pp.hip): first task of every row group, task -> group, task counter
   int *d_counters = nullptr;   // small device counter block
   int *h_counters = nullptr;   // pinned mirror

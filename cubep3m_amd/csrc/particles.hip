@@ -270,7 +270,7 @@ struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, r
 struct RowCompact { int *crow; int w, ncn, ms, T, pt, lo, fb; };   // crow == nullptr: write the full cell_end row
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
                                                  float4 *__restrict__ spos,
-                                                 int *__restrict__ cand, int *__restrict__ ncand, int cand_cap, RowDep dep, RowCompact cc) {
+                                                 int *__restrict__ cand, int *__restrict__ cand_cnt, int cand_seg, RowDep dep, RowCompact cc) {
   extern __shared__ int bins[];
   const int row = blockIdx.x, lane = threadIdx.x;
   const int r0 = rs[row], r1 = rs[row + 1];
@@ -349,8 +349,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const int s = atomicAdd(&bins[(int)floorf(p.x) + (int)nb], 1);
     spos[s] = p;
     if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) {
-      const int k = atomicAdd(ncand, 1);
-      if (k < cand_cap) cand[k] = s;
+      const int slot = row & (P3M_CAND_SLOTS - 1);            // one of 64 lists (p3m_internal.h)
+      const int k = atomicAdd(&cand_cnt[slot * 16], 1);
+      if (k < cand_seg) cand[(int64_t)slot * cand_seg + k] = s; else cand_cnt[16 * P3M_CAND_SLOTS] = 1;
     }
   };
 #pragma unroll
@@ -459,9 +460,10 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   RowCompact cc{nullptr, c->crow_w, g.ncn, g.ms, g.T, g.pt, g.nb - 2, g.fb};
   c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT)) && !full_always;
   if (c->cells_compact) cc.crow = c->crow;
+  HIP_TRY(hipMemsetAsync(c->cand_cnt, 0, sizeof(int) * (16 * P3M_CAND_SLOTS + 16), c->stream));   // empty candidate lists
   hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos,
-                     (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->cand, cnt + 5,
-                     (int)c->cap, dep, cc);
+                     (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->cand, c->cand_cnt,
+                     c->cand_seg, dep, cc);
   HIP_TRY(hipGetLastError());
   // records that left the chaining mesh were dropped (link_list.f90:26-53): the sorted arrays hold n_cur - deleted records.
   // The slots behind them get a position no range test accepts, so everything downstream may run over n_cur records

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356
   }
   for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_down(mag, o, 64));
-  if ((threadIdx.x & 63) == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(fmax_out) + p3m_slot() * 16, __float_as_uint(mag));
+  if ((threadIdx.x & 63) == 0 && mag > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, mag);
 }
 
 static float first_r2_with_root_above(float t);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
     mymax = fmaxf(mymax, sqrtf(ax * ax + ay * ay + az * az));                     // :617
   }
   for (int o = 32; o > 0; o >>= 1) mymax = fmaxf(mymax, __shfl_down(mymax, o, 64));
-  if (threadIdx.x == 0 && mymax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(mymax));
+  if (threadIdx.x == 0 && mymax > 0.f) p3m_atomic_max_nonneg(tile_max + tile, mymax);
 }
 
 // The same sums from LDS: one 256-thread workgroup per block of PB_X x PB_Y x PB_Z home cells of a tile's extended
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__
   __syncthreads();
   if (threadIdx.x == 0) {
     const float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    if (m4 > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(m4));
+    if (m4 > 0.f) p3m_atomic_max_nonneg(tile_max + tile, m4);
   }
 }
 
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
-      if (lane == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(mag));
+      if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(tile_max + tile, mag);
     }
   }
 }
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ s
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
-    if (lane == 0 && mag > 0.f) atomicMax(reinterpret_cast<unsigned int *>(tile_max + tile), __float_as_uint(mag));
+    if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(tile_max + tile, mag);
   }
 }
 

@@ -612,19 +612,30 @@ def test_long_lines_forward_transform_vs_numpy(PM, n):
     assert np.abs(back[:, :, :n] - a[:, :, :n]).max() < 1e-4 and np.all(back[:, :, n:] == 0)
 
 
-@pytest.mark.parametrize("switch", ["P3M_FFT_STOCKHAM", "P3M_SEPARATE_COARSE_KICK", "P3M_Z_UNFUSED", "P3M_PP_EXT_V3"])
+FALLBACKS = {
+    # switch -> the tests that run through the code it selects
+    "P3M_FFT_STOCKHAM": "test_tile_force_vs_oracle or (config1_kick_parity and pm_ngp_uniform) or (config1_kick_parity and pm_cic_uniform) or "
+                        "(register_fft_sizes and 176) or (test_fft_forward and 176)",
+    "P3M_SEPARATE_COARSE_KICK": "(config1_kick_parity and pm_) or two_steps_with_drift",
+    "P3M_Z_UNFUSED": "test_tile_force_vs_oracle or (register_fft_sizes and 176) or (config1_kick_parity and pm_ngp_uniform)",
+    "P3M_PP_EXT_V3": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",
+    "P3M_CAND_SEG": "half_an_ulp or fine_deposit_vs or heavy_blob or (config1_kick_parity and pm_ngp_uniform)",   # = 1: every candidate list overflows
+}
+
+
+@pytest.mark.parametrize("switch", list(FALLBACKS))
 def test_fallback_paths_stay_at_parity(switch):
-    """The run-time switches select the LDS Stockham FFT kernels for every size, the coarse kick in its own pass, and the
-    un-fused z pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run, the
-    LDS-staged extended-PP kernel (k_pp_ext3, the faster one where cells are heavy): all are paths other tile sizes / PP runs take, so they are held to the same parity tests (in a child process: the
-    switches are read once per process)."""
+    """The run-time switches select the LDS Stockham FFT kernels for every size, the coarse kick in its own pass, the un-fused z
+    pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run, and the LDS-staged
+    extended-PP kernel (k_pp_ext3, the faster one where cells are heavy), candidate lists of one entry (the NGP face fix-up then
+    scans every record, as it does when a list overflows): all are paths other tile sizes / PP runs take, so they are held to the
+    parity tests that reach them (in a child process: the switches are read once per process)."""
     import os
     import subprocess
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "test_tile_force_vs_oracle or config1_kick_parity or register_fft_sizes and 176 or test_fft_forward and 176 or two_steps_with_drift or fine_deposit_vs or heavy_blob or dense_blob or other_tilings"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k", FALLBACKS[switch]],
                        env=dict(os.environ, **{switch: "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
