@@ -530,8 +530,15 @@ __device__ __forceinline__ int axis_shift(float x, float Nn, float nb, float *im
   }
   *img = x; return 0;
 }
-constexpr int GP_RPT = 8;   // records per thread: <= 52 reservation atomics per 2048 records
-__global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid_home,
+constexpr int GP_RPT = 8;   // records per thread
+// 1024 threads: <= 52 reservation atomics per 8192 records.  The +x / -x face slots are reserved by nearly every workgroup, and
+// global atomics on ONE address are served one at a time (~12 ns each on this part): 10 000 workgroups of 256 threads spent
+// 126 us of the kernel's 182 us queueing there
+#ifndef P3M_GP_NT
+#define P3M_GP_NT 1024
+#endif
+constexpr int GP_NT = P3M_GP_NT;
+__global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid_home,
                                                    int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts, int all_full) {
   __shared__ int lc[GSLOTS], base[GSLOTS];
   if (threadIdx.x < GSLOTS) lc[threadIdx.x] = 0;
@@ -549,13 +556,13 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
   };
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {   // all loads first: eight independent requests in flight per lane
-    const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
+    const int i = (blockIdx.x * GP_RPT + r) * GP_NT + threadIdx.x;
     p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) p[r] = pos[i];
   }
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
-    const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
+    const int i = (blockIdx.x * GP_RPT + r) * GP_NT + threadIdx.x;
     sh[r] = 0;
     if (i >= n || !in_hoc_range(p[r], -nb, Nn + nb)) continue;   // dropped by link_list ("PARTICLE DELETED")
     float ix, iy, iz;
@@ -565,16 +572,24 @@ __global__ __launch_bounds__(PT) void k_ghost_pack(const float4 *__restrict__ po
     for (int t = 1; t < 8; t++) {
       const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
       float4 img;
+#ifdef P3M_ABL_GP_NOLDS
+      if (ok) rk[r][t - 1] = threadIdx.x;
+#else
       if (ok) rk[r][t - 1] = atomicAdd(&lc[slot_of(p[r], t, sx, sy, sz, ix, iy, iz, &img)], 1);
+#endif
     }
   }
   __syncthreads();
+#ifdef P3M_ABL_GP_NOATOMIC
+  if (threadIdx.x < GSLOTS) base[threadIdx.x] = 0;
+#else
   if (threadIdx.x < GSLOTS) base[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]) : 0;
+#endif
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
     if (sh[r] == 0) continue;
-    const int i = (blockIdx.x * GP_RPT + r) * PT + threadIdx.x;
+    const int i = (blockIdx.x * GP_RPT + r) * GP_NT + threadIdx.x;
     const int sx = sh[r] & 3, sy = (sh[r] >> 2) & 3, sz = sh[r] >> 4;
     float ix, iy, iz;
     (void)axis_shift(p[r].x, Nn, nb, &ix); (void)axis_shift(p[r].y, Nn, nb, &iy); (void)axis_shift(p[r].z, Nn, nb, &iz);
@@ -635,7 +650,7 @@ int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int64_t *seg_off, const
   P3M_TRY(particles_resolve(c));
   if (c->np_local == 0) return P3M_OK;
   GhostSegs S; for (int k = 0; k < GSLOTS; k++) { S.off[k] = seg_off[k]; S.cap[k] = seg_cap[k]; }
-  hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, PT * GP_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid_home,
+  hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, GP_NT * GP_RPT)), dim3(GP_NT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid_home,
                      c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return P3M_OK;

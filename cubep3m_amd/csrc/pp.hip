@@ -61,19 +61,38 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
   bool phys = false, slow = false;
   int cc[3] = {0, 0, 0}, sub[3] = {0, 0, 0}, q0 = 0, q1 = 0;
+  // The records of a fine cell are neighbours in the sorted order: a record's cell mates are found by comparing cell indices along
+  // the wavefront (plus the record before and the one after it) instead of two look-ups in cell_end per record, which at the mean
+  // density cost four times the bytes of the records themselves.  Only a run that crosses the wavefront's ends reads cell_end
+  int64_t cell = -1, ncell = -1;
+  {
+    const int t = lane == 0 ? s - 1 : s + 1;           // the neighbours beyond the wavefront's ends
+    if ((lane == 0 || lane == 63) && t >= 0 && t < n) {
+      const float4 o = spos[t];
+      ncell = ((int64_t)((int)floorf(o.z) + G.nb) * G.E + ((int)floorf(o.y) + G.nb)) * G.E + ((int)floorf(o.x) + G.nb);
+    }
+  }
   if (s < n) {
     p = spos[s];
     const float fNn = (float)G.Nn;
     phys = p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;
+    cell = ((int64_t)((int)floorf(p.z) + G.nb) * G.E + ((int)floorf(p.y) + G.nb)) * G.E + ((int)floorf(p.x) + G.nb);
     if (phys) {
       ref_bucket(p, G, cc, sub);
       const int Ec = G.E / G.ms, cb = G.nb / G.ms;
       slow = cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] != 0;
-      if (!slow) {
-        const int bx = (int)floorf(p.x) + G.nb, by = (int)floorf(p.y) + G.nb, bz = (int)floorf(p.z) + G.nb;
-        const int64_t cell = ((int64_t)bz * G.E + by) * G.E + bx;
-        q0 = cs[cell]; q1 = cs[cell + 1];
-      }
+    }
+  }
+  {
+    const int64_t before = __shfl_up(cell, 1, 64);
+    const unsigned long long heads = __ballot(lane == 0 || cell != before);            // bit l: a run of equal cells starts at lane l
+    const bool open_l = __shfl(cell == ncell ? 1 : 0, 0, 64) != 0, open_r = __shfl(cell == ncell ? 1 : 0, 63, 64) != 0;
+    const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
+    const unsigned long long after = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
+    const int end = after ? __ffsll((long long)after) - 1 : 64;
+    if (phys && !slow) {
+      if ((start == 0 && open_l) || (end == 64 && open_r)) { q0 = cs[cell]; q1 = cs[cell + 1]; }
+      else { const int s0 = s - lane; q0 = s0 + start; q1 = s0 + end; }
     }
   }
   float ax = 0.f, ay = 0.f, az = 0.f;
@@ -447,20 +466,45 @@ __global__ __launch_bounds__(256) void k_pp_fill(const int *__restrict__ plan, i
   const int k1 = min(plan[g + 1], cap);
   for (int k = plan[g]; k < k1; k++) task_group[k] = g;
 }
+__global__ __launch_bounds__(256) void k_pp_fill2(const int *__restrict__ plan, int ngroups, int2 *__restrict__ task2, int cap) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const int k0 = plan[g], k1 = min(plan[g + 1], cap);
+  for (int k = k0; k < k1; k++) task2[k] = make_int2(g, k - k0);
+}
 struct PPForce { float mass_p, pp_bias, ibias, incut, r2_soft, r2_taper; };
+// One partner of the extended sweep.  The hard cut (:558) is decided on r^2 computed in the reference's order; the force itself is
+// formed with fused multiply-adds and the taper in Horner form, 26 instructions instead of 37 (the kick differs from the
+// reference's association in the last bit: 1e-7 relative against the 1e-5 bar), without branches: a lane outside the cut adds zero
 __device__ __forceinline__ void pp_ext_eval(const float4 &p, float ox, float oy, float oz, const PPForce &F, float &ax, float &ay, float &az) {
   const float sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
   const float r2 = sx * sx + sy * sy + sz * sz;
-  if (r2 >= F.r2_soft) {                                                 // :558, decided exactly on r^2 (see k_pp_ext_tiled)
-    const float ir = __builtin_amdgcn_rsqf(r2), rb1 = (r2 * ir) * F.pp_bias, ib = ir * F.ibias, irb3 = ib * ib * ib;
-    float fx = F.mass_p * (sx * irb3), fy = F.mass_p * (sy * irb3), fz = F.mass_p * (sz * irb3);
-    if (r2 < F.r2_taper) {                                               // :559-564
-      const float qq = rb1 * F.incut;
-      const float taper = 1.f - (7.0f / 4.0f) * (qq * qq * qq) + (3.0f / 4.0f) * (qq * qq * qq * qq * qq);
-      fx *= taper; fy *= taper; fz *= taper;
-    }
-    ax -= fx; ay -= fy; az -= fz;                                        // :571
-  }
+  const float ir = __builtin_amdgcn_rsqf(r2), qq = (r2 * ir) * (F.pp_bias * F.incut), ib = ir * F.ibias;
+  const float q2 = qq * qq, q3 = q2 * qq;
+  float taper = __builtin_fmaf(q3, __builtin_fmaf(0.75f, q2, -1.75f), 1.0f);   // 1 - 7/4 q^3 + 3/4 q^5 (:559-564)
+  taper = r2 < F.r2_taper ? taper : 1.0f;
+  float f = (F.mass_p * taper) * (ib * ib * ib);
+  f = r2 >= F.r2_soft ? f : 0.0f;                                        // :558, decided exactly on r^2 (see k_pp_ext_tiled)
+  ax = __builtin_fmaf(-sx, f, ax); ay = __builtin_fmaf(-sy, f, ay); az = __builtin_fmaf(-sz, f, az);   // :571
+}
+// Two partners at once in the halves of packed registers (v_pk_add / v_pk_mul / v_pk_fma_f32: one instruction slot for both):
+// 17 slots per partner.  A half that is not a partner (okA / okB false) adds zero.  Every half goes through the operations of
+// pp_ext_eval; a home record's sum is formed as two partial sums, added at the end
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pp_ext_eval2(const float4 &p, const float4 &A, const float4 &B, bool okA, bool okB, const PPForce &F,
+                                             f32x2 &ax, f32x2 &ay, f32x2 &az) {
+  const f32x2 ox = {A.x, B.x}, oy = {A.y, B.y}, oz = {A.z, B.z};
+  const f32x2 sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
+  const f32x2 r2 = sx * sx + sy * sy + sz * sz;
+  const f32x2 ir = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+  const f32x2 qq = (r2 * ir) * (F.pp_bias * F.incut), ib = ir * F.ibias;
+  const f32x2 q2 = qq * qq, q3 = q2 * qq;
+  const f32x2 c34 = {0.75f, 0.75f}, c74 = {-1.75f, -1.75f}, one = {1.0f, 1.0f};
+  f32x2 taper = __builtin_elementwise_fma(q3, __builtin_elementwise_fma(c34, q2, c74), one);   // :559-564
+  taper.x = r2.x < F.r2_taper ? taper.x : 1.0f; taper.y = r2.y < F.r2_taper ? taper.y : 1.0f;
+  f32x2 f = (F.mass_p * taper) * (ib * ib * ib);
+  f.x = (okA && r2.x >= F.r2_soft) ? f.x : 0.0f; f.y = (okB && r2.y >= F.r2_soft) ? f.y : 0.0f;   // :558
+  ax = __builtin_elementwise_fma(-sx, f, ax); ay = __builtin_elementwise_fma(-sy, f, ay); az = __builtin_elementwise_fma(-sz, f, az);   // :571
 }
 template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
 __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
@@ -645,6 +689,7 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
 #define PP3_NT 256
 #define PP3_PCAP 704
 #define PP3_LCAP 28
+#define PP3_NSEG 8      // task counters (each hands out a contiguous eighth of the tasks)
 __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PPGeo G, int npy, int npx, int xbw, int ngroups, int *__restrict__ plan) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= ngroups) return;
@@ -660,46 +705,56 @@ __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PP
   }
   plan[g] = (count + PP3_NT - 1) / PP3_NT;
 }
-__global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
+template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
+__global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
                                                     float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
-                                                    const int *__restrict__ task_group, int ngroups, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
-                                                    int Wp, int NRmax) {   // Wp: entries per row of the offset table (xbw + 2r + 1 rounded up to even); NRmax: partner rows
+                                                    const int2 *__restrict__ task2, int ngroups, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
+                                                    int Wp, int NRmax) {   // task2: {group, sub-task} of every task; Wp: entries per row of the offset table (xbw + 2r + 1 rounded up to even); NRmax: partner rows
   extern __shared__ int sm[];
   constexpr int NH = PP3_HZ * PP3_HY, NW = PP3_NT / 64;
+  // LDS: prec | offs | list | rowg | cum | rstart | roff | misc.  The unrolled window walk below reads offs and cum at rows up to
+  // 2 NRY + 2 outside the region for lanes whose window is clipped away (their counts are forced to zero): with this order such
+  // reads land in prec / list resp. rowg / rstart (5.4 KB and 168 B at most), inside the allocation
   float4 *prec = reinterpret_cast<float4 *>(sm);                              // [PP3_PCAP]  staged partner records (16-byte aligned: first)
-  unsigned short *list = reinterpret_cast<unsigned short *>(prec + PP3_PCAP); // [NW][PP3_LCAP][64]
-  unsigned short *offs = list + NW * PP3_LCAP * 64;                           // [NRmax][Wp]  records of partner row r before cell X0 + i
-  int *rowg = reinterpret_cast<int *>(offs + (size_t)NRmax * Wp);             // [NRmax]      sorted index of the row segment's first record
+  unsigned short *offs = reinterpret_cast<unsigned short *>(prec + PP3_PCAP); // [NRmax][Wp]  records of partner row r before cell X0 + i
+  unsigned short *list = offs + (size_t)NRmax * Wp;                           // [NW][PP3_LCAP + 3][64]  (three rows for the stores past the capacity)
+  int *rowg = reinterpret_cast<int *>(list + NW * (PP3_LCAP + 3) * 64);       // [NRmax]      sorted index of the row segment's first record
   int *cum = rowg + NRmax;                          // [NRmax + 1]  records of the rows before r in the concatenated partner sequence
   int *rstart = cum + NRmax + 1, *roff = rstart + NH;   // home rows: first record, exclusive prefix of the home counts ([NH + 1])
   int *misc = roff + NH + 1;                        // [0] task, [1] fat flag, [2..5] wave maxima
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  unsigned short *mylist = list + wv * PP3_LCAP * 64;
+  unsigned short *mylist = list + wv * (PP3_LCAP + 3) * 64;
   const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int ntask = min(plan[ngroups], ntask_cap);
-  const int per = (ntask + PP_NSEG - 1) / PP_NSEG;
-  int seg = blockIdx.x % PP_NSEG;
-  // thread 0 draws the NEXT task (counter, task -> group, group -> first task: three dependent round trips) while the
-  // workgroup works on the current one; nxt_* are its registers, misc[] hands them to the others
-  int nxt_t = 0, nxt_g = 0, nxt_sub = 0;
-  auto draw = [&]() {   // thread 0 only: a task of segment `seg`, or t >= send when it has run dry
-    const int sbeg = min(seg * per, ntask), send = min(sbeg + per, ntask);
-    int tf = __hip_atomic_load(counter + 32 * seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tf < send - sbeg) tf = atomicAdd(counter + 32 * seg, 1);
-    nxt_t = sbeg + tf;
-    if (nxt_t < send) { nxt_g = task_group[nxt_t]; nxt_sub = nxt_t - plan[nxt_g]; }
+  const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
+  int seg = blockIdx.x % PP3_NSEG;
+  // Thread 0 runs a two-stage pipeline of task draws, one stage per task worked: the counter atomic of the task after the next
+  // (stage A) and the {group, sub-task} look-up of the next one (stage B) are in flight while the workgroup works; each result is
+  // first touched a whole task after its request, so the workgroup never waits for a draw (drawn in one go -- counter, task ->
+  // group, group -> first task -- wavefront 0 stood still for three round trips at the head of every task and the others
+  // waited for it at the first barrier).  A segment that has run dry costs one idle trip through the loop.
+  int a_tf = 0, a_seg = 0, tried = 0;
+  bool a_live = false, b_live = false;
+  int2 b_val = make_int2(0, 0);
+  auto advance = [&]() {   // thread 0 only
+    b_live = false;
+    if (a_live) {
+      const int sbeg = min(a_seg * per, ntask), send = min(sbeg + per, ntask), t = sbeg + a_tf;
+      if (t < send) { b_val = task2[t]; b_live = true; tried = 0; }
+      else { tried++; seg = (seg + 1) % PP3_NSEG; }
+    }
+    a_live = tried < PP3_NSEG;
+    if (a_live) { a_seg = seg; a_tf = atomicAdd(counter + 32 * seg, 1); }
   };
-  if (tid == 0) draw();
-  for (int tried = 0; tried < PP_NSEG;) {
-    const int send = min(min(seg * per, ntask) + per, ntask);
+  if (tid == 0) { a_live = true; a_seg = seg; a_tf = atomicAdd(counter + 32 * seg, 1); advance(); }
+  for (;;) {
     __syncthreads();                                  // the previous task's readers of the LDS tables (and of misc) are done
-    if (tid == 0) { misc[0] = nxt_t; misc[1] = 0; misc[6] = nxt_g; misc[7] = nxt_sub; }
+    if (tid == 0) { misc[0] = b_live ? 1 : (a_live ? 0 : -1); misc[1] = 0; misc[6] = b_val.x; misc[7] = b_val.y; advance(); }
     __syncthreads();
-    const int t = misc[0];
-    if (t >= send) { seg = (seg + 1) % PP_NSEG; tried++; if (tid == 0) draw(); continue; }
-    tried = 0;
+    const int state = misc[0];
+    if (state < 0) break;                             // every segment has run dry
+    if (state == 0) continue;                         // a dry segment: the next draw is on its way
     const int g = misc[6], sub = misc[7];
-    if (tid == 0) draw();                             // in flight during this task
     const int xb = g % npx, gy = (g / npx) % npy, gz = (g / (npx * npy)) % npz, tile = g / (npx * npy * npz);
     const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
     const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
@@ -716,23 +771,33 @@ __global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ s
       const int rz = gz * PP3_HZ + tid / PP3_HY, ry = gy * PP3_HY + tid % PP3_HY;
       if (rz < e && ry < e) { const int64_t rb = ((int64_t)(loz + rz) * E + (loy + ry)) * E; hst = cs[rb + hx0]; hcnt = cs[rb + hx1] - hst; }
     }
-    constexpr int RCH = 20;
-    for (int rc = wv; rc < NR; rc += NW * RCH) {      // RCH rows of this wavefront at a time: their loads are in flight together
-      int o[RCH];
+    constexpr int RCH = 40;                           // (HZ + 4) (HY + 4) / NW rows: one trip at the default reach
+    {
+      // this wavefront's rows wv, wv + NW, ...: the row index and its (z, y) are walked in scalar registers (as quotients of
+      // a per-lane row number they cost 30 vector instructions per row, half of the kernel's instructions)
+      const int wvu = __builtin_amdgcn_readfirstlane(wv);
+      int yy = Y0 + wvu, zz = Z0;
+      while (yy > Y1) { yy -= NRY; zz++; }
+      for (int rc = wvu; rc < NR; rc += NW * RCH) {   // RCH rows at a time: their loads are in flight together
+        int o[RCH];
 #pragma unroll
-      for (int u = 0; u < RCH; u++) {
-        const int r = rc + u * NW;
-        o[u] = 0;
-        if (r < NR && lane < W) { const int zz = Z0 + r / NRY, yy = Y0 + r % NRY; o[u] = cs[((int64_t)zz * E + yy) * E + X0 + lane]; }
-      }
+        for (int u = 0; u < RCH; u++) {
+          o[u] = 0;
+          if (rc + u * NW < NR) {
+            if (lane < W) o[u] = cs[((int64_t)zz * E + yy) * E + X0 + lane];
+            yy += NW;
+            while (yy > Y1) { yy -= NRY; zz++; }
+          }
+        }
 #pragma unroll
-      for (int u = 0; u < RCH; u++) {
-        const int r = rc + u * NW;
-        if (r >= NR) break;
-        const int first = __shfl(o[u], 0, 64), d = o[u] - first;
-        if (lane < W) offs[r * Wp + lane] = (unsigned short)min(d, 65535);
-        if (lane == W - 1) { if (d > 65534) misc[1] = 1; }
-        if (lane == 0) rowg[r] = first;
+        for (int u = 0; u < RCH; u++) {
+          const int r = rc + u * NW;
+          if (r >= NR) break;
+          const int first = __builtin_amdgcn_readfirstlane(o[u]), d = o[u] - first;
+          if (lane < W) offs[r * Wp + lane] = (unsigned short)min(d, 65535);
+          if (lane == W - 1) { if (d > 65534) misc[1] = 1; }
+          if (lane == 0) rowg[r] = first;
+        }
       }
     }
     if (wv == 0) {
@@ -765,10 +830,38 @@ __global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ s
     const bool valid = h < total;
     int j = 0;
     { int lo = 0, hi = NH; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= h) lo = mid; else hi = mid; } j = lo; }
-    const int s = valid ? rstart[j] + (h - roff[j]) : 0;
-    const float4 p = valid ? spos[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int cx = valid ? (int)floorf(p.x) + G.nb : hx0;                       // :412
     const int cz = hz0 + (valid ? j / PP3_HY : 0), cy = hy0 + (valid ? j % PP3_HY : 0);
+    __syncthreads();
+    const int Ptot = cum[NR];                         // uniform
+    // flat copy of the partner records [b0, b1) of the concatenated sequence: v -> (row, index) by bisection over cum; the loads of
+    // a thread's records are in flight together
+    auto stage = [&](int b0, int b1) {
+      constexpr int NV = (PP3_PCAP + PP3_NT - 1) / PP3_NT;
+      float4 q[NV];
+#pragma unroll
+      for (int u = 0; u < NV; u++) {
+        const int v = b0 + tid + u * PP3_NT;
+        q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < b1) {
+          int lo = 0, hi = NR;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cum[mid] <= v) lo = mid; else hi = mid; }
+          q[u] = spos[rowg[lo] + (v - cum[lo])];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NV; u++) { const int v = b0 + tid + u * PP3_NT; if (v < b1) prec[v - b0] = q[u]; }
+    };
+    // The whole region in one batch (the rule away from blobs): the home records are among the staged ones -- they are read from
+    // LDS, not in a round trip of their own before the staging (a task is a chain of dependent round trips: cell offsets, records,
+    // velocities; the kernel's time is set by how many of them a task waits for, not by its instructions)
+    const bool single = PPR > 0 && !fat && Ptot <= PP3_PCAP;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (single) {
+      stage(0, Ptot);
+      __syncthreads();
+      if (valid) { const int r = (cz - Z0) * NRY + (cy - Y0); p = prec[cum[r] + (int)offs[r * Wp + (hx0 - X0)] + (h - roff[j])]; }
+    } else if (valid) p = spos[rstart[j] + (h - roff[j])];
+    const int cx = valid ? (int)floorf(p.x) + G.nb : hx0;                       // :412
     int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);
     // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): see k_pp_ext
     if (cz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
@@ -778,8 +871,6 @@ __global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ s
     const int vi = rec_index(p);                      // the velocity stays in arrival order (p3m_internal.h); fetched now, needed after the sums
     float4 vrec = make_float4(0.f, 0.f, 0.f, 0.f);
     if (phys) vrec = vel[vi];
-    __syncthreads();
-    const int Ptot = cum[NR];                         // uniform
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (fat) {
       // a row segment holds more records than a 16-bit offset counts: windows and partners straight from global memory
@@ -797,6 +888,7 @@ __global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ s
             }
           }
     } else {
+      f32x2 ax2 = {0.f, 0.f}, ay2 = {0.f, 0.f}, az2 = {0.f, 0.f};
       // own cell, excluded (:515-516), as positions of the concatenated sequence
       int own0 = 0, own1 = 0;
       if (valid) {
@@ -805,29 +897,46 @@ __global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ s
       }
       for (int b0 = 0; b0 < max(Ptot, 1); b0 += PP3_PCAP) {   // batches of the concatenated partner sequence (one, unless a blob sits here)
         const int b1 = min(b0 + PP3_PCAP, Ptot);
-        if (b0 > 0) __syncthreads();                  // the previous batch's readers are done
-        {                                             // flat copy: v -> (row, index) by bisection over cum; the loads of a thread's records are in flight together
-          constexpr int NV = (PP3_PCAP + PP3_NT - 1) / PP3_NT;
-          float4 q[NV];
+        if (!single) {
+          if (b0 > 0) __syncthreads();                // the previous batch's readers are done
+          stage(b0, b1);
+          __syncthreads();
+        }
+        // pass 1: list the LDS indices of this lane's partners inside the batch.  A window holds 0.6 partners on average
+        int n = 0;
+        if (single) {
+          // the whole region is staged and the reach is known: the (2r+1)^2 windows unrolled, a window's
+          // first three records stored unconditionally at the list's end and the end advanced by a compare (no branches: 25
+          // windows cost ~700 instructions per wavefront where the predicated version below took 2500); a window of more
+          // than three records anywhere in the wavefront sends it through the tail loop
+          const int rh = valid ? (cz - Z0) * NRY + (cy - Y0) : 0;
+          const unsigned short *wa = offs + rh * Wp + (x0 - X0), *wb = offs + rh * Wp + (x1 + 1 - X0);
+          const int *wc = cum + rh;
+          bool yok[2 * PPR + 1];
 #pragma unroll
-          for (int u = 0; u < NV; u++) {
-            const int v = b0 + tid + u * PP3_NT;
-            q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < b1) {
-              int lo = 0, hi = NR;
-              while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cum[mid] <= v) lo = mid; else hi = mid; }
-              q[u] = spos[rowg[lo] + (v - cum[lo])];
+          for (int dy = -PPR; dy <= PPR; dy++) yok[dy + PPR] = valid && cy + dy >= y0 && cy + dy <= y1;
+          // three consecutive slots take a, a+1, a+2 whatever the count: the next window overwrites what was not a partner
+          auto append = [&](int a, int cnt) {
+            unsigned short *o = mylist + min(n, PP3_LCAP) * 64 + lane;   // a lane past the capacity is walked, not listed
+            o[0] = (unsigned short)a; o[64] = (unsigned short)(a + 1); o[128] = (unsigned short)(a + 2);
+            if (__any(cnt > 3))
+              for (int k = 3; k < cnt; k++) mylist[min(n + k, PP3_LCAP + 2) * 64 + lane] = (unsigned short)(a + k);
+            n += cnt;
+          };
+#pragma unroll 1
+          for (int dz = -PPR; dz <= PPR; dz++) {        // one plane of windows per trip: the tail loops are not replicated 25 times
+            const bool zok = cz + dz >= z0 && cz + dz <= z1;
+#pragma unroll
+            for (int dy = -PPR; dy <= PPR; dy++) {
+              const bool rv = zok && yok[dy + PPR];
+              const int d = dz * NRY + dy;             // uniform
+              const int cr = wc[d], a = cr + (int)wa[d * Wp], b = cr + (int)wb[d * Wp];
+              if (dz == 0 && dy == 0) { append(a, rv ? own0 - a : 0); append(own1, rv ? b - own1 : 0); }   // the own cell splits the own row's window (:515-516)
+              else append(a, rv ? b - a : 0);
             }
           }
-#pragma unroll
-          for (int u = 0; u < NV; u++) { const int v = b0 + tid + u * PP3_NT; if (v < b1) prec[v - b0] = q[u]; }
-        }
-        __syncthreads();
-        // pass 1: list the LDS indices of this lane's partners inside the batch.  A window holds 0.6 partners on average: the
-        // first three of every window are appended by predicated stores (no loop whose trip count is the wavefront's maximum),
-        // a rare tail loop takes the rest
-        int n = 0;
-        if (valid) {
+        } else if (valid) {
+          // any reach, any batch: the first three of every window are appended by predicated stores, a tail loop takes the rest
           for (int zz = z0; zz <= z1; zz++)
             for (int yy = y0; yy <= y1; yy++) {
               const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r] - b0;
@@ -851,27 +960,31 @@ __global__ __launch_bounds__(PP3_NT) void k_pp_ext3(const float4 *__restrict__ s
         const bool listed = n <= PP3_LCAP;
         const int nl = listed ? n : 0;
         const int nmax = wave_max_i(nl);
-        for (int k = 0; k < nmax; k += 4) {           // four partners in flight at a time
+        for (int k = 0; k < nmax; k += 4) {           // four partners in flight at a time, two per evaluation; no branches: a slot past the list's end reads record 0 and adds zero
           float4 o[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { o[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (k + u < nl) o[u] = prec[mylist[(k + u) * 64 + lane]]; }
-#pragma unroll
-          for (int u = 0; u < 4; u++) if (k + u < nl) pp_ext_eval(p, o[u].x, o[u].y, o[u].z, F, ax, ay, az);
+          for (int u = 0; u < 4; u++) { const int i = mylist[(k + u) * 64 + lane]; o[u] = prec[k + u < nl ? i : 0]; }
+          pp_ext_eval2(p, o[0], o[1], k < nl, k + 1 < nl, F, ax2, ay2, az2);
+          pp_ext_eval2(p, o[2], o[3], k + 2 < nl, k + 3 < nl, F, ax2, ay2, az2);
         }
-        // dense lanes and multi-batch regions: walk the windows, partners from the staged batch
+        // dense lanes and multi-batch regions: walk the windows, partners from the staged batch, two at a time
         if (valid && !listed) {
           for (int zz = z0; zz <= z1; zz++)
             for (int yy = y0; yy <= y1; yy++) {
               const int r = (zz - Z0) * NRY + (yy - Y0);
               const int va = max(cum[r] + (int)offs[r * Wp + (x0 - X0)], b0), vb = min(cum[r] + (int)offs[r * Wp + (x1 + 1 - X0)], b1);
-              for (int v = va; v < vb; v++) {
-                if (v >= own0 && v < own1) { v = own1 - 1; continue; }
-                const float4 o = prec[v - b0];
-                pp_ext_eval(p, o.x, o.y, o.z, F, ax, ay, az);
+              int v = va;
+              while (v < vb) {
+                if (v >= own0 && v < own1) { v = own1; continue; }            // own cell is excluded (:515-516)
+                const int w = v + 1;
+                const bool okB = w < vb && !(w >= own0 && w < own1);
+                pp_ext_eval2(p, prec[v - b0], prec[(okB ? w : v) - b0], true, okB, F, ax2, ay2, az2);
+                v += 2;
               }
             }
         }
       }
+      ax += ax2.x + ax2.y; ay += ay2.x + ay2.y; az += az2.x + az2.y;
     }
     float mag = 0.f;
     if (valid) {
@@ -903,10 +1016,10 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   const int e = g.pt + 2 * g.pp_range;
   static const bool v1 = getenv("P3M_PP_EXT_V1") && getenv("P3M_PP_EXT_V1")[0] == '1';   // A/B switch: the LDS-tiled kernel of round 1
-  // P3M_PP_EXT_V3=1: the LDS-staged kernel (k_pp_ext3).  Measured on a 560 tile against k_pp_ext2 (ms per launch, uniform /
-  // blobs of 205 / blobs of 13 000): 4.0 / 10.7 / 534 against 4.1 / 10.1 / 715 -- thirteen times fewer cache lines, but as many
-  // instruction slots: it only wins where cells are heavy, so the gather kernel stays the default
-  static const bool v3 = getenv("P3M_PP_EXT_V3") && getenv("P3M_PP_EXT_V3")[0] == '1';
+  // The LDS-staged kernel (k_pp_ext3) is the default.  P3M_PP_EXT_V2=1 selects the gather kernel k_pp_ext2 (ms per launch on a 560 tile,
+  // uniform / blobs of 205 / blobs of 13 000: 3.22 / 8.9 / 632 against 2.40 / 8.9 / 439 for k_pp_ext3)
+  static const bool v2 = getenv("P3M_PP_EXT_V2") && getenv("P3M_PP_EXT_V2")[0] == '1';
+  const bool v3 = !v2;
   if (!v1 && v3) {
     // patches of PP3_HZ x PP3_HY rows x xbw cells holding 7/8 of PP3_NT home records at the mean density (one task)
     static const int xbw_env = getenv("P3M_PP_XBW") ? atoi(getenv("P3M_PP_XBW")) : 0;
@@ -921,24 +1034,25 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     if (ngroups_max > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many patches"); return P3M_EINVAL; }
     const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
     if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
-    if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)ntask_cap64));
+    if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int2) * (size_t)ntask_cap64));   // {group, sub-task} per task
     if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
     P3M_TRY(scan_reserve(c, ngroups_max + 8));
     HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
     hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
     HIP_TRY(hipGetLastError());
     P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
-    hipLaunchKernelGGL(k_pp_fill, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, c->pp_task_group, ntask_cap);
+    hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int2 *>(c->pp_task_group), ntask_cap);
     HIP_TRY(hipGetLastError());
     PPForce F{mass_p, G.pp_bias, 1.0f / G.pp_bias, 1.0f / G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f))};
     const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
-    const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * ((size_t)(PP3_NT / 64) * PP3_LCAP * 64 + (size_t)NRmax * Wp) +
+    const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * ((size_t)(PP3_NT / 64) * (PP3_LCAP + 3) * 64 + (size_t)NRmax * Wp) +
                        sizeof(int) * ((size_t)2 * NRmax + 1 + 2 * PP3_HZ * PP3_HY + 1 + 8);   // 8: misc
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pp_ext3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kern = g.pp_range == 2 ? k_pp_ext3<2> : k_pp_ext3<0>;
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const int wpc3 = getenv("P3M_PP_WPC") ? atoi(getenv("P3M_PP_WPC")) : 0;
     int wpc = wpc3 > 0 ? wpc3 : (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));   // resident workgroups per CU by LDS
-    hipLaunchKernelGGL(k_pp_ext3, dim3(256 * wpc), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
-                       c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter, Wp, NRmax);
+    hipLaunchKernelGGL(kern, dim3(256 * wpc), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
+                       c->d_tile_ext, (const int *)c->pp_plan, (const int2 *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter, Wp, NRmax);
     HIP_TRY(hipGetLastError());
     return P3M_OK;
   }

@@ -618,7 +618,7 @@ FALLBACKS = {
                         "(register_fft_sizes and 176) or (test_fft_forward and 176)",
     "P3M_SEPARATE_COARSE_KICK": "(config1_kick_parity and pm_) or two_steps_with_drift",
     "P3M_Z_UNFUSED": "test_tile_force_vs_oracle or (register_fft_sizes and 176) or (config1_kick_parity and pm_ngp_uniform)",
-    "P3M_PP_EXT_V3": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",
+    "P3M_PP_EXT_V2": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",
     "P3M_CAND_SEG": "half_an_ulp or fine_deposit_vs or heavy_blob or (config1_kick_parity and pm_ngp_uniform)",   # = 1: every candidate list overflows
 }
 
@@ -626,8 +626,8 @@ FALLBACKS = {
 @pytest.mark.parametrize("switch", list(FALLBACKS))
 def test_fallback_paths_stay_at_parity(switch):
     """The run-time switches select the LDS Stockham FFT kernels for every size, the coarse kick in its own pass, the un-fused z
-    pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run, and the LDS-staged
-    extended-PP kernel (k_pp_ext3, the faster one where cells are heavy), candidate lists of one entry (the NGP face fix-up then
+    pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run, the gather
+    extended-PP kernel (k_pp_ext2, round 2's default), candidate lists of one entry (the NGP face fix-up then
     scans every record, as it does when a list overflows): all are paths other tile sizes / PP runs take, so they are held to the
     parity tests that reach them (in a child process: the switches are read once per process)."""
     import os
