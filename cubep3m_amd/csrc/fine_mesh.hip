@@ -403,14 +403,20 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 // COARSE: the coarse-mesh kick of coarse_velocity.f90:137-179 (k_coarse_kick, same arithmetic, same order of the eight
 // corner terms) follows the fine kick of a record in registers -- PM-only runs, where nothing else touches the
 // velocities between the two kicks, so the sums are the ones two separate passes would form.
+#ifndef P3M_KICK_WPB
+#define P3M_KICK_WPB 1      // force-box rows (wavefronts) per workgroup
+#endif
 template <bool COARSE>
-__global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G,
+__global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G,
                                                       int Nn, int ms, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
                                                       float *__restrict__ fmax_out, const float *__restrict__ fc, int ncn, const int *__restrict__ crow, int crow_w,
                                                       int *__restrict__ cnt256) {   // cnt256: survivors per block of 256 sorted records, counted on the way (or nullptr)
-  extern __shared__ float frow[];   // [3][fbp]
-  const int fb = G.fb, fbp = G.fbp, lo = G.nb - 2, lane = threadIdx.x;
-  const int jj = blockIdx.x % fb, kk = (blockIdx.x / fb) % fb, tile = blockIdx.x / (fb * fb);
+  extern __shared__ float frow_all[];   // [rows of the workgroup][3][fbp]
+  const int fb = G.fb, fbp = G.fbp, lo = G.nb - 2, lane = threadIdx.x & 63;
+  const int brow = blockIdx.x * P3M_KICK_WPB + (threadIdx.x >> 6);   // the wavefront's row of the force boxes; rows never wait for each other
+  if (brow >= G.T * G.T * G.T * fb * fb) return;
+  float *frow = frow_all + (threadIdx.x >> 6) * 3 * fbp;
+  const int jj = brow % fb, kk = (brow / fb) % fb, tile = brow / (fb * fb);
   int tx, ty, tz; tile_xyz(tile, G.T, tx, ty, tz);
   const float *f0 = fbox + (int64_t)tile * fb * fb * fbp;
   const int64_t ro = ((int64_t)kk * fb + jj) * fbp;
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(64) void k_fine_kick_rows(const float4 *__restrict_
   }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
   if (lane == 0 && m > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, m);
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   const float fNn = (float)Nn;
   const int nct = G.pt / ms;
   const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
@@ -529,11 +535,11 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
     c->cnt_from_kick = c->np_all;
   }
   if (c->coarse_first)
-    hipLaunchKernelGGL(k_fine_kick_rows<true>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
+    hipLaunchKernelGGL(k_fine_kick_rows<true>, dim3((unsigned)cdiv((int64_t)g.ntiles * g.fb * g.fb, P3M_KICK_WPB)), dim3(64 * P3M_KICK_WPB), sizeof(float) * 3 * g.fbp * P3M_KICK_WPB, c->stream,
                        (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
                        (const float *)c->force_c, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w, cnt256);
   else
-    hipLaunchKernelGGL(k_fine_kick_rows<false>, dim3((unsigned)((int64_t)g.ntiles * g.fb * g.fb)), dim3(64), sizeof(float) * 3 * g.fbp, c->stream,
+    hipLaunchKernelGGL(k_fine_kick_rows<false>, dim3((unsigned)cdiv((int64_t)g.ntiles * g.fb * g.fb, P3M_KICK_WPB)), dim3(64 * P3M_KICK_WPB), sizeof(float) * 3 * g.fbp * P3M_KICK_WPB, c->stream,
                        (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,
                        (const float *)nullptr, g.ncn, c->cells_compact ? (const int *)c->crow : (const int *)nullptr, c->crow_w, cnt256);
   HIP_TRY(hipGetLastError());

@@ -268,11 +268,18 @@ struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, r
 // compact cell table (p3m_internal.h, crow): entry ci < ncn+2 = start of cell ms*ci - ms/2 + nb (what k_coarse_moments reads),
 // entries ncn+2 + 2*tx, +1 = start of cells tx*pt + lo and tx*pt + lo + fb (the force-box row of tile column tx)
 struct RowCompact { int *crow; int w, ncn, ms, T, pt, lo, fb; };   // crow == nullptr: write the full cell_end row
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
+#ifndef P3M_SORT_WPB
+#define P3M_SORT_WPB 1      // rows (wavefronts) per workgroup
+#endif
+// the rows of a workgroup never wait for each other: their barriers are wavefront-wide (LDS operations of a wavefront complete in order)
+__device__ __forceinline__ void row_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
                                                  float4 *__restrict__ spos,
                                                  int *__restrict__ cand, int *__restrict__ cand_cnt, int cand_seg, RowDep dep, RowCompact cc) {
-  extern __shared__ int bins[];
-  const int row = blockIdx.x, lane = threadIdx.x;
+  extern __shared__ int bins_all[];
+  const int row = blockIdx.x * P3M_SORT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  int *bins = bins_all + (threadIdx.x >> 6) * E;
   const int r0 = rs[row], r1 = rs[row + 1];
   // the first 128 records of the row (a row holds ~70 at the reference's density) live in registers from here on: their
   // positions feed both the histogram and the scatter.  Only positions move: the fourth lane carries the arrival index
@@ -282,11 +289,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
   for (int u = 0; u < RR; u++) { const int i = r0 + u * 64 + lane; rin[u] = i < r1; rp[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (rin[u]) rp[u] = tpos[i]; }
   for (int j = lane; j < E; j += 64) bins[j] = 0;
-  __syncthreads();
+  row_sync();
 #pragma unroll
   for (int u = 0; u < RR; u++) if (rin[u]) atomicAdd(&bins[(int)floorf(rp[u].x) + (int)nb], 1);
   for (int i = r0 + RR * 64 + lane; i < r1; i += 64) atomicAdd(&bins[(int)floorf(tpos[i].x) + (int)nb], 1);
-  __syncthreads();
+  row_sync();
   const int chunk = (E + 63) / 64, j0 = min(lane * chunk, E), j1 = min(j0 + chunk, E);
   int sum = 0;
   for (int j = j0; j < j1; j++) sum += bins[j];
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
   int run = r0 + inc - sum;
   for (int j = j0; j < j1; j++) { const int t = bins[j]; bins[j] = run; run += t; }
-  __syncthreads();
+  row_sync();
   if (cc.crow) {
     int *o = cc.crow + (int64_t)row * cc.w;
     const int nbi = (int)nb, ntab = cc.ncn + 2 + 2 * cc.T;
@@ -461,7 +468,7 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT)) && !full_always;
   if (c->cells_compact) cc.crow = c->crow;
   HIP_TRY(hipMemsetAsync(c->cand_cnt, 0, sizeof(int) * (16 * P3M_CAND_SLOTS + 16), c->stream));   // empty candidate lists
-  hipLaunchKernelGGL(k_row_sort, dim3(nrows), dim3(64), (size_t)g.E * sizeof(int), c->stream, (const float4 *)c->tpos,
+  hipLaunchKernelGGL(k_row_sort, dim3(cdiv(nrows, P3M_SORT_WPB)), dim3(64 * P3M_SORT_WPB), (size_t)g.E * sizeof(int) * P3M_SORT_WPB, c->stream, (const float4 *)c->tpos,
                      (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->cand, c->cand_cnt,
                      c->cand_seg, dep, cc);
   HIP_TRY(hipGetLastError());
@@ -531,13 +538,10 @@ __device__ __forceinline__ int axis_shift(float x, float Nn, float nb, float *im
   *img = x; return 0;
 }
 constexpr int GP_RPT = 8;   // records per thread
-// 1024 threads: <= 52 reservation atomics per 8192 records.  The +x / -x face slots are reserved by nearly every workgroup, and
-// global atomics on ONE address are served one at a time (~12 ns each on this part): 10 000 workgroups of 256 threads spent
-// 126 us of the kernel's 182 us queueing there
-#ifndef P3M_GP_NT
-#define P3M_GP_NT 1024
-#endif
-constexpr int GP_NT = P3M_GP_NT;
+// 512 threads: <= 52 reservation atomics per 4096 records.  Measured on the default step (us per launch, 16.7 M records): 256 / 512 /
+// 1024 threads 165 / 159 / 161; without the global reservation 153, without the LDS ranks as well 110 -- the kernel is bound by
+// its instruction count (two passes over seven image subsets per record), not by the atomics
+constexpr int GP_NT = 512;
 __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid_home,
                                                    int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts, int all_full) {
   __shared__ int lc[GSLOTS], base[GSLOTS];
@@ -568,23 +572,20 @@ __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__
     float ix, iy, iz;
     const int sx = axis_shift(p[r].x, Nn, nb, &ix), sy = axis_shift(p[r].y, Nn, nb, &iy), sz = axis_shift(p[r].z, Nn, nb, &iz);
     sh[r] = sx | (sy << 2) | (sz << 4);
+    // the x-only image first: every wavefront of cell-sorted records holds +-x face records, but only the rows near a y or z
+    // face (18 % of them) have any other subset -- those six are skipped by one branch elsewhere
+    float4 img;
+    if (sx) rk[r][0] = atomicAdd(&lc[slot_of(p[r], 1, sx, sy, sz, ix, iy, iz, &img)], 1);
+    if (sy | sz) {
 #pragma unroll
-    for (int t = 1; t < 8; t++) {
-      const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
-      float4 img;
-#ifdef P3M_ABL_GP_NOLDS
-      if (ok) rk[r][t - 1] = threadIdx.x;
-#else
-      if (ok) rk[r][t - 1] = atomicAdd(&lc[slot_of(p[r], t, sx, sy, sz, ix, iy, iz, &img)], 1);
-#endif
+      for (int t = 2; t < 8; t++) {
+        const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
+        if (ok) rk[r][t - 1] = atomicAdd(&lc[slot_of(p[r], t, sx, sy, sz, ix, iy, iz, &img)], 1);
+      }
     }
   }
   __syncthreads();
-#ifdef P3M_ABL_GP_NOATOMIC
-  if (threadIdx.x < GSLOTS) base[threadIdx.x] = 0;
-#else
   if (threadIdx.x < GSLOTS) base[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]) : 0;
-#endif
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
@@ -593,20 +594,25 @@ __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__
     const int sx = sh[r] & 3, sy = (sh[r] >> 2) & 3, sz = sh[r] >> 4;
     float ix, iy, iz;
     (void)axis_shift(p[r].x, Nn, nb, &ix); (void)axis_shift(p[r].y, Nn, nb, &iy); (void)axis_shift(p[r].z, Nn, nb, &iz);
-#pragma unroll
-    for (int t = 1; t < 8; t++) {
-      const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
-      if (!ok) continue;
+    auto send = [&](int t) {
       float4 img;
       const int k = slot_of(p[r], t, sx, sy, sz, ix, iy, iz, &img);
       const int s = base[k] + rk[r][t - 1];
-      if (s >= S.cap[k]) continue;
+      if (s >= S.cap[k]) return;
       if (k & 1) {   // migrant: the whole record
         const float4 v = vel[i]; const int64_t id = pid_home[rec_index(v)];
         float4 *o = sbuf + (int64_t)S.off[k] + 2 * (int64_t)s;
         img.w = v.x;
         o[0] = img; o[1] = make_float4(v.y, v.z, __int_as_float((int)(id & 0xffffffffLL)), __int_as_float((int)(id >> 32)));
       } else sbuf[(int64_t)S.off[k] + s] = img;
+    };
+    if (sx) send(1);
+    if (sy | sz) {
+#pragma unroll
+      for (int t = 2; t < 8; t++) {
+        const bool ok = (!(t & 1) || sx) && (!(t & 2) || sy) && (!(t & 4) || sz);
+        if (ok) send(t);
+      }
     }
   }
 }
