@@ -709,7 +709,7 @@ template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's
 __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
                                                     float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
                                                     const int2 *__restrict__ task2, int ngroups, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
-                                                    int Wp, int NRmax) {   // task2: {group, sub-task} of every task; Wp: entries per row of the offset table (xbw + 2r + 1 rounded up to even); NRmax: partner rows
+                                                    int Wp, int NRmax, int fat_limit) {   // fat_limit: 65534 (see "fat" below); task2: {group, sub-task} of every task; Wp: entries per row of the offset table (xbw + 2r + 1 rounded up to even); NRmax: partner rows
   extern __shared__ int sm[];
   constexpr int NH = PP3_HZ * PP3_HY, NW = PP3_NT / 64;
   // LDS: prec | offs | list | rowg | cum | rstart | roff | misc.  The unrolled window walk below reads offs and cum at rows up to
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
           if (r >= NR) break;
           const int first = __builtin_amdgcn_readfirstlane(o[u]), d = o[u] - first;
           if (lane < W) offs[r * Wp + lane] = (unsigned short)min(d, 65535);
-          if (lane == W - 1) { if (d > 65534) misc[1] = 1; }
+          if (lane == W - 1) { if (d > fat_limit) misc[1] = 1; }
           if (lane == 0) rowg[r] = first;
         }
       }
@@ -1047,12 +1047,15 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
     const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * ((size_t)(PP3_NT / 64) * (PP3_LCAP + 3) * 64 + (size_t)NRmax * Wp) +
                        sizeof(int) * ((size_t)2 * NRmax + 1 + 2 * PP3_HZ * PP3_HY + 1 + 8);   // 8: misc
+    // a partner row segment of more than 65 534 records does not fit the 16-bit offsets: its task takes the per-lane path over
+    // global memory.  P3M_PP_FAT_LIMIT=n lowers the limit (a test switch: ordinary inputs then run that path)
+    static const int fat_limit = getenv("P3M_PP_FAT_LIMIT") ? std::max(1, std::min(65534, atoi(getenv("P3M_PP_FAT_LIMIT")))) : 65534;
     auto kern = g.pp_range == 2 ? k_pp_ext3<2> : k_pp_ext3<0>;
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const int wpc3 = getenv("P3M_PP_WPC") ? atoi(getenv("P3M_PP_WPC")) : 0;
     int wpc = wpc3 > 0 ? wpc3 : (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));   // resident workgroups per CU by LDS
     hipLaunchKernelGGL(kern, dim3(256 * wpc), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
-                       c->d_tile_ext, (const int *)c->pp_plan, (const int2 *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter, Wp, NRmax);
+                       c->d_tile_ext, (const int *)c->pp_plan, (const int2 *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter, Wp, NRmax, fat_limit);
     HIP_TRY(hipGetLastError());
     return P3M_OK;
   }
