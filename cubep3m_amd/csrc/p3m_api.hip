@@ -93,6 +93,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   c->cand_seg = (int)std::max<int64_t>(1024, c->cap / 16);   // a list holds 4x its share of ALL records; beyond that the fix-up scans everything
   if (getenv("P3M_CAND_SEG")) c->cand_seg = std::max(1, atoi(getenv("P3M_CAND_SEG")));   // tests of the overflow path
   A(dalloc(&c->cand, (size_t)c->cand_seg * P3M_CAND_SLOTS)); A(dalloc(&c->cand_cnt, 16 * P3M_CAND_SLOTS + 16));
+  A(dalloc(&c->gl_cnt, 16 * P3M_GL_SLOTS)); c->gl_cap = (int)std::min<int64_t>(0x7fffffff, (4 * c->cap) / P3M_GL_SLOTS);   // the lists live in a float4-per-record buffer
   const int64_t ncell = (int64_t)g.E * g.E * g.E;
   int *raw = nullptr; A(dalloc(&raw, ncell + 16)); c->cell_end = raw + 3;  // every entry of [0, ncell] is rewritten by each sort; the pads stay zero
   if (hipMemset(raw, 0, (size_t)(ncell + 16) * sizeof(int)) != hipSuccess) return fail(P3M_EDEVICE);
@@ -144,7 +145,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->vel_alt); dfree(c->pid_home); dfree(c->spos);
-  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
+  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);
@@ -271,7 +272,7 @@ extern "C" int p3m_hip_upload_particles(p3m_ctx *c, const float *xv6, const int6
   if (!c || np_local < 0 || (np_local > 0 && !xv6)) return P3M_EINVAL;
   if (np_local > c->cap) { p3m_set_error("np_local %d exceeds max_np %lld", np_local, (long long)c->cap); return P3M_ECAPACITY; }
   HIP_TRY(hipSetDevice(c->device));
-  c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false; c->cnt_from_kick = 0; c->n_home = 0;
+  c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false; c->gl_valid = false; c->cnt_from_kick = 0; c->n_home = 0;
   if (np_local == 0) return P3M_OK;
   float *tmp = nullptr; P3M_TRY(dalloc(&tmp, (size_t)np_local * 6));
   HIP_TRY(hipMemcpyAsync(tmp, xv6, sizeof(float) * 6 * (size_t)np_local, hipMemcpyHostToDevice, c->stream));
@@ -466,7 +467,7 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
 // after an error in the middle of a step: nothing that was queued for "later" may be trusted by the next call -- the next sort
 // counts its rows itself (k_row_hist), no survivor counts, no deferred counters, no half-finished ghost removal
 void particles_reset_after_error(p3m_ctx *c) {
-  c->hist_done = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false;
+  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 }

@@ -29,6 +29,7 @@ void p3m_set_error(const char *fmt, ...);
   } while (0)
 
 #define P3M_CAND_SLOTS 64
+#define P3M_GL_SLOTS 8
 #define P3M_NSLOT 64
 #define P3M_SUM_SPAN (P3M_NSLOT * 8)    // doubles per reduced sum
 #define P3M_RED_SPAN (P3M_NSLOT * 16)   // floats per reduced maximum
@@ -123,6 +124,11 @@ struct p3m_ctx {
   hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;   // single-rank whole steps: the coarse force forms on stream2 underneath the fine-mesh force sweep
   int sort_ncur = 0;           // records handed to the sort queued by particles_sort_enqueue
   int cnt_from_kick = 0;       // records the NGP kick counted into c->flags per block of 256 (survivors of delete_particles without move_grid_back); 0: not counted
+  // Ghost candidates: the arrival indices of the records within nf_buf of a face of the rank's volume (the only ones the ghost
+  // pass sends anywhere), listed by the compaction + drift pass that forms their positions -- P3M_GL_SLOTS lists in the dead
+  // arrival buffer (tpos after the swap), their lengths on cache lines of their own in gl_cnt[slot * 16].  Valid exactly as long
+  // as hist_done is (same writers, same invalidations); the ghost pack then reads a quarter of the records
+  int *gl_cnt = nullptr; int gl_cap = 0; bool gl_valid = false; int64_t gl_longest = 0;   // gl_longest: no list holds more (the records of its blocks)
   bool hist_done = false;      // the x-row counts of the next sort were accumulated while the arrival arrays were written (particles.hip)
   bool finalize_queued = false; // particles_finalize_enqueue ran, particles_finalize_finish has not
   bool lazy_counters = false;  // whole steps: the sort's deleted count has not been read yet, np_all is its upper bound (the tail is padded)

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(PT) void k_drift(float4 *__restrict__ pos, const fl
 
 int particles_drift(p3m_ctx *c, float dt, float dt_old, const float *offset) {
   if (c->pending_compact) return particles_compact(c, true, dt, dt_old, offset);   // ghost removal of the last step + this drift in one pass
-  c->hist_done = false;                                                             // positions change in place: no row counts carried
+  c->hist_done = false; c->gl_valid = false;                                        // positions change in place: no row counts carried
   if (c->np_local == 0) return P3M_OK;
   hipLaunchKernelGGL(k_drift, dim3(cdiv(c->np_local, PT)), dim3(PT), 0, c->stream, c->pos, (const float4 *)c->vel, c->np_local, dt, dt_old,
                      offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0);
@@ -439,7 +439,7 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   const bool want_cflag = (c->p.flags & P3M_FLAG_PPINT) != 0;
   const int nblk = cdiv(n_cur, PT * SORT_RPT);
   const bool counted = c->hist_done;   // the rows were counted by the kernels that wrote the arrival arrays (k_compact_drift_hist, ...)
-  c->hist_done = false;
+  c->hist_done = false; c->gl_valid = false;
   c->cnt_from_kick = 0;                // spos is rewritten: per-block survivor counts of an earlier kick are stale
   if (!counted) {
     HIP_TRY(hipMemsetAsync(cnt + 4, 0, 2 * sizeof(int), c->stream));
@@ -542,9 +542,19 @@ constexpr int GP_RPT = 8;   // records per thread
 // 1024 threads 165 / 159 / 161; without the global reservation 153, without the LDS ranks as well 110 -- the kernel is bound by
 // its instruction count (two passes over seven image subsets per record), not by the atomics
 constexpr int GP_NT = 512;
+// LIST: the records to look at are the ghost candidates the compaction listed (blockIdx.y = list, p3m_internal.h): a quarter of the
+// records at the bench's geometry; otherwise every record of the arrival array
+template <bool LIST>
 __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid_home,
-                                                   int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts, int all_full) {
+                                                   int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts, int all_full,
+                                                   const int *__restrict__ glist, const int *__restrict__ gl_cnt, int gl_cap) {
   __shared__ int lc[GSLOTS], base[GSLOTS];
+  int nl = n;
+  if (LIST) {
+    nl = min(gl_cnt[blockIdx.y * 16], gl_cap);
+    if ((int)(blockIdx.x * GP_RPT * GP_NT) >= nl) return;   // the whole workgroup: past the list's end
+    glist += (int64_t)blockIdx.y * gl_cap;
+  }
   if (threadIdx.x < GSLOTS) lc[threadIdx.x] = 0;
   __syncthreads();
   // the images of a record are the non-empty subsets t = 1..7 of its shifted axes (bit 0: x, 1: y, 2: z)
@@ -558,17 +568,21 @@ __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__
     const bool phys = all_full || (x >= 0.f && x < Nn && y >= 0.f && y < Nn && z >= 0.f && z < Nn);
     return 2 * m + (phys ? 1 : 0);
   };
+  int idx[GP_RPT];   // the record's arrival index, -1: none
+#pragma unroll
+  for (int r = 0; r < GP_RPT; r++) {
+    const int e = (blockIdx.x * GP_RPT + r) * GP_NT + threadIdx.x;
+    idx[r] = e < nl ? (LIST ? glist[e] : e) : -1;
+  }
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {   // all loads first: eight independent requests in flight per lane
-    const int i = (blockIdx.x * GP_RPT + r) * GP_NT + threadIdx.x;
     p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) p[r] = pos[i];
+    if (idx[r] >= 0) p[r] = pos[idx[r]];
   }
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
-    const int i = (blockIdx.x * GP_RPT + r) * GP_NT + threadIdx.x;
     sh[r] = 0;
-    if (i >= n || !in_hoc_range(p[r], -nb, Nn + nb)) continue;   // dropped by link_list ("PARTICLE DELETED")
+    if (idx[r] < 0 || !in_hoc_range(p[r], -nb, Nn + nb)) continue;   // dropped by link_list ("PARTICLE DELETED")
     float ix, iy, iz;
     const int sx = axis_shift(p[r].x, Nn, nb, &ix), sy = axis_shift(p[r].y, Nn, nb, &iy), sz = axis_shift(p[r].z, Nn, nb, &iz);
     sh[r] = sx | (sy << 2) | (sz << 4);
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__
 #pragma unroll
   for (int r = 0; r < GP_RPT; r++) {
     if (sh[r] == 0) continue;
-    const int i = (blockIdx.x * GP_RPT + r) * GP_NT + threadIdx.x;
+    const int i = idx[r];
     const int sx = sh[r] & 3, sy = (sh[r] >> 2) & 3, sz = sh[r] >> 4;
     float ix, iy, iz;
     (void)axis_shift(p[r].x, Nn, nb, &ix); (void)axis_shift(p[r].y, Nn, nb, &iy); (void)axis_shift(p[r].z, Nn, nb, &iz);
@@ -656,8 +670,16 @@ int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int64_t *seg_off, const
   P3M_TRY(particles_resolve(c));
   if (c->np_local == 0) return P3M_OK;
   GhostSegs S; for (int k = 0; k < GSLOTS; k++) { S.off[k] = seg_off[k]; S.cap[k] = seg_cap[k]; }
-  hipLaunchKernelGGL(k_ghost_pack, dim3(cdiv(c->np_local, GP_NT * GP_RPT)), dim3(GP_NT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid_home,
-                     c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? 1 : 0);
+  static const bool scan_all = getenv("P3M_GHOST_SCAN") && getenv("P3M_GHOST_SCAN")[0] == '1';   // A/B and test switch: never use the candidate lists
+  const int all_full = (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? 1 : 0;
+  if (c->gl_valid && !scan_all) {
+    // a list holds at most the records of its blocks of the compaction pass (c->gl_longest)
+    hipLaunchKernelGGL(k_ghost_pack<true>, dim3((unsigned)cdiv(std::min<int64_t>(c->gl_longest, c->gl_cap), GP_NT * GP_RPT), P3M_GL_SLOTS), dim3(GP_NT), 0, c->stream,
+                       (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid_home, c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts,
+                       all_full, reinterpret_cast<const int *>(c->tpos), (const int *)c->gl_cnt, c->gl_cap);
+  } else
+    hipLaunchKernelGGL(k_ghost_pack<false>, dim3(cdiv(c->np_local, GP_NT * GP_RPT)), dim3(GP_NT), 0, c->stream, (const float4 *)c->pos, (const float4 *)c->vel,
+                       (const int64_t *)c->pid_home, c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts, all_full, (const int *)nullptr, (const int *)nullptr, 0);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -776,9 +798,12 @@ __global__ __launch_bounds__(PT) void k_compact(const float4 *__restrict__ spos,
 __global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restrict__ spos, const float4 *__restrict__ vel_old,
                                                            const int *__restrict__ offs, int n, float Nn, float4 *__restrict__ pos, float4 *__restrict__ vel,
                                                            float mx, float my, float mz, float hs, float ox, float oy, float oz, int use_off,
-                                                           float nb, int E, int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt) {
+                                                           float nb, int E, int *__restrict__ rs, int *__restrict__ ndeleted, unsigned char *__restrict__ cflag, int ms, int pt,
+                                                           int *__restrict__ glist, int *__restrict__ gl_cnt, int gl_cap) {   // ghost candidates (p3m_internal.h)
   __shared__ int key[SORT_HB], val[SORT_HB];
   __shared__ int wc[SORT_RPT][PT / 64];
+  __shared__ int gl[PT * SORT_RPT], gn, gbase;   // this block's candidates, then one reservation in the block's list
+  if (threadIdx.x == 0) gn = 0;
   for (int e = threadIdx.x; e < SORT_HB; e += PT) { key[e] = -1; val[e] = 0; }
   float4 pl[SORT_RPT];
 #pragma unroll
@@ -801,7 +826,8 @@ __global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restr
   for (int u = 0; u < SORT_RPT; u++) {
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
     float4 p = pl[u];
-    int row = -1;
+    int row = -1, oc = 0;
+    bool cand = false;
     if (i < n && survives(p, Nn, mx, my, mz)) {   // delete_particles.f90:17-47
       p.x -= mx; p.y -= my; p.z -= mz;
       int o = offs[blockIdx.x * SORT_RPT + u] + rk[u];   // offs: first destination of every block of PT records
@@ -814,12 +840,29 @@ __global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restr
       if (in_hoc_range(p, -nb, Nn + nb)) {
         row = ((int)floorf(p.z) + (int)nb) * E + (int)floorf(p.y) + (int)nb;
         if (cflag && p.x >= 0.f && p.x < Nn && p.y >= 0.f && p.y < Nn && p.z >= 0.f && p.z < Nn) flag_displaced(p, nb, E, ms, pt, cflag);
+        // the records k_ghost_pack would find a shift for (axis_shift != 0 on some axis)
+        cand = p.x >= Nn - nb || p.x < nb || p.y >= Nn - nb || p.y < nb || p.z >= Nn - nb || p.z < nb;
+        oc = o;
       } else atomicAdd(ndeleted, 1);
+    }
+    {
+      const unsigned long long m = __ballot(cand);
+      if (m) {
+        int b = 0;
+        if (lane == __ffsll((long long)m) - 1) b = atomicAdd(&gn, __popcll(m));
+        b = __shfl(b, __ffsll((long long)m) - 1, 64);
+        if (cand) gl[b + __popcll(m & ((1ull << lane) - 1ull))] = oc;
+      }
     }
     hist_row(key, val, rs, row);
   }
   __syncthreads();
   hist_flush(key, val, rs);
+  // the block's candidates go to one of P3M_GL_SLOTS lists (by block: the lists fill evenly; one global atomic per block)
+  const int slot = blockIdx.x & (P3M_GL_SLOTS - 1);
+  if (threadIdx.x == 0) gbase = gn ? atomicAdd(&gl_cnt[slot * 16], gn) : 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < gn; e += PT) if (gbase + e < gl_cap) glist[(int64_t)slot * gl_cap + gbase + e] = gl[e];
 }
 
 // delete_particles: the survivors are counted now (the step's np_local), but the copy back to the arrival arrays is
@@ -869,6 +912,7 @@ static int particles_hist_begin(p3m_ctx *c) {
   const Geometry &g = c->g;
   const int nrows = g.E * g.E;
   HIP_TRY(hipMemsetAsync(c->d_counters + 4, 0, 2 * sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(c->gl_cnt, 0, 16 * P3M_GL_SLOTS * sizeof(int), c->stream));
   HIP_TRY(hipMemsetAsync(c->row_end - 3, 0, (size_t)(nrows + 8) * sizeof(int), c->stream));
   if (c->p.flags & P3M_FLAG_PPINT) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
   return P3M_OK;
@@ -886,8 +930,10 @@ int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const floa
     hipLaunchKernelGGL(k_compact_drift_hist, dim3(cdiv(n, PT * SORT_RPT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->vel,
                        (const int *)c->flags, n, (float)g.Nn, c->tpos, c->vel_alt, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
                        offset ? offset[0] : 0.f, offset ? offset[1] : 0.f, offset ? offset[2] : 0.f, offset ? 1 : 0, (float)g.nb, g.E, c->row_end, c->d_counters + 4,
-                       (c->p.flags & P3M_FLAG_PPINT) ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt);
-    c->hist_done = true;
+                       (c->p.flags & P3M_FLAG_PPINT) ? c->cflag : (unsigned char *)nullptr, g.ms, g.pt,
+                       reinterpret_cast<int *>(c->pos), c->gl_cnt, c->gl_cap);   // c->pos: the arrival buffer this pass retires (tpos after the swap below)
+    c->hist_done = true; c->gl_valid = c->cap >= 4096;   // (a list's capacity, cap / 2, holds any list's blocks from two blocks' worth of records on)
+    c->gl_longest = (int64_t)cdiv(cdiv(n, PT * SORT_RPT), P3M_GL_SLOTS) * PT * SORT_RPT;   // every P3M_GL_SLOTS-th block of this pass (n counts the ghosts it drops, too)
   } else if (drift)
     hipLaunchKernelGGL(k_compact<true>, dim3(cdiv(n, PT)), dim3(PT), 0, c->stream, (const float4 *)c->spos, (const float4 *)c->vel,
                        (const int *)c->flags, n, (float)c->g.Nn, c->tpos, c->vel_alt, c->pend_mb[0], c->pend_mb[1], c->pend_mb[2], hs,
