@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
   float4 rp[RR]; bool rin[RR];
 #pragma unroll
   for (int u = 0; u < RR; u++) { const int i = r0 + u * 64 + lane; rin[u] = i < r1; rp[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (rin[u]) rp[u] = tpos[i]; }
-  for (int j = lane; j < E; j += 64) bins[j] = 0;
+  for (int j = lane * 4; j < E; j += 256) *reinterpret_cast<int4 *>(bins + j) = make_int4(0, 0, 0, 0);   // E is a multiple of four
   row_sync();
 #pragma unroll
   for (int u = 0; u < RR; u++) if (rin[u]) atomicAdd(&bins[(int)floorf(rp[u].x) + (int)nb], 1);
@@ -332,15 +332,31 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
         const bool row_int = (j >= nbi && j < dep.nf - nbi && k >= nbi && k < dep.nf - nbi);
         for (int tx = 0; tx < dep.T; tx++) {
           float *out = dep.rho + ((((int64_t)(tz * dep.T + ty) * dep.T + tx) * dep.nf + k) * dep.nf + j) * dep.rp;
-          for (int i = lane; i < dep.rp; i += 64) {
-            float r = 0.f;
-            if (row_in && i >= 4 && i < dep.nf - 4) {
-              const int c = tx * dep.pt + i;
-              const int cnt = (c + 1 < E ? bins[c + 1] : r1) - bins[c];
-              for (int q = 0; q < cnt; q++) r = r + dep.mass_p;                      // :148, same partial sums
-              if (row_int && i >= nbi && i < dep.nf - nbi) part += r;                // :167-173
+          // four cells per lane and trip (the kernel is bound by its instruction count: 650 vector instructions per row, half of
+          // them here when every lane wrote one cell per trip); rp, pt and E are multiples of four
+          for (int i4 = lane * 4; i4 < dep.rp; i4 += 256) {
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (row_in) {
+              const int c = tx * dep.pt + i4;
+              int b[5];
+              if (c + 4 <= E) { const int4 q = *reinterpret_cast<const int4 *>(bins + c); b[0] = q.x; b[1] = q.y; b[2] = q.z; b[3] = q.w; b[4] = c + 4 < E ? bins[c + 4] : r1; }
+              else {
+#pragma unroll
+                for (int u = 0; u < 5; u++) b[u] = c + u < E ? bins[c + u] : r1;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int i = i4 + u;
+                if (i >= 4 && i < dep.nf - 4) {
+                  const int cnt = b[u + 1] - b[u];
+                  float r = 0.f;
+                  for (int q = 0; q < cnt; q++) r = r + dep.mass_p;                  // :148, same partial sums
+                  rr[u] = r;
+                  if (row_int && i >= nbi && i < dep.nf - nbi) part += r;            // :167-173
+                }
+              }
             }
-            out[i] = r;
+            *reinterpret_cast<float4 *>(out + i4) = make_float4(rr[0], rr[1], rr[2], rr[3]);
           }
         }
       }
