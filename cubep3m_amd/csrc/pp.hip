@@ -78,9 +78,14 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     phys = p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;
     cell = ((int64_t)((int)floorf(p.z) + G.nb) * G.E + ((int)floorf(p.y) + G.nb)) * G.E + ((int)floorf(p.x) + G.nb);
     if (phys) {
-      ref_bucket(p, G, cc, sub);
+      // the hoc coarse cell alone decides the path (ref_bucket's three float and six integer divisions were a third of this
+      // kernel's instructions; x / mesh_scale is x * (1 / mesh_scale) bit for bit when mesh_scale is a power of two)
+      const float fms = (float)G.ms, ims = 1.0f / fms;
+      const bool pow2 = (G.ms & (G.ms - 1)) == 0;
+      cc[0] = (int)floorf(pow2 ? p.x * ims : p.x / fms); cc[1] = (int)floorf(pow2 ? p.y * ims : p.y / fms); cc[2] = (int)floorf(pow2 ? p.z * ims : p.z / fms);
       const int Ec = G.E / G.ms, cb = G.nb / G.ms;
       slow = cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] != 0;
+      if (slow) ref_bucket(p, G, cc, sub);             // the sub-cell is only compared on the slow path
     }
   }
   {
@@ -690,8 +695,10 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
 #define PP3_PCAP 704
 #define PP3_LCAP 28
 #define PP3_NSEG 8      // task counters (each hands out a contiguous eighth of the tasks)
+// one wavefront per patch, one lane per home row (PP3_HZ * PP3_HY = 64): a thread per patch walked its 64 rows alone, 130 us per tile
 __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PPGeo G, int npy, int npx, int xbw, int ngroups, int *__restrict__ plan) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
+  static_assert(PP3_HZ * PP3_HY == 64, "one lane per home row");
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), j = threadIdx.x & 63;
   if (g >= ngroups) return;
   const int e = G.pt + 2 * G.ppr, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int xb = g % npx, gy = (g / npx) % npy, gz = (g / (npx * npy)) % npz, tile = g / (npx * npy * npz);
@@ -699,11 +706,11 @@ __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PP
   const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
   const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);
   int count = 0;
-  for (int j = 0; j < PP3_HZ * PP3_HY; j++) {
-    const int rz = gz * PP3_HZ + j / PP3_HY, ry = gy * PP3_HY + j % PP3_HY;
-    if (rz < e && ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count += cs[rb + hx1] - cs[rb + hx0]; }
-  }
-  plan[g] = (count + PP3_NT - 1) / PP3_NT;
+  const int rz = gz * PP3_HZ + j / PP3_HY, ry = gy * PP3_HY + j % PP3_HY;
+  if (rz < e && ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count = cs[rb + hx1] - cs[rb + hx0]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
+  if (j == 0) plan[g] = (count + PP3_NT - 1) / PP3_NT;
 }
 template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
 __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
@@ -1038,7 +1045,7 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
     P3M_TRY(scan_reserve(c, ngroups_max + 8));
     HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
-    hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
+    hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
     HIP_TRY(hipGetLastError());
     P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
     hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int2 *>(c->pp_task_group), ntask_cap);
