@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
   if (!physical) return;
   const int nct = G.pt / ms;
   // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
-  const int tx = ((int)floorf(p.x / (float)ms)) / nct, ty = ((int)floorf(p.y / (float)ms)) / nct, tz = ((int)floorf(p.z / (float)ms)) / nct;
+  int tx = 0, ty = 0, tz = 0;
+  if (G.T > 1) { tx = ((int)floorf(p.x / (float)ms)) / nct; ty = ((int)floorf(p.y / (float)ms)) / nct; tz = ((int)floorf(p.z / (float)ms)) / nct; }
   const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
   const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
   const int lo = G.nb - 2, fb = G.fb;
@@ -447,7 +448,8 @@ __global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const floa
     const float4 p = first ? pf : spos[s];
     if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) continue;  // chains of hoc(1..ncn) only (:234-236)
     // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
-    if (((int)floorf(p.x / (float)ms)) / nct != tx || ((int)floorf(p.y / (float)ms)) / nct != ty || ((int)floorf(p.z / (float)ms)) / nct != tz) continue;
+    // (one tile per rank: every physical record is this tile's -- the three float and three integer divisions were 40 % of the loop's instructions)
+    if (G.T > 1 && (((int)floorf(p.x / (float)ms)) / nct != tx || ((int)floorf(p.y / (float)ms)) / nct != ty || ((int)floorf(p.z / (float)ms)) / nct != tz)) continue;
     if (cnt256) {
       // every physical record passes here exactly once (in its owner tile): they are the survivors of delete_particles.
       // The lanes hold consecutive sorted indices, i.e. at most two blocks of 256: one atomic per block and wavefront
