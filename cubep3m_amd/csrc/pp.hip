@@ -689,11 +689,15 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
 // (blobs) are worked off in batches of PP3_PCAP records of the concatenated row segments; a row segment of more than 65 534
 // records sends the task down a plain per-lane path over global memory.  The partner order per home record (rows in z, y
 // order, ascending sorted index) is that of k_pp_ext.
-#define PP3_HZ 4
-#define PP3_HY 16
+#define PP3_HZ 8        // patch: 8 planes x 8 rows (4 x 16 measured 4.5 % slower: 160 partner rows per task against 144)
+#define PP3_HY 8
 #define PP3_NT 256
 #define PP3_PCAP 704
-#define PP3_LCAP 28
+#define PP3_LCAP 32      // list entries per lane
+#ifndef PP3_WPE
+#define PP3_WPE 5        // wavefronts per SIMD the register allocation aims at (96 VGPRs): five workgroups of 32 KB LDS per CU at the reference density
+#endif
+#define PP3_LSTR 36      // bytes per lane of the list (entries + room for the stores past the capacity; 9 words: conflict-free across lanes)
 #define PP3_NSEG 8      // task counters (each hands out a contiguous eighth of the tasks)
 // one wavefront per patch, one lane per home row (PP3_HZ * PP3_HY = 64): a thread per patch walked its 64 rows alone, 130 us per tile
 __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PPGeo G, int npy, int npx, int xbw, int ngroups, int *__restrict__ plan) {
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PP
   if (j == 0) plan[g] = (count + PP3_NT - 1) / PP3_NT;
 }
 template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
-__global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
+__global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE, PP3_WPE))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
                                                     float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
                                                     const int2 *__restrict__ task2, int ngroups, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
                                                     int Wp, int NRmax, int fat_limit) {   // fat_limit: 65534 (see "fat" below); task2: {group, sub-task} of every task; Wp: entries per row of the offset table (xbw + 2r + 1 rounded up to even); NRmax: partner rows
@@ -724,13 +728,16 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   // reads land in prec / list resp. rowg / rstart (5.4 KB and 168 B at most), inside the allocation
   float4 *prec = reinterpret_cast<float4 *>(sm);                              // [PP3_PCAP]  staged partner records (16-byte aligned: first)
   unsigned short *offs = reinterpret_cast<unsigned short *>(prec + PP3_PCAP); // [NRmax][Wp]  records of partner row r before cell X0 + i
-  unsigned short *list = offs + (size_t)NRmax * Wp;                           // [NW][PP3_LCAP + 3][64]  (three rows for the stores past the capacity)
-  int *rowg = reinterpret_cast<int *>(list + NW * (PP3_LCAP + 3) * 64);       // [NRmax]      sorted index of the row segment's first record
+  // partner lists: one byte per entry, the partner's position in the staged batch minus the position of the lane's first window
+  // (a lane's windows span ~200 positions at the reference's density with 8 x 8-row patches; a lane whose span exceeds 255 is
+  // walked, not listed): 9 KB per workgroup instead of 16 KB of 16-bit entries, which is what lets a fifth workgroup stay on a CU
+  unsigned char *list = reinterpret_cast<unsigned char *>(offs + (size_t)NRmax * Wp);   // [NW][64][PP3_LSTR]
+  int *rowg = reinterpret_cast<int *>(list + NW * 64 * PP3_LSTR);             // [NRmax]      sorted index of the row segment's first record
   int *cum = rowg + NRmax;                          // [NRmax + 1]  records of the rows before r in the concatenated partner sequence
   int *rstart = cum + NRmax + 1, *roff = rstart + NH;   // home rows: first record, exclusive prefix of the home counts ([NH + 1])
   int *misc = roff + NH + 1;                        // [0] task, [1] fat flag, [2..5] wave maxima
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  unsigned short *mylist = list + wv * (PP3_LCAP + 3) * 64;
+  unsigned char *mylist = list + (wv * 64 + lane) * PP3_LSTR;                 // this lane's entries
   const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int ntask = min(plan[ngroups], ntask_cap);
   const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
@@ -911,6 +918,10 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
         // pass 1: list the LDS indices of this lane's partners inside the batch.  A window holds 0.6 partners on average
         int n = 0;
+        bool ovf = false;
+        // the lane's first window starts the lowest position it will list (the windows come in the order of the staged sequence)
+        int base = 0;
+        if (valid) { const int r = (z0 - Z0) * NRY + (y0 - Y0); base = max(cum[r] + (int)offs[r * Wp + (x0 - X0)] - b0, 0); }
         if (single) {
           // the whole region is staged and the reach is known: the (2r+1)^2 windows unrolled, a window's
           // first three records stored unconditionally at the list's end and the end advanced by a compare (no branches: 25
@@ -924,10 +935,12 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
           for (int dy = -PPR; dy <= PPR; dy++) yok[dy + PPR] = valid && cy + dy >= y0 && cy + dy <= y1;
           // three consecutive slots take a, a+1, a+2 whatever the count: the next window overwrites what was not a partner
           auto append = [&](int a, int cnt) {
-            unsigned short *o = mylist + min(n, PP3_LCAP) * 64 + lane;   // a lane past the capacity is walked, not listed
-            o[0] = (unsigned short)a; o[64] = (unsigned short)(a + 1); o[128] = (unsigned short)(a + 2);
+            unsigned char *o = mylist + min(n, PP3_LCAP);   // a lane past the capacity is walked, not listed
+            const int e = a - base;
+            o[0] = (unsigned char)e; o[1] = (unsigned char)(e + 1); o[2] = (unsigned char)(e + 2);
+            ovf = ovf || (cnt > 0 && e + cnt > 256);
             if (__any(cnt > 3))
-              for (int k = 3; k < cnt; k++) mylist[min(n + k, PP3_LCAP + 2) * 64 + lane] = (unsigned short)(a + k);
+              for (int k = 3; k < cnt; k++) mylist[min(n + k, PP3_LCAP + 2)] = (unsigned char)(e + k);
             n += cnt;
           };
 #pragma unroll 1
@@ -943,7 +956,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
           }
         } else if (valid) {
-          // any reach, any batch: the first three of every window are appended by predicated stores, a tail loop takes the rest
+          // any reach, any batch: window by window
           for (int zz = z0; zz <= z1; zz++)
             for (int yy = y0; yy <= y1; yy++) {
               const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r] - b0;
@@ -956,21 +969,19 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
               for (int half = 0; half < 2; half++) {
                 const int a = half == 0 ? va : o1, b = half == 0 ? o0 : vb;
                 if (half == 1 && !ownrow) break;
-                const int cnt = b - a;
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                  if (k < cnt) { if (n < PP3_LCAP) mylist[n * 64 + lane] = (unsigned short)(a + k); n++; }
-                for (int v = a + 3; v < b; v++) { if (n < PP3_LCAP) mylist[n * 64 + lane] = (unsigned short)v; n++; }
+                if (b > a && b - base > 256) ovf = true;
+                for (int v = a; v < b; v++) { if (n < PP3_LCAP) mylist[n] = (unsigned char)(v - base); n++; }
               }
             }
         }
-        const bool listed = n <= PP3_LCAP;
+        const bool listed = !ovf && n <= PP3_LCAP;
         const int nl = listed ? n : 0;
         const int nmax = wave_max_i(nl);
         for (int k = 0; k < nmax; k += 4) {           // four partners in flight at a time, two per evaluation; no branches: a slot past the list's end reads record 0 and adds zero
           float4 o[4];
+          const unsigned e4 = *reinterpret_cast<const unsigned *>(mylist + k);   // four entries
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const int i = mylist[(k + u) * 64 + lane]; o[u] = prec[k + u < nl ? i : 0]; }
+          for (int u = 0; u < 4; u++) { const int i = base + (int)((e4 >> (8 * u)) & 255u); o[u] = prec[k + u < nl ? i : 0]; }
           pp_ext_eval2(p, o[0], o[1], k < nl, k + 1 < nl, F, ax2, ay2, az2);
           pp_ext_eval2(p, o[2], o[3], k + 2 < nl, k + 3 < nl, F, ax2, ay2, az2);
         }
@@ -1052,7 +1063,7 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     HIP_TRY(hipGetLastError());
     PPForce F{mass_p, G.pp_bias, 1.0f / G.pp_bias, 1.0f / G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f))};
     const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
-    const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * ((size_t)(PP3_NT / 64) * (PP3_LCAP + 3) * 64 + (size_t)NRmax * Wp) +
+    const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * (size_t)NRmax * Wp + (size_t)(PP3_NT / 64) * 64 * PP3_LSTR +
                        sizeof(int) * ((size_t)2 * NRmax + 1 + 2 * PP3_HZ * PP3_HY + 1 + 8);   // 8: misc
     // a partner row segment of more than 65 534 records does not fit the 16-bit offsets: its task takes the per-lane path over
     // global memory.  P3M_PP_FAT_LIMIT=n lowers the limit (a test switch: ordinary inputs then run that path)
