@@ -1035,7 +1035,7 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   const int e = g.pt + 2 * g.pp_range;
   static const bool v1 = getenv("P3M_PP_EXT_V1") && getenv("P3M_PP_EXT_V1")[0] == '1';   // A/B switch: the LDS-tiled kernel of round 1
   // The LDS-staged kernel (k_pp_ext3) is the default.  P3M_PP_EXT_V2=1 selects the gather kernel k_pp_ext2 (ms per launch on a 560 tile,
-  // uniform / blobs of 205 / blobs of 13 000: 3.22 / 8.9 / 632 against 2.40 / 8.9 / 439 for k_pp_ext3)
+  // uniform / blobs of 205 / blobs of 13 000: 3.2 / 9.0 / 636 against 2.0 / 7.5 / 422 for k_pp_ext3)
   static const bool v2 = getenv("P3M_PP_EXT_V2") && getenv("P3M_PP_EXT_V2")[0] == '1';
   const bool v3 = !v2;
   if (!v1 && v3) {
