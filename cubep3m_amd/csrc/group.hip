@@ -1185,9 +1185,8 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); }   // every rank's sort queued ...
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort_finish(c, false));                                      // ... and nobody waits: the counters come in with the step's results
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
-  // fine-mesh force sweeps (many small kernels and the all-to-all exchanges against bandwidth-bound FFT passes).  PM-only
-  // NGP runs then apply its kick inside the fine kick's pass (k_fine_kick_rows<true>); with a PP kick in between
-  // (reference order fine, PP, coarse) it keeps its own pass.
+  // fine-mesh force sweeps (many small kernels and the all-to-all exchanges against bandwidth-bound FFT passes).  Its kick
+  // is then applied inside the fine kick's pass (coarse_kick_rides_on_fine, p3m_api.hip).
   const bool ride = !G->ctx.empty() && coarse_kick_rides_on_fine(G->ctx[0]);
   for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                     // coarse_mass
   if (G->stream2) {

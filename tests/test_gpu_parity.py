@@ -616,7 +616,7 @@ FALLBACKS = {
     # switch -> the tests that run through the code it selects
     "P3M_FFT_STOCKHAM": "test_tile_force_vs_oracle or (config1_kick_parity and pm_ngp_uniform) or (config1_kick_parity and pm_cic_uniform) or "
                         "(register_fft_sizes and 176) or (test_fft_forward and 176)",
-    "P3M_SEPARATE_COARSE_KICK": "(config1_kick_parity and pm_) or two_steps_with_drift",
+    "P3M_SEPARATE_COARSE_KICK": "(config1_kick_parity and (pm_ or p3m_ext)) or two_steps_with_drift",
     "P3M_Z_UNFUSED": "test_tile_force_vs_oracle or (register_fft_sizes and 176) or (config1_kick_parity and pm_ngp_uniform)",
     "P3M_PP_EXT_V2": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",
     "P3M_PP_FAT_LIMIT": "(config1_kick_parity and p3m_ext) or dense_blob",   # = 1: every task with a row of two records takes the global-memory path
