@@ -1158,6 +1158,7 @@ static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out, bool do
 
 extern "C" int p3m_hip_group_update_position(p3m_group *G, float dt, float dt_old, const float *offset) {
   if (!G) return P3M_EINVAL;
+  P3M_TRY(need_particles(G->ctx[0], "p3m_hip_group_update_position"));
   HIP_TRY(hipSetDevice(G->device));
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));
   return P3M_OK;
@@ -1231,6 +1232,7 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
 int projection_rank(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz, double *rho_node);   // p3m_api.hip
 extern "C" int p3m_hip_group_projection(p3m_group *G, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_tot) {
   if (!G || !pxy || !pxz || !pyz) return P3M_EINVAL;
+  P3M_TRY(need_particles(G->ctx[0], "p3m_hip_group_projection"));
   HIP_TRY(hipSetDevice(G->device));
   const Geometry &g = G->ctx[0]->g;
   const size_t n2 = (size_t)g.Nn * g.nodes_dim * g.Nn * g.nodes_dim;
@@ -1267,6 +1269,7 @@ extern "C" int p3m_hip_group_projection(p3m_group *G, float mass_p, float *pxy, 
 // probes for the parity tests: local coarse density / force of local rank i in the reference layout
 extern "C" int p3m_hip_group_probe_coarse(p3m_group *G, float mass_p, int32_t i, float *rho_c, float *force_c) {
   if (!G || i < 0 || i >= (int)G->ctx.size()) return P3M_EINVAL;
+  P3M_TRY(need_particles(G->ctx[0], "p3m_hip_group_probe_coarse"));   // it deposits the records; a coarse-only group takes p3m_hip_group_set_coarse_density
   HIP_TRY(hipSetDevice(G->device));
   const Geometry &g = G->ctx[0]->g;
   if (G->nodes == 1) return p3m_hip_probe_coarse(G->ctx[0], mass_p, rho_c, force_c);

@@ -145,7 +145,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->vel_alt); dfree(c->pid_home); dfree(c->spos);
-  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter);
+  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter); dfree(c->pp_htask);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);
@@ -235,7 +235,8 @@ extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const fl
 
 extern "C" int p3m_hip_get_kernels(p3m_ctx *c, float *kern_f, float *kern_c) {
   if (!c) return P3M_EINVAL;
-  if (!c->have_kf || !c->have_kc) { p3m_set_error("kernels not set"); return P3M_ESTATE; }
+  if (kern_f) P3M_TRY(need_particles(c, "p3m_hip_get_kernels (fine kernel)"));
+  if ((kern_f && !c->have_kf) || !c->have_kc) { p3m_set_error("kernels not set"); return P3M_ESTATE; }
   HIP_TRY(hipSetDevice(c->device));
   const Geometry &g = c->g;
   const size_t nf = (size_t)g.nf * g.nf * g.px, ncx = (size_t)g.nc * g.nc * g.pxc;
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256) void k_iota_pid(int64_t *pid, int n) {
 
 extern "C" int p3m_hip_upload_particles(p3m_ctx *c, const float *xv6, const int64_t *pid, int32_t np_local) {
   if (!c || np_local < 0 || (np_local > 0 && !xv6)) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_upload_particles"));
   if (np_local > c->cap) { p3m_set_error("np_local %d exceeds max_np %lld", np_local, (long long)c->cap); return P3M_ECAPACITY; }
   HIP_TRY(hipSetDevice(c->device));
   c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false; c->gl_valid = false; c->cnt_from_kick = 0; c->n_home = 0;
@@ -287,6 +289,7 @@ extern "C" int p3m_hip_upload_particles(p3m_ctx *c, const float *xv6, const int6
 
 extern "C" int p3m_hip_download_particles(p3m_ctx *c, float *xv6, int64_t *pid, int32_t *np_local) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_download_particles"));
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(particles_resolve(c));
   if (np_local) *np_local = c->np_local;
@@ -316,12 +319,14 @@ static int need_kernels(p3m_ctx *c) {
 
 extern "C" int p3m_hip_update_position(p3m_ctx *c, float dt, float dt_old, const float *offset) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_update_position"));
   HIP_TRY(hipSetDevice(c->device));
   return particles_drift(c, dt, dt_old, offset);
 }
 
 extern "C" int p3m_hip_link_list_and_pass(p3m_ctx *c) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_link_list_and_pass"));
   HIP_TRY(hipSetDevice(c->device));
   const int r = particles_pass_and_sort(c);
   if (r != P3M_OK) particles_reset_after_error(c);   // e.g. P3M_ECAPACITY after the images were counted into the row histogram
@@ -379,12 +384,14 @@ int fine_mesh_kick_phase(p3m_ctx *c, float a_mid, float dt, float mass_p) {
 }
 extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_fine_mesh"));
   P3M_TRY(fine_mesh_force_phase(c, mass_p, true));
   return fine_mesh_kick_phase(c, a_mid, dt, mass_p);
 }
 
 extern "C" int p3m_hip_coarse_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_coarse_mesh"));
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
   P3M_TRY(coarse_deposit(c, mass_p));
@@ -395,6 +402,7 @@ extern "C" int p3m_hip_coarse_mesh(p3m_ctx *c, float a_mid, float dt, float mass
 
 extern "C" int p3m_hip_delete_particles(p3m_ctx *c, const float *move_back) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_delete_particles"));
   HIP_TRY(hipSetDevice(c->device));
   return particles_finalize(c, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr);
 }
@@ -412,6 +420,7 @@ int projection_rank(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float 
 }
 extern "C" int p3m_hip_projection(p3m_ctx *c, float mass_p, float *pxy, float *pxz, float *pyz, double *rho_node) {
   if (!c || !pxy || !pxz || !pyz) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_projection"));
   HIP_TRY(hipSetDevice(c->device));
   const size_t n2 = (size_t)c->g.Nn * c->g.nodes_dim * c->g.Nn * c->g.nodes_dim;
   float *d = nullptr;
@@ -478,6 +487,7 @@ static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, f
 extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt_old, float mass_p, const float *offset,
                                      const float *move_back, p3m_step_out *out) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_particle_mesh"));
   const int r = particle_mesh_step(c, a_mid, dt, dt_old, mass_p, offset, move_back, out);
   if (r != P3M_OK && r != P3M_ESTATE && r != P3M_ECOMM && r != P3M_EINVAL) particles_reset_after_error(c);   // the three leave before the first state change
   return r;
@@ -533,6 +543,7 @@ static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, f
 // ------------------------------------------------------------------ probes
 extern "C" int p3m_hip_probe_tile_density(p3m_ctx *c, int32_t tx, int32_t ty, int32_t tz, float mass_p, float *rho_f) {
   if (!c || !rho_f) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_probe_tile_density"));
   const Geometry &g = c->g;
   if (tx < 0 || ty < 0 || tz < 0 || tx >= g.T || ty >= g.T || tz >= g.T) return P3M_EINVAL;
   HIP_TRY(hipSetDevice(c->device));
@@ -546,6 +557,7 @@ extern "C" int p3m_hip_probe_tile_density(p3m_ctx *c, int32_t tx, int32_t ty, in
 
 extern "C" int p3m_hip_probe_tile_force(p3m_ctx *c, const float *rho_f, float *force_f, float *force_max2) {
   if (!c || !rho_f || !force_f) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_probe_tile_force"));
   if (!c->have_kf) { p3m_set_error("fine kernel not set"); return P3M_ESTATE; }
   const Geometry &g = c->g;
   HIP_TRY(hipSetDevice(c->device));
@@ -570,6 +582,7 @@ extern "C" int p3m_hip_probe_tile_force(p3m_ctx *c, const float *rho_f, float *f
 
 extern "C" int p3m_hip_probe_coarse(p3m_ctx *c, float mass_p, float *rho_c, float *force_c) {
   if (!c) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_probe_coarse"));
   const Geometry &g = c->g;
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(reductions_clear(c));
@@ -610,6 +623,7 @@ extern "C" int p3m_hip_fft3d(p3m_ctx *c, float *data, int32_t n, int32_t dir) {
 
 extern "C" int p3m_hip_time_fine_sweep(p3m_ctx *c, float mass_p, int32_t reps, float *ms_per_sweep) {
   if (!c || reps < 1 || !ms_per_sweep) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_time_fine_sweep"));
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
   hipEvent_t e0, e1;
@@ -630,6 +644,7 @@ int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float
 
 extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch) {
   if (!c || reps < 1 || !ms_per_launch) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_time_fft_pass"));
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
   const Geometry &g = c->g;

@@ -115,7 +115,7 @@ struct p3m_ctx {
   // of their own in cand_cnt[slot * 16] -- appending to ONE list cost k_row_sort half its run time (66 000 atomics on one
   // address serialise at ~12 ns each); cand_cnt[16 * slots] is set when a list overflowed: the fix-up then scans every record
   int *cand = nullptr; int *cand_cnt = nullptr; int cand_seg = 0;
-  int *pp_plan = nullptr, *pp_task_group = nullptr, *pp_counter = nullptr;   // extended PP (pp.hip): first task of every row group, task -> group, task counter
+  int *pp_plan = nullptr, *pp_task_group = nullptr, *pp_counter = nullptr, *pp_htask = nullptr;   // extended PP (pp.hip): first task of every patch, task -> {patch, sub-task}, task counters, the heavy-task list
   int *d_counters = nullptr;   // small device counter block
   int *h_counters = nullptr;   // pinned mirror
   // ---- fine mesh, all tiles batched
@@ -165,6 +165,12 @@ struct p3m_ctx {
 };
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// A P3M_FLAG_COARSE_ONLY context holds the coarse mesh of its rank and nothing else (no particle store, no fine mesh: p3m_api.hip):
+// every entry point that touches records, cells or fine arrays refuses it instead of launching kernels on null pointers
+static inline int need_particles(const p3m_ctx *c, const char *what) {
+  if (c->p.flags & P3M_FLAG_COARSE_ONLY) { p3m_set_error("%s on a P3M_FLAG_COARSE_ONLY context (it holds the coarse mesh only)", what); return P3M_ESTATE; }
+  return P3M_OK;
+}
 
 // ---- fft.hip
 extern int p3m_ctx_share_hint;   // p3m_api.hip: contexts that share the device's free memory (set by group.hip around p3m_hip_create)

@@ -7,6 +7,8 @@
 #include "p3m_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <numeric>
+#include <vector>
 
 struct PPGeo { int T, nb, pt, E, Nn, ms, ppr; float rsoft, pp_bias, ncut; };
 
@@ -267,234 +269,48 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
   if (threadIdx.x == 0 && mymax > 0.f) p3m_atomic_max_nonneg(tile_max + tile, mymax);
 }
 
-// The same sums from LDS: one 256-thread workgroup per block of PB_X x PB_Y x PB_Z home cells of a tile's extended
-// region.  The records of the block's halo (home rows +- pp_range, x range +- pp_range) and the cell offsets of
-// those row segments are staged in LDS with coalesced loads; every home record then walks its partners -- same
-// rows and cells as k_pp_ext -- without touching global memory.  A block whose
-// halo does not fit the staging area (strong clustering) falls back to global loads for what was not staged.
-#define PB_Y 4
-#define PB_Z 4
-#define PPT_CAP 2048    // staged records per block
-#define PP_LPH 2        // lanes per home record
-__global__ __launch_bounds__(256) void k_pp_ext_tiled(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G,
-                                                      float mass_p, float a_mid, float dt, float *__restrict__ tile_max, int bx_cells, int nbx, int nby,
-                                                      float r2_soft, float r2_taper) {
-  extern __shared__ int lds_i[];
-  const int ppr = G.ppr, e = G.pt + 2 * ppr;
-  const int HR = (PB_Y + 2 * ppr) * (PB_Z + 2 * ppr);        // halo rows
-  const int wseg = bx_cells + 2 * ppr + 1;                     // cell offsets per staged row segment
-  int *rp0 = lds_i;                 // [HR] first record of the staged segment (global sorted index)
-  int *rcnt = rp0 + HR;             // [HR] records staged of it
-  int *roff = rcnt + HR;            // [HR] their offset in lp
-  int *rtot = roff + HR;            // [HR] records in the segment
-  int *hpre = rtot + HR;            // [PB_Y*PB_Z + 1] prefix of home record counts
-  int *cseg = hpre + PB_Y * PB_Z + 1;   // [HR][wseg] cell offsets relative to rp0
-  float4 *lp = reinterpret_cast<float4 *>(cseg + ((HR * wseg + 3) & ~3));
-  __shared__ float wmax[4];
-  int b = blockIdx.x;
-  const int ibx = b % nbx; b /= nbx;
-  const int iby = b % nby; b /= nby;
-  const int nbz = nby, ibz = b % nbz, tile = b / nbz;
-  const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
-  const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;   // extended region [lo, lo+e)
-  const int hx0 = lox + ibx * bx_cells, hx1 = min(hx0 + bx_cells, lox + e);      // home cells in x
-  const int hy0 = loy + iby * PB_Y, hz0 = loz + ibz * PB_Z;
-  const int sx0 = max(hx0 - ppr, lox), sx1 = min(hx1 + ppr, lox + e);           // staged cells in x
-  const int ny = PB_Y + 2 * ppr;
-  // ---- stage: segment ranges and cell offsets
-  for (int r = threadIdx.x; r < HR; r += 256) {
-    const int yy = hy0 - ppr + r % ny, zz = hz0 - ppr + r / ny;
-    int p0 = 0, p1 = 0;
-    if (yy >= loy && yy < loy + e && zz >= loz && zz < loz + e) { const int64_t rb = ((int64_t)zz * G.E + yy) * G.E; p0 = cs[rb + sx0]; p1 = cs[rb + sx1]; }
-    rp0[r] = p0; rtot[r] = p1 - p0;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int r = 0; r < HR; r++) { roff[r] = run; const int c = min(rtot[r], PPT_CAP - run); rcnt[r] = c; run += c; }
-    hpre[PB_Y * PB_Z] = run;   // borrowed until the home prefix is built: number of staged records
-  }
-  for (int r = threadIdx.x >> 6; r < HR; r += 4) {   // one wavefront per row segment: no per-element index divisions
-    const int ry_ = r % ny, yy = hy0 - ppr + ry_, zz = hz0 - ppr + r / ny;
-    const bool inside = yy >= loy && yy < loy + e && zz >= loz && zz < loz + e;
-    const int *src = cs + ((int64_t)zz * G.E + yy) * G.E + sx0;
-    const int base = rp0[r];
-    for (int k = threadIdx.x & 63; k < wseg; k += 64) cseg[r * wseg + k] = (inside && sx0 + k <= sx1) ? src[k] - base : 0;
-  }
-  __syncthreads();
-  {
-    const int nst = hpre[PB_Y * PB_Z];
-    for (int t = threadIdx.x; t < nst; t += 256) {   // staged record t belongs to the last row r with roff[r] <= t
-      int lo_r = 0, hi_r = HR - 1;
-      while (lo_r < hi_r) { const int mid = (lo_r + hi_r + 1) >> 1; if (roff[mid] <= t) lo_r = mid; else hi_r = mid - 1; }
-      lp[t] = spos[rp0[lo_r] + (t - roff[lo_r])];
-    }
-  }
-  __syncthreads();
-  // home records: rows (jy, jz) of the block, cells [hx0, hx1)
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int hr = 0; hr < PB_Y * PB_Z; hr++) {
-      hpre[hr] = run;
-      const int r = (hr / PB_Y + ppr) * ny + (hr % PB_Y + ppr);
-      const int yy = hy0 + hr % PB_Y, zz = hz0 + hr / PB_Y;
-      if (yy < loy + e && zz < loz + e && hx1 > hx0) run += cseg[r * wseg + (hx1 - sx0)] - cseg[r * wseg + (hx0 - sx0)];
-    }
-    hpre[PB_Y * PB_Z] = run;
-  }
-  __syncthreads();
-  const int nhome = hpre[PB_Y * PB_Z];
-  float mymax = 0.f;
-  auto partner = [&](int r, int q) -> float4 { const int k = q - rp0[r]; return k < rcnt[r] ? lp[roff[r] + k] : spos[q]; };
-  // PP_LPH lanes share one home record: lane u takes the partner rows u, u+PP_LPH, ... of the (zz,yy) sweep and walks
-  // them with a flat cursor (a wavefront pays for its busiest lane, not for the busiest lane of every row); the
-  // partial sums are added across the lanes at the end.
-  const float incut = 1.0f / G.ncut, ibias = 1.0f / G.pp_bias;
-  const int nround = (nhome * PP_LPH + 255) / 256;
-  for (int rd = 0; rd < nround; rd++) {
-    const int t = rd * 256 + (int)threadIdx.x, hidx = t / PP_LPH, u = t - hidx * PP_LPH;
-    const bool live = hidx < nhome;
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0, cx = 0, cy = 0, cz = 0;
-    if (live) {
-      int hr = 0;
-#pragma unroll
-      for (int k = 1; k < PB_Y * PB_Z; k++) hr += (hidx >= hpre[k]) ? 1 : 0;
-      const int jy = hr % PB_Y, jz = hr / PB_Y;
-      const int r_own = (jz + ppr) * ny + (jy + ppr);
-      s = rp0[r_own] + cseg[r_own * wseg + (hx0 - sx0)] + (hidx - hpre[hr]);
-      p = partner(r_own, s);
-      cy = hy0 + jy; cz = hz0 + jz;
-      cx = (int)floorf(p.x) + G.nb;                                // :412 (floor(xv)+1, global)
-      int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);
-      // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): a pair whose two cells
-      // both lie in the top pp_range planes of the region is never formed
-      if (cz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
-      const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1);
-      const int x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
-      const int nyr = y1 - y0 + 1, nrow = (z1 - z0 + 1) * nyr;
-      int zi = 0, yi = u - PP_LPH, q = 0, q1 = 0, s0 = 0, s1 = 0, r = 0;   // (zi, yi): the row ordinal u, u+PP_LPH, ... as a mixed-radix counter
-      const int nzr = z1 - z0 + 1;
-      (void)nrow;
-      for (;;) {
-        if (q >= q1) {
-          yi += PP_LPH;
-          while (yi >= nyr) { yi -= nyr; zi++; }
-          if (zi >= nzr) break;
-          const int zz = z0 + zi, yy = y0 + yi;
-          r = (zz - hz0 + ppr) * ny + (yy - hy0 + ppr);
-          const int *cr = cseg + r * wseg - sx0;
-          q = rp0[r] + cr[x0]; q1 = rp0[r] + cr[x1 + 1];
-          const bool own = (zz == cz && yy == cy);
-          s0 = own ? rp0[r] + cr[cx] : 0; s1 = own ? rp0[r] + cr[cx + 1] : 0;   // own cell is excluded (:515-516)
-          continue;
-        }
-        if (q >= s0 && q < s1) { q = s1; continue; }
-        const float4 o = partner(r, q);
-        q++;
-        const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;            // :551
-        const float r2 = sx * sx + sy * sy + sz * sz;
-        // rmag = sqrt(r2) > rsoft decided EXACTLY on r2 (r2_soft = the smallest float whose correctly rounded root exceeds
-        // rsoft, found on the host), the magnitudes from the hardware reciprocal square root: no IEEE sqrt or division in
-        // the pair loop (about a third of its instructions); the force differs from sep/(rmag*pp_bias)^3 by a few ulp
-        if (r2 >= r2_soft) {                                                    // :558
-          const float ir = __builtin_amdgcn_rsqf(r2), rb1 = (r2 * ir) * G.pp_bias, ib = ir * ibias, irb3 = ib * ib * ib;
-          float fx = mass_p * (sx * irb3), fy = mass_p * (sy * irb3), fz = mass_p * (sz * irb3);
-          if (r2 < r2_taper) {                                                  // :559-564, not (rmag > ncut + sqrt(3))
-            const float qq = rb1 * incut;
-            const float taper = 1.f - (7.0f / 4.0f) * (qq * qq * qq) + (3.0f / 4.0f) * (qq * qq * qq * qq * qq);
-            fx *= taper; fy *= taper; fz *= taper;
-          }
-          ax -= fx; ay -= fy; az -= fz;                                         // :571
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 1; o < PP_LPH; o <<= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
-    if (live && u == 0) {
-      const int ry = cy - loy, rz = cz - loz;
-      const bool phys = (cx >= lox + ppr && cx < lox + ppr + G.pt && ry >= ppr && ry < ppr + G.pt && rz >= ppr && rz < ppr + G.pt);
-      if (phys) {                                                                   // :576-582
-        const int vi = __float_as_int(spos[s].w); float4 v = vel[vi];   // the velocity stays in arrival order (p3m_internal.h)
-        v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
-        vel[vi] = v;
-      }
-      mymax = fmaxf(mymax, sqrtf(ax * ax + ay * ay + az * az));                     // :617
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) mymax = fmaxf(mymax, __shfl_down(mymax, o, 64));
-  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mymax;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    if (m4 > 0.f) p3m_atomic_max_nonneg(tile_max + tile, m4);
-  }
-}
 
-// ------------------------------------------------------------------ extended PP, version 2: one wavefront per 64 home records
-// No block-level staging, no barriers between wavefronts: at the reference's density (1/8 particle per fine cell, ~15
-// partners per record) k_pp_ext_tiled spent 94 % of its instructions on staging and on walking 25 mostly empty row
-// windows per record (rocprofv3: 530 lane-instructions per pair evaluation), and with strong clustering a few workgroups
-// did all the work.  Here a TASK is 64 consecutive home records of a group of PP_RG x-rows of one tile's extended region;
-// k_pp_plan counts the tasks of every group, a scan turns the counts into first-task numbers, k_pp_fill writes the
-// task -> group table, and persistent wavefronts draw tasks from a counter (dense tasks take thousands of times longer
-// than sparse ones: no static split balances them).  One lane per home record:
-//   sparse path: the lane collects the sorted indices of its partners (the clipped row windows of k_pp_ext, read straight
-//     from cell_end through L1/L2) in a list in LDS, then sums over the list -- every lane busy with its own partners;
-//   dense path (a lane's list would overflow): the wavefront walks the union of its lanes' windows row by row, loads 64
-//     partners at a time (one per lane, coalesced) and broadcasts them one by one (v_readlane); each lane keeps the
-//     partners inside its own window.  Neighbouring home records share almost all partners, so each partner is loaded once
-//     per 64 home records.
-#define PP_RG 16
-#define PP_LCAP 40
-#define PP_CHUNK 4
-#define PP_NSEG 64
-__global__ __launch_bounds__(256) void k_pp_plan(const int *__restrict__ cs, PPGeo G, int ngy, int nxb, int xbw, int ngroups, int *__restrict__ plan) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= ngroups) return;
-  const int e = G.pt + 2 * G.ppr;
-  const int xb = g % nxb, gy = (g / nxb) % ngy, rz = (g / (nxb * ngy)) % e, tile = g / (nxb * ngy * e);
-  const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
-  const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
-  const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);   // the group's home cells
-  int count = 0;
-  for (int j = 0; j < PP_RG; j++) {
-    const int ry = gy * PP_RG + j;
-    if (ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count += cs[rb + hx1] - cs[rb + hx0]; }
-  }
-  plan[g] = (count + 63) >> 6;
-}
-__global__ __launch_bounds__(256) void k_pp_fill(const int *__restrict__ plan, int ngroups, int *__restrict__ task_group, int cap) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= ngroups) return;
-  const int k1 = min(plan[g + 1], cap);
-  for (int k = plan[g]; k < k1; k++) task_group[k] = g;
-}
 __global__ __launch_bounds__(256) void k_pp_fill2(const int *__restrict__ plan, int ngroups, int2 *__restrict__ task2, int cap) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= ngroups) return;
   const int k0 = plan[g], k1 = min(plan[g + 1], cap);
   for (int k = k0; k < k1; k++) task2[k] = make_int2(g, k - k0);
 }
-struct PPForce { float mass_p, pp_bias, ibias, incut, r2_soft, r2_taper; };
-// One partner of the extended sweep.  The hard cut (:558) is decided on r^2 computed in the reference's order; the force itself is
-// formed with fused multiply-adds and the taper in Horner form, 26 instructions instead of 37 (the kick differs from the
-// reference's association in the last bit: 1e-7 relative against the 1e-5 bar), without branches: a lane outside the cut adds zero
+// Constants of one pair evaluation.  The force of a partner at separation s, r = |s| (:551-571):
+//   -mass_p s / (r pp_bias)^3 * taper(q),  q = r pp_bias / ncut,  taper = 1 - 7/4 q^3 + 3/4 q^5 while r <= ncut + sqrt(3), else 1
+// is formed as  -s * [K taper(q)] * (1/r)^3  with K = mass_p / pp_bias^3 folded into the taper's coefficients
+struct PPForce { float c1, K, K34, K74, r2_soft, r2_taper, big_s, nrp_big, nbig_t, r2t_big; };
+// The two cuts as arithmetic 0/1 factors (the swept evaluation, pp_sweep_row): with rp the float below r2_soft,
+//   r2 >= r2_soft  <=>  r2 - rp > 0  <=>  clamp((r2 - rp) * 2^k) = 1   once 2^k * ulp(rp) >= 1   (else the difference is <= 0: factor 0)
+// and r2 < r2_taper <=> clamp((r2_taper - r2) * 2^m) = 1 likewise.  Scaling by a power of two is exact and the fused multiply-add
+// rounds once, so sign and zero of the differences are exact: the factors decide exactly as the comparisons do
+static PPForce pp_force_constants(float mass_p, float pp_bias, float ncut, float r2_soft, float r2_taper) {
+  const float ib = 1.0f / pp_bias, K = mass_p * (ib * ib * ib);
+  const float rp = nextafterf(r2_soft, 0.0f);
+  const float big_s = ldexpf(1.0f, std::min(120, 1 - ilogbf(r2_soft - rp)));
+  const float rt_below = nextafterf(r2_taper, 0.0f);
+  const float big_t = ldexpf(1.0f, std::min(100, 1 - ilogbf(r2_taper - rt_below)));
+  return PPForce{pp_bias * (1.0f / ncut), K, 0.75f * K, -1.75f * K, r2_soft, r2_taper, big_s, -rp * big_s, -big_t, r2_taper * big_t};
+}
+// One partner of the extended sweep.  The hard cut (:558) is decided on r^2 computed in the reference's order (unfused); the force
+// itself is formed from the hardware reciprocal square root with fused multiply-adds and the taper in Horner form, 25 instructions
+// (the kick differs from the reference's association in the last bits: ~4e-7 relative per pair against the 1e-5 bar; k_pp_ext
+// above keeps the reference's sqrt / division arithmetic, P3M_PP_EXT_REF=1), without branches: a lane outside the cut adds zero
 __device__ __forceinline__ void pp_ext_eval(const float4 &p, float ox, float oy, float oz, const PPForce &F, float &ax, float &ay, float &az) {
   const float sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
   const float r2 = sx * sx + sy * sy + sz * sz;
-  const float ir = __builtin_amdgcn_rsqf(r2), qq = (r2 * ir) * (F.pp_bias * F.incut), ib = ir * F.ibias;
+  const float ir = __builtin_amdgcn_rsqf(r2), qq = (r2 * ir) * F.c1;
   const float q2 = qq * qq, q3 = q2 * qq;
-  float taper = __builtin_fmaf(q3, __builtin_fmaf(0.75f, q2, -1.75f), 1.0f);   // 1 - 7/4 q^3 + 3/4 q^5 (:559-564)
-  taper = r2 < F.r2_taper ? taper : 1.0f;
-  float f = (F.mass_p * taper) * (ib * ib * ib);
-  f = r2 >= F.r2_soft ? f : 0.0f;                                        // :558, decided exactly on r^2 (see k_pp_ext_tiled)
+  float tp = __builtin_fmaf(q3, __builtin_fmaf(q2, F.K34, F.K74), F.K);    // K (1 - 7/4 q^3 + 3/4 q^5) (:559-564)
+  tp = r2 < F.r2_taper ? tp : F.K;
+  float f = tp * ((ir * ir) * ir);
+  f = r2 >= F.r2_soft ? f : 0.0f;                                        // :558, decided exactly on r^2 (first_r2_with_root_above)
   ax = __builtin_fmaf(-sx, f, ax); ay = __builtin_fmaf(-sy, f, ay); az = __builtin_fmaf(-sz, f, az);   // :571
 }
-// Two partners at once in the halves of packed registers (v_pk_add / v_pk_mul / v_pk_fma_f32: one instruction slot for both):
-// 17 slots per partner.  A half that is not a partner (okA / okB false) adds zero.  Every half goes through the operations of
-// pp_ext_eval; a home record's sum is formed as two partial sums, added at the end
+// Two partners at once in the halves of packed registers (v_pk_add / v_pk_mul / v_pk_fma_f32: one issue slot for both).  A half
+// that is not a partner (okA / okB false) adds zero -- by selection, not by a zero factor: a masked half may be the home record
+// itself (r = 0).  Every half goes through the operations of pp_ext_eval; a home record's sum is formed as two partial sums,
+// added at the end
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pp_ext_eval2(const float4 &p, const float4 &A, const float4 &B, bool okA, bool okB, const PPForce &F,
                                              f32x2 &ax, f32x2 &ay, f32x2 &az) {
@@ -502,178 +318,63 @@ __device__ __forceinline__ void pp_ext_eval2(const float4 &p, const float4 &A, c
   const f32x2 sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
   const f32x2 r2 = sx * sx + sy * sy + sz * sz;
   const f32x2 ir = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-  const f32x2 qq = (r2 * ir) * (F.pp_bias * F.incut), ib = ir * F.ibias;
+  const f32x2 qq = (r2 * ir) * F.c1;
   const f32x2 q2 = qq * qq, q3 = q2 * qq;
-  const f32x2 c34 = {0.75f, 0.75f}, c74 = {-1.75f, -1.75f}, one = {1.0f, 1.0f};
-  f32x2 taper = __builtin_elementwise_fma(q3, __builtin_elementwise_fma(c34, q2, c74), one);   // :559-564
-  taper.x = r2.x < F.r2_taper ? taper.x : 1.0f; taper.y = r2.y < F.r2_taper ? taper.y : 1.0f;
-  f32x2 f = (F.mass_p * taper) * (ib * ib * ib);
+  const f32x2 k34 = {F.K34, F.K34}, k74 = {F.K74, F.K74}, kk = {F.K, F.K};
+  f32x2 tp = __builtin_elementwise_fma(q3, __builtin_elementwise_fma(q2, k34, k74), kk);   // :559-564
+  tp.x = r2.x < F.r2_taper ? tp.x : F.K; tp.y = r2.y < F.r2_taper ? tp.y : F.K;
+  f32x2 f = tp * ((ir * ir) * ir);
   f.x = (okA && r2.x >= F.r2_soft) ? f.x : 0.0f; f.y = (okB && r2.y >= F.r2_soft) ? f.y : 0.0f;   // :558
   ax = __builtin_elementwise_fma(-sx, f, ax); ay = __builtin_elementwise_fma(-sy, f, ay); az = __builtin_elementwise_fma(-sz, f, az);   // :571
 }
-template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
-__global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
-                                                float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
-                                                const int *__restrict__ task_group, int ngroups, int ngy, int nxb, int xbw, int ntask_cap, int *__restrict__ counter) {
-  __shared__ int list[PP_LCAP][64];
-  __shared__ int rstart[PP_RG], roff[PP_RG];
-  const int lane = threadIdx.x;
-  const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E;
-  const int ntask = min(plan[ngroups], ntask_cap);
-  // PP_NSEG task counters on cache lines of their own, each handing out the tasks of one contiguous segment (atomics on ONE
-  // address serialise at ~12 ns each: 145 000 fetches from a single counter were half of this kernel's run time); a
-  // wavefront starts at its own segment and moves on round robin when a segment runs dry
-  const int per = (ntask + PP_NSEG - 1) / PP_NSEG;
-  int seg = blockIdx.x % PP_NSEG;
-  for (int tried = 0; tried < PP_NSEG;) {
-    const int sbeg = min(seg * per, ntask), send = min(sbeg + per, ntask);
-    int tf = 0;
-    if (lane == 0) {   // a plain (agent-coherent) load first: a dry segment costs no read-modify-write
-      tf = __hip_atomic_load(counter + 32 * seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tf < send - sbeg) tf = atomicAdd(counter + 32 * seg, PP_CHUNK);
-    }
-    tf = sbeg + __builtin_amdgcn_readfirstlane(tf);
-    if (tf >= send) { seg = (seg + 1) % PP_NSEG; tried++; continue; }
-    tried = 0;
-    const int tl = min(tf + PP_CHUNK, send);
-    for (int t = tf; t < tl; t++) {
-      const int g = task_group[t], sub = t - plan[g];
-      const int xb = g % nxb, gy = (g / nxb) % ngy, rz = (g / (nxb * ngy)) % e, tile = g / (nxb * ngy * e);
-      const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
-      const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
-      const int cz = loz + rz;
-      const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);   // the group's home cells: a patch of PP_RG rows x xbw cells
-      // the group's rows: first record and exclusive prefix of the home counts
-      int cnt = 0, st = 0;
-      if (lane < PP_RG) {
-        const int ry = gy * PP_RG + lane;
-        if (ry < e) { const int64_t rb = ((int64_t)cz * E + (loy + ry)) * E; st = cs[rb + hx0]; cnt = cs[rb + hx1] - st; }
-      }
-      int inc = cnt;
-#pragma unroll
-      for (int o = 1; o < PP_RG; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-      const int total = __shfl(inc, PP_RG - 1, 64);
-      __syncthreads();                                    // the previous task's readers of rstart / roff / list are done
-      if (lane < PP_RG) { rstart[lane] = st; roff[lane] = inc - cnt; }
-      __syncthreads();
-      const int h = sub * 64 + lane;
-      const bool valid = h < total;
-      int j = 0;
-#pragma unroll
-      for (int k = 1; k < PP_RG; k++) j += (roff[k] <= h) ? 1 : 0;
-      const int s = valid ? rstart[j] + (h - roff[j]) : 0;
-      const float4 p = valid ? spos[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const int cx = valid ? (int)floorf(p.x) + G.nb : lox + ppr;                // :412
-      const int cy = loy + gy * PP_RG + (valid ? j : 0);
-      int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);               // uniform over the wavefront
-      // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): see k_pp_ext
-      if (cz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
-      const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1);
-      const int x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
-      float ax = 0.f, ay = 0.f, az = 0.f;
-      // ---- sparse attempt: list the partners
-      int n = 0;
-      if (PPR > 0) {
-        // compile-time reach: every window of the (2 PPR + 1)^2 partner rows is loaded before the first one is used
-        constexpr int NW = PPR > 0 ? (2 * PPR + 1) * (2 * PPR + 1) : 1, ND = 2 * PPR + 1;
-        int wa[NW], wb[NW];
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-          const int zz = cz - PPR + w / ND, yy = cy - PPR + w % ND;
-          const bool ok = valid && zz >= z0 && zz <= z1 && yy >= y0 && yy <= y1;
-          const int64_t rb = ((int64_t)(ok ? zz : cz) * E + (ok ? yy : cy)) * E;
-          wa[w] = 0; wb[w] = 0;
-          if (ok) { wa[w] = cs[rb + x0]; wb[w] = cs[rb + x1 + 1]; }
-        }
-        int s0 = 0, s1 = 0;
-        if (valid) { const int64_t rb = ((int64_t)cz * E + cy) * E; s0 = cs[rb + cx]; s1 = cs[rb + cx + 1]; }   // own cell is excluded (:515-516)
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-          const bool own = (w == NW / 2);
-          for (int q = wa[w]; q < wb[w]; q++) {
-            if (own && q >= s0 && q < s1) { q = s1 - 1; continue; }
-            if (n < PP_LCAP) list[n][lane] = q;
-            n++;
-          }
-        }
-      } else {
-        for (int zz = z0; zz <= z1; zz++)
-          for (int dy = -ppr; dy <= ppr; dy++) {
-            const int yy = cy + dy;
-            const bool yok = valid && yy >= y0 && yy <= y1;
-            const int64_t rb = ((int64_t)zz * E + (yok ? yy : cy)) * E;
-            int a = 0, b = 0, s0 = 0, s1 = 0;
-            if (yok) { a = cs[rb + x0]; b = cs[rb + x1 + 1]; }
-            if (yok && zz == cz && dy == 0) { s0 = cs[rb + cx]; s1 = cs[rb + cx + 1]; }    // own cell is excluded (:515-516)
-            for (int q = a; q < b; q++) {
-              if (q >= s0 && q < s1) { q = s1 - 1; continue; }
-              if (n < PP_LCAP) list[n][lane] = q;
-              n++;
-            }
-          }
-      }
-      // lanes whose partners fit their list sum over it; the others (records in or next to dense cells) are served in
-      // GROUPS of lanes that are close in x -- a blob's members -- by the broadcast path over the union of the group's
-      // windows only: a row that crosses a blob holds a few dozen blob members and a few dozen background records spread
-      // over hundreds of cells, and one union over all of them would test every lane against every record of 25 whole rows
-      const bool big = n > PP_LCAP;
-      const int nl = big ? 0 : n;
-      const int nmax = wave_max_i(nl);
-      for (int k = 0; k < nmax; k += 4) {   // four partners in flight at a time
-        float4 o[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { o[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (k + u < nl) o[u] = spos[list[k + u][lane]]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (k + u < nl) pp_ext_eval(p, o[u].x, o[u].y, o[u].z, F, ax, ay, az);
-      }
-      bool todo = big;
-      unsigned long long pend;
-      while ((pend = __ballot(todo)) != 0ull) {
-        const int lead = __ffsll((long long)pend) - 1;
-        const int xa = __builtin_amdgcn_readlane(cx, lead);
-        const bool mine = todo && cx >= xa - 4 && cx <= xa + 8;          // the group: dense lanes within a dozen cells of the first one
-        const int Y0 = wave_min_i(mine ? y0 : 0x7fffffff), Y1 = wave_max_i(mine ? y1 : -1);
-        const int X0 = wave_min_i(mine ? x0 : 0x7fffffff), X1 = wave_max_i(mine ? x1 : -1);
-        for (int zz = z0; zz <= z1; zz++)
-          for (int yy = Y0; yy <= Y1; yy++) {
-            const int64_t rb = ((int64_t)zz * E + yy) * E;
-            const int A = cs[rb + X0], B = cs[rb + X1 + 1];
-            const bool rowok = mine && yy >= y0 && yy <= y1;
-            const bool ownrow = (zz == cz && yy == cy);
-            for (int base = A; base < B; base += 64) {
-              const int m = min(64, B - base);
-              float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (lane < m) o = spos[base + lane];
-              const int ocx = (int)floorf(o.x) + G.nb;
-              for (int jj = 0; jj < m; jj++) {
-                const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), jj));
-                const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), jj));
-                const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), jj));
-                const int pcx = __builtin_amdgcn_readlane(ocx, jj);
-                if (rowok && pcx >= x0 && pcx <= x1 && !(ownrow && pcx == cx)) pp_ext_eval(p, px, py, pz, F, ax, ay, az);
-              }
-            }
-          }
-        todo = todo && !mine;
-      }
-      float mag = 0.f;
-      if (valid) {
-        const int ry = cy - loy;
-        const bool phys = (cx >= lox + ppr && cx < lox + ppr + G.pt && ry >= ppr && ry < ppr + G.pt && rz >= ppr && rz < ppr + G.pt);
-        if (phys) {                                                                   // :576-582
-          const int vi = __float_as_int(spos[s].w); float4 v = vel[vi];   // the velocity stays in arrival order (p3m_internal.h)
-          v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
-          vel[vi] = v;
-        }
-        mag = sqrtf(ax * ax + ay * ay + az * az);                                     // :617
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
-      if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(tile_max + tile, mag);
-    }
-  }
-}
 
+
+// The swept evaluation: every lane holds one home record (hx, hy, hz) and the wavefront walks the staged positions [ua, ub) of one
+// partner row together, one LDS broadcast per partner.  A lane's window of the row and its own cell are intervals of positions:
+// with d = v - (centre of the window) and k4 = 4 * (half width) + 1 the factor clamp(k4 - 4 |d|) is 1 inside and 0 outside (d and
+// the half width are multiples of 1/2: exact), one fused multiply-add with the clamp modifier and one add per partner; the two
+// cuts on r^2 are factors of the same kind (pp_force_constants).  All operands sit in vector registers; no compare, no select,
+// no scalar-register operand (4.3 cycles of a SIMD's issue each against 2.6 for plain vector arithmetic: tools/valubench.hip):
+// 26 vector instructions per partner.  OWN: some lane's own cell lies in this stretch (a masked partner may be the home record
+// itself: r = 0, so the reciprocal square root is taken of max(r^2, tiny) and every factor stays finite)
+struct PPSweepK { float c1, K, K34, K74, big_s, nrp_big, nbig_t, r2t_big; };
+template <bool OWN, bool TAPER_ALL>
+__device__ __forceinline__ void pp_sweep_row(const float4 *pr, int ua, int ub, float hx, float hy, float hz, float d, float k4, float dO, float k4o,
+                                             const PPSweepK &S, float &ax, float &ay, float &az) {
+  auto step = [&](const float4 &o) {
+    float m;
+    asm("v_fma_f32 %0, |%1|, -4.0, %2 clamp" : "=v"(m) : "v"(d), "v"(k4));          // 1 inside this lane's window of the row
+    d += 1.0f;
+    if (OWN) {
+      float mo;
+      asm("v_fma_f32 %0, |%1|, 4.0, %2 clamp" : "=v"(mo) : "v"(dO), "v"(k4o));      // 0 inside this lane's own cell (:515-516)
+      dO += 1.0f;
+      m *= mo;
+    }
+    const float sx = hx - o.x, sy = hy - o.y, sz = hz - o.z;               // :551
+    const float r2 = sx * sx + sy * sy + sz * sz;                           // the reference's order, unfused: the cut is decided on it
+    const float r2c = OWN ? __builtin_fmaxf(r2, 1.0e-20f) : r2;
+    const float ir = __builtin_amdgcn_rsqf(r2c), qq = (r2c * ir) * S.c1;
+    const float q2 = qq * qq;
+    float q3 = q2 * qq;
+    if (!TAPER_ALL) {
+      float mt;
+      asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(mt) : "v"(r2), "v"(S.nbig_t), "v"(S.r2t_big));   // 1 while r2 < r2_taper (:559)
+      q3 *= mt;
+    }
+    const float tp = __builtin_fmaf(q3, __builtin_fmaf(q2, S.K34, S.K74), S.K);   // K (1 - 7/4 q^3 + 3/4 q^5) (:559-564)
+    float ms;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(ms) : "v"(r2), "v"(S.big_s), "v"(S.nrp_big));        // 1 when r2 >= r2_soft (:558)
+    const float f = (tp * ((ir * ir) * ir)) * (ms * m);
+    ax = __builtin_fmaf(-sx, f, ax); ay = __builtin_fmaf(-sy, f, ay); az = __builtin_fmaf(-sz, f, az);   // :571
+  };
+  int v = ua;
+  for (; v + 1 < ub; v += 2) {                       // two partners per trip: both broadcasts in flight before the first is used
+    const float4 o0 = pr[v], o1 = pr[v + 1];
+    step(o0); step(o1);
+  }
+  if (v < ub) step(pr[v]);
+}
 
 // ------------------------------------------------------------------ extended PP, version 3: the partner region of a patch through LDS
 // k_pp_ext2 at the reference's density is bound by cache-line traffic: every home record reads 50 cell offsets and ~15 partner
@@ -692,7 +393,16 @@ __global__ __launch_bounds__(64) void k_pp_ext2(const float4 *__restrict__ spos,
 #define PP3_HZ 8        // patch: 8 planes x 8 rows (4 x 16 measured 4.5 % slower: 160 partner rows per task against 144)
 #define PP3_HY 8
 #define PP3_NT 256
+// A patch of more than PP3_DENSE home records (a blob) is cut into tasks of PP3_NTD home records instead of PP3_NT: its tasks are
+// thousands of times longer than those of the background, and the kernel ends when the last of them does -- 2700 tasks of 256
+// records on 1280 resident workgroups left the chip 22 % idle (48 blobs of 13 000).  The wavefronts without home records share
+// the sweep of the others' (see "wpg" in k_pp_ext3)
+#define PP3_DENSE 1024
+#define PP3_NTD 128
+__host__ __device__ __forceinline__ int pp3_task_homes(int count) { return count > PP3_DENSE ? PP3_NTD : PP3_NT; }
+#ifndef PP3_PCAP
 #define PP3_PCAP 704
+#endif
 #define PP3_LCAP 32      // list entries per lane
 #ifndef PP3_WPE
 #define PP3_WPE 5        // wavefronts per SIMD the register allocation aims at (96 VGPRs): five workgroups of 32 KB LDS per CU at the reference density
@@ -714,13 +424,22 @@ __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PP
   if (rz < e && ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count = cs[rb + hx1] - cs[rb + hx0]; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
-  if (j == 0) plan[g] = (count + PP3_NT - 1) / PP3_NT;
+  if (j == 0) { const int nt = pp3_task_homes(count); plan[g] = (count + nt - 1) / nt; }
 }
-template <int PPR>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any
-__global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE, PP3_WPE))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
+// Two launches of one kernel.  PASS 0 (the light pass) works every task of the plan: its lanes list or walk their partners; the
+// records that are HEAVY (more than PP3_LCAP partners: members and neighbours of a blob) are left out and the task is entered, with
+// a bit per heavy lane, in the heavy-task list.  PASS 1 (the heavy pass) works that list: it stages the same region again and
+// SWEEPS it for the heavy records.  Two launches because the two halves want different registers (the sweep's live state spilled
+// the list path's: 2.19 -> 2.52 ms per tile at uniform density with both in one kernel) and because a launch of heavy tasks only
+// balances itself (the heavy tasks of one kernel ended long after its light ones: a quarter of the chip's time idle)
+#define PP3_HREC 16      // ints per heavy-task record: patch, sub-task, the heavy lanes' box of partner rows and cells (3 words), 8 words of lane bits
+template <int PPR, bool TAPER_ALL, int PASS>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any.  TAPER_ALL: no pair within reach is beyond the taper's range
+__global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 0 ? PP3_WPE : PP3_WPE - 1, PASS == 0 ? PP3_WPE : PP3_WPE - 1))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
                                                     float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
                                                     const int2 *__restrict__ task2, int ngroups, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
-                                                    int Wp, int NRmax, int fat_limit) {   // fat_limit: 65534 (see "fat" below); task2: {group, sub-task} of every task; Wp: entries per row of the offset table (xbw + 2r + 1 rounded up to even); NRmax: partner rows
+                                                    int Wp, int NRmax, int fat_limit, int *__restrict__ htask, int *__restrict__ hcount) {
+  // fat_limit: 65534 (see "fat" below); task2: {group, sub-task} of every task; Wp: entries per row of the offset table (xbw + 2r + 1 rounded
+  // up to even); NRmax: partner rows; htask / hcount: the heavy-task list (PP3_HREC ints per task, written by pass 0, read by pass 1) and its length
   extern __shared__ int sm[];
   constexpr int NH = PP3_HZ * PP3_HY, NW = PP3_NT / 64;
   // LDS: prec | offs | list | rowg | cum | rstart | roff | misc.  The unrolled window walk below reads offs and cum at rows up to
@@ -735,11 +454,16 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
   int *rowg = reinterpret_cast<int *>(list + NW * 64 * PP3_LSTR);             // [NRmax]      sorted index of the row segment's first record
   int *cum = rowg + NRmax;                          // [NRmax + 1]  records of the rows before r in the concatenated partner sequence
   int *rstart = cum + NRmax + 1, *roff = rstart + NH;   // home rows: first record, exclusive prefix of the home counts ([NH + 1])
-  int *misc = roff + NH + 1;                        // [0] task, [1] fat flag, [2..5] wave maxima
+  int *misc = roff + NH + 1;                        // [48]: [0] task state, [1] fat flag, [4] the task has heavy lanes, [5..7] the drawn task, [8..15] heavy lanes (bits) per wavefront, [16..19] light lanes per wavefront, [20..22] pass 1: the task's box, [24..47] the wavefronts' boxes
+  // pass 1 has no lists: the area holds the task's heavy records, their home rows and the wavefronts' partial sums
+  float4 *hrec = reinterpret_cast<float4 *>(list);                            // [PP3_NT]
+  float *part = reinterpret_cast<float *>(hrec + PP3_NT);                     // [NW][64][3]
+  unsigned char *hj = reinterpret_cast<unsigned char *>(part + NW * 64 * 3);  // [PP3_NT]
+  static_assert(PP3_NT * 16 + (PP3_NT / 64) * 64 * 12 + PP3_NT <= (PP3_NT / 64) * 64 * PP3_LSTR, "the heavy pass's tables fit the list area");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned char *mylist = list + (wv * 64 + lane) * PP3_LSTR;                 // this lane's entries
   const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E, npz = (e + PP3_HZ - 1) / PP3_HZ;
-  const int ntask = min(plan[ngroups], ntask_cap);
+  const int ntask = PASS == 0 ? min(plan[ngroups], ntask_cap) : min(*hcount, ntask_cap);
   const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
   int seg = blockIdx.x % PP3_NSEG;
   // Thread 0 runs a two-stage pipeline of task draws, one stage per task worked: the counter atomic of the task after the next
@@ -750,20 +474,51 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
   int a_tf = 0, a_seg = 0, tried = 0;
   bool a_live = false, b_live = false;
   int2 b_val = make_int2(0, 0);
+  int b_t = 0, b_box0 = 0, b_box1 = 0, b_box2 = 0;
   auto advance = [&]() {   // thread 0 only
     b_live = false;
     if (a_live) {
       const int sbeg = min(a_seg * per, ntask), send = min(sbeg + per, ntask), t = sbeg + a_tf;
-      if (t < send) { b_val = task2[t]; b_live = true; tried = 0; }
+      if (t < send) {
+        if (PASS == 0) b_val = task2[t];
+        else { const int4 r4 = *reinterpret_cast<const int4 *>(htask + (size_t)PP3_HREC * t); b_val = make_int2(r4.x, r4.y); b_box0 = r4.z; b_box1 = r4.w; b_box2 = htask[(size_t)PP3_HREC * t + 4]; }
+        b_t = t; b_live = true; tried = 0;
+      }
       else { tried++; seg = (seg + 1) % PP3_NSEG; }
     }
     a_live = tried < PP3_NSEG;
     if (a_live) { a_seg = seg; a_tf = atomicAdd(counter + 32 * seg, 1); }
   };
   if (tid == 0) { a_live = true; a_seg = seg; a_tf = atomicAdd(counter + 32 * seg, 1); advance(); }
+  if (tid < 2 * NW) misc[8 + tid] = 0;
+  if (tid == 0) misc[4] = 0;
+  int prev_g = 0, prev_sub = 0;                       // thread 0: the task just worked
   for (;;) {
     __syncthreads();                                  // the previous task's readers of the LDS tables (and of misc) are done
-    if (tid == 0) { misc[0] = b_live ? 1 : (a_live ? 0 : -1); misc[1] = 0; misc[6] = b_val.x; misc[7] = b_val.y; advance(); }
+    if (PASS == 0 && tid == 0 && misc[4]) {
+      // the task just worked has heavy lanes: a bit per lane (left in misc[8..15] by the wavefronts' first lanes) and the box of
+      // partner rows and cells those lanes reach (misc[24 + 6 w ..]) into the heavy-task list: here, behind a barrier the loop has
+      // anyway, instead of one more barrier per task
+      const int slot = atomicAdd(hcount, 1);
+      int bz0 = 0x7fff, bz1 = 0, by0 = 0x7fff, by1 = 0, bx0 = 0x7fff, bx1 = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++)
+        if (misc[8 + 2 * w] | misc[9 + 2 * w]) {
+          const int *bw = misc + 24 + 6 * w;
+          bz0 = min(bz0, bw[0]); bz1 = max(bz1, bw[1]); by0 = min(by0, bw[2]); by1 = max(by1, bw[3]); bx0 = min(bx0, bw[4]); bx1 = max(bx1, bw[5]);
+        }
+      if (slot < ntask_cap) {
+        int *rec = htask + (size_t)PP3_HREC * slot;
+        rec[0] = prev_g; rec[1] = prev_sub; rec[2] = bz0 | (bz1 << 16); rec[3] = by0 | (by1 << 16); rec[4] = bx0 | (bx1 << 16);
+#pragma unroll
+        for (int k = 0; k < 2 * NW; k++) rec[5 + k] = misc[8 + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 2 * NW; k++) misc[8 + k] = 0;
+      misc[4] = 0;
+    }
+    if (PASS == 0 && tid == 0) { prev_g = b_val.x; prev_sub = b_val.y; }
+    if (tid == 0) { misc[0] = b_live ? 1 : (a_live ? 0 : -1); misc[1] = 0; misc[5] = b_t; misc[6] = b_val.x; misc[7] = b_val.y; if (PASS == 1) { misc[20] = b_box0; misc[21] = b_box1; misc[22] = b_box2; } advance(); }
     __syncthreads();
     const int state = misc[0];
     if (state < 0) break;                             // every segment has run dry
@@ -775,10 +530,12 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
     const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);           // home cells [hx0, hx1)
     const int hz0 = loz + gz * PP3_HZ, hy0 = loy + gy * PP3_HY;
     // the partner region: rows [Z0, Z1] x [Y0, Y1], cells [X0, X1]
-    const int Z0 = max(hz0 - ppr, loz), Z1 = min(hz0 + PP3_HZ - 1 + ppr, loz + e - 1);
-    const int Y0 = max(hy0 - ppr, loy), Y1 = min(hy0 + PP3_HY - 1 + ppr, loy + e - 1);
-    const int X0 = max(hx0 - ppr, lox), X1 = min(hx1 - 1 + ppr, lox + e - 1);
+    // (pass 1: only what the task's heavy lanes reach -- the box pass 0 recorded: a blob's neighbourhood is a third of the patch's)
+    const int Z0 = PASS == 0 ? max(hz0 - ppr, loz) : (misc[20] & 0xffff), Z1 = PASS == 0 ? min(hz0 + PP3_HZ - 1 + ppr, loz + e - 1) : (misc[20] >> 16);
+    const int Y0 = PASS == 0 ? max(hy0 - ppr, loy) : (misc[21] & 0xffff), Y1 = PASS == 0 ? min(hy0 + PP3_HY - 1 + ppr, loy + e - 1) : (misc[21] >> 16);
+    const int X0 = PASS == 0 ? max(hx0 - ppr, lox) : (misc[22] & 0xffff), X1 = PASS == 0 ? min(hx1 - 1 + ppr, lox + e - 1) : (misc[22] >> 16);
     const int NRY = Y1 - Y0 + 1, NR = (Z1 - Z0 + 1) * NRY, W = X1 - X0 + 2;
+    if (PASS == 1 && tid < 2 * NW) misc[8 + tid] = htask[(size_t)PP3_HREC * misc[5] + 5 + tid];   // the task's heavy lanes (read behind the next barrier)
     // home rows of the patch (wavefront 0), cell offsets of every partner row (one coalesced load per row, all wavefronts)
     int hcnt = 0, hst = 0;
     if (tid < NH) {
@@ -840,8 +597,9 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
       if (lane == 0) cum[NR] = carry;
     }
     // this thread's home record
-    const int h = sub * PP3_NT + tid;
-    const bool valid = h < total;
+    const int nth = pp3_task_homes(total);           // home records per task of this patch (uniform)
+    const int h = sub * nth + tid;
+    const bool valid = tid < nth && h < total;
     int j = 0;
     { int lo = 0, hi = NH; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= h) lo = mid; else hi = mid; } j = lo; }
     const int cz = hz0 + (valid ? j / PP3_HY : 0), cy = hy0 + (valid ? j % PP3_HY : 0);
@@ -865,6 +623,19 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
 #pragma unroll
       for (int u = 0; u < NV; u++) { const int v = b0 + tid + u * PP3_NT; if (v < b1) prec[v - b0] = q[u]; }
     };
+    // a record's windows: rows [z0, z1] x [y0, y1], cells [x0, x1] -- Chebyshev distance <= pp_range clipped to the tile's extended
+    // region; the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): see k_pp_ext
+    auto reach = [&](int ccx, int ccy, int ccz, int &z0, int &z1, int &y0, int &y1, int &x0, int &x1) {
+      z0 = max(ccz - ppr, loz); z1 = min(ccz + ppr, loz + e - 1);
+      if (ccz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
+      y0 = max(ccy - ppr, loy); y1 = min(ccy + ppr, loy + e - 1);
+      x0 = max(ccx - ppr, lox); x1 = min(ccx + ppr, lox + e - 1);
+    };
+    auto is_phys = [&](int ccx, int ccy, int ccz) {                                // :576-582: only records of the physical tile are kicked
+      return ccx >= lox + ppr && ccx < lox + ppr + G.pt && ccy - loy >= ppr && ccy - loy < ppr + G.pt && ccz - loz >= ppr && ccz - loz < ppr + G.pt;
+    };
+    float mag = 0.f;
+    if constexpr (PASS == 0) {
     // The whole region in one batch (the rule away from blobs): the home records are among the staged ones -- they are read from
     // LDS, not in a round trip of their own before the staging (a task is a chain of dependent round trips: cell offsets, records,
     // velocities; the kernel's time is set by how many of them a task waits for, not by its instructions)
@@ -876,16 +647,14 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
       if (valid) { const int r = (cz - Z0) * NRY + (cy - Y0); p = prec[cum[r] + (int)offs[r * Wp + (hx0 - X0)] + (h - roff[j])]; }
     } else if (valid) p = spos[rstart[j] + (h - roff[j])];
     const int cx = valid ? (int)floorf(p.x) + G.nb : hx0;                       // :412
-    int z0 = max(cz - ppr, loz), z1 = min(cz + ppr, loz + e - 1);
-    // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): see k_pp_ext
-    if (cz - loz >= G.pt + ppr) z1 = min(z1, loz + G.pt + ppr - 1);
-    const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1);
-    const int x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
-    const bool phys = valid && (cx >= lox + ppr && cx < lox + ppr + G.pt && cy - loy >= ppr && cy - loy < ppr + G.pt && cz - loz >= ppr && cz - loz < ppr + G.pt);
+    int z0, z1, y0, y1, x0, x1;
+    reach(cx, cy, cz, z0, z1, y0, y1, x0, x1);
+    const bool phys = valid && is_phys(cx, cy, cz);
     const int vi = rec_index(p);                      // the velocity stays in arrival order (p3m_internal.h); fetched now, needed after the sums
     float4 vrec = make_float4(0.f, 0.f, 0.f, 0.f);
     if (phys) vrec = vel[vi];
     float ax = 0.f, ay = 0.f, az = 0.f;
+    bool heavy = false;                               // this lane's home record is left to the heavy pass
     if (fat) {
       // a row segment holds more records than a 16-bit offset counts: windows and partners straight from global memory
       if (valid)
@@ -909,73 +678,91 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
         const int r = (cz - Z0) * NRY + (cy - Y0);
         own0 = cum[r] + offs[r * Wp + (cx - X0)]; own1 = cum[r] + offs[r * Wp + (cx - X0) + 1];
       }
-      for (int b0 = 0; b0 < max(Ptot, 1); b0 += PP3_PCAP) {   // batches of the concatenated partner sequence (one, unless a blob sits here)
-        const int b1 = min(b0 + PP3_PCAP, Ptot);
-        if (!single) {
-          if (b0 > 0) __syncthreads();                // the previous batch's readers are done
-          stage(b0, b1);
-          __syncthreads();
-        }
-        // pass 1: list the LDS indices of this lane's partners inside the batch.  A window holds 0.6 partners on average
-        int n = 0;
+      // ---- who lists, who walks, who is left to the heavy pass.  A lane lists its partners' positions (one byte each, relative to
+      // the start of its first window) when they are at most PP3_LCAP and span at most 256 positions; with few partners over a
+      // longer span (7 % of the lanes at the reference's density: the windows of five planes lie ~230 positions apart) it walks
+      // its windows itself; the records of a blob and their neighbours (more than PP3_LCAP partners) are HEAVY
+      int n = 0, base = 0;
+      bool walker = false;
+      if (single) {
+        // the whole region is staged and the reach is known: the (2r+1)^2 windows unrolled, a window's
+        // first three records stored unconditionally at the list's end and the end advanced by a compare (no branches: 25
+        // windows cost ~700 instructions per wavefront where a predicated version took 2500); a window of more
+        // than three records anywhere in the wavefront sends it through the tail loop
         bool ovf = false;
         // the lane's first window starts the lowest position it will list (the windows come in the order of the staged sequence)
-        int base = 0;
-        if (valid) { const int r = (z0 - Z0) * NRY + (y0 - Y0); base = max(cum[r] + (int)offs[r * Wp + (x0 - X0)] - b0, 0); }
-        if (single) {
-          // the whole region is staged and the reach is known: the (2r+1)^2 windows unrolled, a window's
-          // first three records stored unconditionally at the list's end and the end advanced by a compare (no branches: 25
-          // windows cost ~700 instructions per wavefront where the predicated version below took 2500); a window of more
-          // than three records anywhere in the wavefront sends it through the tail loop
-          const int rh = valid ? (cz - Z0) * NRY + (cy - Y0) : 0;
-          const unsigned short *wa = offs + rh * Wp + (x0 - X0), *wb = offs + rh * Wp + (x1 + 1 - X0);
-          const int *wc = cum + rh;
-          bool yok[2 * PPR + 1];
+        if (valid) { const int r = (z0 - Z0) * NRY + (y0 - Y0); base = cum[r] + (int)offs[r * Wp + (x0 - X0)]; }
+        const int rh = valid ? (cz - Z0) * NRY + (cy - Y0) : 0;
+        const unsigned short *wa = offs + rh * Wp + (x0 - X0), *wb = offs + rh * Wp + (x1 + 1 - X0);
+        const int *wc = cum + rh;
+        bool yok[2 * PPR + 1];
 #pragma unroll
-          for (int dy = -PPR; dy <= PPR; dy++) yok[dy + PPR] = valid && cy + dy >= y0 && cy + dy <= y1;
-          // three consecutive slots take a, a+1, a+2 whatever the count: the next window overwrites what was not a partner
-          auto append = [&](int a, int cnt) {
-            unsigned char *o = mylist + min(n, PP3_LCAP);   // a lane past the capacity is walked, not listed
-            const int e = a - base;
-            o[0] = (unsigned char)e; o[1] = (unsigned char)(e + 1); o[2] = (unsigned char)(e + 2);
-            ovf = ovf || (cnt > 0 && e + cnt > 256);
-            if (__any(cnt > 3))
-              for (int k = 3; k < cnt; k++) mylist[min(n + k, PP3_LCAP + 2)] = (unsigned char)(e + k);
-            n += cnt;
-          };
+        for (int dy = -PPR; dy <= PPR; dy++) yok[dy + PPR] = valid && cy + dy >= y0 && cy + dy <= y1;
+        // three consecutive slots take a, a+1, a+2 whatever the count: the next window overwrites what was not a partner
+        auto append = [&](int a, int cnt) {
+          unsigned char *o = mylist + min(n, PP3_LCAP);   // a lane past the capacity is heavy, not listed
+          const int e = a - base;
+          o[0] = (unsigned char)e; o[1] = (unsigned char)(e + 1); o[2] = (unsigned char)(e + 2);
+          ovf = ovf || (cnt > 0 && e + cnt > 256);
+          if (__any(cnt > 3))
+            for (int k = 3; k < min(cnt, PP3_LCAP + 3); k++) mylist[min(n + k, PP3_LCAP + 2)] = (unsigned char)(e + k);
+          n += cnt;
+        };
 #pragma unroll 1
-          for (int dz = -PPR; dz <= PPR; dz++) {        // one plane of windows per trip: the tail loops are not replicated 25 times
-            const bool zok = cz + dz >= z0 && cz + dz <= z1;
+        for (int dz = -PPR; dz <= PPR; dz++) {        // one plane of windows per trip: the tail loops are not replicated 25 times
+          const bool zok = cz + dz >= z0 && cz + dz <= z1;
 #pragma unroll
-            for (int dy = -PPR; dy <= PPR; dy++) {
-              const bool rv = zok && yok[dy + PPR];
-              const int d = dz * NRY + dy;             // uniform
-              const int cr = wc[d], a = cr + (int)wa[d * Wp], b = cr + (int)wb[d * Wp];
-              if (dz == 0 && dy == 0) { append(a, rv ? own0 - a : 0); append(own1, rv ? b - own1 : 0); }   // the own cell splits the own row's window (:515-516)
-              else append(a, rv ? b - a : 0);
-            }
+          for (int dy = -PPR; dy <= PPR; dy++) {
+            const bool rv = zok && yok[dy + PPR];
+            const int d = dz * NRY + dy;             // uniform
+            const int cr = wc[d], a = cr + (int)wa[d * Wp], b = cr + (int)wb[d * Wp];
+            if (dz == 0 && dy == 0) { append(a, rv ? own0 - a : 0); append(own1, rv ? b - own1 : 0); }   // the own cell splits the own row's window (:515-516)
+            else append(a, rv ? b - a : 0);
           }
-        } else if (valid) {
-          // any reach, any batch: window by window
-          for (int zz = z0; zz <= z1; zz++)
-            for (int yy = y0; yy <= y1; yy++) {
-              const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r] - b0;
-              int va = cr + (int)offs[r * Wp + (x0 - X0)], vb = cr + (int)offs[r * Wp + (x1 + 1 - X0)];   // positions in the batch
-              va = max(va, 0); vb = min(vb, b1 - b0);
-              const bool ownrow = (zz == cz && yy == cy);
-              // the own cell [o0, o1) splits the own row's window in two (:515-516)
-              const int o0 = ownrow ? min(max(own0 - b0, va), vb) : vb, o1 = ownrow ? min(max(own1 - b0, va), vb) : vb;
-#pragma unroll
-              for (int half = 0; half < 2; half++) {
-                const int a = half == 0 ? va : o1, b = half == 0 ? o0 : vb;
-                if (half == 1 && !ownrow) break;
-                if (b > a && b - base > 256) ovf = true;
-                for (int v = a; v < b; v++) { if (n < PP3_LCAP) mylist[n] = (unsigned char)(v - base); n++; }
-              }
-            }
         }
-        const bool listed = !ovf && n <= PP3_LCAP;
-        const int nl = listed ? n : 0;
+        heavy = valid && n > PP3_LCAP;
+        walker = valid && !heavy && ovf;
+      } else if (valid) {
+        // several batches (or any reach): count first -- a lane is heavy or light for the whole task
+        int first = 0, last = 0;
+        for (int zz = z0; zz <= z1; zz++)
+          for (int yy = y0; yy <= y1; yy++) {
+            const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r];
+            const int va = cr + (int)offs[r * Wp + (x0 - X0)], vb = cr + (int)offs[r * Wp + (x1 + 1 - X0)];
+            if (zz == z0 && yy == y0) first = va;
+            last = vb;
+            n += vb - va;
+          }
+        n -= own1 - own0;
+        heavy = n > PP3_LCAP;
+        walker = !heavy && last - first > 256;
+      }
+      // ---- the task's heavy lanes, one bit each, for the heavy-task list (thread 0 enters them at the top of the loop)
+      unsigned long long hb = __ballot(heavy);
+      if (hb) {                                       // uniform per wavefront, and rare away from blobs
+        // one or two heavy lanes with moderately many partners (the tail of the background's distribution; the fringe of a blob
+        // in the next patch) walk: a task of the heavy pass for them would cost more than their walk
+        if (__popcll(hb) <= 2 && wave_max_i(heavy ? n : 0) <= 2 * PP3_LCAP) { walker = walker || heavy; heavy = false; hb = 0ull; }
+        else {
+          const int bz0 = wave_min_i(heavy ? z0 : 0x7fff), bz1 = wave_max_i(heavy ? z1 : 0), by0 = wave_min_i(heavy ? y0 : 0x7fff), by1 = wave_max_i(heavy ? y1 : 0);
+          const int bx0 = wave_min_i(heavy ? x0 : 0x7fff), bx1 = wave_max_i(heavy ? x1 : 0);
+          if (lane == 0) {
+            misc[8 + 2 * wv] = (int)(unsigned)hb; misc[9 + 2 * wv] = (int)(unsigned)(hb >> 32); misc[4] = 1;
+            int *bw = misc + 24 + 6 * wv;
+            bw[0] = bz0; bw[1] = bz1; bw[2] = by0; bw[3] = by1; bw[4] = bx0; bw[5] = bx1;
+          }
+        }
+      }
+      int NL = 0;
+      if (!single) {                                  // several batches: staged (with barriers) only if somebody lists or walks
+        const unsigned long long lb = __ballot(valid && !heavy);
+        if (lane == 0) misc[16 + wv] = __popcll(lb);
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; w++) NL += misc[16 + w];
+      }
+      // ---- the light records: sums over their lists
+      auto eval_list = [&](int nl) {
         const int nmax = wave_max_i(nl);
         for (int k = 0; k < nmax; k += 4) {           // four partners in flight at a time, two per evaluation; no branches: a slot past the list's end reads record 0 and adds zero
           float4 o[4];
@@ -985,33 +772,202 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PP3_WPE,
           pp_ext_eval2(p, o[0], o[1], k < nl, k + 1 < nl, F, ax2, ay2, az2);
           pp_ext_eval2(p, o[2], o[3], k + 2 < nl, k + 3 < nl, F, ax2, ay2, az2);
         }
-        // dense lanes and multi-batch regions: walk the windows, partners from the staged batch, two at a time
-        if (valid && !listed) {
-          for (int zz = z0; zz <= z1; zz++)
-            for (int yy = y0; yy <= y1; yy++) {
-              const int r = (zz - Z0) * NRY + (yy - Y0);
-              const int va = max(cum[r] + (int)offs[r * Wp + (x0 - X0)], b0), vb = min(cum[r] + (int)offs[r * Wp + (x1 + 1 - X0)], b1);
-              int v = va;
-              while (v < vb) {
-                if (v >= own0 && v < own1) { v = own1; continue; }            // own cell is excluded (:515-516)
-                const int w = v + 1;
-                const bool okB = w < vb && !(w >= own0 && w < own1);
-                pp_ext_eval2(p, prec[v - b0], prec[(okB ? w : v) - b0], true, okB, F, ax2, ay2, az2);
-                v += 2;
-              }
+      };
+      // a walker's windows inside the batch [b0, b1), partners from the staged batch, two at a time
+      auto walk = [&](int b0, int b1) {
+        for (int zz = z0; zz <= z1; zz++)
+          for (int yy = y0; yy <= y1; yy++) {
+            const int r = (zz - Z0) * NRY + (yy - Y0);
+            const int va = max(cum[r] + (int)offs[r * Wp + (x0 - X0)], b0), vb = min(cum[r] + (int)offs[r * Wp + (x1 + 1 - X0)], b1);
+            int v = va;
+            while (v < vb) {
+              if (v >= own0 && v < own1) { v = own1; continue; }            // own cell is excluded (:515-516)
+              const int w = v + 1;
+              const bool okB = w < vb && !(w >= own0 && w < own1);
+              pp_ext_eval2(p, prec[v - b0], prec[(okB ? w : v) - b0], true, okB, F, ax2, ay2, az2);
+              v += 2;
             }
+          }
+      };
+      if (single) {
+        eval_list(heavy || walker ? 0 : n);
+        if (walker) walk(0, Ptot);
+      } else if (NL > 0) {
+        for (int b0 = 0; b0 < Ptot; b0 += PP3_PCAP) {   // batches of the concatenated partner sequence
+          const int b1 = min(b0 + PP3_PCAP, Ptot);
+          __syncthreads();                            // the previous batch's readers are done (the first trip: nothing is staged yet)
+          stage(b0, b1);
+          __syncthreads();
+          int nb = 0;
+          if (walker) walk(b0, b1);
+          else if (valid && !heavy) {
+            // window by window: the positions of this batch, relative to the lane's first position in it
+            bool have = false;
+            for (int zz = z0; zz <= z1; zz++)
+              for (int yy = y0; yy <= y1; yy++) {
+                const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r] - b0;
+                int va = cr + (int)offs[r * Wp + (x0 - X0)], vb = cr + (int)offs[r * Wp + (x1 + 1 - X0)];   // positions in the batch
+                va = max(va, 0); vb = min(vb, b1 - b0);
+                const bool ownrow = (zz == cz && yy == cy);
+                // the own cell [o0, o1) splits the own row's window in two (:515-516)
+                const int o0 = ownrow ? min(max(own0 - b0, va), vb) : vb, o1 = ownrow ? min(max(own1 - b0, va), vb) : vb;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                  const int a = half == 0 ? va : o1, b = half == 0 ? o0 : vb;
+                  if (half == 1 && !ownrow) break;
+                  if (b > a && !have) { base = a; have = true; }
+                  for (int v = a; v < b; v++) { if (nb < PP3_LCAP) mylist[nb] = (unsigned char)(v - base); nb++; }
+                }
+              }
+          }
+          eval_list(nb);
         }
       }
       ax += ax2.x + ax2.y; ay += ay2.x + ay2.y; az += az2.x + az2.y;
     }
-    float mag = 0.f;
-    if (valid) {
+    if (valid && !heavy) {
       if (phys) {                                                                   // :576-582
         float4 v = vrec;
         v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;
         vel[vi] = v;
       }
       mag = sqrtf(ax * ax + ay * ay + az * az);                                     // :617
+    }
+    } else {
+    // ================================================================ PASS 1: the heavy records of the task
+    // The task's heavy lanes (bits set by pass 0), compacted in lane order (the order of the home records) into groups of 64: the
+    // records and their home rows in LDS.  Every group is swept by all four wavefronts, each taking its share of the partners (of
+    // every chunk of 64 union rows: shares of equal length in the row-major partner sequence); the partial sums are added in the
+    // order of the shares afterwards.  A lane's partners come in the order of the list path (rows in z, y order, ascending
+    // position) within a share.  The sweep itself: pp_sweep_row
+    const unsigned long long hb = ((unsigned long long)(unsigned)misc[9 + 2 * wv] << 32) | (unsigned)misc[8 + 2 * wv];
+    const bool heavy = valid && ((hb >> lane) & 1ull);
+    int hoff = 0, Hn = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { const int c = __popc((unsigned)misc[8 + 2 * w]) + __popc((unsigned)misc[9 + 2 * w]); if (w < wv) hoff += c; Hn += c; }
+    if (heavy) {
+      const int k = hoff + __popcll(hb & ((1ull << lane) - 1ull));
+      hrec[k] = spos[rstart[j] + (h - roff[j])];
+      hj[k] = (unsigned char)j;
+    }
+    const int ngrp = (Hn + 63) >> 6;                  // uniform, <= NW
+    PPSweepK SK{F.c1, F.K, F.K34, F.K74, F.big_s, F.nrp_big, F.nbig_t, F.r2t_big};
+    // the constants of the swept evaluation in VECTOR registers: an instruction with a scalar-register operand costs 4.3 cycles of
+    // a SIMD's issue against 2.6 (tools/valubench.hip, profiles/r04_valubench.txt)
+    asm volatile("" : "+v"(SK.c1), "+v"(SK.K), "+v"(SK.K34), "+v"(SK.K74), "+v"(SK.big_s), "+v"(SK.nrp_big), "+v"(SK.nbig_t), "+v"(SK.r2t_big));
+    float acc[NW][3];
+#pragma unroll
+    for (int gi = 0; gi < NW; gi++) { acc[gi][0] = 0.f; acc[gi][1] = 0.f; acc[gi][2] = 0.f; }
+    const int nbat = (Ptot + PP3_PCAP - 1) / PP3_PCAP;
+    for (int ib = 0; ib < nbat; ib++) {
+      const int b0 = ib * PP3_PCAP, b1 = min(b0 + PP3_PCAP, Ptot);
+      __syncthreads();                                // hrec / hj are written (first trip); the previous batch's readers are done
+      stage(b0, b1);
+      __syncthreads();
+      const float4 *pr = prec - b0;
+#pragma unroll
+      for (int gi = 0; gi < NW; gi++) {
+        if (gi >= ngrp) break;
+        // the group's records, one per lane, their windows and the union of them
+        const int k = gi * 64 + lane;
+        const bool hvalid = k < Hn;
+        float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
+        int hcx = hx0, hcy = hy0, hcz = hz0, hz0_ = 0, hz1_ = -1, hy0_ = 0, hy1_ = -1, hx0_ = 0, hx1_ = 0, hown0 = 0, hown1 = 0;
+        if (hvalid) {
+          hp = hrec[k];
+          const int hjj = hj[k];
+          hcz = hz0 + hjj / PP3_HY; hcy = hy0 + hjj % PP3_HY; hcx = (int)floorf(hp.x) + G.nb;                      // :412
+          reach(hcx, hcy, hcz, hz0_, hz1_, hy0_, hy1_, hx0_, hx1_);
+          const int r = (hcz - Z0) * NRY + (hcy - Y0);
+          hown0 = cum[r] + offs[r * Wp + (hcx - X0)]; hown1 = cum[r] + offs[r * Wp + (hcx - X0) + 1];
+        }
+        const float hx = hp.x, hy = hp.y, hz = hp.z;
+        const int uz0 = wave_min_i(hvalid ? hz0_ : 0x7fffffff), uz1 = wave_max_i(hvalid ? hz1_ : -0x7fffffff);
+        const int uy0 = wave_min_i(hvalid ? hy0_ : 0x7fffffff), uy1 = wave_max_i(hvalid ? hy1_ : -0x7fffffff);
+        const int ux0 = wave_min_i(hvalid ? hx0_ : 0x7fffffff), ux1 = wave_max_i(hvalid ? hx1_ : -0x7fffffff);
+        float sx_ = acc[gi][0], sy_ = acc[gi][1], sz_ = acc[gi][2];
+        // The union's rows, 64 at a time with one row per lane: the stretch [ua, ub) of the row inside the batch, cut down to this
+        // wavefront's share.  Rows with an empty stretch are never visited; for the others the lanes' own window ends are fetched
+        // one row ahead of the sweep (a blob of 205 spreads over ~40 rows of ~6 partners: fetched row by row in the loop, the
+        // three dependent LDS round trips per row cost more than the sweep itself)
+        const int nuy = uy1 - uy0 + 1, nur = (uz1 - uz0 + 1) * nuy;
+        const int inv = (65536 + nuy - 1) / nuy;                                            // i / nuy = (i * inv) >> 16 for i < 4096
+        for (int rc = 0; rc < nur; rc += 64) {
+          const int i = rc + lane;
+          int ua_l = 0, ub_l = 0, crow_l = 0, zy_l = 0;
+          if (i < nur) {
+            const int zq = (i * inv) >> 16, zz = uz0 + zq, yy = uy0 + (i - zq * nuy);
+            const int r = (zz - Z0) * NRY + (yy - Y0);
+            crow_l = cum[r];
+            ua_l = max(crow_l + (int)offs[r * Wp + (ux0 - X0)], b0); ub_l = min(crow_l + (int)offs[r * Wp + (ux1 + 1 - X0)], b1);
+            zy_l = (zz << 16) | yy;
+          }
+          {
+            // this wavefront's share of the chunk's partners: positions [lo, hi) of the concatenation of the rows' stretches
+            const int cnt = max(ub_l - ua_l, 0);
+            int inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+            const int tot = __shfl(inc, 63, 64), per_w = (tot + NW - 1) / NW, lo = wv * per_w, hi = min(lo + per_w, tot);
+            const int before = inc - cnt;                                                  // partners of the rows before this one
+            ua_l += max(lo - before, 0); ub_l -= max(inc - hi, 0);
+          }
+          unsigned long long todo = __ballot(ua_l < ub_l);
+          int n_zy = 0, n_crow = 0, n_ua = 0, n_ub = 0, n_araw = 0, n_braw = 0;
+          bool n_rowok = false;
+          auto prefetch = [&](int ln) {            // ln: uniform
+            n_zy = __builtin_amdgcn_readlane(zy_l, ln); n_crow = __builtin_amdgcn_readlane(crow_l, ln);
+            n_ua = __builtin_amdgcn_readlane(ua_l, ln); n_ub = __builtin_amdgcn_readlane(ub_l, ln);
+            const int zz = n_zy >> 16, yy = n_zy & 0xffff, r = (zz - Z0) * NRY + (yy - Y0);
+            n_rowok = hvalid && zz >= hz0_ && zz <= hz1_ && yy >= hy0_ && yy <= hy1_;
+            n_araw = 0; n_braw = 0;
+            if (n_rowok) { n_araw = (int)offs[r * Wp + (hx0_ - X0)]; n_braw = (int)offs[r * Wp + (hx1_ + 1 - X0)]; }
+          };
+          if (todo) prefetch(__builtin_ctzll(todo));
+          while (todo) {
+            const int zy = n_zy, crow = n_crow, ua = n_ua, ub = n_ub, araw = n_araw, braw = n_braw;
+            const bool rowok = n_rowok;
+            todo &= todo - 1ull;
+            if (todo) prefetch(__builtin_ctzll(todo));
+            // this lane's window of the row [a, a + len) and, on its own row, its own cell [own0, own0 + olen) (:515-516), as
+            // the centre and half width of an interval test on the position
+            const int a = rowok ? crow + araw : ua, len = braw - araw;
+            const bool ownrow = rowok && (zy >> 16) == hcz && (zy & 0xffff) == hcy;
+            const float lenf = (float)len, olenf = ownrow ? (float)(hown1 - hown0) : 0.0f;
+            const float d0 = (float)(ua - a) - 0.5f * (lenf - 1.0f), k4 = 2.0f * lenf - 1.0f;
+            if (__any(ownrow)) {
+              const float dO = (float)(ua - hown0) - 0.5f * (olenf - 1.0f), k4o = 1.0f - 2.0f * olenf;
+              pp_sweep_row<true, TAPER_ALL>(pr, ua, ub, hx, hy, hz, d0, k4, dO, k4o, SK, sx_, sy_, sz_);
+            } else pp_sweep_row<false, TAPER_ALL>(pr, ua, ub, hx, hy, hz, d0, k4, 0.f, 0.f, SK, sx_, sy_, sz_);
+          }
+        }
+        acc[gi][0] = sx_; acc[gi][1] = sy_; acc[gi][2] = sz_;
+      }
+    }
+    // the wavefronts' shares of a group's sums, added in the order of the shares by wavefront (group mod NW), which kicks
+#pragma unroll
+    for (int gi = 0; gi < NW; gi++) {
+      if (gi >= ngrp) break;
+      __syncthreads();                                // (the previous group's partial sums are read)
+      float *ps = part + (wv * 64 + lane) * 3;
+      ps[0] = acc[gi][0]; ps[1] = acc[gi][1]; ps[2] = acc[gi][2];
+      __syncthreads();
+      const int k = gi * 64 + lane;
+      if (wv == gi && k < Hn) {
+        float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; q++) { const float *pq = part + (q * 64 + lane) * 3; sx_ += pq[0]; sy_ += pq[1]; sz_ += pq[2]; }
+        const float4 hp = hrec[k];
+        const int hjj = hj[k];
+        if (is_phys((int)floorf(hp.x) + G.nb, hy0 + hjj % PP3_HY, hz0 + hjj / PP3_HY)) {      // :576-582
+          const int hvi = rec_index(hp);
+          float4 v = vel[hvi];
+          v.x = v.x + sx_ * a_mid * P3M_G_F * dt; v.y = v.y + sy_ * a_mid * P3M_G_F * dt; v.z = v.z + sz_ * a_mid * P3M_G_F * dt;
+          vel[hvi] = v;
+        }
+        mag = sqrtf(sx_ * sx_ + sy_ * sy_ + sz_ * sz_);                             // :617
+      }
+    }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
@@ -1033,112 +989,65 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   if (g.pp_range == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   const int e = g.pt + 2 * g.pp_range;
-  static const bool v1 = getenv("P3M_PP_EXT_V1") && getenv("P3M_PP_EXT_V1")[0] == '1';   // A/B switch: the LDS-tiled kernel of round 1
-  // The LDS-staged kernel (k_pp_ext3) is the default.  P3M_PP_EXT_V2=1 selects the gather kernel k_pp_ext2 (ms per launch on a 560 tile,
-  // uniform / blobs of 205 / blobs of 13 000: 3.2 / 9.0 / 636 against 2.0 / 7.5 / 422 for k_pp_ext3)
-  static const bool v2 = getenv("P3M_PP_EXT_V2") && getenv("P3M_PP_EXT_V2")[0] == '1';
-  const bool v3 = !v2;
-  if (!v1 && v3) {
-    // patches of PP3_HZ x PP3_HY rows x xbw cells holding 7/8 of PP3_NT home records at the mean density (one task)
-    static const int xbw_env = getenv("P3M_PP_XBW") ? atoi(getenv("P3M_PP_XBW")) : 0;
-    const double rho_mean = (double)c->np_all / ((double)g.E * g.E * g.E);
-    int xbw = xbw_env > 0 ? xbw_env : (int)std::lround((0.875 * PP3_NT) / std::max(1e-9, rho_mean * PP3_HZ * PP3_HY));
-    xbw = std::max(4, std::min(std::min(xbw, e), 64 - 2 * g.pp_range - 1));      // one load instruction per partner row
-    const int npx = (e + xbw - 1) / xbw, npy = (e + PP3_HY - 1) / PP3_HY, npz = (e + PP3_HZ - 1) / PP3_HZ;
-    const int64_t ngroups64 = (int64_t)g.ntiles * npz * npy * npx;
-    const int64_t mult1 = std::min<int64_t>(g.T, 2 + (2 * g.pp_range) / g.pt), mult = mult1 * mult1 * mult1;
-    const int64_t ngroups_max = (int64_t)g.ntiles * npz * npy * ((e + 3) / 4);
-    const int64_t ntask_cap64 = mult * (c->cap / PP3_NT + 1) + ngroups_max + 64;
-    if (ngroups_max > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many patches"); return P3M_EINVAL; }
-    const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
-    if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
-    if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int2) * (size_t)ntask_cap64));   // {group, sub-task} per task
-    if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
-    P3M_TRY(scan_reserve(c, ngroups_max + 8));
-    HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
-    hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
-    HIP_TRY(hipGetLastError());
-    P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
-    hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int2 *>(c->pp_task_group), ntask_cap);
-    HIP_TRY(hipGetLastError());
-    PPForce F{mass_p, G.pp_bias, 1.0f / G.pp_bias, 1.0f / G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f))};
-    const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
-    const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * (size_t)NRmax * Wp + (size_t)(PP3_NT / 64) * 64 * PP3_LSTR +
-                       sizeof(int) * ((size_t)2 * NRmax + 1 + 2 * PP3_HZ * PP3_HY + 1 + 8);   // 8: misc
-    // a partner row segment of more than 65 534 records does not fit the 16-bit offsets: its task takes the per-lane path over
-    // global memory.  P3M_PP_FAT_LIMIT=n lowers the limit (a test switch: ordinary inputs then run that path)
-    static const int fat_limit = getenv("P3M_PP_FAT_LIMIT") ? std::max(1, std::min(65534, atoi(getenv("P3M_PP_FAT_LIMIT")))) : 65534;
-    auto kern = g.pp_range == 2 ? k_pp_ext3<2> : k_pp_ext3<0>;
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    static const int wpc3 = getenv("P3M_PP_WPC") ? atoi(getenv("P3M_PP_WPC")) : 0;
-    int wpc = wpc3 > 0 ? wpc3 : (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));   // resident workgroups per CU by LDS
-    hipLaunchKernelGGL(kern, dim3(256 * wpc), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
-                       c->d_tile_ext, (const int *)c->pp_plan, (const int2 *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter, Wp, NRmax, fat_limit);
+  // P3M_PP_EXT_REF=1: the plain kernel k_pp_ext -- one lane per record of a row, partners straight from global memory, the force
+  // in the reference's own arithmetic (sqrt and divisions, :551-571) -- instead of the LDS-staged kernel with its reciprocal
+  // square root and fused multiply-adds.  A test switch (tests/test_gpu_parity.py FALLBACKS): both have to meet the oracle
+  static const bool ref_arith = getenv("P3M_PP_EXT_REF") && getenv("P3M_PP_EXT_REF")[0] == '1';
+  if (ref_arith) {
+    const unsigned blocks = (unsigned)((int64_t)g.ntiles * e * e);
+    hipLaunchKernelGGL(k_pp_ext, dim3(blocks), dim3(64), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, mass_p, a_mid,
+                       dt, c->d_tile_ext);
     HIP_TRY(hipGetLastError());
     return P3M_OK;
   }
-  if (!v1) {
-    // a group is a patch of PP_RG rows x xbw cells holding ~192 records (three tasks) at the mean density.  Measured on a 560
-    // tile (ms per launch, uniform / 30 % of the particles in blobs of 205): whole rows 3.85 / 13.1, 96 cells 4.02 / 9.9,
-    // 24 cells 4.83 / 10.0: compact patches keep a blob's members in one wavefront (the broadcast path then serves dozens
-    // of lanes at once instead of a handful), whole rows keep the window loads of a uniform task on the fewest rows
-    static const int xbw_env = getenv("P3M_PP_XBW") ? atoi(getenv("P3M_PP_XBW")) : 0;
-    const double rho_mean = (double)c->np_all / ((double)g.E * g.E * g.E);
-    int xbw = xbw_env > 0 ? xbw_env : (int)std::lround(192.0 / std::max(1e-9, rho_mean * PP_RG));
-    xbw = std::max(4, std::min(xbw, e));
-    const int nxb = (e + xbw - 1) / xbw;
-    const int ngy = (e + PP_RG - 1) / PP_RG;
-    const int64_t ngroups64 = (int64_t)g.ntiles * e * ngy * nxb;
-    // a record is a home record of every tile whose extended region holds its cell: per axis at most 2 + 2*ppr/pt tiles
-    const int64_t mult1 = std::min<int64_t>(g.T, 2 + (2 * g.pp_range) / g.pt), mult = mult1 * mult1 * mult1;
-    const int64_t ntask_cap64 = mult * (c->cap / 64 + 1) + ngroups64 + 64;
-    if (ngroups64 > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many row groups"); return P3M_EINVAL; }
-    const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
-    const int64_t ngroups_max = (int64_t)g.ntiles * e * ngy * ((e + 3) / 4);
-    if (ngroups_max > 0x3fffffff) { p3m_set_error("extended PP: too many row groups"); return P3M_EINVAL; }
-    // each buffer under its own check: a failed allocation must not leave the others looking ready
-    if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
-    if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int) * (size_t)(mult * (c->cap / 64 + 1) + ngroups_max + 64)));   // any patch width
-    if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * 32 * PP_NSEG));
-    P3M_TRY(scan_reserve(c, ngroups_max + 8));
-    HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * 32 * PP_NSEG, c->stream));
-    hipLaunchKernelGGL(k_pp_plan, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, ngy, nxb, xbw, ngroups, c->pp_plan);
-    HIP_TRY(hipGetLastError());
-    P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
-    hipLaunchKernelGGL(k_pp_fill, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, c->pp_task_group, ntask_cap);
-    HIP_TRY(hipGetLastError());
-    PPForce F{mass_p, G.pp_bias, 1.0f / G.pp_bias, 1.0f / G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f))};
-    static const int wpc = getenv("P3M_PP_WPC") ? atoi(getenv("P3M_PP_WPC")) : 15;          // resident wavefronts per CU (10.4 KB of LDS each)
-    static const bool unr = getenv("P3M_PP_UNROLL") && getenv("P3M_PP_UNROLL")[0] == '1';    // compile-time reach: all 25 windows loaded up front (116 VGPRs)
-    if (g.pp_range == 2 && unr)
-      hipLaunchKernelGGL(k_pp_ext2<2>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
-                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, nxb, xbw, ntask_cap, c->pp_counter);
-    else
-      hipLaunchKernelGGL(k_pp_ext2<0>, dim3(256 * wpc), dim3(64), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
-                         c->d_tile_ext, (const int *)c->pp_plan, (const int *)c->pp_task_group, ngroups, ngy, nxb, xbw, ntask_cap, c->pp_counter);
-    HIP_TRY(hipGetLastError());
-    return P3M_OK;
-  }
-  if (g.pp_range <= 4) {
-    // x extent of a block: about 200 busy lanes (home records x PP_LPH) at the mean density, at most 128 cells
-    const double rho = (double)c->np_all / ((double)g.E * g.E * g.E);
-    int nbx = (int)std::ceil((double)e * PB_Y * PB_Z * rho * PP_LPH / 200.0);
-    nbx = std::max(nbx, (e + 127) / 128); nbx = std::min(nbx, std::max(1, e / 8));
-    const int bx_cells = (e + nbx - 1) / nbx, nby = (e + PB_Y - 1) / PB_Y;
-    nbx = (e + bx_cells - 1) / bx_cells;
-    const int HR = (PB_Y + 2 * g.pp_range) * (PB_Z + 2 * g.pp_range), wseg = bx_cells + 2 * g.pp_range + 1;
-    const size_t lds = sizeof(int) * (4 * HR + PB_Y * PB_Z + 1 + ((HR * wseg + 3) & ~3) + 4) + sizeof(float4) * PPT_CAP;
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pp_ext_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned blocks = (unsigned)((int64_t)g.ntiles * nbx * nby * nby);
-    hipLaunchKernelGGL(k_pp_ext_tiled, dim3(blocks), dim3(256), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, mass_p, a_mid,
-                       dt, c->d_tile_ext, bx_cells, nbx, nby, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f)));
-    HIP_TRY(hipGetLastError());
-    return P3M_OK;
-  }
-  const unsigned blocks = (unsigned)((int64_t)g.ntiles * e * e);
-  hipLaunchKernelGGL(k_pp_ext, dim3(blocks), dim3(64), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, mass_p, a_mid,
-                     dt, c->d_tile_ext);
+  // patches of PP3_HZ x PP3_HY rows x xbw cells holding 7/8 of PP3_NT home records at the mean density (one task)
+  const double rho_mean = (double)c->np_all / ((double)g.E * g.E * g.E);
+  int xbw = (int)std::lround((0.875 * PP3_NT) / std::max(1e-9, rho_mean * PP3_HZ * PP3_HY));
+  xbw = std::max(4, std::min(std::min(xbw, e), 64 - 2 * g.pp_range - 1));      // one load instruction per partner row
+  const int npx = (e + xbw - 1) / xbw, npy = (e + PP3_HY - 1) / PP3_HY, npz = (e + PP3_HZ - 1) / PP3_HZ;
+  const int64_t ngroups64 = (int64_t)g.ntiles * npz * npy * npx;
+  // a record is a home record of every tile whose extended region holds its cell: per axis at most 2 + 2*ppr/pt tiles
+  const int64_t mult1 = std::min<int64_t>(g.T, 2 + (2 * g.pp_range) / g.pt), mult = mult1 * mult1 * mult1;
+  const int64_t ngroups_max = (int64_t)g.ntiles * npz * npy * ((e + 3) / 4);
+  const int64_t ntask_cap64 = mult * (c->cap / PP3_NTD + 1) + ngroups_max + 64;
+  if (ngroups_max > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many patches"); return P3M_EINVAL; }
+  const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
+  // each buffer under its own check: a failed allocation must not leave the others looking ready
+  if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
+  if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int2) * (size_t)ntask_cap64));   // {group, sub-task} per task
+  if (!c->pp_htask) HIP_TRY(hipMalloc(&c->pp_htask, sizeof(int) * PP3_HREC * (size_t)ntask_cap64));    // the heavy-task list (a task enters it once at most)
+  // task counters of the two passes (PP3_NSEG each, on cache lines of their own) and the length of the heavy-task list
+  constexpr int NCNT = 2 * 32 * PP3_NSEG + 32;
+  if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * NCNT));
+  P3M_TRY(scan_reserve(c, ngroups_max + 8));
+  HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * NCNT, c->stream));
+  int *hcount = c->pp_counter + 2 * 32 * PP3_NSEG;
+  hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
   HIP_TRY(hipGetLastError());
+  P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
+  hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int2 *>(c->pp_task_group), ntask_cap);
+  HIP_TRY(hipGetLastError());
+  const PPForce F = pp_force_constants(mass_p, G.pp_bias, G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f)));
+  const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
+  const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * (size_t)NRmax * Wp + (size_t)(PP3_NT / 64) * 64 * PP3_LSTR +
+                     sizeof(int) * ((size_t)2 * NRmax + 1 + 2 * PP3_HZ * PP3_HY + 1 + 48);   // 48: misc
+  // a partner row segment of more than 65 534 records does not fit the 16-bit offsets: its task takes the per-lane path over
+  // global memory.  P3M_PP_FAT_LIMIT=n lowers the limit (a test switch: ordinary inputs then run that path)
+  static const int fat_limit = getenv("P3M_PP_FAT_LIMIT") ? std::max(1, std::min(65534, atoi(getenv("P3M_PP_FAT_LIMIT")))) : 65534;
+  // no two records within reach of each other are further apart than sqrt(3) (pp_range + 1) cells: when that is inside the taper's
+  // range (the rule: nf_cutoff = 16) the taper needs no switch
+  const float far2 = 3.0f * (float)((g.pp_range + 1) * (g.pp_range + 1));
+  const bool taper_all = far2 < F.r2_taper;
+  const int wpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));   // resident workgroups per CU by LDS
+  for (int pass = 0; pass < 2; pass++) {               // resident workgroups per CU: by LDS, the heavy pass also by its registers
+    auto kern = pass == 0 ? (g.pp_range == 2 ? (taper_all ? k_pp_ext3<2, true, 0> : k_pp_ext3<2, false, 0>) : (taper_all ? k_pp_ext3<0, true, 0> : k_pp_ext3<0, false, 0>))
+                          : (g.pp_range == 2 ? (taper_all ? k_pp_ext3<2, true, 1> : k_pp_ext3<2, false, 1>) : (taper_all ? k_pp_ext3<0, true, 1> : k_pp_ext3<0, false, 1>));
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(256 * (pass == 0 ? wpc : std::min(wpc, PP3_WPE - 1))), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
+                       c->d_tile_ext, (const int *)c->pp_plan, (const int2 *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter + pass * 32 * PP3_NSEG, Wp, NRmax,
+                       fat_limit, c->pp_htask, hcount);
+    HIP_TRY(hipGetLastError());
+  }
   return P3M_OK;
 }
 
@@ -1193,6 +1102,7 @@ __global__ __launch_bounds__(64) void k_pp_count_ext(const float4 *__restrict__ 
 extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, int32_t reps, float *ms_intra, float *ms_ext, int64_t *evals_intra,
                                int64_t *evals_ext) {
   if (!c || reps < 1 || !ms_intra || !ms_ext || !evals_intra || !evals_ext) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_time_pp"));
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(particles_full_cells(c));
   const Geometry &g = c->g;

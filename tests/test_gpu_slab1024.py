@@ -11,6 +11,8 @@ from common import COARSE_TABLE
 from cubep3m_amd.group import rank_coords
 from cubep3m_amd.params import Params
 
+P3M_ESTATE = -5   # include/p3m_hip.h:70
+
 pytestmark = pytest.mark.gpu
 
 
@@ -135,4 +137,18 @@ def test_coarse_only_group_refuses_the_particle_path():
         g.particle_mesh(0.5, 0.05, 0.05, 8.0)
     with pytest.raises(P3MError):
         g.upload_particles(0, np.zeros((10, 6), np.float32))
+    # every other entry point that would touch records, cells or fine arrays: an error code, not a launch on null pointers
+    for call in (lambda: g.download_particles(0), lambda: g.update_position(0.05, 0.05), lambda: g.projection(8.0),
+                 lambda: g.coarse(8.0, 0)):
+        with pytest.raises(P3MError):
+            call()
+    import ctypes as C
+
+    ctx = g.L.p3m_hip_group_ctx(g.h, 0)      # the phase-level API reached through the rank's context refuses as well
+    buf = np.zeros(64, np.float32)
+    assert g.L.p3m_hip_update_position(ctx, 0.05, 0.05, None) == P3M_ESTATE
+    assert g.L.p3m_hip_link_list_and_pass(ctx) == P3M_ESTATE
+    assert g.L.p3m_hip_probe_coarse(ctx, 8.0, buf.ctypes.data_as(C.c_void_p), None) == P3M_ESTATE
+    assert g.L.p3m_hip_delete_particles(ctx, None) == P3M_ESTATE
+    assert g.L.p3m_hip_fine_mesh(ctx, 0.5, 0.05, 8.0) == P3M_ESTATE
     g.close()

@@ -1,3 +1,5 @@
+set -u
+: "${GRAFT_REPO_ROOT:?}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 IC=${1:-uniform}; GEO=${2:-cfg3}
