@@ -22,8 +22,7 @@ struct CGeo { int nb, E, Nn, ms, ncn, nc, cngp; };   // cngp: -DCOARSE_NGP (whol
 #ifndef CM_FLY
 #define CM_FLY 4
 #endif
-#define CM_CAP 16   // listed record indices per lane (k_coarse_moments<0>)
-template <int CROWS>   // 0: listed walk; else fine rows whose range / first record loads are in flight together
+#define CM_CAP 16   // listed record indices per lane
 __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ mom, CGeo G,
                                                        float mass_p, float *__restrict__ rho_c, const int *__restrict__ crow, int crow_w) {
   const int m1 = G.ncn + 1;
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
     }
   };
   const int nrow = G.ms * G.ms;
-  if (CROWS == 0) {
+  {
     // Listed: a lane's records come from ms^2 short ranges (half a record each at the reference's density).  Walking them
     // row by row makes the wavefront run `add` once per row and again for every extra record any lane has in that row --
     // several times the work of its busiest lane (PMC: 58 % VALU-busy at 34 % active lanes).  Instead the row loop only
@@ -87,27 +86,6 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
       }
     }
     drain();
-  } else
-  for (int r0 = 0; r0 < nrow; r0 += (CROWS ? CROWS : 1)) {
-    constexpr int CR = CROWS ? CROWS : 1;
-    int p0[CR], p1[CR];
-#pragma unroll
-    for (int u = 0; u < CR; u++) {
-      const int r = r0 + u, zz = r / G.ms, yy = r - zz * G.ms;
-      p0[u] = 0; p1[u] = 0;
-      if (r < nrow) {
-        if (crow) { const int *row = crow + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * crow_w + ci; p0[u] = row[0]; p1[u] = row[1]; }   // compact table: entry ci = start(x0)
-        else { const int *row = cs + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * G.E + x0; p0[u] = row[0]; p1[u] = row[G.ms]; }
-      }
-    }
-    float4 first[CR];
-#pragma unroll
-    for (int u = 0; u < CR; u++) { first[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (p1[u] > p0[u]) first[u] = spos[p0[u]]; }
-#pragma unroll
-    for (int u = 0; u < CR; u++) {
-      if (p1[u] > p0[u]) add(first[u]);
-      for (int s = p0[u] + 1; s < p1[u]; s++) add(spos[s]);
-    }
   }
 #pragma unroll
   for (int c = 0; c < 8; c++) mom[c * tot + t] = acc[c];
@@ -140,12 +118,9 @@ int coarse_deposit(p3m_ctx *c, float mass_p) {
   if (g.ms / 2 > g.nb) { p3m_set_error("coarse_deposit: mesh_scale/2 > nf_buf"); return P3M_EINVAL; }
   const int64_t m1 = g.ncn + 1, tot = m1 * m1 * m1, n3 = (int64_t)g.ncn * g.ncn * g.ncn;
   HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));
-  static const int crows = getenv("P3M_CROWS") ? atoi(getenv("P3M_CROWS")) : 0;   // 0: listed walk (default); 1..16: row by row, that many rows in flight
   const int *crow = c->cells_compact ? (const int *)c->crow : (const int *)nullptr;
-#define LAUNCH_CM(N) hipLaunchKernelGGL(k_coarse_moments<N>, dim3((unsigned)cdiv(tot, 256)), dim3(256), (N) ? 0 : sizeof(int) * CM_CAP * 256, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G, \
-                                        mass_p, c->rho_c, crow, c->crow_w)
-  if (crows >= 16) LAUNCH_CM(16); else if (crows >= 8) LAUNCH_CM(8); else if (crows >= 4) LAUNCH_CM(4); else if (crows >= 2) LAUNCH_CM(2); else if (crows >= 1) LAUNCH_CM(1); else LAUNCH_CM(0);
-#undef LAUNCH_CM
+  hipLaunchKernelGGL(k_coarse_moments, dim3((unsigned)cdiv(tot, 256)), dim3(256), sizeof(int) * CM_CAP * 256, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G,
+                     mass_p, c->rho_c, crow, c->crow_w);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_coarse_collect, dim3((unsigned)std::min<int64_t>(1024, cdiv(n3, 256))), dim3(256), 0, c->stream, (const float *)c->cmom, c->rho_c, g.ncn, c->d_sums + 1 * P3M_SUM_SPAN);
   HIP_TRY(hipGetLastError());

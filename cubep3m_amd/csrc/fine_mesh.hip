@@ -499,10 +499,9 @@ int fine_kick(p3m_ctx *c, float a_mid, float dt) {
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   // the kick visits every record once: it counts the physical ones per block of 256 sorted records for delete_particles
   // (particles_finalize_enqueue) -- unless the grid moves back before the deletion
-  static const bool nocount = getenv("P3M_SEPARATE_COUNT") && getenv("P3M_SEPARATE_COUNT")[0] == '1';
   int *cnt256 = nullptr;
   c->cnt_from_kick = 0;
-  if (!nocount && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK)) {
+  if (!(c->p.flags & P3M_FLAG_MOVE_GRID_BACK)) {
     cnt256 = c->flags;
     HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
     c->cnt_from_kick = c->np_all;
@@ -528,10 +527,9 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   // the kick visits every physical record once: it counts them per block of 256 sorted records for delete_particles
   // (particles_finalize_enqueue), which then needs no pass of its own over the positions -- unless the grid moves back first
-  static const bool nocount = getenv("P3M_SEPARATE_COUNT") && getenv("P3M_SEPARATE_COUNT")[0] == '1';
   int *cnt256 = nullptr;
   c->cnt_from_kick = 0;
-  if (!nocount && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK) && c->np_all > 0) {
+  if (!(c->p.flags & P3M_FLAG_MOVE_GRID_BACK) && c->np_all > 0) {
     cnt256 = c->flags;
     HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
     c->cnt_from_kick = c->np_all;

@@ -4,8 +4,8 @@
 //   link_list's chaining mesh hoc/ll (and llf, hoc_fine/ll_fine) -> sort by extended fine cell:
 //     k_row_hist / exclusive scan / k_row_scatter (by x-row), k_row_sort (inside each row)
 //   delete_particles.f90 + move_grid_back.f90 -> k_count_physical / scan of the block counts / k_compact
-// Records: float4 positions whose fourth lane carries an index (p3m_internal.h), 12-byte velocities in arrival order, PIDs at
-// rest in pid_home.  Everything here is HBM-bound streaming
+// Records: float4 positions whose fourth lane carries an index (p3m_internal.h), float4 velocities in arrival order whose fourth
+// lane carries the PID slot (12-byte velocity records were measured and dropped: DESIGN section 5, round 3), PIDs at rest in pid_home.  Everything here is HBM-bound streaming
 // (the row histogram / scatter aggregate their atomics per block in LDS).
 #include "p3m_internal.h"
 #include <stdlib.h>
@@ -479,9 +479,8 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
     dep.rho = c->rho; dep.sum_interior = c->d_sums; dep.mass_p = deposit_mass; c->rho_from_sort = true;
   }
   // whole-step PM-only NGP calls: nothing downstream reads per-cell offsets, only the compact table (p3m_internal.h)
-  static const bool full_always = getenv("P3M_FULL_CELLS") && getenv("P3M_FULL_CELLS")[0] == '1';
   RowCompact cc{nullptr, c->crow_w, g.ncn, g.ms, g.T, g.pt, g.nb - 2, g.fb};
-  c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT)) && !full_always;
+  c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT));
   if (c->cells_compact) cc.crow = c->crow;
   HIP_TRY(hipMemsetAsync(c->cand_cnt, 0, sizeof(int) * (16 * P3M_CAND_SLOTS + 16), c->stream));   // empty candidate lists
   hipLaunchKernelGGL(k_row_sort, dim3(cdiv(nrows, P3M_SORT_WPB)), dim3(64 * P3M_SORT_WPB), (size_t)g.E * sizeof(int) * P3M_SORT_WPB, c->stream, (const float4 *)c->tpos,
@@ -686,9 +685,8 @@ int particles_ghost_pack(p3m_ctx *c, float4 *sbuf, const int64_t *seg_off, const
   P3M_TRY(particles_resolve(c));
   if (c->np_local == 0) return P3M_OK;
   GhostSegs S; for (int k = 0; k < GSLOTS; k++) { S.off[k] = seg_off[k]; S.cap[k] = seg_cap[k]; }
-  static const bool scan_all = getenv("P3M_GHOST_SCAN") && getenv("P3M_GHOST_SCAN")[0] == '1';   // A/B and test switch: never use the candidate lists
   const int all_full = (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? 1 : 0;
-  if (c->gl_valid && !scan_all) {
+  if (c->gl_valid) {
     // a list holds at most the records of its blocks of the compaction pass (c->gl_longest)
     hipLaunchKernelGGL(k_ghost_pack<true>, dim3((unsigned)cdiv(std::min<int64_t>(c->gl_longest, c->gl_cap), GP_NT * GP_RPT), P3M_GL_SLOTS), dim3(GP_NT), 0, c->stream,
                        (const float4 *)c->pos, (const float4 *)c->vel, (const int64_t *)c->pid_home, c->np_local, (float)c->g.Nn, (float)c->g.nb, sbuf, S, d_counts,
@@ -938,8 +936,7 @@ int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const floa
   c->pending_compact = false;
   const int n = c->pend_n;
   const float hs = 0.5f * (dt + dt_old);
-  static const bool nofuse = getenv("P3M_SEPARATE_HIST") && getenv("P3M_SEPARATE_HIST")[0] == '1';   // A/B: k_row_hist as its own pass
-  if (drift && !nofuse) {
+  if (drift) {
     // the sort follows: count its x-rows here and in the kernels that append the ghosts (c->hist_done)
     P3M_TRY(particles_hist_begin(c));
     const Geometry &g = c->g;

@@ -376,20 +376,22 @@ __device__ __forceinline__ void pp_sweep_row(const float4 *pr, int ua, int ub, f
   if (v < ub) step(pr[v]);
 }
 
-// ------------------------------------------------------------------ extended PP, version 3: the partner region of a patch through LDS
-// k_pp_ext2 at the reference's density is bound by cache-line traffic: every home record reads 50 cell offsets and ~15 partner
-// records straight from global memory, 44 cache lines per load instruction -- ~200 KB of lines per 64 home records through an
-// L2 that hits 44 % of the time.  Here a task is up to PP3_NT home records of a 3-D PATCH (PP3_HZ planes x PP3_HY rows x xbw
-// cells, 7/8 of PP3_NT home records at the mean density) worked by PP3_NT / 64 wavefronts, and everything its homes can reach -- the
-// (HZ+2r) x (HY+2r) partner rows clipped to the patch's x range +-r -- is brought into LDS ONCE per task by row-wise coalesced
-// loads: the cell offsets of every partner row (one load instruction per row, kept as 16-bit offsets from the row's first
-// record) and the partner records themselves (a flat copy over the concatenated row segments).  A home lane then finds its
-// (2r+1)^2 row windows in the LDS offsets, lists the partners' LDS indices (lanes with few partners) or walks the windows
-// directly (dense cells), and reads the partners from LDS: a partner record is fetched from HBM once per ~3 home records it
-// serves instead of once per home record, the offsets once per patch.  Regions with more records than the staging area holds
-// (blobs) are worked off in batches of PP3_PCAP records of the concatenated row segments; a row segment of more than 65 534
-// records sends the task down a plain per-lane path over global memory.  The partner order per home record (rows in z, y
-// order, ascending sorted index) is that of k_pp_ext.
+// ------------------------------------------------------------------ extended PP: the partner region of a patch through LDS
+// A task is up to PP3_NT home records of a 3-D PATCH (PP3_HZ planes x PP3_HY rows x xbw cells, 7/8 of PP3_NT home records at the
+// mean density) worked by PP3_NT / 64 wavefronts, and everything its homes can reach -- the (HZ+2r) x (HY+2r) partner rows clipped
+// to the patch's x range +-r -- is brought into LDS ONCE per task by row-wise coalesced loads: the cell offsets of every partner
+// row (one load instruction per row, kept as 16-bit offsets from the row's first record) and the partner records themselves (a
+// flat copy over the concatenated row segments).  (Gathering windows and partners straight from global memory, round 2's
+// kernel, was bound by cache-line traffic: 50 cell offsets and ~15 partner records per home record, 44 cache lines per load
+// instruction through an L2 that hit 44 % of the time.)  A home lane then finds its (2r+1)^2 row windows in the LDS offsets and
+//   * lists the partners' LDS positions and sums over the list (the rule: ~15 partners), or
+//   * walks its windows itself (few partners spread over more than 256 positions), or
+//   * is HEAVY (more than PP3_LCAP partners: a blob's members and neighbours) and left to the second launch, which sweeps the
+//     staged region wavefront-cooperatively (pp_sweep_row).
+// Regions with more records than the staging area holds are worked off in batches of PP3_PCAP records of the concatenated row
+// segments; a row segment of more than 65 534 records sends the task down a plain per-lane path over global memory.  The partner
+// order per home record (rows in z, y order, ascending sorted index) is that of k_pp_ext for listed and walked records; swept
+// records add four partial sums (the wavefronts' shares of that order).
 #define PP3_HZ 8        // patch: 8 planes x 8 rows (4 x 16 measured 4.5 % slower: 160 partner rows per task against 144)
 #define PP3_HY 8
 #define PP3_NT 256
@@ -404,6 +406,7 @@ __host__ __device__ __forceinline__ int pp3_task_homes(int count) { return count
 #define PP3_PCAP 704
 #endif
 #define PP3_LCAP 32      // list entries per lane
+#define PP3_CROWDED (PP3_PCAP - 24)   // staged records of a region from which the window lists are built with care (the background's: 648 +- 25)
 #ifndef PP3_WPE
 #define PP3_WPE 5        // wavefronts per SIMD the register allocation aims at (96 VGPRs): five workgroups of 32 KB LDS per CU at the reference density
 #endif
@@ -698,14 +701,20 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
         bool yok[2 * PPR + 1];
 #pragma unroll
         for (int dy = -PPR; dy <= PPR; dy++) yok[dy + PPR] = valid && cy + dy >= y0 && cy + dy <= y1;
-        // three consecutive slots take a, a+1, a+2 whatever the count: the next window overwrites what was not a partner
+        // three consecutive slots take a, a+1, a+2 whatever the count: the next window overwrites what was not a partner.
+        // crowded (uniform: the region holds more records than the background's, i.e. part of a blob): a lane that is past the
+        // capacity stores nothing more, so a wavefront next to a blob runs the tail loop 35 times in all, not 35 times per window
+        const bool crowded = Ptot > PP3_CROWDED;
         auto append = [&](int a, int cnt) {
           unsigned char *o = mylist + min(n, PP3_LCAP);   // a lane past the capacity is heavy, not listed
           const int e = a - base;
           o[0] = (unsigned char)e; o[1] = (unsigned char)(e + 1); o[2] = (unsigned char)(e + 2);
           ovf = ovf || (cnt > 0 && e + cnt > 256);
-          if (__any(cnt > 3))
-            for (int k = 3; k < min(cnt, PP3_LCAP + 3); k++) mylist[min(n + k, PP3_LCAP + 2)] = (unsigned char)(e + k);
+          if (!crowded) {
+            if (__any(cnt > 3))
+              for (int k = 3; k < min(cnt, PP3_LCAP + 3); k++) mylist[min(n + k, PP3_LCAP + 2)] = (unsigned char)(e + k);
+          } else if (__any(cnt > 3 && n <= PP3_LCAP))
+            for (int k = 3; k < cnt && n + k < PP3_LCAP + 3; k++) mylist[n + k] = (unsigned char)(e + k);
           n += cnt;
         };
 #pragma unroll 1

@@ -479,9 +479,9 @@ def test_capacity_overflow_in_the_ghost_pass_is_one_error_for_the_whole_group():
     assert e.value.code == -3 and "max_np" in str(e.value)
 
 
-@pytest.mark.parametrize("switch", ["P3M_COARSE_PER_RANK", "P3M_COARSE_COPY"])
+@pytest.mark.parametrize("switch", ["P3M_COARSE_PER_RANK", "P3M_COARSE_COPY", "P3M_ONE_STREAM"])
 def test_per_rank_coarse_path_stays_at_parity(switch):
-    """P3M_COARSE_PER_RANK=1 runs the distributed coarse transform rank by rank (the path of pencil decompositions and of mesh
+    """P3M_ONE_STREAM=1 keeps the coarse force on the main stream (no second stream, no events).  P3M_COARSE_PER_RANK=1 runs the distributed coarse transform rank by rank (the path of pencil decompositions and of mesh
     sizes without register-stage FFT kernels) where the default batches every stage over the local ranks; P3M_COARSE_COPY=1
     keeps the batched stages but moves the three redistributions as messages (what several processes run) where a single
     process gathers / stores them in place: both held to the same tests, in a child process (the switches are read when the

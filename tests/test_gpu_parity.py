@@ -618,7 +618,7 @@ FALLBACKS = {
                         "(register_fft_sizes and 176) or (test_fft_forward and 176)",
     "P3M_SEPARATE_COARSE_KICK": "(config1_kick_parity and (pm_ or p3m_ext)) or two_steps_with_drift",
     "P3M_Z_UNFUSED": "test_tile_force_vs_oracle or (register_fft_sizes and 176) or (config1_kick_parity and pm_ngp_uniform)",
-    "P3M_PP_EXT_V2": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",
+    "P3M_PP_EXT_REF": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",   # k_pp_ext: the reference's own sqrt / division arithmetic
     "P3M_PP_FAT_LIMIT": "(config1_kick_parity and p3m_ext) or dense_blob",   # = 1: every task with a row of two records takes the global-memory path
     "P3M_CAND_SEG": "half_an_ulp or fine_deposit_vs or heavy_blob or (config1_kick_parity and pm_ngp_uniform)",   # = 1: every candidate list overflows
 }
@@ -627,8 +627,9 @@ FALLBACKS = {
 @pytest.mark.parametrize("switch", list(FALLBACKS))
 def test_fallback_paths_stay_at_parity(switch):
     """The run-time switches select the LDS Stockham FFT kernels for every size, the coarse kick in its own pass, the un-fused z
-    pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run, the gather
-    extended-PP kernel (k_pp_ext2, round 2's default), the per-lane global-memory path of k_pp_ext3 that row segments of more than 65 534
+    pair (forward z in place, then multiply + inverse z from rho-hat) that tiles longer than 608 cells run, the plain extended-PP
+    kernel in the reference's own arithmetic (k_pp_ext: sqrt and divisions where the default kernels use the reciprocal square root and
+    fused multiply-adds), the per-lane global-memory path of k_pp_ext3 that row segments of more than 65 534
     records take (P3M_PP_FAT_LIMIT=1: of more than one), candidate lists of one entry (the NGP face fix-up then
     scans every record, as it does when a list overflows): all are paths other tile sizes / PP runs take, so they are held to the
     parity tests that reach them (in a child process: the switches are read once per process)."""
