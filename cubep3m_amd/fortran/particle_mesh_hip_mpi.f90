@@ -1,10 +1,14 @@
 !! particle_mesh_hip_mpi.f90 -- the same drop-in `subroutine particle_mesh` for MPI builds of the reference
 !! (nodes_dim > 1): ONE MPI rank = one cubic sub-volume = one logical rank of a p3m_group = one GPU.
-!! The library's exchanges (ghost particles, slab transposes, force halo, dt reductions; what particle_pass.f90,
-!! fftw3ds.f90, coarse_force_buffer.f90 and the mpi_reduce/mpi_bcast pairs do in the reference) go through the three
-!! host-transport callbacks of include/p3m_hip.h, implemented below with the MPI calls the host already has.
-!! (A host that links RCCL instead calls p3m_hip_group_comm_init_rccl with an id broadcast by MPI_Bcast and needs none
-!! of the callbacks.)  Particles stay resident on the device between output steps exactly as in particle_mesh_hip.f90 (see
+!! The library's exchanges (ghost particles, slab transposes, force halo, dt reductions; what particle_pass.f90:69-722,
+!! fftw3ds.f90:24-39,84-99, coarse_force_buffer.f90:25-63 and the mpi_reduce/mpi_bcast pairs do in the reference) travel
+!!   * over RCCL / xGMI, device buffer to device buffer, when every MPI rank of a node drives a GPU of its own: rank 0 obtains
+!!     the 128-byte id (p3m_hip_rccl_unique_id), MPI broadcasts it, every rank calls p3m_hip_group_comm_init_rccl -- MPI is then
+!!     used for nothing else on this path;
+!!   * through the three host-transport callbacks of include/p3m_hip.h, implemented below with the MPI calls the host already
+!!     has (pinned host staging), when ranks share a GPU (more ranks on a node than GPUs: RCCL refuses two ranks of one
+!!     communicator on one device) or when P3M_HIP_TRANSPORT=mpi asks for it.  P3M_HIP_TRANSPORT=rccl insists on RCCL.
+!! Particles stay resident on the device between output steps exactly as in particle_mesh_hip.f90 (see
 !! there: opt-in, P3M_HIP_RESIDENT=1; the default copies the particles in and out every step).  Link instead of particle_mesh_threaded.o, with -lp3m_hip.  Compile like the reference:
 !!   mpif90 -cpp -ffree-form -I<source_threads> -DNGP -DPPINT -DPP_EXT -DDISP_MESH -c particle_mesh_hip_mpi.f90
 module p3m_mpi_transport
@@ -91,6 +95,16 @@ subroutine particle_mesh
       integer(c_int32_t), value :: proc, nprocs
       type(c_ptr), intent(out) :: g
     end function
+    integer(c_int) function p3m_hip_rccl_unique_id(id) bind(C, name="p3m_hip_rccl_unique_id")
+      import :: c_int, c_int8_t
+      integer(c_int8_t), intent(out) :: id(128)
+    end function
+    integer(c_int) function p3m_hip_group_comm_init_rccl(g, id, force_local) bind(C, name="p3m_hip_group_comm_init_rccl")
+      import :: c_int, c_int8_t, c_int32_t, c_ptr
+      type(c_ptr), value :: g
+      integer(c_int8_t), intent(in) :: id(128)
+      integer(c_int32_t), value :: force_local
+    end function
     integer(c_int) function p3m_hip_group_set_transport(g, t) bind(C, name="p3m_hip_group_set_transport")
       import :: c_int, c_ptr, p3m_transport
       type(c_ptr), value :: g
@@ -138,6 +152,10 @@ subroutine particle_mesh
   real(c_float) :: offset(3), fine_tab(3, 16, 16, 16), coarse_tab(3, 4, 4, 4), rt(3)
   integer(c_int32_t) :: np_c
   integer :: ierr_c, i, j, k, temp(3), fstat
+  integer :: node_comm, node_rank, node_size, ndev, want_rccl, all_rccl, failed, any_failed
+  integer(c_int8_t) :: nccl_id(128)
+  character(len=8) :: trv
+  integer :: trl
 
   if (.not. c_associated(grp)) then
     par%nodes_dim = nodes_dim; par%tiles_node_dim = tiles_node_dim; par%nf_tile = nf_tile
@@ -167,17 +185,52 @@ subroutine particle_mesh
 #endif
     par%rsoft = rsoft; par%pp_bias = pp_bias; par%dt_pp_scale = dt_pp_scale; par%density_buffer = density_buffer
     par%rank = 0                       ! the group assigns the logical ranks
-    par%device = mod(rank, max(1, p3m_hip_device_count()))   ! one GPU per MPI rank of the node (ranks share GPUs if there are fewer)
+    ! one GPU per MPI rank of the node (mpi_initialization.f90:55-76 places the ranks; which of them share a node is MPI's
+    ! knowledge): the ranks of a node count themselves and take the node's GPUs in turn (they share GPUs if there are fewer)
+    call mpi_comm_split_type(mpi_comm_world, mpi_comm_type_shared, 0, mpi_info_null, node_comm, ierr)
+    call mpi_comm_rank(node_comm, node_rank, ierr)
+    call mpi_comm_size(node_comm, node_size, ierr)
+    call mpi_comm_free(node_comm, ierr)
+    ndev = max(1, p3m_hip_device_count())
+    par%device = mod(node_rank, ndev)
     ierr_c = p3m_hip_group_create(par, int(rank, c_int32_t), int(nodes, c_int32_t), grp)   ! process `rank` of `nodes`: one logical rank each
     if (ierr_c /= 0) stop 'p3m_hip_group_create failed'
     call get_environment_variable('P3M_HIP_RESIDENT', envv, envl)
     if (envl > 0) resident = (envv(1:1) == '1')
-    tr%user = c_null_ptr
-    tr%exchange = c_funloc(p3m_exchange)
-    tr%allreduce_max_f32 = c_funloc(p3m_allreduce_max_f32)
-    tr%allreduce_sum_f64 = c_funloc(p3m_allreduce_sum_f64)
-    ierr_c = p3m_hip_group_set_transport(grp, tr)
-    if (ierr_c /= 0) stop 'p3m_hip_group_set_transport failed'
+    ! the transport: RCCL when EVERY rank has a GPU of its own (all ranks take the same decision), else the MPI callbacks
+    want_rccl = 0
+    if (node_size <= ndev) want_rccl = 1
+    call get_environment_variable('P3M_HIP_TRANSPORT', trv, trl)
+    if (trl >= 3) then
+      if (trv(1:3) == 'mpi') want_rccl = 0
+      if (trl >= 4) then
+        if (trv(1:4) == 'rccl') want_rccl = 1
+      endif
+    endif
+    call mpi_allreduce(want_rccl, all_rccl, 1, mpi_integer, mpi_min, mpi_comm_world, ierr)
+    if (all_rccl == 1) then
+      nccl_id = 0
+      failed = 0
+      if (rank == 0) then
+        if (p3m_hip_rccl_unique_id(nccl_id) /= 0) failed = 1
+      endif
+      call mpi_bcast(nccl_id, 128, mpi_byte, 0, mpi_comm_world, ierr)
+      if (p3m_hip_group_comm_init_rccl(grp, nccl_id, 0_c_int32_t) /= 0) failed = 1
+      call mpi_allreduce(failed, any_failed, 1, mpi_integer, mpi_max, mpi_comm_world, ierr)
+      if (any_failed /= 0) then
+        if (rank == 0) write(*,*) 'particle_mesh (HIP): the RCCL communicator could not be set up (P3M_HIP_TRANSPORT=mpi selects the MPI transport)'
+        call mpi_abort(mpi_comm_world, ierr, ierr)
+      endif
+      if (rank == 0) write(*,*) 'particle_mesh (HIP): exchanges over RCCL,', nodes, 'ranks,', ndev, 'GPUs per node'
+    else
+      tr%user = c_null_ptr
+      tr%exchange = c_funloc(p3m_exchange)
+      tr%allreduce_max_f32 = c_funloc(p3m_allreduce_max_f32)
+      tr%allreduce_sum_f64 = c_funloc(p3m_allreduce_sum_f64)
+      ierr_c = p3m_hip_group_set_transport(grp, tr)
+      if (ierr_c /= 0) stop 'p3m_hip_group_set_transport failed'
+      if (rank == 0) write(*,*) 'particle_mesh (HIP): exchanges through MPI (host staging),', node_size, 'ranks on', ndev, 'GPUs per node'
+    endif
     ! the same tables fine_kernel / coarse_kernel read (kernel_initialization.f90:15,344)
     open(unit=18, file=kernel_path//'wfxyzf.3.ascii', status='old', iostat=fstat)
     if (fstat /= 0) stop 'error opening fine mesh kernel'
