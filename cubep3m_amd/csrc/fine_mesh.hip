@@ -41,10 +41,14 @@ __device__ __forceinline__ float block_sum_f(float v, float *sh) {
 // membership by coarse cell = exact test on x because the boundaries are multiples of mesh_scale.
 template <bool NGP>
 __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho,
-                                                     int tile0, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
+                                                     int tile0, TileGeo G, float mass_p, double *__restrict__ sum_interior, int nrows) {
   extern __shared__ float row[];  // rp floats
   const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb;
-  const int j = blockIdx.x % nf, k = (blockIdx.x / nf) % nf, tl = blockIdx.x / (nf * nf);
+  // workgroups go to the eight XCDs in turn: XCD x works the rows x * ceil(nrows / 8) ... of the launch, a slab in z, so that the
+  // sorted cell rows a CIC output row gathers from (each feeds four output rows) are fetched into ONE XCD's L2
+  const int per8 = (nrows + 7) >> 3, brow = (int)(blockIdx.x & 7u) * per8 + (int)(blockIdx.x >> 3);
+  if (brow >= nrows) return;
+  const int j = brow % nf, k = (brow / nf) % nf, tl = brow / (nf * nf);
   int tx, ty, tz; tile_xyz(tile0 + tl, G.T, tx, ty, tz);
   for (int i = threadIdx.x; i < G.rp; i += 64) row[i] = 0.f;
   __syncthreads();
@@ -224,8 +228,8 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
   P3M_TRY(particles_full_cells(c));
   const unsigned blocks = (unsigned)((int64_t)ntile * g.nf * g.nf);
   const size_t lds = sizeof(float) * (2 * g.px);
-  hipLaunchKernelGGL(k_fine_deposit<false>, dim3(blocks), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
-                     tile0, G, mass_p, c->d_sums);
+  hipLaunchKernelGGL(k_fine_deposit<false>, dim3(8 * cdiv(blocks, 8)), dim3(64), lds, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->rho,
+                     tile0, G, mass_p, c->d_sums, (int)blocks);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -279,8 +283,8 @@ int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float 
   P3M_TRY(particles_full_cells(c));
   for (int t0 = 0; t0 < g.ntiles; t0 += c->tile_batch) {
     const int nt = std::min(c->tile_batch, g.ntiles - t0);
-    hipLaunchKernelGGL(k_fine_deposit<false>, dim3((unsigned)((int64_t)nt * g.nf * g.nf)), dim3(64), sizeof(float) * (2 * g.px), c->stream,
-                       (const float4 *)c->spos, (const int *)c->cell_end, c->rho, t0, G, mass_p, (double *)nullptr);
+    hipLaunchKernelGGL(k_fine_deposit<false>, dim3(8 * cdiv((int64_t)nt * g.nf * g.nf, 8)), dim3(64), sizeof(float) * (2 * g.px), c->stream,
+                       (const float4 *)c->spos, (const int *)c->cell_end, c->rho, t0, G, mass_p, (double *)nullptr, (int)((int64_t)nt * g.nf * g.nf));
     HIP_TRY(hipGetLastError());
     for (int t = 0; t < nt; t++) {   // tile order of :24-32 (x fastest)
       const int tl = t0 + t, tz = tl / (g.T * g.T), ty = (tl / g.T) % g.T, tx = tl % g.T;
@@ -326,44 +330,90 @@ int fine_force_max(p3m_ctx *c) {
   return P3M_OK;
 }
 
-// ------------------------------------------------------------------ :227-319 gather + kick of the physical particles
-// COARSE: the coarse-mesh kick (coarse_velocity.f90:137-179, same arithmetic and order as k_coarse_kick) follows the fine kick of
-// a record in registers -- PM-only whole steps, where nothing else touches the velocities between the two kicks.  cnt256: the
-// survivors of delete_particles (the physical records) per block of 256 sorted records = per workgroup, counted on the way.
-template <bool NGP, bool COARSE = false>
-__global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ spos, float4 *__restrict__ vel, int n, TileGeo G, int Nn, int ms,
-                                                   const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
-                                                   const float *__restrict__ fc, int ncn, int *__restrict__ cnt256) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  float4 p = make_float4(-1.f, -1.f, -1.f, 0.f);
-  if (s < n) p = spos[s];
-  const float fNn = (float)Nn;
-  const bool physical = p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;   // chains of hoc(1..ncn) only (:234-236)
-  if (cnt256) {
-    const unsigned long long m = __ballot(physical);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt256[blockIdx.x], __popcll(m));
+// ------------------------------------------------------------------ :208-319 CIC: max |F|^2, gather + kick of the physical particles
+// One workgroup per BLOCK of the force box: CK_BK x CK_BJ cell rows, CK_XS cells long.  A record interpolates between the eight
+// box points around it, so the block stages (CK_BK + 1) x (CK_BJ + 1) box rows of CK_XS + 4 points, all three components, in LDS
+// -- 1.6 times its own volume, 39 KB -- with coalesced 16-byte loads, forms the maximum of |F|^2 over the points that are its
+// own on the way (every box point is some block's own exactly once: the pass over the box that k_force_max used to be), and its
+// records -- CK_BK * CK_BJ short ranges of the sorted store, ~256 in all, flattened over the threads -- take their 24 values from
+// LDS.  (The per-record gather from global memory this replaces re-fetched every box row for four cell rows: 753 us + 313 us for
+// the maximum per 560-tile; one wavefront per cell row with its four box rows in LDS was tried in round 3: 25 KB per wavefront,
+// six wavefronts per CU, 1.99 ms.)  Blocks go to the XCDs in contiguous eighths (an XCD's L2 then holds the rows its neighbouring
+// blocks share).  Same terms, same order of the eight corners as :293-316.  COARSE: the coarse-mesh kick
+// (coarse_velocity.f90:137-179, same arithmetic and order as k_coarse_kick) follows the fine kick of a record in registers --
+// PM-only whole steps, where nothing else touches the velocities between the two kicks.  A record whose reference cell
+// floor(xv + offset_tile) lies outside the staged rows (rounding at a face of the block) reads global memory.
+#define CK_BK 4
+#define CK_BJ 4
+#define CK_XS 128
+#define CK_XP (CK_XS + 4)
+template <bool COARSE>
+__global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G, int Nn, int ms,
+                                                       const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt, float *__restrict__ fmax_out,
+                                                       const float *__restrict__ fc, int ncn, int nxs, int nbj, int nbk, int nblk) {
+  __shared__ float sb[(CK_BK + 1) * (CK_BJ + 1) * 3 * CK_XP];
+  __shared__ int rp0[CK_BK * CK_BJ], rpre[CK_BK * CK_BJ + 1];
+  const int per = (nblk + 7) >> 3, lb = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);   // workgroups go to the XCDs in turn: each gets one contiguous eighth
+  if (lb >= nblk) return;
+  const int tid = threadIdx.x, fb = G.fb, fbp = G.fbp, lo = G.nb - 2;
+  const int xs = lb % nxs, bj = (lb / nxs) % nbj, bk = (lb / (nxs * nbj)) % nbk, tile = lb / (nxs * nbj * nbk);
+  int tx, ty, tz; tile_xyz(tile, G.T, tx, ty, tz);
+  const int k0 = bk * CK_BK, j0 = bj * CK_BJ, x0 = xs * CK_XS;
+  const int nk = min(CK_BK + 1, fb - k0), nj = min(CK_BJ + 1, fb - j0), nx4 = min(CK_XP, fbp - x0) >> 2;
+  const float *f0 = fbox + (int64_t)tile * fb * fb * fbp;
+  // the cell rows' record ranges (started first: range -> record -> velocity are three dependent round trips)
+  int rcnt = 0;
+  if (tid < CK_BK * CK_BJ) {
+    const int kk = k0 + tid / CK_BJ, jj = j0 + tid % CK_BJ;
+    int st = 0;
+    if (kk < fb && jj < fb) {
+      const int64_t row = ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * G.E + tx * G.pt + lo;   // box column i <-> extended cell tx*pt + lo + i
+      st = cs[row + x0]; rcnt = cs[row + min(x0 + CK_XS, fb)] - st;
+    }
+    rp0[tid] = st;
   }
-  if (!physical) return;
+  float m = 0.f;
+  for (int e = tid; e < nk * nj * nx4; e += 256) {
+    const int q = e % nx4, t = e / nx4, rj = t % nj, rk = t / nj;
+    const int64_t off = ((int64_t)(k0 + rk) * fb + (j0 + rj)) * fbp + x0 + 4 * q;
+    const float4 a = *reinterpret_cast<const float4 *>(f0 + off), b = *reinterpret_cast<const float4 *>(f0 + off + comp_stride),
+                 d = *reinterpret_cast<const float4 *>(f0 + off + 2 * comp_stride);
+    float *dst = sb + (rk * (CK_BJ + 1) + rj) * 3 * CK_XP + 4 * q;
+    *reinterpret_cast<float4 *>(dst) = a; *reinterpret_cast<float4 *>(dst + CK_XP) = b; *reinterpret_cast<float4 *>(dst + 2 * CK_XP) = d;
+    if (rk < CK_BK && rj < CK_BJ && 4 * q < CK_XS)                                                                   // this block's own points (pad columns are zero)
+      m = fmaxf(m, fmaxf(fmaxf(a.x * a.x + b.x * b.x + d.x * d.x, a.y * a.y + b.y * b.y + d.y * d.y),                // :217-218
+                         fmaxf(a.z * a.z + b.z * b.z + d.z * d.z, a.w * a.w + b.w * b.w + d.w * d.w)));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((tid & 63) == 0 && m > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, m);
+  if (tid < 64) {   // exclusive prefix of the CK_BK * CK_BJ counts
+    int inc = rcnt;
+#pragma unroll
+    for (int o = 1; o < CK_BK * CK_BJ; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (tid >= o) inc += u; }
+    if (tid < CK_BK * CK_BJ) rpre[tid] = inc - rcnt;
+    if (tid == CK_BK * CK_BJ - 1) rpre[CK_BK * CK_BJ] = inc;
+  }
+  __syncthreads();
+  const int total = rpre[CK_BK * CK_BJ];
+  const float fNn = (float)Nn;
   const int nct = G.pt / ms;
-  // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
-  int tx = 0, ty = 0, tz = 0;
-  if (G.T > 1) { tx = ((int)floorf(p.x / (float)ms)) / nct; ty = ((int)floorf(p.y / (float)ms)) / nct; tz = ((int)floorf(p.z / (float)ms)) / nct; }
   const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
-  const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
-  const int lo = G.nb - 2, fb = G.fb;
-  const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
-  const int tile = (tz * G.T + ty) * G.T + tx;
-  const float *f0 = fbox + (int64_t)tile * fb * fb * G.fbp;
-  const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
-  float4 v = vel[vi];
-  if (NGP) {
-    const int64_t o = ((int64_t)k1 * fb + j1) * G.fbp + i1;
-    v.x = v.x + f0[o] * a_mid * P3M_G_F * dt;                                                         // :265-266
-    v.y = v.y + f0[o + comp_stride] * a_mid * P3M_G_F * dt;
-    v.z = v.z + f0[o + 2 * comp_stride] * a_mid * P3M_G_F * dt;
-  } else {
+  for (int t = tid; t < total; t += 256) {
+    int r = 0;
+#pragma unroll
+    for (int k = 1; k < CK_BK * CK_BJ; k++) r += (rpre[k] <= t) ? 1 : 0;
+    const float4 p = spos[rp0[r] + (t - rpre[r])];
+    if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) continue;  // chains of hoc(1..ncn) only (:234-236)
+    // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
+    if (G.T > 1 && (((int)floorf(p.x / (float)ms)) / nct != tx || ((int)floorf(p.y / (float)ms)) / nct != ty || ((int)floorf(p.z / (float)ms)) / nct != tz)) continue;
+    const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
+    float4 v = vel[vi];
+    const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
+    const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
     const float dx1 = (float)(i1 + lo + 1) - x, dy1 = (float)(j1 + lo + 1) - y, dz1 = (float)(k1 + lo + 1) - z;  // :290
     const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+    const int li = i1 - x0, lj = j1 - j0, lk = k1 - k0;
+    const bool staged = li >= 0 && li + 1 < 4 * nx4 && lj >= 0 && lj + 1 < nj && lk >= 0 && lk + 1 < nk;
 #pragma unroll
     for (int cz = 0; cz < 2; cz++)
 #pragma unroll
@@ -371,29 +421,31 @@ __global__ __launch_bounds__(256) void k_fine_kick(const float4 *__restrict__ sp
 #pragma unroll
         for (int cx = 0; cx < 2; cx++) {                                                                // order of :293-316
           const float dVc = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
-          const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * G.fbp + (i1 + cx);
-          v.x = v.x + f0[o] * dVc; v.y = v.y + f0[o + comp_stride] * dVc; v.z = v.z + f0[o + 2 * comp_stride] * dVc;
+          float fx, fy, fz;
+          if (staged) { const float *q = sb + ((lk + cz) * (CK_BJ + 1) + (lj + cy)) * 3 * CK_XP + (li + cx); fx = q[0]; fy = q[CK_XP]; fz = q[2 * CK_XP]; }
+          else { const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * fbp + (i1 + cx); fx = f0[o]; fy = f0[o + comp_stride]; fz = f0[o + 2 * comp_stride]; }
+          v.x = v.x + fx * dVc; v.y = v.y + fy * dVc; v.z = v.z + fz * dVc;
         }
+    if (COARSE) {
+      const float inv = 1.0f / (float)ms;
+      const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
+      const int ci = (int)floorf(cx_) + 1, cj = (int)floorf(cy_) + 1, ck = (int)floorf(cz_) + 1;
+      const float ex1 = (float)ci - cx_, ey1 = (float)cj - cy_, ez1 = (float)ck - cz_;
+      const float ex2 = 1.0f - ex1, ey2 = 1.0f - ey1, ez2 = 1.0f - ez1;
+      const int mm = ncn + 2; const int64_t ccs = (int64_t)mm * mm * mm;
+#pragma unroll
+      for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+        for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+          for (int cx = 0; cx < 2; cx++) {                                                              // :153-168
+            const float dV = a_mid * P3M_G_F * dt * (cx ? ex2 : ex1) * (cy ? ey2 : ey1) * (cz ? ez2 : ez1);
+            const int64_t o = ((int64_t)(ck + cz) * mm + (cj + cy)) * mm + (ci + cx);
+            v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
+          }
+    }
+    vel[vi] = v;
   }
-  if (COARSE) {
-    const float inv = 1.0f / (float)ms;
-    const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
-    const int ci = (int)floorf(cx_) + 1, cj = (int)floorf(cy_) + 1, ck = (int)floorf(cz_) + 1;
-    const float ex1 = (float)ci - cx_, ey1 = (float)cj - cy_, ez1 = (float)ck - cz_;
-    const float ex2 = 1.0f - ex1, ey2 = 1.0f - ey1, ez2 = 1.0f - ez1;
-    const int m = ncn + 2; const int64_t ccs = (int64_t)m * m * m;
-#pragma unroll
-    for (int cz = 0; cz < 2; cz++)
-#pragma unroll
-      for (int cy = 0; cy < 2; cy++)
-#pragma unroll
-        for (int cx = 0; cx < 2; cx++) {                                                              // :153-168
-          const float dV = a_mid * P3M_G_F * dt * (cx ? ex2 : ex1) * (cy ? ey2 : ey1) * (cz ? ez2 : ez1);
-          const int64_t o = ((int64_t)(ck + cz) * m + (cj + cy)) * m + (ci + cx);
-          v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
-        }
-  }
-  vel[vi] = v;
 }
 
 // NGP: max |F|^2 (:208-223) and the kick (:244-270) in ONE pass over the force box.  One wavefront per box row
@@ -492,37 +544,30 @@ __global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const floa
   }
 }
 
-int fine_kick(p3m_ctx *c, float a_mid, float dt) {
+// CIC fine mesh: the maximum and the kick in one pass over the force box (k_fine_kick_cic)
+static int fine_max_and_kick_cic(p3m_ctx *c, float a_mid, float dt) {
   const Geometry &g = c->g;
-  if (c->np_all == 0) return P3M_OK;
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
-  // the kick visits every record once: it counts the physical ones per block of 256 sorted records for delete_particles
-  // (particles_finalize_enqueue) -- unless the grid moves back before the deletion
-  int *cnt256 = nullptr;
-  c->cnt_from_kick = 0;
-  if (!(c->p.flags & P3M_FLAG_MOVE_GRID_BACK)) {
-    cnt256 = c->flags;
-    HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
-    c->cnt_from_kick = c->np_all;
-  }
-  const float *fc = nullptr;
-  if (c->p.flags & P3M_FLAG_NGP)
-    hipLaunchKernelGGL((k_fine_kick<true, false>), dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
-                       g.ms, (const float *)c->fbox, cs, a_mid, dt, fc, g.ncn, cnt256);
-  else if (c->coarse_first)
-    hipLaunchKernelGGL((k_fine_kick<false, true>), dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
-                       g.ms, (const float *)c->fbox, cs, a_mid, dt, (const float *)c->force_c, g.ncn, cnt256);
+  P3M_TRY(particles_full_cells(c));
+  c->cnt_from_kick = 0;                      // delete_particles counts its survivors itself
+  const int nxs = cdiv(g.fb, CK_XS), nbj = cdiv(g.fb, CK_BJ), nbk = cdiv(g.fb, CK_BK);
+  const int64_t nblk = (int64_t)g.ntiles * nbk * nbj * nxs;
+  if (nblk > 0x0fffffff) { p3m_set_error("CIC kick: too many force-box blocks"); return P3M_EINVAL; }
+  const unsigned grid = 8u * (unsigned)cdiv(nblk, 8);
+  if (c->coarse_first)
+    hipLaunchKernelGGL(k_fine_kick_cic<true>, dim3(grid), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms,
+                       (const float *)c->fbox, cs, a_mid, dt, c->d_red, (const float *)c->force_c, g.ncn, nxs, nbj, nbk, (int)nblk);
   else
-    hipLaunchKernelGGL((k_fine_kick<false, false>), dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, c->np_all, G, g.Nn,
-                       g.ms, (const float *)c->fbox, cs, a_mid, dt, fc, g.ncn, cnt256);
+    hipLaunchKernelGGL(k_fine_kick_cic<false>, dim3(grid), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms,
+                       (const float *)c->fbox, cs, a_mid, dt, c->d_red, (const float *)nullptr, g.ncn, nxs, nbj, nbk, (int)nblk);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
 // :208-319 for every tile: maximum and kick; fused into one pass over the force box for NGP
 int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
   const Geometry &g = c->g;
-  if (!(c->p.flags & P3M_FLAG_NGP)) { P3M_TRY(fine_force_max(c)); return fine_kick(c, a_mid, dt); }
+  if (!(c->p.flags & P3M_FLAG_NGP)) return fine_max_and_kick_cic(c, a_mid, dt);
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   // the kick visits every physical record once: it counts them per block of 256 sorted records for delete_particles

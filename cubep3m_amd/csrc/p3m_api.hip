@@ -358,7 +358,7 @@ void reductions_fold(p3m_ctx *c) {
   for (int k = 0; k < 4; k++) { double t = 0.0; for (int sl = 0; sl < P3M_NSLOT; sl++) t += c->h_sums_raw[k * P3M_SUM_SPAN + sl * 8]; c->h_sums[k] = t; }
 }
 
-// whole-step calls only: the fine kick carries the coarse kick (NGP: k_fine_kick_rows<true>; CIC fine mesh: k_fine_kick<false, true>).
+// whole-step calls only: the fine kick carries the coarse kick (NGP: k_fine_kick_rows<true>; CIC fine mesh: k_fine_kick_cic<true>).
 // With PPINT / PP_EXT the reference adds the PP kicks between the two mesh kicks (fine, PP, coarse); here the sum is formed as
 // fine, coarse, PP -- the same terms, each formed as in the reference, added in another order: 1e-7 relative on a velocity against
 // the 1e-5 bar, for one pass over the records less (295 us per rank at the bench's size).  P3M_SEPARATE_COARSE_KICK=1 keeps the

@@ -467,6 +467,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
   unsigned char *mylist = list + (wv * 64 + lane) * PP3_LSTR;                 // this lane's entries
   const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int ntask = PASS == 0 ? min(plan[ngroups], ntask_cap) : min(*hcount, ntask_cap);
+  if (PASS == 1 && ntask == 0) return;             // no blob anywhere (the rule at the background's density): the launch costs its dispatch only
   const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
   int seg = blockIdx.x % PP3_NSEG;
   // Thread 0 runs a two-stage pipeline of task draws, one stage per task worked: the counter atomic of the task after the next

@@ -110,3 +110,80 @@ def test_distributed_coarse_mesh_at_the_bench_size(pencil):
         assert np.abs(rg - ro).max() <= 4e-6 * np.abs(ro).max(), i
         assert rel_rms(fg, fo) < 3e-6, i
     g.close()
+
+
+def test_config4_full_eight_rank_step_properties():
+    """BASELINE configs[3] as bench.py runs it -- 1024^3 fine cells / 512^3 particles as 2x2x2 logical ranks of one 560^3 tile and
+    256^3 particles each, 256^3 coarse mesh in slabs -- through the group API at FULL size, held to size-independent properties (the
+    oracle would need hours): every particle back exactly once and inside the volume of the rank that now owns it, the mass on
+    both meshes, the momentum of the kicks, ghost counts, and independence of the order the particles are handed over in.  Two steps:
+    the second one drifts (dt_old > 0) with velocities that carry ~1 % of the particles across rank boundaries, so the migrants'
+    full records (velocity, PID) travel with the ghost pass (particle_pass.f90:69-722, mpi_initialization.f90:42-76)."""
+    import gc
+
+    from cubep3m_amd.group import ParticleMeshGroup
+
+    p = Params(nodes_dim=2, tiles_node_dim=1, nf_tile=560, ngp=True, density_buffer=1.3)
+    nside, Nn = 256, float(p.nf_physical_node_dim)
+    n_rank, n_tot = nside ** 3, 8 * nside ** 3
+    mass_p = float((p.nf_physical_node_dim / nside) ** 3)
+
+    def particles(r):
+        rng = np.random.default_rng(4000 + r)
+        xv = np.empty((n_rank, 6), np.float32)
+        xv[:, :3] = rng.random((n_rank, 3), dtype=np.float32) * np.float32(Nn)
+        np.minimum(xv[:, :3], np.float32(Nn * (1 - 2e-6)), out=xv[:, :3])
+        xv[:, 3:] = rng.normal(0, 12.0, (n_rank, 3)).astype(np.float32)      # |v| dt ~ 1 cell: ~1 % of a 512-cell rank's particles cross a face
+        return xv
+
+    def run(order_seed):
+        g = ParticleMeshGroup(p, fine_table=FINE_TABLE, coarse_table=COARSE_TABLE)
+        for i, r in enumerate(g.local_ranks):
+            xv = particles(r)
+            pid = np.arange(1, n_rank + 1, dtype=np.int64) + r * n_rank
+            if order_seed is not None:
+                o = np.random.default_rng(order_seed + r).permutation(n_rank)
+                xv, pid = xv[o], pid[o]
+            g.upload_particles(i, xv, pid)
+            del xv, pid
+        o1 = g.particle_mesh(0.5, 0.05, 0.0, mass_p)          # a kick, no drift
+        o2 = g.particle_mesh(0.5, 0.05, 0.05, mass_p)         # drift across rank boundaries, then the next kick
+        return g, o1, o2
+
+    g, o1, o2 = run(None)
+    for o in (o1, o2):
+        assert o.np_total == n_tot
+        assert o.sum_rho_f == pytest.approx(mass_p * n_tot, rel=1e-9) and o.sum_rho_c == pytest.approx(mass_p * n_tot, rel=1e-6)
+    seen = np.zeros(n_tot + 1, np.uint8)
+    mom = np.zeros(3)
+    sq = 0.0
+    moved = 0
+    held = 0
+    for i, r in enumerate(g.local_ranks):
+        xo, pid = g.download_particles(i)
+        held += len(pid)
+        assert pid.min() >= 1 and pid.max() <= n_tot
+        seen[pid] += 1                                        # (the PIDs one rank holds are distinct: a duplicate would show up as a missing one)
+        assert xo[:, :3].min() >= 0.0 and xo[:, :3].max() < Nn                                  # inside the volume of its (new) owner
+        home = (pid - 1) // n_rank
+        moved += int((home != r).sum())
+        # the kick of the two steps: velocity now minus the velocity the particle was created with
+        v0 = np.empty((len(pid), 3), np.float32)
+        for hr in np.unique(home):
+            sel = home == hr
+            v0[sel] = particles(int(hr))[(pid[sel] - 1) % n_rank, 3:]
+        dv = (xo[:, 3:] - v0).astype(np.float64)
+        mom += dv.sum(0); sq += (dv ** 2).sum()
+        del xo, pid, v0, dv
+    assert held == n_tot and seen[0] == 0 and np.all(seen[1:] == 1)   # every PID exactly once over the eight ranks
+    assert 0.002 * n_tot < moved < 0.05 * n_tot               # and a percent of them changed owner
+    assert np.abs(mom / n_tot).max() < 2e-3 * np.sqrt(sq / (3 * n_tot))
+    ref = (o2.dt_f_acc, o2.dt_c_acc, o2.np_ghost, o1.dt_f_acc, o1.dt_c_acc, o1.np_ghost)
+    g.close(); del g, seen
+    gc.collect()
+    # order independence: the same particle SET handed over in another order gives the same limits and ghost counts
+    g, o1, o2 = run(77)
+    assert (o2.np_ghost, o1.np_ghost) == (ref[2], ref[5])
+    assert o1.dt_f_acc == pytest.approx(ref[3], rel=1e-6) and o1.dt_c_acc == pytest.approx(ref[4], rel=1e-6)
+    assert o2.dt_f_acc == pytest.approx(ref[0], rel=1e-6) and o2.dt_c_acc == pytest.approx(ref[1], rel=1e-6)
+    g.close()
