@@ -140,9 +140,10 @@ def cpu_baseline(scal):
     tile loop of particle_mesh_threaded.f90:84, coarse_mass.f90:83, coarse_velocity.f90:137, update_position.f90:68,
     coarse_force.f90:37-86; link_list, particle_pass and delete_particles are serial there and here) on a bounded sample: a
     256^3-cell sub-volume (BASELINE configs[1]: 128^3 particles of the same uniform density), full particle_mesh steps, 4^3
-    tiles of 112 (64 work items; 2^3 tiles of 176 on boxes with <= 8 cores).  The thread count is swept (8, 16, 32, 64, bounded
-    by the box) with the phases timed one by one; the best count is reported.  Checker-side code, used here only as the
-    reported baseline."""
+    tiles of 112 (64 work items; 2^3 tiles of 176 on boxes with <= 8 cores).  BASELINE.md section 3: one warm-up step, then the
+    thread count is swept (8 ... the box's cores, one timed step each), then THREE timed steps at the best count with the phases
+    timed one by one -- that is `value` -- and the same three steps for the PM + PPINT + PP_EXT flag set (`pm_pp`, the figure that
+    stands beside the bench line's pm_pp leg).  Checker-side code, used here only as the reported baseline."""
     import ctypes
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -154,10 +155,8 @@ def cpu_baseline(scal):
     except Exception:
         cores_avail = cores
     key = "cfg2" if cores_avail <= 8 else "cfg2_t4"
-    p = Params(**CONFIGS[key]["params"])
-    ntile = p.tiles_node_dim ** 3
     fine, coarse = default_tables()
-    os.environ["OMP_NUM_THREADS"] = str(max(1, min(cores_avail, 64)))
+    os.environ["OMP_NUM_THREADS"] = str(max(1, cores_avail))
     omp = None
     for name in ("libgomp.so.1", "libomp.so", "libomp.so.5"):
         try:
@@ -168,45 +167,69 @@ def cpu_baseline(scal):
     xv = make_particles(128, 256.0)
     a_mid, dt, dt_old, mass_p = scal
     phases = ("update_position", "link_list", "particle_pass", "fine_mesh", "coarse_mesh", "delete_particles")
-    sweep = {}
     t_all = time.perf_counter()
-    for threads in sorted({t for t in (8, 16, 32, 64) if t <= cores_avail} or {max(1, cores_avail)}):
-        if omp is not None:
-            omp.omp_set_num_threads(threads)
-        o = ol.Oracle(p)
-        o.set_kernel_tables(fine, coarse)
-        o.set_particles(0, xv)
-        o.particle_mesh(a_mid, dt, dt_old, mass_p)          # warm-up step (first touch of the tile work spaces)
+
+    def timed_steps(o, nsteps):
         split = dict.fromkeys(phases, 0.0)
-        steps = 0
         t0 = time.perf_counter()
-        while steps < 2 and (steps == 0 or time.perf_counter() - t_all < 25.0):
+        for _ in range(nsteps):
             for name, call in (("update_position", lambda: o.update_position(dt, dt_old)), ("link_list", o.link_list),
                                ("particle_pass", o.particle_pass), ("fine_mesh", lambda: o.fine_mesh(a_mid, dt, mass_p)),
                                ("coarse_mesh", lambda: o.coarse_mesh(a_mid, dt, mass_p)), ("delete_particles", o.delete_particles)):
                 t1 = time.perf_counter()
                 call()
                 split[name] += time.perf_counter() - t1
-            steps += 1
         el = time.perf_counter() - t0
-        o.close()
-        sweep[threads] = {"particle_updates_per_s": len(xv) * steps / el, "s_per_step": el / steps,
-                          "phase_s_per_step": {k: v / steps for k, v in split.items()}}
-        if time.perf_counter() - t_all > 25.0:
+        return {"particle_updates_per_s": len(xv) * nsteps / el, "s_per_step": el / nsteps, "steps": nsteps,
+                "phase_s_per_step": {k: v / nsteps for k, v in split.items()}}
+
+    def oracle_for(**flags):
+        q = Params(**dict(CONFIGS[key]["params"], **flags))
+        o = ol.Oracle(q)
+        o.set_kernel_tables(fine, coarse)
+        o.set_particles(0, xv)
+        return q, o
+
+    counts = sorted({t for t in (8, 16, 32, 64, 128, 256) if t <= cores_avail} | {max(1, min(cores_avail, 256))})
+    p, o = oracle_for()
+    ntile = p.tiles_node_dim ** 3
+    if omp is not None:
+        omp.omp_set_num_threads(min(32, cores_avail))
+    o.particle_mesh(a_mid, dt, dt_old, mass_p)              # warm-up step (first touch of the tile work spaces)
+    sweep = {}
+    for threads in counts:
+        if omp is not None:
+            omp.omp_set_num_threads(threads)
+        sweep[threads] = timed_steps(o, 1)
+        if time.perf_counter() - t_all > 20.0:
             break
     best = max(sweep, key=lambda t: sweep[t]["particle_updates_per_s"])
+    if omp is not None:
+        omp.omp_set_num_threads(best)
+    final = timed_steps(o, 3)
+    o.close()
+    # the short-range flag set at the same thread count (the tile loop is the only OpenMP region that grows)
+    _, opp = oracle_for(ppint=True, pp_ext=True)
+    opp.particle_mesh(a_mid, dt, dt_old, mass_p)
+    pp = timed_steps(opp, 3 if time.perf_counter() - t_all < 28.0 else 1)
+    opp.close()
     el_all = time.perf_counter() - t_all
-    return {"value": sweep[best]["particle_updates_per_s"], "unit": "particle-updates/s", "cores": best, "kind": "port",
-            "host_cpus": cores, "host_cpus_usable": cores_avail, "thread_sweep": sweep,
+    return {"value": final["particle_updates_per_s"], "unit": "particle-updates/s", "cores": best, "kind": "port",
+            "host_cpus": cores, "host_cpus_usable": cores_avail, "timed_steps": final["steps"], "s_per_step": final["s_per_step"],
+            "phase_s_per_step": final["phase_s_per_step"], "thread_sweep": sweep,
+            "pm_pp": {"value": pp["particle_updates_per_s"], "unit": "particle-updates/s", "cores": best, "timed_steps": pp["steps"],
+                      "s_per_step": pp["s_per_step"], "phase_s_per_step": pp["phase_s_per_step"],
+                      "flags": "PM + PPINT + PP_EXT (the flag set of the bench line's pm_pp leg), same sample"},
             "sample": "full particle_mesh steps of a 256^3-cell / 128^3-particle sub-volume (same density, nf_tile=%d, %d^3 tiles = %d work items) "
                       "on the CPU oracle (C port of the reference path with the reference's OpenMP regions; link_list, particle_pass, "
-                      "delete_particles serial as in the reference), swept over %s threads with one warm-up and up to two timed steps each "
-                      "on a box with %d CPUs, %.1f s in all; best: %d threads, %.2f s per step (%s).  Context (survey-time probe of the "
+                      "delete_particles serial as in the reference): one warm-up step, one timed step at each of %s threads, then %d timed "
+                      "steps at the best count (%d threads: %.2f s per step; %s) and %d timed steps with PPINT + PP_EXT (%.2f s per step) on a "
+                      "box with %d CPUs, %.1f s in all.  Context (survey-time probe of the "
                       "reference Fortran itself, amdflang + MKL FFT shim, dev container, 4 OpenMP threads, same 256^3/128^3 problem, "
                       "BASELINE.md section 2): 1.65e6 particle-updates/s PM-only, 0.96e6 with PP + extended PP; the reference's own 2007 log "
                       "(8 cores, 128^3 particles, PM+PP): 8.8e4"
-                      % (p.nf_tile, p.tiles_node_dim, ntile, sorted(sweep), cores, el_all, best, sweep[best]["s_per_step"],
-                         ", ".join("%s %.3f" % (k, v) for k, v in sweep[best]["phase_s_per_step"].items()))}
+                      % (p.nf_tile, p.tiles_node_dim, ntile, sorted(sweep), final["steps"], best, final["s_per_step"],
+                         ", ".join("%s %.3f" % (k, v) for k, v in final["phase_s_per_step"].items()), pp["steps"], pp["s_per_step"], cores, el_all)}
 
 
 def open_group(p, torch, dist, rank, world, ddev, uid, require_rccl, dist_backend):
@@ -548,6 +571,8 @@ def main():
             res["pp"] = pp_leg()
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(scal)
+            if "pm_pp" in res:   # the CPU figure of the same flag set beside the PM + PP leg
+                res["pm_pp"]["cpu_baseline"] = {k: res["cpu_baseline"]["pm_pp"][k] for k in ("value", "unit", "cores", "timed_steps", "s_per_step")}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
