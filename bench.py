@@ -548,9 +548,28 @@ def main():
                 torch.cuda.synchronize()
                 el2 = time.perf_counter() - t1
                 assert o2.np_total == n_total
-                g2.close()
                 leg = {"metric": "particle_updates_per_sec", "value": n_total * k2 / el2, "ms_per_step": 1e3 * el2 / k2, "steps": k2,
                        "workload": CONFIGS[cfg_name]["workload"], "data": data}
+                if not p2.ngp:
+                    # the north star's "fine-mesh FFT+CIC sweep": CIC deposit + the five FFT launches of one tile against 10.5 S, and
+                    # the CIC gather (maximum + interpolation + kick in one pass over the force box) against its own bytes
+                    pm2 = g2.rank_context(0)
+                    S2 = 4.0 * (p2.nf_tile + 2) * p2.nf_tile ** 2
+                    nt2 = p2.tiles_node_dim ** 3
+                    sw = pm2.time_fine_sweep(mass_p, reps=3)
+                    ga = pm2.time_fine_gather(reps=3)
+                    fbx = p2.nf_physical_tile_dim + 3
+                    gbytes = 12.0 * fbx ** 3 * nt2 + 48.0 * (n_total / p2.nodes)       # 12 fb^3 per tile + 48 B per particle
+                    leg["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "fine_sweep": {"ms": sw, "algorithmic_bytes": 10.5 * S2 * nt2, "achieved_GBs": 10.5 * S2 * nt2 / (sw * 1e-3) / 1e9,
+                                                      "frac": 10.5 * S2 * nt2 / (sw * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                      "what": "CIC deposit (fine_cic_mass.f90:13-43) + forward x, y, fused z, inverse y, inverse x of one rank's tiles"},
+                                       "cic_gather": {"ms": ga, "algorithmic_bytes": gbytes, "achieved_GBs": gbytes / (ga * 1e-3) / 1e9,
+                                                      "frac": gbytes / (ga * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                      "what": "max |F|^2 + CIC interpolation + kick (particle_mesh_threaded.f90:208-223,289-316), one pass over the force box"},
+                                       "sweep_and_gather": {"ms": sw + ga, "algorithmic_bytes": 10.5 * S2 * nt2 + gbytes,
+                                                            "frac": (10.5 * S2 * nt2 + gbytes) / ((sw + ga) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                g2.close()
                 if p2.ppint:
                     leg.update(dt_pp_acc=o2.dt_pp_acc, dt_pp_ext_acc=o2.dt_pp_ext_acc)
                 return leg

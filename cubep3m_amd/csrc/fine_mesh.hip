@@ -545,12 +545,12 @@ __global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const floa
 }
 
 // CIC fine mesh: the maximum and the kick in one pass over the force box (k_fine_kick_cic)
-static int fine_max_and_kick_cic(p3m_ctx *c, float a_mid, float dt) {
+static int fine_max_and_kick_cic(p3m_ctx *c, float a_mid, float dt, bool count_survivors_reset) {
   const Geometry &g = c->g;
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   P3M_TRY(particles_full_cells(c));
-  c->cnt_from_kick = 0;                      // delete_particles counts its survivors itself
+  if (count_survivors_reset) c->cnt_from_kick = 0;   // delete_particles counts its survivors itself
   const int nxs = cdiv(g.fb, CK_XS), nbj = cdiv(g.fb, CK_BJ), nbk = cdiv(g.fb, CK_BK);
   const int64_t nblk = (int64_t)g.ntiles * nbk * nbj * nxs;
   if (nblk > 0x0fffffff) { p3m_set_error("CIC kick: too many force-box blocks"); return P3M_EINVAL; }
@@ -565,16 +565,16 @@ static int fine_max_and_kick_cic(p3m_ctx *c, float a_mid, float dt) {
   return P3M_OK;
 }
 // :208-319 for every tile: maximum and kick; fused into one pass over the force box for NGP
-int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt) {
+int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt, bool count_survivors) {
   const Geometry &g = c->g;
-  if (!(c->p.flags & P3M_FLAG_NGP)) return fine_max_and_kick_cic(c, a_mid, dt);
+  if (!(c->p.flags & P3M_FLAG_NGP)) return fine_max_and_kick_cic(c, a_mid, dt, count_survivors);
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   // the kick visits every physical record once: it counts them per block of 256 sorted records for delete_particles
   // (particles_finalize_enqueue), which then needs no pass of its own over the positions -- unless the grid moves back first
   int *cnt256 = nullptr;
-  c->cnt_from_kick = 0;
-  if (!(c->p.flags & P3M_FLAG_MOVE_GRID_BACK) && c->np_all > 0) {
+  if (count_survivors) c->cnt_from_kick = 0;
+  if (count_survivors && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK) && c->np_all > 0) {
     cnt256 = c->flags;
     HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
     c->cnt_from_kick = c->np_all;

@@ -642,6 +642,34 @@ extern "C" int p3m_hip_time_fine_sweep(p3m_ctx *c, float mass_p, int32_t reps, f
 int fft_single_pass(p3m_ctx *c, const FftPlan &pl, int which, float *data, float *work, const float *kern, int batch, float *box, int fb, int lo,
                     int64_t bcs);
 
+extern "C" int p3m_hip_time_fine_gather(p3m_ctx *c, int32_t reps, float *ms_per_pass) {
+  if (!c || reps < 1 || !ms_per_pass) return P3M_EINVAL;
+  P3M_TRY(need_particles(c, "p3m_hip_time_fine_gather"));
+  HIP_TRY(hipSetDevice(c->device));
+  P3M_TRY(need_kernels(c));
+  if (c->np_all == 0) { p3m_set_error("p3m_hip_time_fine_gather: no sorted records (run a step or link_list_and_pass first)"); return P3M_ESTATE; }
+  const bool cf = c->coarse_first;
+  c->coarse_first = false;                      // the fine kick alone (the coarse force of a finished step may be gone)
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.f;
+  auto body = [&]() -> int {
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    P3M_TRY(fine_max_and_kick(c, 0.5f, 0.0f, false));  // warm-up
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; i++) P3M_TRY(fine_max_and_kick(c, 0.5f, 0.0f, false));
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    return P3M_OK;
+  };
+  const int rc = body();
+  c->coarse_first = cf;
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  P3M_TRY(rc);
+  *ms_per_pass = ms / reps;
+  return P3M_OK;
+}
 extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch) {
   if (!c || reps < 1 || !ms_per_launch) return P3M_EINVAL;
   P3M_TRY(need_particles(c, "p3m_hip_time_fft_pass"));

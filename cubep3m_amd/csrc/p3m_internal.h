@@ -208,7 +208,7 @@ int particles_resolve(p3m_ctx *c);   // finish a deferred ghost removal before t
 // ---- fine_mesh.hip
 int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p);
 int fine_force(p3m_ctx *c, int tile0, int ntile);
-int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt);
+int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt, bool count_survivors = true);   // false: timing hook (leaves c->flags and cnt_from_kick alone)
 int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz);   // projection.f90: adds this rank's tiles to the device maps
 bool coarse_kick_rides_on_fine(const p3m_ctx *c);   // p3m_api.hip
 int fine_mesh_force_phase(p3m_ctx *c, float mass_p, bool may_clear);          // p3m_api.hip: density + force box of every tile; may_clear: phase-level call, the reductions were not cleared before the sort

@@ -25,7 +25,7 @@ EXPORTS = [
     "p3m_hip_get_kernels", "p3m_hip_upload_particles", "p3m_hip_download_particles", "p3m_hip_particle_mesh",
     "p3m_hip_update_position", "p3m_hip_link_list_and_pass", "p3m_hip_fine_mesh", "p3m_hip_coarse_mesh",
     "p3m_hip_delete_particles", "p3m_hip_get_step_out", "p3m_hip_probe_tile_density", "p3m_hip_probe_tile_force",
-    "p3m_hip_probe_coarse", "p3m_hip_fft3d", "p3m_hip_time_fine_sweep", "p3m_hip_time_fft_pass", "p3m_hip_time_pp", "p3m_hip_stream", "particle_mesh_hip_",
+    "p3m_hip_probe_coarse", "p3m_hip_fft3d", "p3m_hip_time_fine_sweep", "p3m_hip_time_fine_gather", "p3m_hip_time_fft_pass", "p3m_hip_time_pp", "p3m_hip_stream", "particle_mesh_hip_",
     "p3m_hip_group_create", "p3m_hip_group_destroy", "p3m_hip_group_comm_init_rccl", "p3m_hip_group_set_transport", "p3m_hip_expansion", "p3m_hip_timestep", "p3m_hip_write_checkpoint", "p3m_hip_read_checkpoint", "p3m_hip_write_pid_checkpoint",
     "p3m_hip_read_pid_checkpoint", "p3m_hip_write_ic", "p3m_hip_read_ic", "p3m_hip_group_nlocal", "p3m_hip_group_local_rank",
     "p3m_hip_group_ctx", "p3m_hip_group_set_kernel_tables", "p3m_hip_group_upload_particles", "p3m_hip_group_download_particles",
@@ -79,6 +79,7 @@ def load():
     L.p3m_hip_probe_coarse.argtypes = [vp, f32, vp, vp]
     L.p3m_hip_fft3d.argtypes = [vp, f32p, i32, i32]
     L.p3m_hip_time_fine_sweep.argtypes = [vp, f32, i32, C.POINTER(f32)]
+    L.p3m_hip_time_fine_gather.argtypes = [vp, i32, C.POINTER(f32)]
     L.p3m_hip_time_fft_pass.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(i32)]
     L.p3m_hip_coarse_power.argtypes = [vp, f32, f32, f32p]
     L.p3m_hip_group_coarse_power.argtypes = [vp, f32, f32, f32p]

@@ -178,6 +178,12 @@ class ParticleMesh:
         _lib.check(self.L.p3m_hip_time_fine_sweep(self.h, mass_p, reps, C.byref(ms)))
         return ms.value
 
+    def time_fine_gather(self, reps=5):
+        """Average ms of the gather half of the fine mesh (maximum + interpolation + kick, dt = 0) over the boxes of the last sweep."""
+        ms = C.c_float()
+        _lib.check(self.L.p3m_hip_time_fine_gather(self.h, reps, C.byref(ms)))
+        return ms.value
+
     def time_pp(self, a_mid, dt, mass_p, reps=5):
         """(ms per k_pp_intra launch, ms per extended-PP launch, pair evaluations of each) on the sorted records with
         ghosts (after link_list_and_pass)."""

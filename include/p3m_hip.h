@@ -204,6 +204,10 @@ int p3m_hip_fft3d(p3m_ctx *ctx, float *data, int32_t n, int32_t dir);
 /* coarse_power.f90 for a single-rank context (see p3m_hip_group_coarse_power) */
 int p3m_hip_coarse_power(p3m_ctx *ctx, float mass_p, float box, float *ps);
 int p3m_hip_time_fine_sweep(p3m_ctx *ctx, float mass_p, int32_t reps, float *ms_per_sweep);
+/* The gather half of the fine mesh (particle_mesh_threaded.f90:208-319: max |F|^2 + NGP or CIC interpolation + kick) over the force
+   boxes the last sweep left, `reps` times with dt = 0 (the velocities keep their values), HIP events on the library's stream;
+   returns the average milliseconds per pass.  Call after a step or after p3m_hip_time_fine_sweep (sorted records, force boxes). */
+int p3m_hip_time_fine_gather(p3m_ctx *ctx, int32_t reps, float *ms_per_pass);
 /* One pass kernel of the fine-mesh FFT over the whole tile batch, launched `reps` times between
    HIP events on the library's stream; returns the average milliseconds per launch.
    which: 0 x-forward (r2c rows), 1 y-forward lines, 2 z-forward lines, 3 z-inverse lines fused with

@@ -9,6 +9,21 @@ from cubep3m_amd.params import Params
 FINE_TABLE, COARSE_TABLE = default_tables()
 
 
+def observed(name, value, bar):
+    """Record what a multi-step parity test actually measured (name, observed error, the bar it is held to) in
+    gpurun_out/observed_errors.txt, so that the bars can be kept at ~1.5x what is observed (DESIGN section 4 holds the table)."""
+    import os
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "observed_errors.txt"), "a") as f:
+            f.write("%-78s observed %.3e   bar %.1e\n" % (name, float(value), float(bar)))
+    except OSError:
+        pass
+    return float(value)
+
+
 def cfg1(**kw):
     """BASELINE config 1: 64^3 fine / 32^3 particles, nf_tile=80, 2^3 tiles, one rank."""
     d = dict(nodes_dim=1, tiles_node_dim=2, nf_tile=80, cores=2, ngp=True)

@@ -153,7 +153,10 @@ def test_config4_full_eight_rank_step_properties():
     g, o1, o2 = run(None)
     for o in (o1, o2):
         assert o.np_total == n_tot
-        assert o.sum_rho_f == pytest.approx(mass_p * n_tot, rel=1e-9) and o.sum_rho_c == pytest.approx(mass_p * n_tot, rel=1e-6)
+        # the fine-mesh sum counts a tile's INTERIOR: a record half an ulp below a rank's upper face is rounded by xv + offset_tile into
+        # the buffer zone (particle_mesh_threaded.f90:134,139) and counted nowhere, in the reference as here -- ~6e-8 of a coordinate's
+        # range per face, i.e. a couple of dozen of the 1.3e8 particles ("Cell assignment is bit-faithful on purpose")
+        assert abs(o.sum_rho_f - mass_p * n_tot) <= mass_p * 100 and o.sum_rho_c == pytest.approx(mass_p * n_tot, rel=1e-6)
     seen = np.zeros(n_tot + 1, np.uint8)
     mom = np.zeros(3)
     sq = 0.0

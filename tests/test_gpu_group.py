@@ -4,7 +4,11 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from common import COARSE_TABLE, FINE_TABLE, by_pid, cfg1, clustered_particles, rel_rms, uniform_particles
+from common import observed, COARSE_TABLE, FINE_TABLE, by_pid, cfg1, clustered_particles, rel_rms, uniform_particles
+
+# multi-step bars (single steps are held to 1e-5): errors of step 1 feed step 2's drift.  The observed values are recorded by
+# common.observed() in gpurun_out/observed_errors.txt and tabulated in DESIGN section 4; the bars sit at ~1.5x of them
+BAR_KICK_2STEP, BAR_KICK_5STEP, BAR_DT_5STEP = 2e-5, 3e-5, 3e-5
 
 pytestmark = pytest.mark.gpu
 
@@ -263,7 +267,7 @@ def test_eight_logical_ranks_with_mesh_offsets_and_move_grid_back():
         dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
         num += ((dg - do) ** 2).sum()
         den += (do ** 2).sum()
-    assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)
+    assert observed("test_eight_logical_ranks_with_mesh_offsets_and_move_grid_back: kick, relative rms over both steps", np.sqrt(num / den), BAR_KICK_2STEP) <= BAR_KICK_2STEP
 
 
 def test_eight_logical_ranks_one_tile_each_like_the_bench_workload():
@@ -285,7 +289,7 @@ def test_eight_logical_ranks_one_tile_each_like_the_bench_workload():
         dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
         num += ((dg - do) ** 2).sum()
         den += (do ** 2).sum()
-    assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)
+    assert observed("test_eight_logical_ranks_one_tile_each_like_the_bench_workload: kick, relative rms over both steps", np.sqrt(num / den), BAR_KICK_2STEP) <= BAR_KICK_2STEP
 
 
 # ------------------------------------------------------------------ the drop-in itself: a Fortran MPI host
@@ -362,7 +366,7 @@ def test_fortran_mpi_host_calls_particle_mesh_through_the_adapter(tmp_path, cfg,
         dg, do = xg[:, 3:].astype(np.float64) - vin, xo[:, 3:].astype(np.float64) - vin
         num += ((dg - do) ** 2).sum()
         den += (do ** 2).sum()
-    assert np.sqrt(num / den) <= 2e-5, np.sqrt(num / den)
+    assert observed("test_fortran_mpi_host_calls_particle_mesh_through_the_adapter: kick, relative rms over both steps", np.sqrt(num / den), BAR_KICK_2STEP) <= BAR_KICK_2STEP
 
 
 def test_standalone_run_reads_ic_and_writes_reference_checkpoints(tmp_path):
@@ -545,7 +549,7 @@ def test_five_steps_with_every_exchange_on_rccl_and_the_second_stream():
     assert info["comm_count"] == 1 and info["comm_rank"] == 0 and len(info["uuid"]) == 32
     assert og.np_total == oo.np_total == len(xv) and og.np_ghost == oo.np_ghost
     for name in ("dt_f_acc", "dt_c_acc", "dt_pp_acc", "dt_pp_ext_acc"):
-        assert getattr(og, name) == pytest.approx(getattr(oo, name), rel=3e-5), name
+        assert observed("test_five_steps_with_every_exchange_on_rccl_and_the_second_stream: " + name, abs(getattr(og, name) / getattr(oo, name) - 1.0), BAR_DT_5STEP) <= BAR_DT_5STEP, name
     v0 = dict(zip(pid.tolist(), xv[:, 3:]))
     num = den = 0.0
     for i, r in enumerate(g.local_ranks):
@@ -556,7 +560,7 @@ def test_five_steps_with_every_exchange_on_rccl_and_the_second_stream():
         vin = np.stack([v0[q] for q in pg.tolist()])
         num += ((xg[:, 3:].astype(np.float64) - xo[:, 3:].astype(np.float64)) ** 2).sum()
         den += ((xo[:, 3:].astype(np.float64) - vin) ** 2).sum()
-    assert np.sqrt(num / den) <= 3e-5
+    assert observed("test_five_steps_with_every_exchange_on_rccl_and_the_second_stream: velocity change, relative rms over five steps", np.sqrt(num / den), BAR_KICK_5STEP) <= BAR_KICK_5STEP
 
 
 def test_one_rank_per_gpu_share_of_config5_fits_the_device():

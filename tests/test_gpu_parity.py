@@ -7,12 +7,13 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from common import COARSE_TABLE, FINE_TABLE, by_pid, cfg1, clustered_particles, grid_jitter_particles, rel_rms, rms, uniform_particles
+from common import COARSE_TABLE, FINE_TABLE, by_pid, cfg1, clustered_particles, grid_jitter_particles, observed, rel_rms, rms, uniform_particles
 from cubep3m_amd.params import Params
 
 pytestmark = pytest.mark.gpu
 
 KICK_TOL = 1e-5   # north_star: <= 1e-5 RMS relative force error vs the CPU reference
+BAR_KICK_2STEP = 2e-5   # two steps with drift: step 1's error feeds step 2's positions (observed values: DESIGN section 4)
 POS_TOL = 1e-4
 DT_TOL = 1e-5
 
@@ -237,7 +238,7 @@ def test_two_steps_with_drift_and_late_time_scalars(PM):
     check_step(xv, xg, pg, xo, po, outs, "pp ext")
     # velocities now hold v0 + two kicks; compare the accumulated change
     v0 = xv[np.argsort(pid), 3:]
-    assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
+    assert observed("test_two_steps_with_drift_and_late_time_scalars: kick, relative rms over both steps", rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0), BAR_KICK_2STEP) <= BAR_KICK_2STEP
 
 
 def test_f77_wrapper_matches_context_api(PM):
@@ -461,7 +462,7 @@ def test_other_tilings_whole_step_parity(PM, T, nf, cores, kw):
     xg, pg, xo, po, outs = run_step(PM, p, xv, (0.2, 0.05, 0.04, 8.0), pid=pid, steps=2)
     check_step(xv, xg, pg, xo, po, outs, "pp ext" if kw.get("pp_ext") else "")
     v0 = xv[np.argsort(pid), 3:]
-    assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
+    assert observed("test_other_tilings_whole_step_parity: kick, relative rms over both steps", rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0), BAR_KICK_2STEP) <= BAR_KICK_2STEP
 
 
 def test_fortran_host_calls_particle_mesh_through_the_single_rank_adapter(tmp_path):
@@ -511,7 +512,7 @@ def test_fortran_host_calls_particle_mesh_through_the_single_rank_adapter(tmp_pa
     for got, name in zip(dts, ("dt_f_acc", "dt_pp_acc", "dt_pp_ext_acc", "dt_c_acc")):
         assert got == pytest.approx(getattr(oo, name), rel=DT_TOL), name
     v0 = xv[np.argsort(pid), 3:]
-    assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 2 * KICK_TOL
+    assert observed("test_fortran_host_calls_particle_mesh_through_the_single_rank_adapter: kick, relative rms over both steps", rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0), BAR_KICK_2STEP) <= BAR_KICK_2STEP
 
 
 def test_bench_sized_tile_properties(PM):
