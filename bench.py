@@ -334,11 +334,19 @@ def slab_leg(args, torch, dist, rank, world, local_dev, ddev, require_rccl):
                                       "three inverse transforms with the K_c multiply, cube<->slab redistribution and force halo (coarse_force.f90)",
                           "name": "slab1024", "logical_ranks": p.nodes, "ranks_per_gpu": p.nodes // world, "transport": transport},
                "ms_per_transform": ms_step / 4.0,
-               "events": {"forward_ms": ms_fwd, "coarse_force_ms": ms_force, "three_inverse_ms": ms_force - ms_fwd},
-               "roofline": {"bound": "hbm" if world == 1 else "xgmi", "kernel": "coarse_force (1 forward + 3 inverse 1024^3 transforms, all passes and exchanges)",
+               "events": {"forward_ms": ms_fwd, "coarse_force_ms": ms_force, "force_minus_forward_ms": ms_force - ms_fwd},
+               # the HBM side of the transforms: algorithmic bytes per GPU against the HBM peak, whatever the number of GPUs (with
+               # several GPUs the all-to-all below travels over xGMI on top of it: xgmi_link gives that side against a link's rate)
+               "roofline": {"bound": "hbm", "kernel": "coarse_force (1 forward + 3 inverse 1024^3 transforms, all passes and exchanges)",
                             "achieved": alg / (ms_force * 1e-3) / 1e9 / world, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
                             "frac": alg / (ms_force * 1e-3) / 1e9 / world / HBM_PEAK_GBS, "traffic": None,
-                            "algorithmic_bytes": alg},
+                            "algorithmic_bytes": alg,
+                            "xgmi_link": None if world == 1 else {
+                                "bytes_per_link_per_step": 4 * per_peer * (p.nodes // world) ** 2, "peak_GBs": 153.0,
+                                "achieved_GBs": 4 * per_peer * (p.nodes // world) ** 2 / (ms_force * 1e-3) / 1e9,
+                                "frac": 4 * per_peer * (p.nodes // world) ** 2 / (ms_force * 1e-3) / 1e9 / 153.0,
+                                "note": "what one GPU sends to ONE other GPU in the four transposes of a step (every pair of their logical ranks "
+                                        "exchanges per_peer bytes per transpose) over the step's whole time: a lower bound of the link's rate"}},
                "all_to_all": {"bytes_per_peer_per_transpose": per_peer, "peers": p.nodes - 1, "transposes_per_step": 4,
                               "bytes_per_rank_per_step": 4 * per_peer * (p.nodes - 1),
                               "note": "each rank sends nc_slab x (nc/2+1 padded to 16) x nc_slab complex to every other rank per transform "

@@ -720,7 +720,10 @@ static int pid_repack(p3m_ctx *c) {
 int particles_ghost_unpack(p3m_ctx *c, const float4 *rbuf, const int64_t *seg_off, const int *cnt, int base) {
   GhostIn T; int mx = 0, run = base; int64_t nmig = 0;
   for (int k = 2; k < GSLOTS; k += 1) if (k & 1) nmig += cnt[k];
-  if ((int64_t)c->n_home + nmig > c->cap) P3M_TRY(pid_repack(c));   // cap >= np_local + arrivals was checked by the caller
+  // pid_home gains a slot per arriving migrant and never frees the slots of the records that left: repacked when the holes exceed a
+  // quarter of the records (every few dozen steps of a run; a pass over np_local records), and in any case before the array is full
+  // (cap >= np_local + arrivals was checked by the caller)
+  if ((int64_t)c->n_home + nmig > std::min<int64_t>(c->cap, (int64_t)c->np_local + c->np_local / 4 + nmig + 64)) P3M_TRY(pid_repack(c));
   int slot = c->n_home;
   for (int k = 0; k < GSLOTS; k++) {
     T.off[k] = seg_off[k]; T.cnt[k] = k >= 2 ? cnt[k] : 0; T.dst[k] = run; run += T.cnt[k]; mx = std::max(mx, T.cnt[k]);

@@ -799,40 +799,40 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
             }
           }
       };
-      if (single) {
-        eval_list(heavy || walker ? 0 : n);
-        if (walker) walk(0, Ptot);
-      } else if (NL > 0) {
+      // one trip for a region staged in one batch (listed above); else batch by batch: stage, list the batch's share, sum
+      if (single || NL > 0)
         for (int b0 = 0; b0 < Ptot; b0 += PP3_PCAP) {   // batches of the concatenated partner sequence
           const int b1 = min(b0 + PP3_PCAP, Ptot);
-          __syncthreads();                            // the previous batch's readers are done (the first trip: nothing is staged yet)
-          stage(b0, b1);
-          __syncthreads();
-          int nb = 0;
-          if (walker) walk(b0, b1);
-          else if (valid && !heavy) {
-            // window by window: the positions of this batch, relative to the lane's first position in it
-            bool have = false;
-            for (int zz = z0; zz <= z1; zz++)
-              for (int yy = y0; yy <= y1; yy++) {
-                const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r] - b0;
-                int va = cr + (int)offs[r * Wp + (x0 - X0)], vb = cr + (int)offs[r * Wp + (x1 + 1 - X0)];   // positions in the batch
-                va = max(va, 0); vb = min(vb, b1 - b0);
-                const bool ownrow = (zz == cz && yy == cy);
-                // the own cell [o0, o1) splits the own row's window in two (:515-516)
-                const int o0 = ownrow ? min(max(own0 - b0, va), vb) : vb, o1 = ownrow ? min(max(own1 - b0, va), vb) : vb;
+          int nl = (heavy || walker) ? 0 : n;
+          if (!single) {
+            __syncthreads();                            // the previous batch's readers are done (the first trip: nothing is staged yet)
+            stage(b0, b1);
+            __syncthreads();
+            nl = 0;
+            if (valid && !heavy && !walker) {
+              // window by window: the positions of this batch, relative to the lane's first position in it
+              bool have = false;
+              for (int zz = z0; zz <= z1; zz++)
+                for (int yy = y0; yy <= y1; yy++) {
+                  const int r = (zz - Z0) * NRY + (yy - Y0), cr = cum[r] - b0;
+                  int va = cr + (int)offs[r * Wp + (x0 - X0)], vb = cr + (int)offs[r * Wp + (x1 + 1 - X0)];   // positions in the batch
+                  va = max(va, 0); vb = min(vb, b1 - b0);
+                  const bool ownrow = (zz == cz && yy == cy);
+                  // the own cell [o0, o1) splits the own row's window in two (:515-516)
+                  const int o0 = ownrow ? min(max(own0 - b0, va), vb) : vb, o1 = ownrow ? min(max(own1 - b0, va), vb) : vb;
 #pragma unroll
-                for (int half = 0; half < 2; half++) {
-                  const int a = half == 0 ? va : o1, b = half == 0 ? o0 : vb;
-                  if (half == 1 && !ownrow) break;
-                  if (b > a && !have) { base = a; have = true; }
-                  for (int v = a; v < b; v++) { if (nb < PP3_LCAP) mylist[nb] = (unsigned char)(v - base); nb++; }
+                  for (int half = 0; half < 2; half++) {
+                    const int a = half == 0 ? va : o1, b = half == 0 ? o0 : vb;
+                    if (half == 1 && !ownrow) break;
+                    if (b > a && !have) { base = a; have = true; }
+                    for (int v = a; v < b; v++) { if (nl < PP3_LCAP) mylist[nl] = (unsigned char)(v - base); nl++; }
+                  }
                 }
-              }
+            }
           }
-          eval_list(nb);
+          eval_list(nl);
+          if (walker) walk(b0, b1);
         }
-      }
       ax += ax2.x + ax2.y; ay += ay2.x + ay2.y; az += az2.x + az2.y;
     }
     if (valid && !heavy) {

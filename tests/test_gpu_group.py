@@ -483,6 +483,27 @@ def test_capacity_overflow_in_the_ghost_pass_is_one_error_for_the_whole_group():
     assert e.value.code == -3 and "max_np" in str(e.value)
 
 
+def test_pid_slots_are_repacked_while_migrants_keep_arriving():
+    """PIDs rest in pid_home; a migrant takes a new slot where it arrives and the slot it leaves is never freed, so the slots in
+    use grow until pid_repack (particles.hip) compacts them -- when the holes exceed a quarter of the records.  Fast particles in
+    small ranks (a fifth of a rank's records change owner per step) make that happen every other step: six steps, then PIDs,
+    positions and velocities by PID against the oracle's eight ranks (delete_particles.f90:17-47, particle_pass.f90:69-722)."""
+    p = cfg1(nodes_dim=2, ngp=True)
+    box = float(p.nf_physical_dim)
+    xv, pid = global_ic("uniform", 60000, box, 31)
+    xv[:, 3:] = np.random.default_rng(32).normal(0, 25.0, (len(xv), 3)).astype(np.float32)     # |v| dt ~ 5 cells of a 64-cell rank
+    g, o, og, oo = run_both(p, xv, pid, (0.5, 0.2, 0.2, 8.0), steps=6)
+    assert og.np_total == oo.np_total == len(xv) and og.np_ghost == oo.np_ghost
+    moved = 0
+    for i, r in enumerate(g.local_ranks):
+        xg, pg = by_pid(*g.download_particles(i))
+        xo, po = by_pid(*o.get_particles(r))
+        assert np.array_equal(pg, po), "rank %d holds a different particle set" % r
+        assert np.abs(xg[:, :3] - xo[:, :3]).max() <= 2e-3 and rel_rms(xg[:, 3:], xo[:, 3:]) <= 1e-5
+        moved += len(pg)
+    assert moved == len(xv)
+
+
 @pytest.mark.parametrize("switch", ["P3M_COARSE_PER_RANK", "P3M_COARSE_COPY", "P3M_ONE_STREAM"])
 def test_per_rank_coarse_path_stays_at_parity(switch):
     """P3M_ONE_STREAM=1 keeps the coarse force on the main stream (no second stream, no events).  P3M_COARSE_PER_RANK=1 runs the distributed coarse transform rank by rank (the path of pencil decompositions and of mesh

@@ -1,4 +1,6 @@
 # SQ / cache counters of every kernel of the default step (bench.py --steps 2 --warmup 1), one rocprofv3 pass per counter set
+set -eu
+: "${GRAFT_REPO_ROOT:?}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/step_pmc

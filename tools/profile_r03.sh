@@ -1,4 +1,6 @@
 # profiles of round 3 (run on the GPU box through gpurun; outputs under gpurun_out/r03p)
+set -eu
+: "${GRAFT_REPO_ROOT:?}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03p; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-extra > $O/stats_cfg4.log 2>&1

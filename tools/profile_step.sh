@@ -1,5 +1,7 @@
 # kernel trace of the default step (run on the GPU box through gpurun; outputs under gpurun_out/$1); $2: extra bench args
 # prints calls / average / MEDIAN per kernel (the first step sorts unsorted records: its launches inflate the averages)
+set -eu
+: "${GRAFT_REPO_ROOT:?}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-stepp}; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-extra $2 > $O/stats.log 2>&1

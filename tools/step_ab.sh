@@ -1,5 +1,7 @@
 # kernel averages of the default step under rocprofv3: bash tools/step_ab.sh <tag> <kernel substrings...>
 # (P3M_HIP_LIB, if set, must be an absolute path: the run starts in /tmp)
+set -eu
+: "${GRAFT_REPO_ROOT:?}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; tag=$1; shift
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ab_$tag -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu --no-extra > $R/gpurun_out/ab_$tag.log 2>&1

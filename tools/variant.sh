@@ -6,10 +6,14 @@ cd "$(dirname "$0")/../cubep3m_amd/csrc"
 tag=$1; src=$2; extra=$3
 make -s -j8
 mkdir -p _obj_var
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -ffp-contract=off $extra -c $src -o _obj_var/${src%.hip}_$tag.o
+# compiler, architecture, flags and the list of sources come from the Makefile (one place to keep them)
+hipcc=$(make -s -pn | sed -n 's/^HIPCC *?*= *//p' | head -1); arch=$(make -s -pn | sed -n 's/^ARCH *?*= *//p' | head -1)
+flags=$(make -s -pn | sed -n 's/^CXXFLAGS *= *//p' | head -1 | sed "s/\$(ARCH)/$arch/")
+srcs=$(make -s -pn | sed -n 's/^SRCS *= *//p' | head -1)
+$hipcc $flags $extra -c $src -o _obj_var/${src%.hip}_$tag.o
 objs=""
-for f in p3m_api fft scan particles fine_mesh pp coarse_mesh group timestep io_formats; do
+for f in ${srcs//.hip/}; do
   if [ "$f.hip" == "$src" ]; then objs="$objs _obj_var/${f}_$tag.o"; else objs="$objs _obj/$f.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libp3m_hip_$tag.so $objs -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+$hipcc --offload-arch=$arch -shared -fPIC -o ../libp3m_hip_$tag.so $objs -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo built ../libp3m_hip_$tag.so
