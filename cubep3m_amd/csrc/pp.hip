@@ -312,6 +312,7 @@ __device__ __forceinline__ void pp_ext_eval(const float4 &p, float ox, float oy,
 // itself (r = 0).  Every half goes through the operations of pp_ext_eval; a home record's sum is formed as two partial sums,
 // added at the end
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool TAPER_ALL>   // no pair within reach is beyond the taper's range: no switch (pp_extended)
 __device__ __forceinline__ void pp_ext_eval2(const float4 &p, const float4 &A, const float4 &B, bool okA, bool okB, const PPForce &F,
                                              f32x2 &ax, f32x2 &ay, f32x2 &az) {
   const f32x2 ox = {A.x, B.x}, oy = {A.y, B.y}, oz = {A.z, B.z};
@@ -322,7 +323,7 @@ __device__ __forceinline__ void pp_ext_eval2(const float4 &p, const float4 &A, c
   const f32x2 q2 = qq * qq, q3 = q2 * qq;
   const f32x2 k34 = {F.K34, F.K34}, k74 = {F.K74, F.K74}, kk = {F.K, F.K};
   f32x2 tp = __builtin_elementwise_fma(q3, __builtin_elementwise_fma(q2, k34, k74), kk);   // :559-564
-  tp.x = r2.x < F.r2_taper ? tp.x : F.K; tp.y = r2.y < F.r2_taper ? tp.y : F.K;
+  if (!TAPER_ALL) { tp.x = r2.x < F.r2_taper ? tp.x : F.K; tp.y = r2.y < F.r2_taper ? tp.y : F.K; }
   f32x2 f = tp * ((ir * ir) * ir);
   f.x = (okA && r2.x >= F.r2_soft) ? f.x : 0.0f; f.y = (okB && r2.y >= F.r2_soft) ? f.y : 0.0f;   // :558
   ax = __builtin_elementwise_fma(-sx, f, ax); ay = __builtin_elementwise_fma(-sy, f, ay); az = __builtin_elementwise_fma(-sz, f, az);   // :571
@@ -779,8 +780,8 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
           const unsigned e4 = *reinterpret_cast<const unsigned *>(mylist + k);   // four entries
 #pragma unroll
           for (int u = 0; u < 4; u++) { const int i = base + (int)((e4 >> (8 * u)) & 255u); o[u] = prec[k + u < nl ? i : 0]; }
-          pp_ext_eval2(p, o[0], o[1], k < nl, k + 1 < nl, F, ax2, ay2, az2);
-          pp_ext_eval2(p, o[2], o[3], k + 2 < nl, k + 3 < nl, F, ax2, ay2, az2);
+          pp_ext_eval2<TAPER_ALL>(p, o[0], o[1], k < nl, k + 1 < nl, F, ax2, ay2, az2);
+          pp_ext_eval2<TAPER_ALL>(p, o[2], o[3], k + 2 < nl, k + 3 < nl, F, ax2, ay2, az2);
         }
       };
       // a walker's windows inside the batch [b0, b1), partners from the staged batch, two at a time
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
               if (v >= own0 && v < own1) { v = own1; continue; }            // own cell is excluded (:515-516)
               const int w = v + 1;
               const bool okB = w < vb && !(w >= own0 && w < own1);
-              pp_ext_eval2(p, prec[v - b0], prec[(okB ? w : v) - b0], true, okB, F, ax2, ay2, az2);
+              pp_ext_eval2<TAPER_ALL>(p, prec[v - b0], prec[(okB ? w : v) - b0], true, okB, F, ax2, ay2, az2);
               v += 2;
             }
           }

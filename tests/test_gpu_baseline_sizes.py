@@ -187,6 +187,10 @@ def test_config4_full_eight_rank_step_properties():
     # order independence: the same particle SET handed over in another order gives the same limits and ghost counts
     g, o1, o2 = run(77)
     assert (o2.np_ghost, o1.np_ghost) == (ref[2], ref[5])
-    assert o1.dt_f_acc == pytest.approx(ref[3], rel=1e-6) and o1.dt_c_acc == pytest.approx(ref[4], rel=1e-6)
-    assert o2.dt_f_acc == pytest.approx(ref[0], rel=1e-6) and o2.dt_c_acc == pytest.approx(ref[1], rel=1e-6)
+    # the NGP fine density is a count: the fine limit is the same to the last bits; the coarse CIC sums add ~500 float terms per cell
+    # in another order
+    assert o1.dt_f_acc == pytest.approx(ref[3], rel=1e-6), (o1.dt_f_acc, ref[3])
+    assert o1.dt_c_acc == pytest.approx(ref[4], rel=1e-5), (o1.dt_c_acc, ref[4])
+    assert o2.dt_f_acc == pytest.approx(ref[0], rel=1e-5), (o2.dt_f_acc, ref[0])      # (step 2 starts from step 1's kicks)
+    assert o2.dt_c_acc == pytest.approx(ref[1], rel=1e-5), (o2.dt_c_acc, ref[1])
     g.close()

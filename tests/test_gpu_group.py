@@ -6,9 +6,10 @@ import pytest
 import oracle_lib as ol
 from common import observed, COARSE_TABLE, FINE_TABLE, by_pid, cfg1, clustered_particles, rel_rms, uniform_particles
 
-# multi-step bars (single steps are held to 1e-5): errors of step 1 feed step 2's drift.  The observed values are recorded by
-# common.observed() in gpurun_out/observed_errors.txt and tabulated in DESIGN section 4; the bars sit at ~1.5x of them
-BAR_KICK_2STEP, BAR_KICK_5STEP, BAR_DT_5STEP = 2e-5, 3e-5, 3e-5
+# multi-step tests: errors of step 1 feed step 2's drift.  Rounds 1-3 held them to 2e-5 / 3e-5 without recording what was observed;
+# common.observed() now records it (gpurun_out/observed_errors.txt, tabulated in DESIGN section 4): 2e-7 ... 2e-6 over two steps,
+# <= 4.7e-6 over five -- so they are held to the single-step bar, 1e-5, like everything else
+BAR_KICK_2STEP, BAR_KICK_5STEP, BAR_DT_5STEP = 1e-5, 1e-5, 1e-5
 
 pytestmark = pytest.mark.gpu
 

@@ -13,7 +13,7 @@ from cubep3m_amd.params import Params
 pytestmark = pytest.mark.gpu
 
 KICK_TOL = 1e-5   # north_star: <= 1e-5 RMS relative force error vs the CPU reference
-BAR_KICK_2STEP = 2e-5   # two steps with drift: step 1's error feeds step 2's positions (observed values: DESIGN section 4)
+BAR_KICK_2STEP = 1e-5   # two steps with drift: step 1's error feeds step 2's positions; observed 2e-7 ... 2e-6: the single-step bar holds
 POS_TOL = 1e-4
 DT_TOL = 1e-5
 
