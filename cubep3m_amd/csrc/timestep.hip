@@ -16,7 +16,32 @@ static float half_step(const p3m_time_params *P, double a_x, float dt_x) {
   const float dt2 = dt_x * dt_x, dt3 = dt2 * dt_x;                                 // dt_x**2, dt_x**3 in real(4)
   return (float)((adot * dt_x + (addot * dt2) / 2.0) + (atdot * dt3) / 6.0);       // :253
 }
+// subroutine Chaplygin (timestep.f90:296-339).  a3rchm, arkm and G_ch are formed ONCE, at a_x = a0 (:310-312): the second half
+// step (:322-329) changes a_x only where it stands explicitly in adot / addot / atdot -- the reference's text, kept
+static void chaplygin(const p3m_time_params *P, float a0, float dt0, float *da1, float *da2) {
+  const float dt_x = dt0 / 2;                                                          // :306
+  double a_x = (double)a0;
+  const double omHsq = (double)(4.0f / 9.0f);                                          // :308
+  const double a3rchm = pow(a_x, -3.0) * P->omega_ch / P->omega_m;                     // :310  a_x**(-3): integer power of a real(8)
+  const double arkm = a_x * ((1.0f - P->omega_m) - P->omega_ch) / P->omega_m;          // :311
+  const float e1 = -3.0f - 3.0f * P->alpha_ch, e2 = -6.0f - 6.0f * P->alpha_ch;        // real(4) exponents
+  const double G_ch = (double)P->A_ch + (double)(1.0f - P->A_ch) * pow(a_x, (double)e1);   // :312
+  const float p1 = 1.0f / (1.0f + P->alpha_ch), p2 = -P->alpha_ch / (1.0f + P->alpha_ch), p3 = 1.0f / (1.0f + P->alpha_ch) - 2.0f;
+  const float c5 = 5.0f * (P->A_ch * P->A_ch), c3 = (3.0f * P->A_ch) * (1.0f - P->A_ch), ch = 2.0f + P->alpha_ch / 2.0f, c1 = (1.0f - P->A_ch) * (1.0f - P->A_ch);
+  auto half = [&](double ax) {
+    const double adot = sqrt(omHsq * ((ax * ax) * ax) * ((1.0 + arkm) + a3rchm * pow(G_ch, (double)p1)));                                 // :314
+    const double addot = (ax * ax) * omHsq * ((1.5 + 2.0 * arkm) + ((3.0 * a3rchm) * P->A_ch) * pow(G_ch, (double)p2));                   // :315
+    const double poly = ((double)c5 + ((double)c3 * pow(ax, (double)e1)) * (double)ch) + (double)c1 * pow(ax, (double)e2);
+    const double atdot = ax * adot * omHsq * ((3.0 + 6.0 * arkm) + ((3.0 * a3rchm) * pow(G_ch, (double)p3)) * poly);                      // :316
+    const float dt2 = dt_x * dt_x, dt3 = dt2 * dt_x;
+    return (float)((adot * dt_x + (addot * dt2) / 2.0) + (atdot * dt3) / 6.0);                                                            // :319
+  };
+  *da1 = half(a_x);
+  a_x = (double)(a0 + *da1);                                                           // :321
+  *da2 = half(a_x);
+}
 extern "C" void p3m_hip_expansion(const p3m_time_params *P, float a0, float dt0, float *da1, float *da2) {
+  if (P->chaplygin) { chaplygin(P, a0, dt0, da1, da2); return; }                       // :251-252
   const float dt_x = dt0 / 2;                          // :236
   *da1 = half_step(P, (double)a0, dt_x);               // :237-253
   *da2 = half_step(P, (double)(a0 + *da1), dt_x);      // :255 a_x = a0 + da1 (real(4) sum)

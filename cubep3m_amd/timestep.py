@@ -24,7 +24,8 @@ class P3MTimeParams(C.Structure):
                 ("dt_scale", C.c_float), ("dt_max", C.c_float), ("ra_max", C.c_float), ("da_max", C.c_float),
                 ("num_checkpoints", C.c_int32), ("num_projections", C.c_int32), ("num_halofinds", C.c_int32),
                 ("a_checkpoint", C.c_float * MAX_INPUT), ("a_projection", C.c_float * MAX_INPUT), ("a_halofind", C.c_float * MAX_INPUT),
-                ("pairwise_ic", C.c_int32), ("pair_infall", C.c_int32), ("shake_test_ic", C.c_int32), ("cur_sep", C.c_float), ("mass_p", C.c_float)]
+                ("pairwise_ic", C.c_int32), ("pair_infall", C.c_int32), ("shake_test_ic", C.c_int32), ("cur_sep", C.c_float), ("mass_p", C.c_float),
+                ("chaplygin", C.c_int32), ("omega_ch", C.c_float), ("A_ch", C.c_float), ("alpha_ch", C.c_float)]
 
 
 class P3MTimeState(C.Structure):
@@ -56,6 +57,11 @@ class TimeParams:
     shake_test_ic: bool = False
     cur_sep: float = 1.0
     mass_p: float = 1.0
+    # -DChaplygin (timestep.f90:296-339): omega_ch from the parameters file, A_ch / alpha_ch from cubepm.par:21-22
+    chaplygin: bool = False
+    omega_ch: float = 0.7
+    A_ch: float = 1.0
+    alpha_ch: float = 0.0
 
     def to_c(self) -> P3MTimeParams:
         c = P3MTimeParams(int(self.cosmo), int(self.restrict_da), self.omega_m, self.omega_l, self.wde, self.dt_scale, self.dt_max, self.ra_max,
@@ -69,6 +75,7 @@ class TimeParams:
                 arr[i] = lst[i] if i < len(lst) else self.pad
         c.pairwise_ic, c.pair_infall, c.shake_test_ic = int(self.pairwise_ic), int(self.pair_infall), int(self.shake_test_ic)
         c.cur_sep, c.mass_p = self.cur_sep, self.mass_p
+        c.chaplygin, c.omega_ch, c.A_ch, c.alpha_ch = int(self.chaplygin), self.omega_ch, self.A_ch, self.alpha_ch
         return c
 
 

@@ -242,6 +242,10 @@ typedef struct p3m_time_params {
      extended-PP limit out (:204-206); cur_sep is what report_pair.f90:49 measured last, the host keeps it current        */
   int32_t pairwise_ic, pair_infall, shake_test_ic;
   float cur_sep, mass_p;
+  /* -DChaplygin (timestep.f90:251-252, subroutine Chaplygin :296-339): expansion() integrates the Friedmann equation of a Chaplygin
+     gas instead; omega_ch from the parameters file, A_ch and alpha_ch from cubepm.par:21-22 (there: 1 and 0)                      */
+  int32_t chaplygin;
+  float omega_ch, A_ch, alpha_ch;
 } p3m_time_params;
 typedef struct p3m_time_state {   /* the COMMON variables timestep.f90 reads and writes (cubepm.fh:19-29) */
   int32_t nts;

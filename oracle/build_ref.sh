@@ -84,6 +84,9 @@ build_cfg  cfg1_1rank  1  2 80  2     2.0  "-DNGP -DPID_FLAG"
 build_cfg  cfg1_8rank  2  2 80  2     2.0  "-DNGP"
 # the PP switches change which limits timestep.f90 takes the minimum of (:93-115)
 build_cfg  cfg1_pp     1  2 80  2     2.0  "-DNGP -DPPINT -DPP_EXT -DPID_FLAG"
+# -DChaplygin: expansion() calls subroutine Chaplygin (timestep.f90:251-252, :296-339); only timestep.o differs.  A plain -DChaplygin
+# cannot compile: cpp replaces the subroutine's own name by 1 (call 1(a0,...)); defined as itself the macro only switches the #ifdef
+build_cfg  cfg1_chap   1  2 80  2     2.0  "-DNGP -DChaplygin=Chaplygin -DPID_FLAG"
 # fine CIC build (no -DNGP): the #else branch of fine_velocity.f90:175-203 (CIC gather + kick)
 build_cfg  cfg1_cic    1  2 80  2     2.0  "-DPID_FLAG"
 # -DCOARSE_NGP: the three #ifdef branches of coarse_cic_mass.f90:21, coarse_cic_mass_buffer.f90:26, coarse_velocity.f90:146

@@ -1201,7 +1201,41 @@ static float orc_half_expansion(const p3m_time_params *P, double ax, float dtx) 
   s = s + (atdot * d3) / 6.0;
   return (float)s;
 }
+/* subroutine Chaplygin (timestep.f90:296-339), statement by statement; a3rchm, arkm, G_ch keep their a_x = a0 values in the
+ * second half step, as the reference's text has it (:321-329 only assigns a_x) */
+static float orc_chap_half(const p3m_time_params *P, double ax, float dtx, double a3rchm, double arkm, double G_ch) {
+  double omHsq = (double)(4.0f / 9.0f);
+  float one_al = 1.0f + P->alpha_ch;
+  double gp = pow(G_ch, (double)(1.0f / one_al));
+  double adot = sqrt((omHsq * (ax * ax * ax)) * ((1.0 + arkm) + a3rchm * gp));                                   /* :314 */
+  double gq = pow(G_ch, (double)(-P->alpha_ch / one_al));
+  double addot = ((ax * ax) * omHsq) * ((1.5 + 2.0 * arkm) + ((3.0 * a3rchm) * P->A_ch) * gq);                   /* :315 */
+  double gr = pow(G_ch, (double)(1.0f / one_al - 2.0f));
+  float e1 = -3.0f - 3.0f * P->alpha_ch, e2 = -6.0f - 6.0f * P->alpha_ch;
+  float c5 = 5.0f * (P->A_ch * P->A_ch), c3 = (3.0f * P->A_ch) * (1.0f - P->A_ch), ch = 2.0f + P->alpha_ch / 2.0f;
+  float c1 = (1.0f - P->A_ch) * (1.0f - P->A_ch);
+  double poly = (c5 + (c3 * pow(ax, (double)e1)) * ch) + c1 * pow(ax, (double)e2);
+  double atdot = ((ax * adot) * omHsq) * ((3.0 + 6.0 * arkm) + ((3.0 * a3rchm) * gr) * poly);                    /* :316 */
+  float d2 = dtx * dtx, d3 = d2 * dtx;
+  double s = adot * dtx;
+  s = s + (addot * d2) / 2.0;
+  s = s + (atdot * d3) / 6.0;                                                                                    /* :319 */
+  return (float)s;
+}
 void orc_expansion(const p3m_time_params *P, float a0, float dt0, float *da1, float *da2) {
+  if (P->chaplygin) {                                                                                            /* :251-252 */
+    float dtx = dt0 / 2;
+    double ax = a0;
+    double a3rchm = pow(ax, -3.0) * P->omega_ch;                                                                 /* :310 */
+    a3rchm = a3rchm / P->omega_m;
+    double arkm = ax * ((1.0f - P->omega_m) - P->omega_ch);                                                      /* :311 */
+    arkm = arkm / P->omega_m;
+    double G_ch = P->A_ch + (1.0f - P->A_ch) * pow(ax, (double)(-3.0f - 3.0f * P->alpha_ch));                    /* :312 */
+    *da1 = orc_chap_half(P, ax, dtx, a3rchm, arkm, G_ch);
+    float a1 = a0 + *da1;                                                                                        /* :321 */
+    *da2 = orc_chap_half(P, a1, dtx, a3rchm, arkm, G_ch);
+    return;
+  }
   float dtx = dt0 / 2;
   *da1 = orc_half_expansion(P, a0, dtx);
   float a1 = a0 + *da1;

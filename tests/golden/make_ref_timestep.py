@@ -16,10 +16,11 @@ TESTS = os.path.dirname(HERE)
 
 def main():
     out = {}
-    for name, cfg in (("pm", "cfg1_1rank"), ("pp", "cfg1_pp")):
+    # label, reference build, scenario of tests/time_scenarios.py ("chap": the -DChaplygin build over the PM-only scenario)
+    for name, cfg, scen in (("pm", "cfg1_1rank", "pm"), ("pp", "cfg1_pp", "pp"), ("chap", "cfg1_chap", "pm")):
         with tempfile.TemporaryDirectory() as d:
             f = os.path.join(d, "o.npz")
-            subprocess.run([sys.executable, os.path.join(TESTS, "ref_time_run.py"), cfg, name, f], check=True, stdout=subprocess.DEVNULL,
+            subprocess.run([sys.executable, os.path.join(TESTS, "ref_time_run.py"), cfg, scen, f], check=True, stdout=subprocess.DEVNULL,
                            env=dict(os.environ, OMP_NUM_THREADS="1"))
             z = np.load(f)
             for k in z.files:
