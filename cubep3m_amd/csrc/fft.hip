@@ -346,7 +346,12 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
   constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P, NLD = C::NLD;
   extern __shared__ float2 lds[];
   c32 *B = reinterpret_cast<c32 *>(lds), *X = B + RB * P, *tw = X + RB * R1 * R2P;
-  __shared__ int64_t src_row[2][RB], dst_off[2][RB];
+  // THREE sets of the per-row tables: the set of batch i is read until the last store of trip i (stage 2), and trip i + 1 -- which a
+  // wavefront enters without a barrier -- writes the set of batch i + 2: with two sets that was the one a slower wavefront of the
+  // workgroup was still reading, and its four rows went to the rows of batch i + 2 (overwritten there later) while their own kept what
+  // they held before (round 4: one step in ten of the full-size 8-rank run, when the fine-mesh passes on the other stream skewed
+  // the wavefronts of the coarse transform; tests/determinism_check.py)
+  __shared__ int64_t src_row[3][RB], dst_off[3][RB];
   for (int i = threadIdx.x; i < h; i += C::TB) tw[i] = reinterpret_cast<const c32 *>(tw_g)[i];
   const int nchunk = px / BXC, fbp = (fb + 3) & ~3;
   const int lane = threadIdx.x & 63, rw = lane / Q, q = lane - rw * Q;
@@ -395,7 +400,8 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
   if (w < nbatch) tables(w, 0);
   __syncthreads();
   if (w < nbatch) fetch(w, 0);
-  for (; w < nbatch; w += gridDim.x, buf ^= 1) {
+  for (; w < nbatch; w += gridDim.x, buf = buf == 2 ? 0 : buf + 1) {
+    const int nxt = buf == 2 ? 0 : buf + 1;
     const int nrows = (int)min((int64_t)RB, (int64_t)rows_total - (int64_t)w * RB);
     const bool rowok = r < nrows;
     const int wn = w + gridDim.x;
@@ -407,9 +413,9 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
         if (k <= h) pb[0] = (c32){g4[u].x, g4[u].y};
         if (k + 1 <= h) pb[1] = (c32){g4[u].z, g4[u].w};
       }
-    if (wn < nbatch) tables(wn, buf ^ 1);
+    if (wn < nbatch) tables(wn, nxt);
     __syncthreads();
-    if (wn < nbatch) fetch(wn, buf ^ 1);
+    if (wn < nbatch) fetch(wn, nxt);
     if (s1 && rowok) {
       const c32 *pk = B + r * P + q, *pm = B + r * P + (h - R2 * (R1 - 1)) - q, *pt = tw + q;
       c32 v[R1];

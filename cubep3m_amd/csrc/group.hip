@@ -59,7 +59,8 @@ struct p3m_group {
   // the coarse slab transform with its all-to-all exchanges (many small kernels, launch- and
   // latency-bound) runs on `stream2` underneath the fine-mesh force sweeps of the local ranks, which need the coarse force
   // only when they kick
-  hipStream_t stream2 = nullptr; hipEvent_t ev_dep = nullptr, ev_cf = nullptr;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_dep = nullptr, ev_cf = nullptr;
   std::vector<p3m_ctx *> ctx; std::vector<int> lrank, owner, lidx;
   std::vector<CoarseDist> cd;
   // The coarse arrays of all local ranks are slices of group-wide allocations.  `batched` (slabs whose line length has
