@@ -1,7 +1,8 @@
 """Diagnostic: the same full-size 8-rank cfg4 step from fresh groups several times -- the dt limits must repeat bit for bit.
     python tests/determinism_check.py [reps]      (P3M_ONE_STREAM=1 in the environment: without the second stream)"""
 import sys
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cubep3m_amd.params import Params
 from cubep3m_amd.group import ParticleMeshGroup

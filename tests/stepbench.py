@@ -1,6 +1,7 @@
 """Per-step wall time of a bench workload from a cold start: python tests/stepbench.py [config] [nsteps] [uniform|clustered]"""
 import sys, time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cubep3m_amd.params import Params
 from cubep3m_amd.group import ParticleMeshGroup
