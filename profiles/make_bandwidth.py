@@ -1,6 +1,6 @@
 """Per-kernel achieved HBM bandwidth table: PMC bytes per launch (make_traffic.py's *_pmc_hbm.csv) over the launch durations of a
 rocprofv3 --kernel-trace run of the same command.
-usage: python profiles/make_bandwidth.py <pmc_hbm.csv> <kernel_trace.csv> <out.md> <title>"""
+usage: python profiles/make_bandwidth.py <pmc_hbm.csv> <kernel_trace.csv | kernel_durations.csv> <out.md> <title>"""
 import collections
 import csv
 import statistics
@@ -10,12 +10,18 @@ import sys
 def main(pmc, trace, out, title):
     byt = {r["kernel"]: (int(r["launches"]), float(r["hbm_bytes_per_launch"])) for r in csv.DictReader(open(pmc))}
     dur = collections.defaultdict(list)
-    for r in csv.DictReader(open(trace)):
-        dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     rows = []
-    for k, v in dur.items():
-        if k in byt:
-            rows.append((k, len(v), sum(v) / len(v), statistics.median(v), byt[k][1]))
+    first = next(csv.DictReader(open(trace)))
+    if "median_us" in first:                        # a *_kernel_durations.csv (launches, avg, median per kernel) instead of the raw trace
+        for r in csv.DictReader(open(trace)):
+            if r["Kernel_Name"] in byt:
+                rows.append((r["Kernel_Name"], int(r["launches"]), float(r["avg_us"]), float(r["median_us"]), byt[r["Kernel_Name"]][1]))
+    else:
+        for r in csv.DictReader(open(trace)):
+            dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        for k, v in dur.items():
+            if k in byt:
+                rows.append((k, len(v), sum(v) / len(v), statistics.median(v), byt[k][1]))
     rows.sort(key=lambda r: -r[1] * r[2])
     with open(out, "w") as f:
         f.write("# %s\n\n" % title)
