@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 struct PPGeo { int T, nb, pt, E, Nn, ms, ppr; float rsoft, pp_bias, ncut; };
@@ -497,35 +498,39 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
   if (tid == 0) { a_live = true; a_seg = seg; a_tf = atomicAdd(counter + 32 * seg, 1); advance(); }
   if (tid < 2 * NW) misc[8 + tid] = 0;
   if (tid == 0) misc[4] = 0;
-  int prev_g = 0, prev_sub = 0;                       // thread 0: the task just worked
+  int prev_g = 0, prev_sub = 0, cur_g = 0, cur_sub = 0;   // thread 0: the task just worked, the task published
   for (;;) {
     __syncthreads();                                  // the previous task's readers of the LDS tables (and of misc) are done
-    if (PASS == 0 && tid == 0 && misc[4]) {
-      // the task just worked has heavy lanes: a bit per lane (left in misc[8..15] by the wavefronts' first lanes) and the box of
-      // partner rows and cells those lanes reach (misc[24 + 6 w ..]) into the heavy-task list: here, behind a barrier the loop has
-      // anyway, instead of one more barrier per task
-      const int slot = atomicAdd(hcount, 1);
-      int bz0 = 0x7fff, bz1 = 0, by0 = 0x7fff, by1 = 0, bx0 = 0x7fff, bx1 = 0;
-#pragma unroll
-      for (int w = 0; w < NW; w++)
-        if (misc[8 + 2 * w] | misc[9 + 2 * w]) {
-          const int *bw = misc + 24 + 6 * w;
-          bz0 = min(bz0, bw[0]); bz1 = max(bz1, bw[1]); by0 = min(by0, bw[2]); by1 = max(by1, bw[3]); bx0 = min(bx0, bw[4]); bx1 = max(bx1, bw[5]);
-        }
-      if (slot < ntask_cap) {
-        int *rec = htask + (size_t)PP3_HREC * slot;
-        rec[0] = prev_g; rec[1] = prev_sub; rec[2] = bz0 | (bz1 << 16); rec[3] = by0 | (by1 << 16); rec[4] = bx0 | (bx1 << 16);
-#pragma unroll
-        for (int k = 0; k < 2 * NW; k++) rec[5 + k] = misc[8 + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 2 * NW; k++) misc[8 + k] = 0;
-      misc[4] = 0;
-    }
-    if (PASS == 0 && tid == 0) { prev_g = b_val.x; prev_sub = b_val.y; }
-    if (tid == 0) { misc[0] = b_live ? 1 : (a_live ? 0 : -1); misc[1] = 0; misc[5] = b_t; misc[6] = b_val.x; misc[7] = b_val.y; if (PASS == 1) { misc[20] = b_box0; misc[21] = b_box1; misc[22] = b_box2; } advance(); }
+    if (tid == 0) { misc[0] = b_live ? 1 : (a_live ? 0 : -1); misc[1] = 0; misc[5] = b_t; misc[6] = b_val.x; misc[7] = b_val.y; cur_g = b_val.x; cur_sub = b_val.y; if (PASS == 1) { misc[20] = b_box0; misc[21] = b_box1; misc[22] = b_box2; } advance(); }
     __syncthreads();
     const int state = misc[0];
+    if (PASS == 0 && tid == 0) {
+      // (the flag is read in the shadow of the state's read; the waves write it, the bits and the boxes again only behind the two
+      // barriers of the table set-up below, so the record is made here, off the path the other wavefronts wait on)
+      if (misc[4]) {
+        // the task just worked has heavy lanes: a bit per lane (left in misc[8..15] by the wavefronts' first lanes) and the box of
+        // partner rows and cells those lanes reach (misc[24 + 6 w ..]) into the heavy-task list: here, behind a barrier the loop has
+        // anyway, instead of one more barrier per task
+        const int slot = atomicAdd(hcount, 1);
+        int bz0 = 0x7fff, bz1 = 0, by0 = 0x7fff, by1 = 0, bx0 = 0x7fff, bx1 = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+          if (misc[8 + 2 * w] | misc[9 + 2 * w]) {
+            const int *bw = misc + 24 + 6 * w;
+            bz0 = min(bz0, bw[0]); bz1 = max(bz1, bw[1]); by0 = min(by0, bw[2]); by1 = max(by1, bw[3]); bx0 = min(bx0, bw[4]); bx1 = max(bx1, bw[5]);
+          }
+        if (slot < ntask_cap) {
+          int *rec = htask + (size_t)PP3_HREC * slot;
+          rec[0] = prev_g; rec[1] = prev_sub; rec[2] = bz0 | (bz1 << 16); rec[3] = by0 | (by1 << 16); rec[4] = bx0 | (bx1 << 16);
+#pragma unroll
+          for (int k = 0; k < 2 * NW; k++) rec[5 + k] = misc[8 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * NW; k++) misc[8 + k] = 0;
+        misc[4] = 0;
+      }
+      prev_g = cur_g; prev_sub = cur_sub;
+    }
     if (state < 0) break;                             // every segment has run dry
     if (state == 0) continue;                         // a dry segment: the next draw is on its way
     const int g = misc[6], sub = misc[7];
@@ -707,30 +712,34 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
         // crowded (uniform: the region holds more records than the background's, i.e. part of a blob): a lane that is past the
         // capacity stores nothing more, so a wavefront next to a blob runs the tail loop 35 times in all, not 35 times per window
         const bool crowded = Ptot > PP3_CROWDED;
-        auto append = [&](int a, int cnt) {
-          unsigned char *o = mylist + min(n, PP3_LCAP);   // a lane past the capacity is heavy, not listed
-          const int e = a - base;
-          o[0] = (unsigned char)e; o[1] = (unsigned char)(e + 1); o[2] = (unsigned char)(e + 2);
-          ovf = ovf || (cnt > 0 && e + cnt > 256);
-          if (!crowded) {
-            if (__any(cnt > 3))
-              for (int k = 3; k < min(cnt, PP3_LCAP + 3); k++) mylist[min(n + k, PP3_LCAP + 2)] = (unsigned char)(e + k);
-          } else if (__any(cnt > 3 && n <= PP3_LCAP))
-            for (int k = 3; k < cnt && n + k < PP3_LCAP + 3; k++) mylist[n + k] = (unsigned char)(e + k);
-          n += cnt;
-        };
+        auto list_planes = [&](auto CR) {             // the whole loop once per case: the choice costs one branch, not one per window
+          constexpr bool CROWDED = decltype(CR)::value;
+          auto append = [&](int a, int cnt) {
+            unsigned char *o = mylist + min(n, PP3_LCAP);   // a lane past the capacity is heavy, not listed
+            const int e = a - base;
+            o[0] = (unsigned char)e; o[1] = (unsigned char)(e + 1); o[2] = (unsigned char)(e + 2);
+            ovf = ovf || (cnt > 0 && e + cnt > 256);
+            if (!CROWDED) {
+              if (__any(cnt > 3))
+                for (int k = 3; k < min(cnt, PP3_LCAP + 3); k++) mylist[min(n + k, PP3_LCAP + 2)] = (unsigned char)(e + k);
+            } else if (__any(cnt > 3 && n <= PP3_LCAP))
+              for (int k = 3; k < cnt && n + k < PP3_LCAP + 3; k++) mylist[n + k] = (unsigned char)(e + k);
+            n += cnt;
+          };
 #pragma unroll 1
-        for (int dz = -PPR; dz <= PPR; dz++) {        // one plane of windows per trip: the tail loops are not replicated 25 times
-          const bool zok = cz + dz >= z0 && cz + dz <= z1;
+          for (int dz = -PPR; dz <= PPR; dz++) {      // one plane of windows per trip: the tail loops are not replicated 25 times
+            const bool zok = cz + dz >= z0 && cz + dz <= z1;
 #pragma unroll
-          for (int dy = -PPR; dy <= PPR; dy++) {
-            const bool rv = zok && yok[dy + PPR];
-            const int d = dz * NRY + dy;             // uniform
-            const int cr = wc[d], a = cr + (int)wa[d * Wp], b = cr + (int)wb[d * Wp];
-            if (dz == 0 && dy == 0) { append(a, rv ? own0 - a : 0); append(own1, rv ? b - own1 : 0); }   // the own cell splits the own row's window (:515-516)
-            else append(a, rv ? b - a : 0);
+            for (int dy = -PPR; dy <= PPR; dy++) {
+              const bool rv = zok && yok[dy + PPR];
+              const int d = dz * NRY + dy;           // uniform
+              const int cr = wc[d], a = cr + (int)wa[d * Wp], b = cr + (int)wb[d * Wp];
+              if (dz == 0 && dy == 0) { append(a, rv ? own0 - a : 0); append(own1, rv ? b - own1 : 0); }   // the own cell splits the own row's window (:515-516)
+              else append(a, rv ? b - a : 0);
+            }
           }
-        }
+        };
+        if (crowded) list_planes(std::true_type{}); else list_planes(std::false_type{});
         heavy = valid && n > PP3_LCAP;
         walker = valid && !heavy && ovf;
       } else if (valid) {
