@@ -244,9 +244,12 @@ template <int R1, int R2> struct X2Cfg {
 // (k1, row) finishes (dft<R2>) and leaves Z^[k1 + R1*k2] in a second LDS array; the split X[k] = E + W^k O, X[h-k] =
 // conj(E - W^k O) then runs with lanes along the 16 columns of a chunk and stores both halves to LY.  Row geometry as
 // in k_fft_x_inv2; the next batch's rows are in flight during stage 2 and the split.
-template <int R1, int R2>
+// CUBES: the rows are not an array of their own -- row (rank r, plane zl, y) of the coarse slab decomposition is read where its cells
+// lie, in plane (r % nd^2)*s + zl of the ncn^3 cubes of the ranks layer(r) + (y/ncn)*nd + i, i < nd (pack_slab, fftw3ds.f90:24-52, with
+// every logical rank in this process: p3m_group::direct), so the redistribution costs no pass over memory of its own
+template <int R1, int R2, bool CUBES = false>
 __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ src, float2 *__restrict__ dst_, int n, int px, int rows_total,
-                                                    const float2 *__restrict__ tw_g, int rpp) {   // rpp: rows per plane of the LY output (n; fewer for a y-split pencil)
+                                                    const float2 *__restrict__ tw_g, int rpp, RowGeom cq) {   // rpp: rows per plane of the LY output (n; fewer for a y-split pencil)
   using C = X2Cfg<R1, R2>;
   constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P;
   extern __shared__ float2 lds[];
@@ -269,9 +272,22 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ sr
 #pragma unroll
     for (int a = 0; a < R1; a++) v[a] = (c32){0.f, 0.f};
     if (s1 && row < rows_total) {
-      const c32 *ps = reinterpret_cast<const c32 *>(src + row * (int64_t)(2 * px)) + q;
+      if constexpr (CUBES) {
+        const fdiv_t d_rpp{cq.m_rpp, cq.rpp}, d_s{cq.m_s, cq.s}, d_ncn{cq.m_ncn, cq.ncn};
+        const unsigned plane = fdiv((int)row, d_rpp), y = (unsigned)row - plane * cq.rpp, rank = fdiv((int)plane, d_s), zl = plane - rank * cq.s;
+        const unsigned j = fdiv((int)y, d_ncn), yy = y - j * cq.ncn, nd2 = cq.nd * cq.nd, layer = rank / nd2, qz = rank - layer * nd2;
+        const int64_t n3 = (int64_t)cq.ncn * cq.ncn * cq.ncn;
+        const float *pc = src + (int64_t)(layer * nd2 + j * cq.nd) * n3 + ((int64_t)(qz * cq.s + zl) * cq.ncn + yy) * cq.ncn;
 #pragma unroll
-      for (int a = 0; a < R1; a++) v[a] = ps[R2 * a];
+        for (int a = 0; a < R1; a++) {
+          const int x = 2 * (R2 * a + q), i = fdiv(x, d_ncn);            // ncn is even: a pair of cells never straddles two cubes
+          v[a] = *reinterpret_cast<const c32 *>(pc + i * (n3 - cq.ncn) + x);
+        }
+      } else {
+        const c32 *ps = reinterpret_cast<const c32 *>(src + row * (int64_t)(2 * px)) + q;
+#pragma unroll
+        for (int a = 0; a < R1; a++) v[a] = ps[R2 * a];
+      }
     }
   };
   // split item e = tid + u*TB: l = e & 15, row = (e >> 4) % RB, chunk = (e >> 4) / RB, k = 16*chunk + l <= h/2
@@ -467,6 +483,136 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
         *reinterpret_cast<c32 *>(box + dst_off[buf][rr] + 2 * (h + (e - rr * npad))) = (c32){0.f, 0.f};
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------ x pass, inverse, coarse slab decomposition with every rank in this process
+// k_fft_x_inv2<.., false> and the copy of its rows into the owners' force arrays (unpack_slab, fftw3ds.f90:69-99) in one pass: row
+// (rank r, plane zl, y) of component c is stored where its cells belong -- plane 1 + (r % nd^2)*s + zl, row 1 + y % ncn of component c
+// of the (ncn+2)^3 force arrays of the ranks layer(r) + (y/ncn)*nd + i -- and max |F| over the interior (coarse_max_dt.f90:24-31)
+// is formed on the way: a workgroup takes the three components of a batch of rows in three consecutive trips and keeps the
+// squares in registers.  ncn % RB == 0: the rows of a batch share rank, plane and y/ncn.  (The stores are 4-byte: the force
+// arrays' rows start one cell in.)
+template <int R1, int R2>
+__global__ __launch_bounds__(256) void k_fft_x_inv2c(const float2 *__restrict__ src, int n, int px, int rows1, const float2 *__restrict__ tw_g, float inv_scale,
+                                                     float *__restrict__ fc, RowGeom cq, RankPtrs red) {
+  using C = X2Cfg<R1, R2>;
+  constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P, NLD = C::NLD;
+  extern __shared__ float2 lds[];
+  c32 *B = reinterpret_cast<c32 *>(lds), *X = B + RB * P, *tw = X + RB * R1 * R2P;
+  __shared__ int64_t src_row[3][RB], dst_off[3][RB];   // three sets: see k_fft_x_inv2
+  __shared__ int owner0[3];
+  for (int i = threadIdx.x; i < h; i += C::TB) tw[i] = reinterpret_cast<const c32 *>(tw_g)[i];
+  const int nchunk = px / BXC, rpp = cq.rpp;
+  const int lane = threadIdx.x & 63, rw = lane / Q, q = lane - rw * Q;
+  const int r = (threadIdx.x >> 6) * C::RPW + rw;
+  const bool act = rw < C::RPW, s1 = act && q < R2, s2 = act && q < R1;
+  const int nb1 = (rows1 + RB - 1) / RB;               // row batches of one component
+  const float rscale = 1.0f / inv_scale;
+  const int64_t cstride = (int64_t)rpp * BXC;
+  const int m = cq.ncn + 2; const int64_t fcs = (int64_t)m * m * m;
+  const fdiv_t d_rpp{cq.m_rpp, cq.rpp}, d_s{cq.m_s, cq.s}, d_ncn{cq.m_ncn, cq.ncn};
+  c32 twq[R1];   // W_h^{q*k1}
+#pragma unroll
+  for (int k1 = 0; k1 < R1; k1++) twq[k1] = reinterpret_cast<const c32 *>(tw_g)[s1 ? 2 * q * k1 : 0];
+  // trip t of this workgroup: row batch blockIdx.x + (t/3)*gridDim.x, component t % 3
+  auto tables = [&](int wb, int comp, int buf) {
+    const int64_t row1 = (int64_t)wb * RB + threadIdx.x;
+    if ((int)threadIdx.x < RB && row1 < rows1) {
+      const unsigned srow = (unsigned)(comp * (int64_t)rows1 + row1), bz = srow / (unsigned)rpp;
+      src_row[buf][threadIdx.x] = (((int64_t)bz * nchunk) * rpp + (srow - bz * rpp)) * BXC;
+      const unsigned plane = fdiv((int)row1, d_rpp), y = (unsigned)row1 - plane * rpp, rank = fdiv((int)plane, d_s), zl = plane - rank * cq.s;
+      const unsigned j = fdiv((int)y, d_ncn), yy = y - j * cq.ncn, nd2 = cq.nd * cq.nd, layer = rank / nd2, qz = rank - layer * nd2;
+      const int own = layer * nd2 + j * cq.nd;
+      dst_off[buf][threadIdx.x] = ((int64_t)own * 3 + comp) * fcs + ((int64_t)(1 + qz * cq.s + zl) * m + (1 + yy)) * m + 1;
+      if (threadIdx.x == 0) owner0[buf] = own;
+    }
+  };
+  int grc[NLD];   // row | chunk << 8 | l4 << 16, or -1
+#pragma unroll
+  for (int u = 0; u < NLD; u++) {
+    const int e = (int)threadIdx.x + u * C::TB, t = e >> 3, ch = t / RB;
+    grc[u] = ch < C::NCH ? ((t - ch * RB) | (ch << 8) | ((e & 7) << 16)) : -1;
+  }
+  float4 g4[NLD];
+  auto fetch = [&](int wb, int buf) {
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows1 - (int64_t)wb * RB);
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+      g4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int rr = grc[u] & 255, ch = (grc[u] >> 8) & 255, l4 = grc[u] >> 16;
+      if (grc[u] >= 0 && rr < nrows) g4[u] = reinterpret_cast<const float4 *>(src + src_row[buf][rr] + ch * cstride)[l4];
+    }
+  };
+  float sq[R2][2];
+  int wb = blockIdx.x, comp = 0, buf = 0;
+  if (wb < nb1) tables(wb, 0, 0);
+  __syncthreads();
+  if (wb < nb1) fetch(wb, 0);
+  while (wb < nb1) {
+    const int nxt = buf == 2 ? 0 : buf + 1;
+    const int nrows = (int)min((int64_t)RB, (int64_t)rows1 - (int64_t)wb * RB);
+    const bool rowok = r < nrows;
+    const int ncomp = comp == 2 ? 0 : comp + 1, nwb = comp == 2 ? wb + (int)gridDim.x : wb;
+#pragma unroll
+    for (int u = 0; u < NLD; u++)
+      if (grc[u] >= 0) {
+        const int rr = grc[u] & 255, k = ((grc[u] >> 8) & 255) * BXC + 2 * (grc[u] >> 16);
+        c32 *pb = B + rr * P + k;
+        if (k <= h) pb[0] = (c32){g4[u].x, g4[u].y};
+        if (k + 1 <= h) pb[1] = (c32){g4[u].z, g4[u].w};
+      }
+    if (nwb < nb1) tables(nwb, ncomp, nxt);
+    __syncthreads();
+    if (nwb < nb1) fetch(nwb, nxt);
+    if (s1 && rowok) {
+      const c32 *pk = B + r * P + q, *pm = B + r * P + (h - R2 * (R1 - 1)) - q, *pt = tw + q;
+      c32 v[R1];
+#pragma unroll
+      for (int a = 0; a < R1; a++) {
+        const c32 xk = pk[R2 * a], xm = pm[R2 * (R1 - 1 - a)], t = pt[R2 * a];
+        const c32 e2 = {xk.x + xm.x, xk.y - xm.y}, d = {xk.x - xm.x, xk.y + xm.y};
+        const c32 o = {d.x * t.x + d.y * t.y, d.y * t.x - d.x * t.y};
+        v[a] = (c32){e2.x - o.y, -(e2.y + o.x)};
+      }
+      dft<R1>(v);
+      c32 *pxw = X + (r * R1) * R2P + q;
+#pragma unroll
+      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twq[k1]) : v[0];
+    }
+    __syncthreads();
+    if (s2 && rowok) {
+      c32 u[R2];
+      const c32 *pxr = X + (r * R1 + q) * R2P;
+#pragma unroll
+      for (int b = 0; b < R2; b++) u[b] = pxr[b];
+      dft<R2>(u);
+      float *pd = fc + dst_off[buf][r];
+      // 4-byte stores: the force arrays' rows start one cell in.  (Measured alternatives, n = 1024: the pair as one 8-byte store at
+      // 4-byte alignment 9.6 ms, the row through LDS to stores of 64 consecutive cells 8.9 ms, this 8.4 ms; at one wavefront per
+      // SIMD -- 400 registers -- the pass is bound by its instruction stream, not by how its stores coalesce)
+#pragma unroll
+      for (int k2 = 0; k2 < R2; k2++) {
+        const int x = 2 * (q + R1 * k2), i = fdiv(x, d_ncn);          // cell x of the row belongs to owner i = x / ncn (x < nc: h = R1*R2)
+        const float a = u[k2].x * rscale, b = -u[k2].y * rscale;
+        float *pp = pd + (int64_t)i * (3 * fcs - cq.ncn) + x;
+        pp[0] = a; pp[1] = b;
+        if (comp == 0) { sq[k2][0] = a * a; sq[k2][1] = b * b; } else { sq[k2][0] += a * a; sq[k2][1] += b * b; }
+      }
+    }
+    if (comp == 2) {   // max |F| of the batch's cells, per owner (uniform branch)
+      for (int i = 0; i < cq.nd; i++) {
+        float mx = 0.f;
+        if (s2 && rowok) {
+#pragma unroll
+          for (int k2 = 0; k2 < R2; k2++)
+            if (fdiv(2 * (q + R1 * k2), d_ncn) == i) mx = fmaxf(mx, fmaxf(sq[k2][0], sq[k2][1]));
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0 && mx > 0.f) p3m_atomic_max_nonneg(red.p[owner0[buf] + i] + p3m_slot() * 16, sqrtf(mx));
+      }
+    }
+    wb = nwb; comp = ncomp; buf = nxt;
   }
 }
 
@@ -979,20 +1125,37 @@ template <int RSET> static int x_fwd_rb(p3m_ctx *c, const FftPlan &pl, const flo
     default: return x_fwd_impl<RSET, 64>(c, pl, src, dst, rows, rpp);
   }
 }
-template <int R1, int R2> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp) {
+template <int R1, int R2, bool CUBES = false> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp, const RowGeom &cq = RowGeom{}) {
   using C = X2Cfg<R1, R2>;
   if (rows > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)rows); return P3M_EINVAL; }
-  P3M_TRY((set_lds(k_fft_x_fwd2<R1, R2>, C::lds)));
+  P3M_TRY((set_lds(k_fft_x_fwd2<R1, R2, CUBES>, C::lds)));
   static int occ = 0;
   if (occ == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_fwd2<R1, R2>), C::TB, C::lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_fwd2<R1, R2, CUBES>), C::TB, C::lds));
     if (occ < 1) occ = 1;
   }
   const int64_t nbatch = cdiv(rows, C::RB), g = (int64_t)256 * occ;
-  hipLaunchKernelGGL((k_fft_x_fwd2<R1, R2>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, src, reinterpret_cast<float2 *>(dst), pl.n,
-                     pl.px, (int)rows, pl.d_tw, rpp);
+  hipLaunchKernelGGL((k_fft_x_fwd2<R1, R2, CUBES>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, src, reinterpret_cast<float2 *>(dst), pl.n,
+                     pl.px, (int)rows, pl.d_tw, rpp, cq);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
+}
+// the coarse sizes whose x passes read the ranks' cubes / write the ranks' force arrays themselves (instantiated for these only)
+#define P3M_X2_CUBE_SIZES(X) X(32, 8, 4) X(64, 8, 8) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16)
+bool fft_x_has_cubes(const FftPlan &pl, const RowGeom &q) {
+  if (lines2_off(pl.n) || q.ncn % 2 || (int64_t)q.nd * q.ncn * q.ncn * q.ncn >= 0x7fffffffLL) return false;
+#define X(H, A, B) if (pl.n == 2 * H) return q.ncn % X2Cfg<A, B>::RB == 0;
+  P3M_X2_CUBE_SIZES(X)
+#undef X
+  return false;
+}
+// forward x pass over the rows (rank, plane, y) of the slab decomposition, read from the ranks' cubes (k_fft_x_fwd2<.., CUBES>)
+int fft_x_forward_cubes(p3m_ctx *c, const FftPlan &pl, const float *cubes, float *dst, const RowGeom &q) {
+  const int64_t rows = (int64_t)q.nl * q.s * q.rpp;
+#define X(H, A, B) if (pl.n == 2 * H) return x_fwd2_impl<A, B, true>(c, pl, cubes, dst, rows, q.rpp, q);
+  P3M_X2_CUBE_SIZES(X)
+#undef X
+  p3m_set_error("fft_x_forward_cubes: n=%d has no cube-reading x pass", pl.n); return P3M_EINVAL;
 }
 // rpp: rows per plane of the LY output; 0 = pl.n (whole planes).  A pencil decomposition hands in planes of fewer rows.
 int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp) {
@@ -1052,6 +1215,31 @@ template <int R1, int R2, bool BOX> static int x_inv2_impl(p3m_ctx *c, const Fft
                      pl.px, (int)rows, pl.d_tw, scale, box, fb, lo, ntile, bcs, rpp);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
+}
+// inverse x pass of the three force components over the rows of the slab decomposition (LY, [comp][rank][plane][y]), stored into the
+// owners' force arrays with max |F| (k_fft_x_inv2c); only where fft_x_has_cubes
+template <int R1, int R2> static int x_inv2c_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *fc, const RowGeom &q, const RankPtrs &red) {
+  using C = X2Cfg<R1, R2>;
+  const int n = pl.n; const int64_t rows1 = (int64_t)q.nl * q.s * q.rpp;
+  if (3 * rows1 > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)(3 * rows1)); return P3M_EINVAL; }
+  const float scale = (float)n * (float)n * (float)n;
+  P3M_TRY((set_lds(k_fft_x_inv2c<R1, R2>, C::lds)));
+  static int occ = 0;
+  if (occ == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_inv2c<R1, R2>), C::TB, C::lds));
+    if (occ < 1) occ = 1;
+  }
+  const int64_t nb1 = cdiv(rows1, C::RB), g = (int64_t)256 * occ;
+  hipLaunchKernelGGL((k_fft_x_inv2c<R1, R2>), dim3((unsigned)(g < nb1 ? g : nb1)), dim3(C::TB), C::lds, c->stream, reinterpret_cast<const float2 *>(src), n, pl.px,
+                     (int)rows1, pl.d_tw, scale, fc, q, red);
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+int fft_x_inverse_cubes(p3m_ctx *c, const FftPlan &pl, const float *src, float *fc, const RowGeom &q, const RankPtrs &red) {
+#define X(H, A, B) if (pl.n == 2 * H) return x_inv2c_impl<A, B>(c, pl, src, fc, q, red);
+  P3M_X2_CUBE_SIZES(X)
+#undef X
+  p3m_set_error("fft_x_inverse_cubes: n=%d has no force-writing x pass", pl.n); return P3M_EINVAL;
 }
 // src in LY; mode 0 writes real ROWS to out, mode 1 the force box; rpp (mode 0): rows per plane of the LY input, 0 = pl.n
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp) {

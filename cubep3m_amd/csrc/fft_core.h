@@ -10,6 +10,12 @@ __host__ __device__ __forceinline__ unsigned fdiv_magic(int d) { return 0xFFFFFF
 __device__ __forceinline__ fdiv_t mk_fdiv(int d) { fdiv_t f; f.m = fdiv_magic(d); f.d = d; return f; }
 __device__ __forceinline__ int fdiv(int x, fdiv_t f) { return f.d == 1 ? x : (int)__umulhi((unsigned)x, f.m); }
 
+// geometry of the coarse slab decomposition's x-line rows (group.hip: row_geom): nl local ranks of s planes each, rpp rows per plane,
+// rows of rp floats (nc real cells + pad); cubes of ncn^3 cells, nd per dimension
+#define P3M_MAX_LOCAL 64        // local ranks one batched launch can address (per-rank pointers in kernel arguments)
+struct RowGeom { int nl, s, nc, ncn, nd, rpp, rp; unsigned m_rpp, m_s, m_ncn; };
+struct RankPtrs { float *p[P3M_MAX_LOCAL]; };
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }

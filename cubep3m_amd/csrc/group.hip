@@ -23,6 +23,9 @@
 
 int fft_x_forward_rows(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp = 0);
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp = 0);
+bool fft_x_has_cubes(const FftPlan &pl, const RowGeom &q);
+int fft_x_forward_cubes(p3m_ctx *c, const FftPlan &pl, const float *cubes, float *dst, const RowGeom &q);
+int fft_x_inverse_cubes(p3m_ctx *c, const FftPlan &pl, const float *src, float *fc, const RowGeom &q, const RankPtrs &red);
 int fft_slab_y_fwd(p3m_ctx *c, const FftPlan &pl, const float *ly, float *send, int planes, int batch = 1, bool direct = false);
 int fft_slab_z_fwd(p3m_ctx *c, const FftPlan &pl, const float *src, float *lz, int planes, int seg, int batch = 1);
 bool fft_has_segmented(const FftPlan &pl);
@@ -36,7 +39,6 @@ int fft_slab_y_inv(p3m_ctx *c, const FftPlan &pl, const float *src, float *ly3, 
     if (_r != ncclSuccess) { p3m_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r)); return P3M_ECOMM; } \
   } while (0)
 
-#define P3M_MAX_LOCAL 64        // local ranks one batched launch can address (per-rank pointers in kernel arguments)
 struct CoarseDist {            // per local logical rank; slabs: nxb = nd^2, rpp = nc, ncl = nchunk; pencils: nxb = nd, rpp = ncn, ncl = nchunk/nd
   float *blocks_in = nullptr;  // [nxb][s][ncn][ncn]       cube -> slab / pencil arrivals
   float *rows = nullptr;       // [3][s][rpp][2*px]        real rows of the local planes
@@ -620,7 +622,6 @@ __global__ __launch_bounds__(256) void k_lrck_slab(float *__restrict__ kern, con
 // ------------------------------------------------------------------ batched layout kernels (G->batched: slabs, ncn % 4 == 0)
 // One launch serves every local rank; a wavefront moves whole rows with 16-byte accesses and does the index arithmetic once per
 // row (the per-element kernels above spend a chain of 64-bit divisions on every float: 1.8 ms for a 1.6 GB array).
-struct RowGeom { int nl, s, nc, ncn, nd, rpp, rp; unsigned m_rpp, m_s, m_ncn; };
 // blocks_in [rank][(j*nd+i)][zl][yy][xx] -> rows [rank][zl][y][x] (component 0 of the rows array), pad columns zero
 __global__ __launch_bounds__(256) void k_blocks_to_rows_b(const float *__restrict__ blocks, float *__restrict__ rows, RowGeom q) {
   const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -678,7 +679,6 @@ __global__ __launch_bounds__(256) void k_rows_to_blocks_b(const float *__restric
 }
 // blocks_back [rank][qz][comp][zl][yy][xx] -> force_c [rank][comp][1+qz*s+zl][1+yy][1+xx], and max |F| over the interior
 // (coarse_max_dt.f90:24-31) on the way: one wavefront per (rank, qz, zl, yy) takes the three component rows
-struct RankPtrs { float *p[P3M_MAX_LOCAL]; };
 __global__ __launch_bounds__(256) void k_blocks_to_force_b(const float *__restrict__ blocks, float *__restrict__ fc, int nl, int nq, int s, int ncn, unsigned m_ncn,
                                                            unsigned m_s, RankPtrs red) {
   const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -808,9 +808,13 @@ template <typename F> static int dist_forward(p3m_group *G, F cube_of) {
   const size_t blk = (size_t)s * ncn * ncn;
   if (G->direct && cube_of(0) == G->a_rho_c) {   // no exchanges: gather from the cubes, store into the peers' receive blocks
     p3m_ctx *c0 = G->ctx[0];
-    hipLaunchKernelGGL(k_cubes_to_rows_b, dim3(cdiv((int64_t)nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_rho_c, G->a_rows, row_geom(G));
-    HIP_TRY(hipGetLastError());
-    P3M_TRY(fft_x_forward_rows(c0, G->plan_c, G->a_rows, G->a_ly, (int64_t)nl * s * rpp, rpp));
+    const RowGeom q = row_geom(G);
+    if (fft_x_has_cubes(G->plan_c, q)) P3M_TRY(fft_x_forward_cubes(c0, G->plan_c, G->a_rho_c, G->a_ly, q));   // the x pass reads the cubes themselves
+    else {
+      hipLaunchKernelGGL(k_cubes_to_rows_b, dim3(cdiv((int64_t)nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_rho_c, G->a_rows, q);
+      HIP_TRY(hipGetLastError());
+      P3M_TRY(fft_x_forward_rows(c0, G->plan_c, G->a_rows, G->a_ly, (int64_t)nl * s * rpp, rpp));
+    }
     P3M_TRY(fft_slab_y_fwd(c0, G->plan_c, G->a_ly, G->a_recv, s, nl, true));
     return fft_slab_z_fwd(c0, G->plan_l, G->a_recv, G->a_lz, s, s, nl);
   }
@@ -945,11 +949,15 @@ static int coarse_force_dist(p3m_group *G) {
     p3m_ctx *c0 = G->ctx[0];
     P3M_TRY(fft_slab_z_inv3(c0, G->plan_l, G->a_lz, G->a_recv, G->a_kern, s, ccs, ccs, nl, (int64_t)NBc, true));
     P3M_TRY(fft_slab_y_inv(c0, G->plan_l, G->a_recv, G->a_ly, s, 3 * nl, s));
-    P3M_TRY(fft_x_inverse(c0, G->plan_c, G->a_ly, G->a_rows, -(3 * nl * s * rpp), 0, nullptr, 0, 0, 1, 0, rpp));
     RankPtrs red;
     for (int i = 0; i < nl; i++) red.p[i] = G->ctx[i]->d_red + 2 * P3M_RED_SPAN;
-    hipLaunchKernelGGL(k_rows_to_force_b, dim3(cdiv((int64_t)nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_rows, G->a_force_c, row_geom(G), (int64_t)G->rstride, red);
-    HIP_TRY(hipGetLastError());
+    const RowGeom q = row_geom(G);
+    if (fft_x_has_cubes(G->plan_c, q)) P3M_TRY(fft_x_inverse_cubes(c0, G->plan_c, G->a_ly, G->a_force_c, q, red));   // the x pass stores into the owners' force arrays
+    else {
+      P3M_TRY(fft_x_inverse(c0, G->plan_c, G->a_ly, G->a_rows, -(3 * nl * s * rpp), 0, nullptr, 0, 0, 1, 0, rpp));
+      hipLaunchKernelGGL(k_rows_to_force_b, dim3(cdiv((int64_t)nl * s * rpp, 4)), dim3(256), 0, G->stream, (const float *)G->a_rows, G->a_force_c, q, (int64_t)G->rstride, red);
+      HIP_TRY(hipGetLastError());
+    }
     return coarse_force_halo(G);
   }
   if (G->batched) P3M_TRY(fft_slab_z_inv3(G->ctx[0], G->plan_l, G->a_lz, G->a_send, G->a_kern, s, ccs, ccs, nl, (int64_t)NBc));
