@@ -55,53 +55,83 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
   const float offx = (float)(-tx * pt + nb), offy = (float)(-ty * pt + nb), offz = (float)(-tz * pt + nb);  // :134
   const int wlo = NGP ? 4 : 0, whi = NGP ? nf - 4 : nf;                                                  // window [wlo,whi)
   const bool row_possible = NGP ? (j >= wlo && j <= whi && k >= wlo && k <= whi) : true;
-  if (row_possible) {
+  if (row_possible && NGP) {
     for (int dk = -1; dk <= 0; dk++) {
       const int ks = k + dk; if (ks < wlo || ks >= whi) continue;   // source cell row must be inside the window
       for (int dj = -1; dj <= 0; dj++) {
         const int js = j + dj; if (js < wlo || js >= whi) continue;
         const int64_t rb = ((int64_t)(tz * pt + ks) * E + (ty * pt + js)) * E + tx * pt;
         const int p0 = cs[rb + wlo], p1 = cs[rb + whi];
-        if (NGP) {
-          for (int s = p0 + threadIdx.x; s < p1; s += 64) {
-            const float4 p = spos[s];
-            const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                 // :139
-            const int i1 = (int)floorf(x), j1 = (int)floorf(y), k1 = (int)floorf(z);                   // 0-based (:143 minus 1)
-            if (j1 == j && k1 == k) atomicAdd(&row[i1], mass_p);                                         // :148
-          }
-        } else {
-          // CIC, fine_cic_mass.f90:17-43 / fine_cic_mass_buffer.f90:25-53 (clipped to 1..nf).  ds_add_f32 costs ~2.6 clocks per
-          // lane on this part (tools/ldsbench.hip: 0.2 T updates/s against 1.16 T/s for a read-add-write), so the scatter avoids
-          // it: the 64 records of a chunk come from ONE sorted cell row, their cells ascend, equal cells are neighbours.  The
-          // first lane of every run of equal cells updates the row buffer with a plain read-add-write -- no two of them touch the
-          // same word -- and the (rare) other lanes of a run follow with atomics; the lower and the upper cell of the records are
-          // two such rounds, and the LDS operations of a wavefront complete in order.  A chunk whose cells do not ascend (xv +
-          // offset rounded a record into the next cell ahead of a neighbour of its own cell) takes the atomics for everybody.
-          for (int s0 = p0; s0 < p1; s0 += 64) {   // uniform trip count: the rounds below are wavefront operations
-            const int s = s0 + (int)threadIdx.x;
-            const bool live = s < p1;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) p = spos[s];
-            const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                 // :139
-            const int i1 = live ? (int)floorf(x) : 0x3fffffff, j1 = (int)floorf(y), k1 = (int)floorf(z);   // 0-based (:143 minus 1)
-            const float dx1 = (float)(i1 + 1) - x, dy1 = (float)(j1 + 1) - y, dz1 = (float)(k1 + 1) - z;
-            const float dx2 = 1.f - dx1, dy2 = 1.f - dy1, dz2 = 1.f - dz1;
-            float wy = 0.f, wz = 0.f; bool use = live;
-            if (j1 == j) wy = dy1; else if (j1 + 1 == j) wy = dy2; else use = false;
-            if (k1 == k) wz = dz1; else if (k1 + 1 == k) wz = dz2; else use = false;
-            const float mx1 = mass_p * dx1, mx2 = mass_p * dx2;                                          // :23-24
-            const float w1 = mx1 * wy * wz, w2 = mx2 * wy * wz;
-            const int prev = __shfl_up(i1, 1, 64);
-            const bool first = threadIdx.x == 0 || prev != i1;          // first lane of a run of equal cells
-            const bool ascending = __ballot(threadIdx.x != 0 && prev > i1) == 0ull;
-            const bool plain = ascending && first;
-            if (use && plain) { const float v = row[i1]; row[i1] = v + w1; }
-            if (use && !plain) atomicAdd(&row[i1], w1);
-            if (use && i1 + 1 < nf) {
-              if (plain) { const float v = row[i1 + 1]; row[i1 + 1] = v + w2; } else atomicAdd(&row[i1 + 1], w2);
-            }
-          }
+        for (int s = p0 + threadIdx.x; s < p1; s += 64) {
+          const float4 p = spos[s];
+          const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                 // :139
+          const int i1 = (int)floorf(x), j1 = (int)floorf(y), k1 = (int)floorf(z);                   // 0-based (:143 minus 1)
+          if (j1 == j && k1 == k) atomicAdd(&row[i1], mass_p);                                         // :148
         }
+      }
+    }
+  }
+  if (!NGP) {
+    // CIC, fine_cic_mass.f90:17-43 / fine_cic_mass_buffer.f90:25-53 (clipped to 1..nf).  ds_add_f32 costs ~2.6 clocks per
+    // lane on this part (tools/ldsbench.hip: 0.2 T updates/s against 1.16 T/s for a read-add-write), so the scatter avoids
+    // it: the 64 records of a chunk come from ONE sorted cell row, their cells ascend, equal cells are neighbours.  The
+    // first lane of every run of equal cells updates the row buffer with a plain read-add-write -- no two of them touch the
+    // same word -- and the (rare) other lanes of a run follow with atomics; the lower and the upper cell of the records are
+    // two such rounds, and the LDS operations of a wavefront complete in order.  A chunk whose cells do not ascend (xv +
+    // offset rounded a record into the next cell ahead of a neighbour of its own cell) takes the atomics for everybody.
+    auto scatter = [&](const float4 &p, bool live) {   // a wavefront operation: every lane calls
+      const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                 // :139
+      const int i1 = live ? (int)floorf(x) : 0x3fffffff, j1 = (int)floorf(y), k1 = (int)floorf(z);   // 0-based (:143 minus 1)
+      const float dx1 = (float)(i1 + 1) - x, dy1 = (float)(j1 + 1) - y, dz1 = (float)(k1 + 1) - z;
+      const float dx2 = 1.f - dx1, dy2 = 1.f - dy1, dz2 = 1.f - dz1;
+      float wy = 0.f, wz = 0.f; bool use = live;
+      if (j1 == j) wy = dy1; else if (j1 + 1 == j) wy = dy2; else use = false;
+      if (k1 == k) wz = dz1; else if (k1 + 1 == k) wz = dz2; else use = false;
+      const float mx1 = mass_p * dx1, mx2 = mass_p * dx2;                                          // :23-24
+      const float w1 = mx1 * wy * wz, w2 = mx2 * wy * wz;
+      const int prev = __shfl_up(i1, 1, 64);
+      const bool first = threadIdx.x == 0 || prev != i1;          // first lane of a run of equal cells
+      const bool ascending = __ballot(threadIdx.x != 0 && prev > i1) == 0ull;
+      const bool plain = ascending && first;
+      if (use && plain) { const float v = row[i1]; row[i1] = v + w1; }
+      if (use && !plain) atomicAdd(&row[i1], w1);
+      if (use && i1 + 1 < nf) {
+        if (plain) { const float v = row[i1 + 1]; row[i1 + 1] = v + w2; } else atomicAdd(&row[i1 + 1], w2);
+      }
+    };
+    // The four source cell rows {k-1,k} x {j-1,j} in the order of the reference's sums; their extents first, then the first 128
+    // records of each (a row holds ~70 at the reference's density), all in flight together: one workgroup used to wait for
+    // eight to twelve dependent round trips (extent, chunk, chunk per source row) and the launch was bound by that chain
+    int p0[4], p1[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ks = k - 1 + (q >> 1), js = j - 1 + (q & 1);
+      p0[q] = 0; p1[q] = 0;
+      if (ks >= wlo && ks < whi && js >= wlo && js < whi) {
+        const int64_t rb = ((int64_t)(tz * pt + ks) * E + (ty * pt + js)) * E + tx * pt;
+        p0[q] = cs[rb + wlo]; p1[q] = cs[rb + whi];
+      }
+    }
+    float4 rec[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int s = p0[q] + u * 64 + (int)threadIdx.x;
+        rec[q][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < p1[q]) rec[q][u] = spos[s];
+      }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        if (p0[q] + u * 64 < p1[q]) scatter(rec[q][u], p0[q] + u * 64 + (int)threadIdx.x < p1[q]);   // uniform
+      for (int s0 = p0[q] + 128; s0 < p1[q]; s0 += 64) {   // uniform trip count
+        const int s = s0 + (int)threadIdx.x;
+        const bool live = s < p1[q];
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) p = spos[s];
+        scatter(p, live);
       }
     }
   }
@@ -343,6 +373,9 @@ int fine_force_max(p3m_ctx *c) {
 // (coarse_velocity.f90:137-179, same arithmetic and order as k_coarse_kick) follows the fine kick of a record in registers --
 // PM-only whole steps, where nothing else touches the velocities between the two kicks.  A record whose reference cell
 // floor(xv + offset_tile) lies outside the staged rows (rounding at a face of the block) reads global memory.
+// (Round 4 also tried to start the chain range -> record -> velocity ahead of the barrier -- ranges by one vector load per wavefront and
+// v_readlane, the thread's record and velocity requested before / underneath the staging loads: 990-1000 us against 870; with the
+// ranges as scalar loads 1360 us: 32 misses of the scalar cache are served one after the other.)
 #define CK_BK 4
 #define CK_BJ 4
 #define CK_XS 128
