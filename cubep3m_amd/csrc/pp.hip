@@ -753,7 +753,8 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
             last = vb;
             n += vb - va;
           }
-        n -= own1 - own0;
+        if (cz >= z0 && cz <= z1) n -= own1 - own0;    // the own cell, if the own row is among the windows at all: a record of the planes
+                                                       // above pt + pp_range sweeps downwards only (reach), its own plane is not one of them
         heavy = n > PP3_LCAP;
         walker = !heavy && last - first > 256;
       }

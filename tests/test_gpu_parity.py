@@ -444,6 +444,28 @@ def test_disp_mesh_offsets_and_move_grid_back(PM, move_back):
     assert rel_rms(xg[:, 3:] - v0, xo[:, 3:] - v0) <= 3 * KICK_TOL
 
 
+def test_extended_pp_force_maximum_repeats(PM):
+    """Round 4: a home record of the planes above pt + pp_range sweeps downwards only (particle_mesh_threaded.f90:496); the count that
+    decides list / heavy pass subtracted its own cell although that cell is in none of its windows, a record with exactly one
+    partner more than the list holds was read one entry past what was written, and the tile's force maximum (dt_pp_ext_acc) came out
+    as garbage in one run out of four -- the kicks were right (such a record is not physical).  The same step eight times: every
+    run has to give the oracle's limit."""
+    p = cfg1(tiles_node_dim=2, nf_tile=80, cores=2, ngp=True, ppint=True, pp_ext=True, pp_range=4)
+    box = float(p.nf_physical_node_dim)
+    n = int(box ** 3 / 8)
+    xv = clustered_particles(n, box, seed=102, frac=0.3, nblobs=20, sigma=1.0, vel_sigma=0.5)
+    g0, o = both(PM, p)
+    g0.close()
+    o.set_particles(0, xv)
+    want = o.particle_mesh(0.2, 0.05, 0.04, 8.0).dt_pp_ext_acc
+    for rep in range(8):
+        g = PM(p, FINE_TABLE, COARSE_TABLE)
+        g.upload_particles(xv)
+        got = g.particle_mesh(0.2, 0.05, 0.04, 8.0).dt_pp_ext_acc
+        g.close()
+        assert got == pytest.approx(want, rel=DT_TOL), "run %d" % rep
+
+
 @pytest.mark.parametrize("T,nf,cores,kw", [
     (3, 64, 2, dict(ngp=True, ppint=True, pp_ext=True)),      # odd tile count, 16-cell physical tiles (fewer than the 24-cell buffer)
     (4, 64, 3, dict(ngp=True, ppint=True, pp_ext=True)),      # 64 tiles on 3 "threads": the per-thread last-tile rule with a remainder
