@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     }
     (void)nct;
   }
-  if (phys) {
-    const int vi = __float_as_int(spos[s].w); float4 v = vel[vi];   // the velocity stays in arrival order (p3m_internal.h)
+  // A record alone in its bucket (15 of 16 at the reference's density) has three zero sums: its kick adds zero and its velocity -- a 16-byte
+  // gather and a 16-byte scatter through the arrival index, twice the bytes of the record itself -- is left where it is
+  if (phys && (ax != 0.f || ay != 0.f || az != 0.f)) {
+    const int vi = __float_as_int(p.w); float4 v = vel[vi];          // the velocity stays in arrival order (p3m_internal.h)
     v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
     vel[vi] = v;
     mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356

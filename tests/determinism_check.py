@@ -33,6 +33,7 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
             print("   rank %d: max |F_c| %.4g at (z,y,x) %s, %d cells above 20; z range %s y range %s x range %s" %
                   (i, mag.max(), k, len(big), (big[:, 0].min(), big[:, 0].max()) if len(big) else None, (big[:, 1].min(), big[:, 1].max()) if len(big) else None,
                    (big[:, 2].min(), big[:, 2].max()) if len(big) else None), flush=True)
-    print("rep %d: step 1 dt_f %.9g dt_c %.9g fmax %.9g | step 2 dt_f %.9g dt_c %.9g fmax %.9g  ghosts %d %d" %
-          (rep, o1.dt_f_acc, o1.dt_c_acc, o1.f_force_max, o2.dt_f_acc, o2.dt_c_acc, o2.f_force_max, o1.np_ghost, o2.np_ghost), flush=True)
+    print("rep %d: step 1 dt_f %.9g dt_c %.9g fmax %.9g dt_pp %.9g dt_pp_ext %.9g | step 2 dt_f %.9g dt_c %.9g fmax %.9g dt_pp %.9g dt_pp_ext %.9g  ghosts %d %d" %
+          (rep, o1.dt_f_acc, o1.dt_c_acc, o1.f_force_max, o1.dt_pp_acc, o1.dt_pp_ext_acc, o2.dt_f_acc, o2.dt_c_acc, o2.f_force_max, o2.dt_pp_acc, o2.dt_pp_ext_acc,
+           o1.np_ghost, o2.np_ghost), flush=True)
     g.close()
