@@ -23,28 +23,31 @@ struct CGeo { int nb, E, Nn, ms, ncn, nc, cngp; };   // cngp: -DCOARSE_NGP (whol
 #define CM_FLY 4
 #endif
 #define CM_CAP 16   // listed record indices per lane
+#define CM_HEAVY 48 // records of a cube from which the whole wavefront sums it
 __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ mom, CGeo G,
                                                        float mass_p, float *__restrict__ rho_c, const int *__restrict__ crow, int crow_w) {
   const int m1 = G.ncn + 1;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)m1 * m1 * m1;
-  if (t >= tot) return;
-  const int ci = (int)(t % m1), cj = (int)((t / m1) % m1), ck = (int)(t / ((int64_t)m1 * m1));   // i1, j1, k1
+  // (threads past the last cube stay: the heavy cubes below are wavefront operations)
+  const int64_t tc = t < tot ? t : tot - 1;
+  const int ci = (int)(tc % m1), cj = (int)((tc / m1) % m1), ck = (int)(tc / ((int64_t)m1 * m1));   // i1, j1, k1
   const int h = G.ms / 2;
   const float inv = 1.0f / (float)G.ms;
   const int x0 = G.ms * ci - h + G.nb, y0 = G.ms * cj - h + G.nb, z0 = G.ms * ck - h + G.nb;      // first fine cell of the cube, extended index
   float acc[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) acc[c] = 0.f;
-  auto add = [&](const float4 &p) {
+  // the sums of one record into a[8], for the cube (ci_, cj_, ck_)
+  auto add_to = [&](const float4 &p, int ci_, int cj_, int ck_, float (&a)[8]) {
     const float x = inv * p.x - 0.5f, y = inv * p.y - 0.5f, z = inv * p.z - 0.5f;     // coarse_cic_mass.f90:18
     const int i1 = (int)floorf(x) + 1, j1 = (int)floorf(y) + 1, k1 = (int)floorf(z) + 1;  // 1-based
     float dx1 = (float)i1 - x, dy1 = (float)j1 - y, dz1 = (float)k1 - z;
     float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
     if (G.cngp) { dx1 = dy1 = dz1 = 0.0f; dx2 = dy2 = dz2 = 1.0f; }                     // :21-24
     dx1 = mass_p * dx1; dx2 = mass_p * dx2;                                             // :32-33
-    if (i1 == ci && j1 == cj && k1 == ck) {
-      acc[0] += dx1 * dy1 * dz1; acc[1] += dx2 * dy1 * dz1; acc[2] += dx1 * dy2 * dz1; acc[3] += dx2 * dy2 * dz1;
-      acc[4] += dx1 * dy1 * dz2; acc[5] += dx2 * dy1 * dz2; acc[6] += dx1 * dy2 * dz2; acc[7] += dx2 * dy2 * dz2;
+    if (i1 == ci_ && j1 == cj_ && k1 == ck_) {
+      a[0] += dx1 * dy1 * dz1; a[1] += dx2 * dy1 * dz1; a[2] += dx1 * dy2 * dz1; a[3] += dx2 * dy2 * dz1;
+      a[4] += dx1 * dy1 * dz2; a[5] += dx2 * dy1 * dz2; a[6] += dx1 * dy2 * dz2; a[7] += dx2 * dy2 * dz2;
     } else {
       // the fp32 expression put the record into a neighbouring cube (possible when 1/ms is inexact): rare, exact, slow
 #pragma unroll
@@ -55,8 +58,62 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
       }
     }
   };
+  auto add = [&](const float4 &p) { add_to(p, ci, cj, ck, acc); };
   const int nrow = G.ms * G.ms;
-  {
+  auto row_range = [&](int ci_, int y0_, int z0_, int x0_, int r, int &a0, int &a1) {
+    const int zz = r / G.ms, yy = r - zz * G.ms;
+    if (crow) { const int *row = crow + ((int64_t)(z0_ + zz) * G.E + (y0_ + yy)) * crow_w + ci_; a0 = row[0]; a1 = row[1]; }
+    else { const int *row = cs + ((int64_t)(z0_ + zz) * G.E + (y0_ + yy)) * G.E + x0_; a0 = row[0]; a1 = row[G.ms]; }
+  };
+  // A cube inside a blob holds hundreds of records where its 63 neighbours in the wavefront hold eight: the lane that owns it would
+  // walk them alone (clustered input: 645 us per rank against 160 us).  Such cubes (more than CM_HEAVY records) are taken one at a
+  // time by the whole wavefront -- the ms^2 ranges flattened over the lanes, eight partial sums per lane, a butterfly at the end --
+  // and their owner only receives the totals.  (The order of the sums inside such a cube differs from the serial walk: rounding
+  // of the last bit, as with any other order of the records of a cell.)
+  bool mine_done = false;
+  constexpr int NRK = 16;                                // rows whose ranges are kept in registers between the count and the listing (ms <= 4)
+  int ka0[NRK], ka1[NRK];
+  const bool kept = nrow <= NRK;
+  if (nrow <= 64) {
+    const int lane = threadIdx.x & 63;
+    int total = 0;
+    if (kept) {
+#pragma unroll
+      for (int r = 0; r < NRK; r++) { ka0[r] = 0; ka1[r] = 0; if (r < nrow && t < tot) row_range(ci, y0, z0, x0, r, ka0[r], ka1[r]); total += ka1[r] - ka0[r]; }
+    } else if (t < tot) for (int r = 0; r < nrow; r++) { int a0, a1; row_range(ci, y0, z0, x0, r, a0, a1); total += a1 - a0; }
+    bool heavy = t < tot && total > CM_HEAVY;
+    unsigned long long pending;
+    while ((pending = __ballot(heavy)) != 0ull) {
+      const int lead = __ffsll((long long)pending) - 1;
+      const int lci = __builtin_amdgcn_readlane(ci, lead), lcj = __builtin_amdgcn_readlane(cj, lead), lck = __builtin_amdgcn_readlane(ck, lead);
+      const int lx0 = G.ms * lci - h + G.nb, ly0 = G.ms * lcj - h + G.nb, lz0 = G.ms * lck - h + G.nb;
+      int ra0 = 0, ra1 = 0;                              // lane r < nrow: the range of row r of the lead's cube
+      if (lane < nrow) row_range(lci, ly0, lz0, lx0, lane, ra0, ra1);
+      int inc = ra1 - ra0;                               // inclusive prefix of the lengths over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+      const int ltot = __builtin_amdgcn_readlane(inc, 63);
+      float pa[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) pa[c] = 0.f;
+      for (int q = lane; q < ltot; q += 64) {
+        int idx = 0;                                     // record q of the cube: in the row whose prefix interval holds q
+        for (int r = 0; r < nrow; r++) {
+          const int hi = __builtin_amdgcn_readlane(inc, r), len = __builtin_amdgcn_readlane(ra1 - ra0, r), st = __builtin_amdgcn_readlane(ra0, r);
+          if (q >= hi - len && q < hi) idx = st + (q - (hi - len));
+        }
+        add_to(spos[idx], lci, lcj, lck, pa);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        float v = pa[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == lead) acc[c] = v;
+      }
+      if (lane == lead) { heavy = false; mine_done = true; }
+    }
+  }
+  if (!mine_done && t < tot) {
     // Listed: a lane's records come from ms^2 short ranges (half a record each at the reference's density).  Walking them
     // row by row makes the wavefront run `add` once per row and again for every extra record any lane has in that row --
     // several times the work of its busiest lane (PMC: 58 % VALU-busy at 34 % active lanes).  Instead the row loop only
@@ -75,11 +132,17 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
       }
       cnt = 0;
     };
+    if (kept) {
+#pragma unroll
+      for (int r = 0; r < NRK; r++)
+        for (int sidx = ka0[r]; sidx < ka1[r]; sidx++) {
+          if (cnt == CM_CAP) drain();
+          lst[cnt * 256 + threadIdx.x] = sidx; cnt++;
+        }
+    } else
     for (int r = 0; r < nrow; r++) {
-      const int zz = r / G.ms, yy = r - zz * G.ms;
       int a0, a1;
-      if (crow) { const int *row = crow + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * crow_w + ci; a0 = row[0]; a1 = row[1]; }
-      else { const int *row = cs + ((int64_t)(z0 + zz) * G.E + (y0 + yy)) * G.E + x0; a0 = row[0]; a1 = row[G.ms]; }
+      row_range(ci, y0, z0, x0, r, a0, a1);
       for (int sidx = a0; sidx < a1; sidx++) {
         if (cnt == CM_CAP) drain();
         lst[cnt * 256 + threadIdx.x] = sidx; cnt++;
@@ -87,6 +150,7 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
     }
     drain();
   }
+  if (t >= tot) return;
 #pragma unroll
   for (int c = 0; c < 8; c++) mom[c * tot + t] = acc[c];
 }
