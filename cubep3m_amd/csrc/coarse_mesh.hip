@@ -23,9 +23,10 @@ struct CGeo { int nb, E, Nn, ms, ncn, nc, cngp; };   // cngp: -DCOARSE_NGP (whol
 #define CM_FLY 4
 #endif
 #define CM_CAP 16   // listed record indices per lane
-#define CM_HEAVY 48 // records of a cube from which the whole wavefront sums it
+#define CM_HEAVY 24 // records of a cube from which the whole wavefront sums it: this, or three times the mean per cube if that is more
+                    // (measured at a mean of 8: 12 -> the uniform case 60 % slower, 16 / 24 / 48 / 96 -> clustered 251 / 258 / 287 / 380 us)
 __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ mom, CGeo G,
-                                                       float mass_p, float *__restrict__ rho_c, const int *__restrict__ crow, int crow_w) {
+                                                       float mass_p, float *__restrict__ rho_c, const int *__restrict__ crow, int crow_w, int heavy_min) {
   const int m1 = G.ncn + 1;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)m1 * m1 * m1;
   // (threads past the last cube stay: the heavy cubes below are wavefront operations)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
     else { const int *row = cs + ((int64_t)(z0_ + zz) * G.E + (y0_ + yy)) * G.E + x0_; a0 = row[0]; a1 = row[G.ms]; }
   };
   // A cube inside a blob holds hundreds of records where its 63 neighbours in the wavefront hold eight: the lane that owns it would
-  // walk them alone (clustered input: 645 us per rank against 160 us).  Such cubes (more than CM_HEAVY records) are taken one at a
+  // walk them alone (clustered input: 645 us per rank against 160 us).  Such cubes (more than `heavy_min` records: CM_HEAVY) are taken one at a
   // time by the whole wavefront -- the ms^2 ranges flattened over the lanes, eight partial sums per lane, a butterfly at the end --
   // and their owner only receives the totals.  (The order of the sums inside such a cube differs from the serial walk: rounding
   // of the last bit, as with any other order of the records of a cell.)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
 #pragma unroll
       for (int r = 0; r < NRK; r++) { ka0[r] = 0; ka1[r] = 0; if (r < nrow && t < tot) row_range(ci, y0, z0, x0, r, ka0[r], ka1[r]); total += ka1[r] - ka0[r]; }
     } else if (t < tot) for (int r = 0; r < nrow; r++) { int a0, a1; row_range(ci, y0, z0, x0, r, a0, a1); total += a1 - a0; }
-    bool heavy = t < tot && total > CM_HEAVY;
+    bool heavy = t < tot && total > heavy_min;
     unsigned long long pending;
     while ((pending = __ballot(heavy)) != 0ull) {
       const int lead = __ffsll((long long)pending) - 1;
@@ -184,7 +185,7 @@ int coarse_deposit(p3m_ctx *c, float mass_p) {
   HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));
   const int *crow = c->cells_compact ? (const int *)c->crow : (const int *)nullptr;
   hipLaunchKernelGGL(k_coarse_moments, dim3((unsigned)cdiv(tot, 256)), dim3(256), sizeof(int) * CM_CAP * 256, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G,
-                     mass_p, c->rho_c, crow, c->crow_w);
+                     mass_p, c->rho_c, crow, c->crow_w, (int)std::max<int64_t>(CM_HEAVY, 3 * (int64_t)c->np_all / tot));
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_coarse_collect, dim3((unsigned)std::min<int64_t>(1024, cdiv(n3, 256))), dim3(256), 0, c->stream, (const float *)c->cmom, c->rho_c, g.ncn, c->d_sums + 1 * P3M_SUM_SPAN);
   HIP_TRY(hipGetLastError());
