@@ -30,11 +30,7 @@
 // forward : x (ROWS -> LY, scratch) ; y (LY -> LZ, back) ; z (LZ in place)
 // inverse : z (LZ * iK -> LY, 3 components) ; y (LY in place) ; x (LY -> force box / ROWS)
 // Pad columns (kx > n/2) are written as zeros by the x pass and stay zero.
-#define BXC 16
-// half lengths h = n/2 = R1*R2 with two-register-stage x kernels (k_fft_x_fwd2, k_fft_x_inv2)
-#define P3M_X2_SIZES(X) X(32, 8, 4) X(40, 8, 5) X(48, 8, 6) X(56, 8, 7) X(64, 8, 8) X(80, 10, 8) X(88, 11, 8) X(96, 12, 8) X(104, 13, 8) X(112, 14, 8) \
-  X(128, 16, 8) X(152, 19, 8) X(160, 16, 10) X(176, 16, 11) X(192, 16, 12) X(224, 16, 14) X(256, 16, 16) X(280, 20, 14) X(304, 19, 16) \
-  X(320, 20, 16) X(352, 22, 16) X(384, 24, 16) X(416, 26, 16) X(448, 28, 16) X(512, 32, 16)
+#include "fft_x2.h"   // BXC, P3M_X2_SIZES, X2Cfg: shared with kick_fused.hip
 // line lengths n = R1*R2 with a two-register-stage y/z kernel (k_fft_lines2, k_fft_lines3r); anything else runs the LDS Stockham kernels
 #define P3M_LINES2_SIZES(X) X(64, 8, 8) X(80, 10, 8) X(96, 12, 8) X(112, 14, 8) X(128, 16, 8) X(160, 16, 10) X(176, 16, 11) X(192, 16, 12) X(208, 16, 13) X(224, 16, 14) \
   X(256, 16, 16) X(304, 19, 16) X(320, 20, 16) X(352, 22, 16) X(384, 24, 16) X(448, 28, 16) X(512, 32, 16) X(560, 28, 20) X(608, 32, 19) \
@@ -230,13 +226,6 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
     __syncthreads();
   }
 }
-
-// row geometry of the two-register-stage x kernels (see k_fft_x_inv2)
-template <int R1, int R2> struct X2Cfg {
-  static constexpr int h = R1 * R2, Q = R1 > R2 ? R1 : R2, RPW = 64 / Q, TB = 256, RB = RPW * (TB / 64), R2P = R2 | 1, P = h + 1;
-  static constexpr int NCH = h / BXC + 1, NLD = (RB * NCH * 8 + TB - 1) / TB;   // chunks holding columns 0..h; 16-byte loads per lane
-  static constexpr size_t lds = sizeof(float2) * ((size_t)RB * P + (size_t)RB * R1 * R2P + h);
-};
 
 // ------------------------------------------------------------------ x pass, forward: two register stages (h = n/2 = R1*R2)
 // Thread (q, row) loads the packed-real elements Z[R2*a + q] of its row straight into registers (8-byte loads at
@@ -1240,6 +1229,14 @@ int fft_x_inverse_cubes(p3m_ctx *c, const FftPlan &pl, const float *src, float *
   P3M_X2_CUBE_SIZES(X)
 #undef X
   p3m_set_error("fft_x_inverse_cubes: n=%d has no force-writing x pass", pl.n); return P3M_EINVAL;
+}
+// the force-box inverse x pass of line length n is k_fft_x_inv2 (and can therefore run as k_fft_x_inv2_kick, kick_fused.hip)
+bool fft_x2_box_pass(int n, int lo) {
+  if ((lo & 1) || lines2_off(n)) return false;
+#define X(H, A, B) if (n == 2 * H) return true;
+  P3M_X2_SIZES(X)
+#undef X
+  return false;
 }
 // src in LY; mode 0 writes real ROWS to out, mode 1 the force box; rpp (mode 0): rows per plane of the LY input, 0 = pl.n
 int fft_x_inverse(p3m_ctx *c, const FftPlan &pl, const float *src, float *out, int batch, int mode, float *box, int fb, int lo, int ntile, int64_t bcs, int rpp) {

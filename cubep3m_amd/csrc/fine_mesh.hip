@@ -13,10 +13,15 @@
 // even one mis-binned particle, every kernel here recomputes the reference expression per record.
 #include "p3m_internal.h"
 #include <algorithm>
+#include <stdlib.h>
 
 int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, float *box, int fb, int lo,
                      int64_t bcs, bool zfwd);
 int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch);
+int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, int fb, int lo, bool zfwd);
+int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, int fb, int lo);
+bool fft_x2_box_pass(int n, int lo);   // fft.hip: the force-box inverse x pass of this size is the two-register-stage kernel
+#include "kick_fused.h"
 
 struct TileGeo { int T, nf, nb, pt, E, fb, rp, fbp; };  // rp: real row pitch of a fine array (2*px); fbp: force box row pitch
 
@@ -189,7 +194,18 @@ __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, 
 // candidates: sorted indices of records within 2^-10 below a cell face in some coordinate, in P3M_CAND_SLOTS lists (k_row_sort;
 // blockIdx.y = list).  ALL: a list overflowed (cand_cnt[16 * slots] != 0): every sorted record is looked at instead (blockIdx.y = 0
 // only; the list kernel then leaves everything to this one)
-__device__ __forceinline__ void ngp_fixup_record(const float4 &p, float *__restrict__ rho, int tile0, int tl, const TileGeo &G, float mass_p, double *__restrict__ sum_interior) {
+// The fused inverse-x + kick pass (kick_fused.hip) kicks a record from the box rows of ITS batch of `fuse_nr` rows: a physical record of
+// this tile whose reference cell lies in a row of another batch than the row it is sorted into gets that row flagged here -- the pass
+// then stores the row to the force box as well and k_kick_fix kicks the record from there.
+struct FuseFlag { unsigned char *rowflag; int nr, Nn, ms; };
+__device__ __forceinline__ bool owner_is(const float4 &p, const TileGeo &G, int Nn, int ms, int tx, int ty, int tz) {
+  const float fNn = (float)Nn;
+  if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) return false;   // chains of hoc(1..ncn) only (:234-236)
+  const int nct = G.pt / ms;
+  return G.T == 1 || (((int)floorf(p.x / (float)ms)) / nct == tx && ((int)floorf(p.y / (float)ms)) / nct == ty && ((int)floorf(p.z / (float)ms)) / nct == tz);
+}
+__device__ __forceinline__ void ngp_fixup_record(const float4 &p, float *__restrict__ rho, int tile0, int tl, const TileGeo &G, float mass_p, double *__restrict__ sum_interior,
+                                                 const FuseFlag &ff) {
   const int nf = G.nf, pt = G.pt, nb = G.nb;
   int t3[3]; tile_xyz(tile0 + tl, G.T, t3[0], t3[1], t3[2]);
   const float xs[3] = {p.x, p.y, p.z};
@@ -202,6 +218,11 @@ __device__ __forceinline__ void ngp_fixup_record(const float4 &p, float *__restr
     moved = moved || (rr[d] != gl[d]);
   }
   if (!member || !moved) return;
+  if (ff.rowflag && (rr[1] != gl[1] || rr[2] != gl[2]) && owner_is(p, G, ff.Nn, ff.ms, t3[0], t3[1], t3[2])) {
+    const int lo = nb - 2, tile = tile0 + tl;
+    const int bs = (tile * G.fb + (gl[2] - lo)) * G.fb + (gl[1] - lo), br = (tile * G.fb + (rr[2] - lo)) * G.fb + (rr[1] - lo);
+    if (bs / ff.nr != br / ff.nr) ff.rowflag[br] = 1;
+  }
   float *base = rho + (int64_t)tl * nf * nf * G.rp;
   atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0]], -mass_p);
   atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0]], mass_p);
@@ -213,7 +234,7 @@ __device__ __forceinline__ void ngp_fixup_record(const float4 &p, float *__restr
 }
 template <bool ALL>
 __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, int nrec, const int *__restrict__ cand, const int *__restrict__ cand_cnt, int cand_seg,
-                                                   float *__restrict__ rho, int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior) {
+                                                   float *__restrict__ rho, int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior, FuseFlag ff) {
   // the candidate counts stay on the device (written by k_row_sort of this step): no host round trip between sort and deposit
   const bool overflow = cand_cnt[16 * P3M_CAND_SLOTS] != 0;
   if (ALL != overflow) return;
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ sp
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nrec * ntile; id += (int64_t)gridDim.x * 256) {
       const int tl = (int)(id / nrec); const int s = (int)(id - (int64_t)tl * nrec);
       const float4 p = spos[s];
-      if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) ngp_fixup_record(p, rho, tile0, tl, G, mass_p, sum_interior);
+      if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) ngp_fixup_record(p, rho, tile0, tl, G, mass_p, sum_interior, ff);
     }
     return;
   }
@@ -230,11 +251,11 @@ __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ sp
   const int *list = cand + (int64_t)slot * cand_seg;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)ncand * ntile; id += (int64_t)gridDim.x * 256) {
     const int tl = (int)(id / ncand); const int ci = (int)(id - (int64_t)tl * ncand);
-    ngp_fixup_record(spos[list[ci]], rho, tile0, tl, G, mass_p, sum_interior);
+    ngp_fixup_record(spos[list[ci]], rho, tile0, tl, G, mass_p, sum_interior, ff);
   }
 }
 
-int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
+int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p, bool fuse) {   // fuse: the kick will run inside the inverse x pass (flag rows for it)
   const Geometry &g = c->g;
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   if (c->p.flags & P3M_FLAG_NGP) {
@@ -247,10 +268,11 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p) {
     if (c->np_all > 0) {
       // records within 2^-10 below a cell face: ~0.3 % of the records; the grids are sized for that share, the loops cover any count
       const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256 / P3M_CAND_SLOTS) * ntile;
+      const FuseFlag ff{fuse ? c->rowflag : (unsigned char *)nullptr, c->fuse_nr, g.Nn, g.ms};
       hipLaunchKernelGGL(k_ngp_fixup<false>, dim3((unsigned)std::min<int64_t>(256, cdiv(guess, 256)), P3M_CAND_SLOTS), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,
-                         (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums);
+                         (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums, ff);
       hipLaunchKernelGGL(k_ngp_fixup<true>, dim3(2048), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,   // leaves at once unless a list overflowed
-                         (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums);
+                         (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums, ff);
       HIP_TRY(hipGetLastError());
     }
     return P3M_OK;
@@ -331,11 +353,15 @@ int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float 
 }
 
 // ------------------------------------------------------------------ :176-204 forward FFT, 3 x (i K_c multiply, inverse FFT, box extract)
-int fine_force(p3m_ctx *c, int tile0, int ntile) {
+int fine_force(p3m_ctx *c, int tile0, int ntile, bool defer_x) {
   const Geometry &g = c->g;
   // forward x and y passes; the forward z pass is the prologue of the inverse z pass (rho-hat never touches HBM)
   P3M_TRY(fft3d_forward_xy(c, c->plan_f, c->rho, c->work, ntile));
   const size_t boxsz = (size_t)g.fb * g.fb * g.fbp;
+  if (defer_x) {   // whole NGP steps: the inverse x pass runs with the kick (fine_xinv_kick_fused), no force box
+    P3M_TRY(fft_inverse3_box_z(c, c->plan_f, c->rho, c->work, c->kern_f, ntile, g.fb, g.nb - 2, true));
+    return fft_inverse3_box_y(c, c->plan_f, c->work, ntile, g.fb, g.nb - 2);
+  }
   // one fused launch per axis for all three components
   return fft_inverse3_box(c, c->plan_f, c->rho, c->work, c->kern_f, ntile, c->fbox + (size_t)tile0 * boxsz, g.fb, g.nb - 2,
                           (int64_t)g.ntiles * boxsz, true);
@@ -577,6 +603,109 @@ __global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const floa
   }
 }
 
+// ------------------------------------------------------------------ the fused inverse-x + NGP kick pass (kick_fused.hip) and its fix-up
+// k_kick_fix: the records the fused pass left out -- reference cell floor(xv + offset_tile) in a box row of another batch than the row
+// they are sorted into (flagged by k_ngp_fixup, stored to the box by the pass) -- get their kick (:244-270), their coarse kick
+// and their survivor count here, from the box.  Candidates as in k_ngp_fixup (lists of k_row_sort; ALL: a list overflowed).
+template <bool COARSE>
+__device__ __forceinline__ void kick_fix_record(const float4 &p, int s, const TileGeo &G, int Nn, int ms, int nr, unsigned char *__restrict__ rowflag, const float *__restrict__ fbox,
+                                                int64_t comp_stride, float a_mid, float dt, float4 *__restrict__ vel, const float *__restrict__ fc, int ncn, int *__restrict__ cnt256) {
+  const float fNn = (float)Nn;
+  if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) return;
+  int tx = 0, ty = 0, tz = 0;
+  if (G.T > 1) { const int nct = G.pt / ms; tx = ((int)floorf(p.x / (float)ms)) / nct; ty = ((int)floorf(p.y / (float)ms)) / nct; tz = ((int)floorf(p.z / (float)ms)) / nct; }
+  const int tile = (tz * G.T + ty) * G.T + tx, lo = G.nb - 2, fb = G.fb;
+  const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
+  const int i1 = (int)floorf(p.x + offx) - lo, j1 = (int)floorf(p.y + offy) - lo, k1 = (int)floorf(p.z + offz) - lo;                     // :248
+  const int js = (int)floorf(p.y) + G.nb - ty * G.pt - lo, ks = (int)floorf(p.z) + G.nb - tz * G.pt - lo;                                   // the row the record is sorted into
+  const int bs = (tile * fb + ks) * fb + js, br = (tile * fb + k1) * fb + j1;
+  if (bs / nr == br / nr) return;                                                                                                        // kicked by the fused pass
+  const int64_t o = (int64_t)br * G.fbp + i1;
+  const float fx = fbox[o], fy = fbox[o + comp_stride], fz = fbox[o + 2 * comp_stride];
+  const int vi = rec_index(p);
+  float4 v = vel[vi];
+  v.x = v.x + fx * a_mid * P3M_G_F * dt;                                                             // :265-266
+  v.y = v.y + fy * a_mid * P3M_G_F * dt;
+  v.z = v.z + fz * a_mid * P3M_G_F * dt;
+  if (COARSE) {
+    const float inv = 1.0f / (float)ms;
+    const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
+    const int ci = (int)floorf(cx_) + 1, cj = (int)floorf(cy_) + 1, ck = (int)floorf(cz_) + 1;
+    const float dx1 = (float)ci - cx_, dy1 = (float)cj - cy_, dz1 = (float)ck - cz_;
+    const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+    const int m = ncn + 2; const int64_t ccs = (int64_t)m * m * m;
+#pragma unroll
+    for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+      for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+        for (int cx = 0; cx < 2; cx++) {                                                              // :153-168
+          const float dV = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
+          const int64_t oc = ((int64_t)(ck + cz) * m + (cj + cy)) * m + (ci + cx);
+          v.x = v.x + fc[oc] * dV; v.y = v.y + fc[oc + ccs] * dV; v.z = v.z + fc[oc + 2 * ccs] * dV;
+        }
+  }
+  vel[vi] = v;
+  if (cnt256) atomicAdd(&cnt256[s >> 8], 1);
+  rowflag[br] = 0;   // every record that needed the row clears it: the flags are all zero again when the step ends
+}
+template <bool ALL, bool COARSE>
+__global__ __launch_bounds__(256) void k_kick_fix(const float4 *__restrict__ spos, int nrec, const int *__restrict__ cand, const int *__restrict__ cand_cnt, int cand_seg, TileGeo G,
+                                                  int Nn, int ms, int nr, unsigned char *__restrict__ rowflag, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
+                                                  float4 *__restrict__ vel, const float *__restrict__ fc, int ncn, int *__restrict__ cnt256) {
+  const bool overflow = cand_cnt[16 * P3M_CAND_SLOTS] != 0;
+  if (ALL != overflow) return;
+  if (ALL) {
+    const float thr = 1.0f - 0.0009765625f;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < nrec; s += (int64_t)gridDim.x * 256) {
+      const float4 p = spos[s];
+      if ((p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) kick_fix_record<COARSE>(p, (int)s, G, Nn, ms, nr, rowflag, fbox, comp_stride, a_mid, dt, vel, fc, ncn, cnt256);
+    }
+    return;
+  }
+  const int slot = blockIdx.y, ncand = min(cand_cnt[slot * 16], cand_seg);
+  const int *list = cand + (int64_t)slot * cand_seg;
+  for (int ci = blockIdx.x * 256 + threadIdx.x; ci < ncand; ci += gridDim.x * 256) {
+    const int s = list[ci];
+    kick_fix_record<COARSE>(spos[s], s, G, Nn, ms, nr, rowflag, fbox, comp_stride, a_mid, dt, vel, fc, ncn, cnt256);
+  }
+}
+
+// Whole NGP steps run the fused pass when the tile size has a two-register-stage x kernel whose staging buffer holds the box rows, all
+// tiles are swept in one batch (the LY rows of every tile must still exist when the kick runs) and the coarse force array can be
+// indexed with 32 bits.  P3M_KICK_UNFUSED=1 keeps the force box + k_fine_kick_rows pair (A/B measurements, tests).
+bool fine_kick_fusable(const p3m_ctx *c) {
+  static const bool off = getenv("P3M_KICK_UNFUSED") && getenv("P3M_KICK_UNFUSED")[0] == '1';
+  const Geometry &g = c->g;
+  const int64_t m = g.ncn + 2;
+  return !off && (c->p.flags & P3M_FLAG_NGP) && c->tile_batch == g.ntiles && c->fuse_nr > 0 && c->rowflag && fft_x2_box_pass(g.nf, g.nb - 2) &&
+         3 * m * m * m < 0x7fffffffLL && (int64_t)g.ntiles * g.fb * g.fb < 0x7fffffffLL;
+}
+static int fine_xinv_kick_fused(p3m_ctx *c, float a_mid, float dt, int *cnt256) {
+  const Geometry &g = c->g;
+  const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
+  KickFuseArgs a{};
+  a.src = reinterpret_cast<const float2 *>(c->work); a.tw_g = c->plan_f.d_tw; a.inv_scale = (float)g.nf * (float)g.nf * (float)g.nf; a.n = g.nf; a.px = g.px;
+  a.fb = g.fb; a.fbp = g.fbp; a.lo = g.nb - 2; a.ntile = g.ntiles; a.rows_total = g.ntiles * g.fb * g.fb;
+  a.T = g.T; a.pt = g.pt; a.E = g.E; a.nb = g.nb; a.Nn = g.Nn; a.ms = g.ms; a.ncn = g.ncn;
+  a.box = c->fbox; a.bcs = cs; a.rowflag = c->rowflag;
+  a.spos = c->spos; a.vel = c->vel; a.cs = c->cell_end; a.crow = c->cells_compact ? c->crow : nullptr; a.crow_w = c->crow_w;
+  a.a_mid = a_mid; a.dt = dt; a.fmax_out = c->d_red; a.fc = c->coarse_first ? c->force_c : nullptr; a.cnt256 = cnt256;
+  P3M_TRY(kick_fused_launch(c, a, c->coarse_first));
+  if (c->np_all > 0) {
+    TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
+    const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256 / P3M_CAND_SLOTS);
+    const dim3 gl((unsigned)std::min<int64_t>(64, cdiv(guess, 256)), P3M_CAND_SLOTS);
+#define P3M_FIX(ALLv, COv, GRID) hipLaunchKernelGGL((k_kick_fix<ALLv, COv>), GRID, dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all, (const int *)c->cand, (const int *)c->cand_cnt, \
+      c->cand_seg, G, g.Nn, g.ms, c->fuse_nr, c->rowflag, (const float *)c->fbox, cs, a_mid, dt, c->vel, (const float *)a.fc, g.ncn, cnt256)
+    if (c->coarse_first) { P3M_FIX(false, true, gl); P3M_FIX(true, true, dim3(2048)); }   // the second leaves at once unless a candidate list overflowed
+    else { P3M_FIX(false, false, gl); P3M_FIX(true, false, dim3(2048)); }
+#undef P3M_FIX
+    HIP_TRY(hipGetLastError());
+  }
+  return P3M_OK;
+}
+
 // CIC fine mesh: the maximum and the kick in one pass over the force box (k_fine_kick_cic)
 static int fine_max_and_kick_cic(p3m_ctx *c, float a_mid, float dt, bool count_survivors_reset) {
   const Geometry &g = c->g;
@@ -612,6 +741,7 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt, bool count_survivors) {
     HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
     c->cnt_from_kick = c->np_all;
   }
+  if (c->xinv_deferred) { c->xinv_deferred = false; return fine_xinv_kick_fused(c, a_mid, dt, cnt256); }   // the force phase stopped after the inverse y pass
   if (c->coarse_first)
     hipLaunchKernelGGL(k_fine_kick_rows<true>, dim3((unsigned)cdiv((int64_t)g.ntiles * g.fb * g.fb, P3M_KICK_WPB)), dim3(64 * P3M_KICK_WPB), sizeof(float) * 3 * g.fbp * P3M_KICK_WPB, c->stream,
                        (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms, (const float *)c->fbox, cs, a_mid, dt, c->d_red,

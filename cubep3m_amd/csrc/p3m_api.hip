@@ -1,6 +1,7 @@
 // p3m_api.hip -- the C ABI of include/p3m_hip.h: context lifecycle, particle upload/download,
 // the `particle_mesh` sequence (particle_mesh_threaded.f90:2-726) and the probes/timers.
 #include "p3m_internal.h"
+#include "kick_fused.h"
 #include <stdlib.h>
 #include <algorithm>
 #include <cmath>
@@ -113,6 +114,9 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   A(dalloc(&c->rho, S * c->tile_batch)); A(dalloc(&c->work, 3 * S * c->tile_batch));
   if (hipMemset(c->rho, 0, S * c->tile_batch * sizeof(float)) != hipSuccess || hipMemset(c->work, 0, 3 * S * c->tile_batch * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
   A(dalloc(&c->fbox, (size_t)3 * g.ntiles * g.fb * g.fb * g.fbp));
+  // the fused inverse-x + kick pass of NGP steps (kick_fused.hip): rows per batch (0: this tile size has none) and the per-row flags, all zero between steps
+  c->fuse_nr = kick_fused_rows(g.nf, g.fbp);
+  if (c->fuse_nr > 0) { A(dalloc(&c->rowflag, (size_t)g.ntiles * g.fb * g.fb + 16)); if (hipMemset(c->rowflag, 0, (size_t)g.ntiles * g.fb * g.fb + 16) != hipSuccess) return fail(P3M_EDEVICE); }
   A(dalloc(&c->kern_f, (size_t)3 * g.nf * g.nf * g.px));
   if (hipMemset(c->kern_f, 0, (size_t)3 * g.nf * g.nf * g.px * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
   A(fft_plan_create(&c->plan_f, g.nf));
@@ -149,7 +153,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);
-  dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->kern_f);
+  dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->rowflag); dfree(c->kern_f);
   dfree(c->rho_c); dfree(c->cmom); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->slab_o); dfree(c->kern_c);
   dfree(c->d_red); dfree(c->d_tile_ext); dfree(c->d_sums);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -335,10 +339,12 @@ extern "C" int p3m_hip_link_list_and_pass(p3m_ctx *c) {
 
 static int fine_sweep(p3m_ctx *c, float mass_p) {
   const Geometry &g = c->g;
+  // NGP: the last pass of the force (inverse x) runs with the kick (kick_fused.hip); fine_max_and_kick picks it up
+  c->xinv_deferred = fine_kick_fusable(c);
   for (int t0 = 0; t0 < g.ntiles; t0 += c->tile_batch) {
     const int nt = std::min(c->tile_batch, g.ntiles - t0);
-    P3M_TRY(fine_deposit(c, t0, nt, mass_p));
-    P3M_TRY(fine_force(c, t0, nt));
+    P3M_TRY(fine_deposit(c, t0, nt, mass_p, c->xinv_deferred));
+    P3M_TRY(fine_force(c, t0, nt, c->xinv_deferred));
   }
   return P3M_OK;
 }
@@ -479,7 +485,7 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
 // after an error in the middle of a step: nothing that was queued for "later" may be trusted by the next call -- the next sort
 // counts its rows itself (k_row_hist), no survivor counts, no deferred counters, no half-finished ghost removal
 void particles_reset_after_error(p3m_ctx *c) {
-  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false;
+  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false; c->xinv_deferred = false;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 }

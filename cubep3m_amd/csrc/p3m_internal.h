@@ -134,6 +134,9 @@ struct p3m_ctx {
   bool lazy_counters = false;  // whole steps: the sort's deleted count has not been read yet, np_all is its upper bound (the tail is padded)
   bool coarse_first = false;   // whole-step PM-only NGP runs: the coarse force is ready before the fine kick, which then adds the coarse kick in the same pass
   bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
+  // NGP steps (round 5): the force phase stops after the inverse y pass (work holds LY rows of the three components) and the inverse x
+  // pass runs inside the kick (kick_fused.hip), fuse_nr box rows per batch; rowflag[ntiles*fb*fb]: rows that also go to the force box
+  bool xinv_deferred = false; int fuse_nr = 0; unsigned char *rowflag = nullptr;
   float *rho = nullptr;        // [batch][nf][nf][2*px]  density -> rho-hat
   float *work = nullptr;       // [3][batch][nf][nf][2*px]  i*K_c*rho-hat -> force, all three components
   float *fbox = nullptr;       // [3][ntiles][fb][fb][fbp] extracted force (SoA planes, pad columns zero)
@@ -206,8 +209,9 @@ void particles_reset_after_error(p3m_ctx *c);   // p3m_api.hip: consistent state
 int particles_resolve(p3m_ctx *c);   // finish a deferred ghost removal before the arrival arrays are read
 
 // ---- fine_mesh.hip
-int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p);
-int fine_force(p3m_ctx *c, int tile0, int ntile);
+int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p, bool fuse = false);   // fuse: flag the box rows the fused kick must also store
+int fine_force(p3m_ctx *c, int tile0, int ntile, bool defer_x = false);                // defer_x: stop after the inverse y pass (the x pass runs with the kick)
+bool fine_kick_fusable(const p3m_ctx *c);                                               // fine_mesh.hip: this context's whole steps run the fused inverse-x + kick pass
 int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt, bool count_survivors = true);   // false: timing hook (leaves c->flags and cnt_from_kick alone)
 int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz);   // projection.f90: adds this rank's tiles to the device maps
 bool coarse_kick_rides_on_fine(const p3m_ctx *c);   // p3m_api.hip
