@@ -185,7 +185,7 @@ def cpu_baseline(scal):
 
     def oracle_for(**flags):
         q = Params(**dict(CONFIGS[key]["params"], **flags))
-        o = ol.Oracle(q)
+        o = ol._RawOracle(q)   # (ol.Oracle memoises whole steps on disk: the timed object is the plain one)
         o.set_kernel_tables(fine, coarse)
         o.set_particles(0, xv)
         return q, o
@@ -274,7 +274,7 @@ def comm_audit(grp, dist, rank, world):
     return allinfo
 
 
-def slab_leg(args, torch, dist, rank, world, local_dev, ddev, require_rccl):
+def slab_leg(args, torch, dist, rank, world, local_dev, ddev, require_rccl, embedded=False):
     """--config slab1024: BASELINE configs[3] read literally (SURVEY section 8, config note (ii)) -- a 1024^3 real coarse field,
     slab-decomposed over the eight logical ranks of the 2x2x2 decomposition (nc_slab = 128, fftw3ds.f90:103-183), one forward
     and three inverse transforms per step (coarse_force.f90:18-90).  A "step" is one coarse_force on device-resident density:
@@ -352,6 +352,10 @@ def slab_leg(args, torch, dist, rank, world, local_dev, ddev, require_rccl):
                               "note": "each rank sends nc_slab x (nc/2+1 padded to 16) x nc_slab complex to every other rank per transform "
                                       "(SURVEY 8d: 67 MB per link at G = 8); between ranks of one GPU these are device copies"},
                "ranks": audit}
+        if embedded:        # a leg of the default line (one GPU): the dictionary goes into the headline's JSON
+            grp.close()
+            res.pop("ranks")
+            return res
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
@@ -375,6 +379,19 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the host side (gloo: debugging on fewer GPUs than ranks)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks (one per GPU) as a CHILD process group -- before anything here has
+        # touched the GPU, and without exec (a process that initialised the GPU must not be replaced) -- and hand its result through
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
 
@@ -461,6 +478,12 @@ def main():
         el = float(tt.item())
     assert out.np_total == n_total, (out.np_total, n_total)
     value = n_total * args.steps / el
+    # per-phase GPU times of one more step (through the C ABI: what a reference host built with -DMPI_TIME prints, timers.f90:68-77);
+    # a collective step: every rank takes it, rank 0 reports the spans of its own ranks
+    grp.phase_timing(True)
+    grp.particle_mesh(a_mid, dt, dt_old, mass_p)
+    phase_ms = grp.last_phase_ms()
+    grp.phase_timing(False)
 
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream (rank 0's first context)
@@ -474,6 +497,14 @@ def main():
         # per sweep over the batch, one launch each: x_fwd, y_fwd, z_fwd, z_inv_fused (3 components), y_inv (3), x_inv_extract (3)
         # on the step's path: x_fwd, y_fwd, z_inv_fused (forward z pass + multiply + inverse z pass of all three components in
         # one kernel), y_inv, x_inv_extract; the stand-alone z_fwd is only used when the Green's functions are built
+        # what NGP whole steps run instead of x_inv_extract + the kick: the inverse x pass with the kick inside (kick_fused.hip)
+        fused_ms = None
+        if p.ngp:
+            try:
+                fused_ms, _ = pm.time_fft_pass(7, reps=10)
+                passes["x_inv_kick_fused"] = fused_ms
+            except Exception:
+                fused_ms = None
         dom = max(("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_extract"), key=lambda k: passes[k])
         sweep_ms = pm.time_fine_sweep(mass_p, reps=3)
         ntile = p.tiles_node_dim ** 3
@@ -511,6 +542,14 @@ def main():
                     # the same launch against the bytes it really moved (PMC): what the memory system sees
                     "traffic_GBs": (traffic / (passes[dom] * 1e-3) / 1e9) if traffic else None,
                     "traffic_frac": (traffic / (passes[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    # The step's own sweep: the NGP deposit rides on the sort (no deposit kernel) and the last launch is the fused inverse-x +
+                    # kick pass, which carries the kick of particle_mesh_threaded.f90:208-270 on top of the transform: four FFT launches + that
+                    # one against the same 10.5 S.  "fine_sweep" below is the stand-alone sweep (k_ngp_counts + five launches + a force box).
+                    "fine_sweep_in_step": None if fused_ms is None else {
+                        "ms": passes["x_fwd"] + passes["y_fwd"] + passes["z_inv_fused"] + passes["y_inv"] + fused_ms,
+                        "algorithmic_bytes": 10.5 * S * ntile,
+                        "frac": 10.5 * S * ntile / ((passes["x_fwd"] + passes["y_fwd"] + passes["z_inv_fused"] + passes["y_inv"] + fused_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "what": "x_fwd, y_fwd, fused z, y_inv, inverse x with the NGP kick, the coarse kick and the survivor count inside (one rank's tiles)"},
                     "fine_sweep": {"ms": sweep_ms, "algorithmic_bytes": 10.5 * S * ntile,
                                    "achieved_GBs": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9,
                                    "frac": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -532,6 +571,7 @@ def main():
             "roofline": roofline,
             "ranks": audit,
         }
+        res["phase_ms"] = phase_ms
         if world == 1 and args.config == "cfg4" and not args.no_extra:
             # non-headline legs (rank 0, one GPU): the same 512^3-particle problem with PPINT + PP_EXT on, and the two
             # short-range kernels on their own
@@ -558,6 +598,10 @@ def main():
                 assert o2.np_total == n_total
                 leg = {"metric": "particle_updates_per_sec", "value": n_total * k2 / el2, "ms_per_step": 1e3 * el2 / k2, "steps": k2,
                        "workload": CONFIGS[cfg_name]["workload"], "data": data}
+                g2.phase_timing(True)
+                g2.particle_mesh(a_mid, dt, dt_old, mass_p)
+                leg["phase_ms"] = g2.last_phase_ms()
+                g2.phase_timing(False)
                 if not p2.ngp:
                     # the north star's "fine-mesh FFT+CIC sweep": CIC deposit + the five FFT launches of one tile against 10.5 S, and
                     # the CIC gather (maximum + interpolation + kick in one pass over the force box) against its own bytes
@@ -590,12 +634,24 @@ def main():
                 xv[:, 3:] = np.random.default_rng(99 + r).normal(0, 0.05, (len(xv), 3)).astype(np.float32)
                 return xv
 
+            def moving_ic(r):      # the headline's particles with velocities that carry them 0.3 cells per step and axis (sigma_v dt = 6 x 0.05)
+                xv = make_particles(nside, box, seed=12345 + r)
+                xv[:, 3:] = np.random.default_rng(777 + r).normal(0, 6.0, (len(xv), 3)).astype(np.float32)
+                return xv
+
             res["cic"] = side_leg("cfg4_cic", uniform_ic, "synthetic uniform (the headline's particles)")
+            # the headline's timed steps move nobody (velocities of 0.05 cells per unit time: the sort sees sorted input); a production step
+            # displaces particles by a fraction of a cell (update_position.f90:68-76 with timestep.f90:106-115's dt)
+            mdata = "synthetic uniform positions, Gaussian velocities with sigma_v dt = 0.3 cells per step and axis"
+            res["moving"] = {"pm": side_leg("cfg4", moving_ic, mdata), "pm_pp": side_leg("cfg4_pp", moving_ic, mdata)}
             res["pm_pp"] = side_leg("cfg4_pp", uniform_ic, "synthetic uniform (the headline's particles)")
             # the same two step types on a clustered particle set: dense cells, unequal rows, heavy pair lists
             cdata = "synthetic clustered: 30 % of the particles in Gaussian blobs of ~205 particles, sigma 0.6 cells (SURVEY Appendix C's recipe at its density)"
             res["clustered"] = {"pm": side_leg("cfg4", clustered_ic, cdata), "pm_pp": side_leg("cfg4_pp", clustered_ic, cdata)}
             res["pp"] = pp_leg()
+            # BASELINE configs[3] read literally: the stand-alone 1024^3 slab transform (--config slab1024), three coarse_force calls
+            sa = argparse.Namespace(**dict(vars(args), steps=3, warmup=1))
+            res["slab1024"] = slab_leg(sa, torch, None, 0, 1, local_dev, ddev, False, embedded=True)
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(scal)
             if "pm_pp" in res:   # the CPU figure of the same flag set beside the PM + PP leg

@@ -97,13 +97,15 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
       float pa[8];
 #pragma unroll
       for (int c = 0; c < 8; c++) pa[c] = 0.f;
-      for (int q = lane; q < ltot; q += 64) {
+      const int rlen = ra1 - ra0;                        // formed at full EXEC: the readlanes below take it from lanes that hold no record
+      for (int q0 = 0; q0 < ltot; q0 += 64) {            // uniform trip count: every readlane runs with all lanes active
+        const int q = q0 + lane;
         int idx = 0;                                     // record q of the cube: in the row whose prefix interval holds q
         for (int r = 0; r < nrow; r++) {
-          const int hi = __builtin_amdgcn_readlane(inc, r), len = __builtin_amdgcn_readlane(ra1 - ra0, r), st = __builtin_amdgcn_readlane(ra0, r);
+          const int hi = __builtin_amdgcn_readlane(inc, r), len = __builtin_amdgcn_readlane(rlen, r), st = __builtin_amdgcn_readlane(ra0, r);
           if (q >= hi - len && q < hi) idx = st + (q - (hi - len));
         }
-        add_to(spos[idx], lci, lcj, lck, pa);
+        if (q < ltot) add_to(spos[idx], lci, lcj, lck, pa);
       }
 #pragma unroll
       for (int c = 0; c < 8; c++) {

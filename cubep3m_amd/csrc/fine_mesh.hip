@@ -681,7 +681,7 @@ bool fine_kick_fusable(const p3m_ctx *c) {
   return !off && (c->p.flags & P3M_FLAG_NGP) && c->tile_batch == g.ntiles && c->fuse_nr > 0 && c->rowflag && fft_x2_box_pass(g.nf, g.nb - 2) &&
          3 * m * m * m < 0x7fffffffLL && (int64_t)g.ntiles * g.fb * g.fb < 0x7fffffffLL;
 }
-static int fine_xinv_kick_fused(p3m_ctx *c, float a_mid, float dt, int *cnt256) {
+static int fine_xinv_kick_fused(p3m_ctx *c, float a_mid, float dt, int *cnt256, bool dry = false) {
   const Geometry &g = c->g;
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   KickFuseArgs a{};
@@ -690,9 +690,10 @@ static int fine_xinv_kick_fused(p3m_ctx *c, float a_mid, float dt, int *cnt256) 
   a.T = g.T; a.pt = g.pt; a.E = g.E; a.nb = g.nb; a.Nn = g.Nn; a.ms = g.ms; a.ncn = g.ncn;
   a.box = c->fbox; a.bcs = cs; a.rowflag = c->rowflag;
   a.spos = c->spos; a.vel = c->vel; a.cs = c->cell_end; a.crow = c->cells_compact ? c->crow : nullptr; a.crow_w = c->crow_w;
-  a.a_mid = a_mid; a.dt = dt; a.fmax_out = c->d_red; a.fc = c->coarse_first ? c->force_c : nullptr; a.cnt256 = cnt256;
+  a.a_mid = a_mid; a.dt = dt; a.fmax_out = c->d_red; a.fc = c->coarse_first ? c->force_c : nullptr; a.cnt256 = cnt256; a.dry = dry ? 1 : 0;
+  if (dry) a.fmax_out = c->d_red + 7 * P3M_RED_SPAN;   // scratch slot: the step's maximum stays what it is
   P3M_TRY(kick_fused_launch(c, a, c->coarse_first));
-  if (c->np_all > 0) {
+  if (c->np_all > 0 && !dry) {
     TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
     const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256 / P3M_CAND_SLOTS);
     const dim3 gl((unsigned)std::min<int64_t>(64, cdiv(guess, 256)), P3M_CAND_SLOTS);
@@ -704,6 +705,17 @@ static int fine_xinv_kick_fused(p3m_ctx *c, float a_mid, float dt, int *cnt256) 
     HIP_TRY(hipGetLastError());
   }
   return P3M_OK;
+}
+
+// timing hook (p3m_hip_time_fft_pass, which = 7): the fused pass as the step runs it, over whatever LY rows `work` holds, without the
+// velocity stores and the fix-up (call after a whole step: sorted records, row tables, coarse force)
+int fine_time_fused_kick(p3m_ctx *c) {
+  if (!fine_kick_fusable(c) || c->np_all == 0) { p3m_set_error("the fused inverse-x + kick pass is not what this context runs (CIC, tile size, P3M_KICK_UNFUSED) or no sorted records"); return P3M_ESTATE; }
+  const bool cf = c->coarse_first;
+  c->coarse_first = coarse_kick_rides_on_fine(c);
+  const int r = fine_xinv_kick_fused(c, 0.5f, 0.0f, nullptr, true);
+  c->coarse_first = cf;
+  return r;
 }
 
 // CIC fine mesh: the maximum and the kick in one pass over the force box (k_fine_kick_cic)

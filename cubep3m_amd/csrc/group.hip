@@ -91,6 +91,7 @@ struct p3m_group {
   float *d_red4 = nullptr; double *d_sum3 = nullptr; float *h_red4 = nullptr; double *h_sum3 = nullptr;
   bool have_k = false;
   p3m_step_out last{};
+  PhaseTimer pt;               // per-phase times of the last step; every context of the group points here
 };
 
 struct XMsg { int src, dst; const void *sptr; void *rptr; size_t bytes; };
@@ -1165,6 +1166,22 @@ static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out, bool do
   return P3M_OK;
 }
 
+// per-phase GPU times of the last whole step of this process's ranks (timers.f90:68-77; the reference prints max / avg / min over ranks)
+extern "C" int p3m_hip_group_phase_timing(p3m_group *G, int32_t on) {
+  if (!G) return P3M_EINVAL;
+  if (G->nodes == 1) return p3m_hip_phase_timing(G->ctx[0], on);
+  G->pt.on = on != 0; G->pt.reset();
+  for (p3m_ctx *c : G->ctx) c->pt = &G->pt;
+  return P3M_OK;
+}
+extern "C" int p3m_hip_group_last_phase_ms(p3m_group *G, float *ms12) {
+  if (!G || !ms12) return P3M_EINVAL;
+  if (G->nodes == 1) return p3m_hip_last_phase_ms(G->ctx[0], ms12);
+  if (!G->pt.on) { p3m_set_error("p3m_hip_group_last_phase_ms: phase timing is off (p3m_hip_group_phase_timing)"); return P3M_ESTATE; }
+  for (int k = 0; k < P3M_NPHASE; k++) ms12[k] = G->pt.ms[k];
+  return P3M_OK;
+}
+
 extern "C" int p3m_hip_group_update_position(p3m_group *G, float dt, float dt_old, const float *offset) {
   if (!G) return P3M_EINVAL;
   P3M_TRY(need_particles(G->ctx[0], "p3m_hip_group_update_position"));
@@ -1190,27 +1207,29 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   if (G->nodes == 1) return p3m_hip_particle_mesh(G->ctx[0], a_mid, dt, dt_old, mass_p, offset, move_back, out);
   if (G->base.flags & P3M_FLAG_COARSE_ONLY) { p3m_set_error("particle_mesh on a P3M_FLAG_COARSE_ONLY group (it holds the coarse mesh only)"); return P3M_ESTATE; }
   for (p3m_ctx *c : G->ctx) if (!c->have_kf || !c->have_kc) { p3m_set_error("particle_mesh before the Green's functions were set"); return P3M_ESTATE; }
-  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset));                       // :56
-  P3M_TRY(ghost_pass(G));                                                                           // :61-63
-  for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); }   // every rank's sort queued ...
+  G->pt.reset();
+  { PhaseScope ps(&G->pt, P3M_PH_DRIFT, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset)); }                      // :56
+  { PhaseScope ps(&G->pt, P3M_PH_GHOST, G->stream); P3M_TRY(ghost_pass(G)); }                                                                          // :61-63
+  { PhaseScope ps(&G->pt, P3M_PH_SORT, G->stream); for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); } }   // every rank's sort queued ...
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort_finish(c, false));                                      // ... and nobody waits: the counters come in with the step's results
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
   // fine-mesh force sweeps (many small kernels and the all-to-all exchanges against bandwidth-bound FFT passes).  Its kick
   // is then applied inside the fine kick's pass (coarse_kick_rides_on_fine, p3m_api.hip).
   const bool ride = !G->ctx.empty() && coarse_kick_rides_on_fine(G->ctx[0]);
-  for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p));                                     // coarse_mass
+  { PhaseScope ps(&G->pt, P3M_PH_COARSE_DEPOSIT, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p)); }                          // coarse_mass
   if (G->stream2) {
     HIP_TRY(hipEventRecord(G->ev_dep, G->stream));
     for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p, false));                     // :72-204 of every tile, queued first
     HIP_TRY(hipStreamWaitEvent(G->stream2, G->ev_dep, 0));
     hipStream_t main = G->stream;
     G->stream = G->stream2; for (p3m_ctx *c : G->ctx) c->stream = G->stream2;
-    int r = coarse_force_dist(G);                                                                   // coarse_force, _buffer, max
+    int r;
+    { PhaseScope ps(&G->pt, P3M_PH_COARSE_FORCE, G->stream2); r = coarse_force_dist(G); }                                         // coarse_force, _buffer, max
     if (r == P3M_OK && hipEventRecord(G->ev_cf, G->stream2) != hipSuccess) r = P3M_EDEVICE;
     G->stream = main; for (p3m_ctx *c : G->ctx) c->stream = main;
     if (r != P3M_OK) { (void)hipStreamSynchronize(G->stream2); return r; }
   } else {
-    P3M_TRY(coarse_force_dist(G));
+    { PhaseScope ps(&G->pt, P3M_PH_COARSE_FORCE, G->stream); P3M_TRY(coarse_force_dist(G)); }
     for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p, false));
   }
   if (ride) {
@@ -1224,12 +1243,13 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   } else {
     for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_kick_phase(c, a_mid, dt, mass_p));                  // :208-628
     if (G->stream2) HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
-    for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt));                                   // coarse_velocity
+    { PhaseScope ps(&G->pt, P3M_PH_COARSE_KICK, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt)); }                          // coarse_velocity
   }
-  for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_enqueue(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));  // :716-720
+  { PhaseScope ps(&G->pt, P3M_PH_DELETE, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_enqueue(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr)); }  // :716-720
   // ONE host wait for everything the host reads back: survivor counts, the sort's counters, maxima and sums
   for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_download(c)); HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, c->g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream)); }
   HIP_TRY(hipStreamSynchronize(G->stream));
+  if (G->pt.on) { if (G->stream2) HIP_TRY(hipStreamSynchronize(G->stream2)); G->pt.collect(); }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_finish(c, false));
   p3m_step_out o;
   P3M_TRY(reduce_step_out(G, a_mid, &o, true));

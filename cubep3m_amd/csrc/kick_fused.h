@@ -16,6 +16,7 @@ struct KickFuseArgs {
   const float4 *spos; float4 *vel; const int *cs; const int *crow; int crow_w;
   float a_mid, dt; float *fmax_out; const float *fc; int *cnt256;
   unsigned m_fb;   // division magic of fb (set by the launcher)
+  int dry;         // timing hook (p3m_hip_time_fft_pass 7): everything but the velocity stores
 };
 
 struct p3m_ctx;

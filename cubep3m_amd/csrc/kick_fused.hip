@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
       if (!have_v) v = a.vel[vi];
       if (COARSE && !have_c) { cc = kf_coarse_cell(p, a); kf_coarse_gather(cf, cc.o0, a); }
       kf_kick<COARSE>(v, fx, fy, fz, cc, cf, a);
-      a.vel[vi] = v;
+      if (!a.dry) a.vel[vi] = v;
     }
   };
 

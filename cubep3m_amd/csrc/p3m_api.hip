@@ -161,6 +161,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   if (c->h_tile_ext) (void)hipHostFree(c->h_tile_ext);
   if (c->h_sums_raw) (void)hipHostFree(c->h_sums_raw);
   fft_plan_destroy(&c->plan_f); fft_plan_destroy(&c->plan_c);
+  if (c->own_pt) { delete c->pt; } c->pt = nullptr;
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
   if (c->ev_cf) (void)hipEventDestroy(c->ev_cf);
@@ -337,14 +338,15 @@ extern "C" int p3m_hip_link_list_and_pass(p3m_ctx *c) {
   return r;
 }
 
-static int fine_sweep(p3m_ctx *c, float mass_p) {
+static int fine_sweep(p3m_ctx *c, float mass_p, bool kick_follows) {
   const Geometry &g = c->g;
-  // NGP: the last pass of the force (inverse x) runs with the kick (kick_fused.hip); fine_max_and_kick picks it up
-  c->xinv_deferred = fine_kick_fusable(c);
+  // NGP, and the kick phase follows: the last pass of the force (inverse x) runs with the kick (kick_fused.hip); fine_max_and_kick picks
+  // it up.  (The timing hook p3m_hip_time_fine_sweep runs the stand-alone sweep: five launches and a force box.)
+  c->xinv_deferred = kick_follows && fine_kick_fusable(c);
   for (int t0 = 0; t0 < g.ntiles; t0 += c->tile_batch) {
     const int nt = std::min(c->tile_batch, g.ntiles - t0);
-    P3M_TRY(fine_deposit(c, t0, nt, mass_p, c->xinv_deferred));
-    P3M_TRY(fine_force(c, t0, nt, c->xinv_deferred));
+    { PhaseScope ps(c->pt, P3M_PH_FINE_DEPOSIT, c->stream); P3M_TRY(fine_deposit(c, t0, nt, mass_p, c->xinv_deferred)); }
+    { PhaseScope ps(c->pt, P3M_PH_FINE_FFT, c->stream); P3M_TRY(fine_force(c, t0, nt, c->xinv_deferred)); }
   }
   return P3M_OK;
 }
@@ -380,12 +382,13 @@ int fine_mesh_force_phase(p3m_ctx *c, float mass_p, bool may_clear) {
   P3M_TRY(need_kernels(c));
   if (may_clear && !c->rho_from_sort) P3M_TRY(reductions_clear(c));   // else cleared before the sort, which already added the NGP mass sum
   HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
-  return fine_sweep(c, mass_p);
+  return fine_sweep(c, mass_p, true);
 }
 int fine_mesh_kick_phase(p3m_ctx *c, float a_mid, float dt, float mass_p) {
-  P3M_TRY(fine_max_and_kick(c, a_mid, dt));
-  if ((c->p.flags & P3M_FLAG_PPINT) && (c->p.flags & P3M_FLAG_NGP)) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
-  if (c->p.flags & P3M_FLAG_PP_EXT) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
+  // (NGP whole steps: the inverse x pass of the force runs inside the kick, kick_fused.hip -- it is timed with the kick)
+  { PhaseScope ps(c->pt, P3M_PH_FINE_KICK, c->stream); P3M_TRY(fine_max_and_kick(c, a_mid, dt)); }
+  if ((c->p.flags & P3M_FLAG_PPINT) && (c->p.flags & P3M_FLAG_NGP)) { PhaseScope ps(c->pt, P3M_PH_PP_INTRA, c->stream); P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); }
+  if (c->p.flags & P3M_FLAG_PP_EXT) { PhaseScope ps(c->pt, P3M_PH_PP_EXT, c->stream); P3M_TRY(pp_extended(c, a_mid, dt, mass_p)); }
   return P3M_OK;
 }
 extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {
@@ -438,6 +441,20 @@ extern "C" int p3m_hip_projection(p3m_ctx *c, float mass_p, float *pxy, float *p
              hipMemcpy(pyz, d + 2 * n2, n2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) { p3m_set_error("projection: download failed"); r = P3M_EDEVICE; }
   (void)hipFree(d);
   return r;
+}
+
+// per-phase GPU times of the last whole step (timers.f90:68-77 prints such a table under -DMPI_TIME)
+extern "C" int p3m_hip_phase_timing(p3m_ctx *c, int32_t on) {
+  if (!c) return P3M_EINVAL;
+  if (!c->pt) { c->pt = new PhaseTimer(); c->own_pt = true; }
+  c->pt->on = on != 0; c->pt->reset();
+  return P3M_OK;
+}
+extern "C" int p3m_hip_last_phase_ms(p3m_ctx *c, float *ms12) {
+  if (!c || !ms12) return P3M_EINVAL;
+  if (!c->pt || !c->pt->on) { p3m_set_error("p3m_hip_last_phase_ms: phase timing is off (p3m_hip_phase_timing)"); return P3M_ESTATE; }
+  for (int k = 0; k < P3M_NPHASE; k++) ms12[k] = c->pt->ms[k];
+  return P3M_OK;
 }
 
 extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) {
@@ -502,29 +519,31 @@ static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, f
   P3M_TRY(need_kernels(c));
   // every parameter / state check comes before the first state change (the drift)
   if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }
-  P3M_TRY(p3m_hip_update_position(c, dt, dt_old, offset));   // :56
+  if (c->pt) c->pt->reset();
+  { PhaseScope ps(c->pt, P3M_PH_DRIFT, c->stream); P3M_TRY(p3m_hip_update_position(c, dt, dt_old, offset)); }   // :56
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(reductions_clear(c));
-  P3M_TRY(particles_pass_self(c));                           // :61-63
-  P3M_TRY(particles_sort_enqueue(c, mass_p));
+  { PhaseScope ps(c->pt, P3M_PH_GHOST, c->stream); P3M_TRY(particles_pass_self(c)); }                           // :61-63
+  { PhaseScope ps(c->pt, P3M_PH_SORT, c->stream); P3M_TRY(particles_sort_enqueue(c, mass_p)); }
   P3M_TRY(particles_sort_finish(c, false));                  // no host wait: the sort's counters come in with the step's results
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
   // fine-mesh force sweep.  Its kick is then applied inside the fine kick's pass
   // (coarse_kick_rides_on_fine).
   const bool ride = coarse_kick_rides_on_fine(c);
-  P3M_TRY(coarse_deposit(c, mass_p));                        // coarse_mass
+  { PhaseScope ps(c->pt, P3M_PH_COARSE_DEPOSIT, c->stream); P3M_TRY(coarse_deposit(c, mass_p)); }   // coarse_mass
   if (c->stream2) {
     HIP_TRY(hipEventRecord(c->ev_dep, c->stream));
     P3M_TRY(fine_mesh_force_phase(c, mass_p, false));        // :72-204 of every tile, queued first
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_dep, 0));
     hipStream_t main = c->stream;
     c->stream = c->stream2;
-    int r = coarse_force(c);                                 // coarse_force, _buffer, max
+    int r;
+    { PhaseScope ps(c->pt, P3M_PH_COARSE_FORCE, c->stream2); r = coarse_force(c); }   // coarse_force, _buffer, max
     if (r == P3M_OK && hipEventRecord(c->ev_cf, c->stream2) != hipSuccess) r = P3M_EDEVICE;
     c->stream = main;
     if (r != P3M_OK) { (void)hipStreamSynchronize(c->stream2); return r; }
   } else {
-    P3M_TRY(coarse_force(c));
+    { PhaseScope ps(c->pt, P3M_PH_COARSE_FORCE, c->stream); P3M_TRY(coarse_force(c)); }
     P3M_TRY(fine_mesh_force_phase(c, mass_p, false));
   }
   if (ride) {
@@ -536,12 +555,13 @@ static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, f
   } else {
     P3M_TRY(fine_mesh_kick_phase(c, a_mid, dt, mass_p));     // :208-628
     if (c->stream2) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_cf, 0));
-    P3M_TRY(coarse_kick(c, a_mid, dt));                      // coarse_velocity (coarse_vel_update = .true., cubepm.par:87)
+    { PhaseScope ps(c->pt, P3M_PH_COARSE_KICK, c->stream); P3M_TRY(coarse_kick(c, a_mid, dt)); }   // coarse_velocity (coarse_vel_update = .true., cubepm.par:87)
   }
   // :716-720; the survivor count, the sort's counters and the step's maxima and sums reach the host behind ONE wait
-  P3M_TRY(particles_finalize_enqueue(c, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr));
+  { PhaseScope ps(c->pt, P3M_PH_DELETE, c->stream); P3M_TRY(particles_finalize_enqueue(c, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr)); }
   p3m_step_out o;
   P3M_TRY(p3m_hip_get_step_out(c, a_mid, &o));               // :643-706 (synchronises the stream)
+  if (c->pt && c->pt->on) { if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2)); c->pt->collect(); }
   if (out) *out = o;
   return P3M_OK;
 }
@@ -634,9 +654,9 @@ extern "C" int p3m_hip_time_fine_sweep(p3m_ctx *c, float mass_p, int32_t reps, f
   P3M_TRY(need_kernels(c));
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-  P3M_TRY(fine_sweep(c, mass_p));  // warm-up
+  P3M_TRY(fine_sweep(c, mass_p, false));  // warm-up
   HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < reps; i++) P3M_TRY(fine_sweep(c, mass_p));
+  for (int i = 0; i < reps; i++) P3M_TRY(fine_sweep(c, mass_p, false));
   HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -686,9 +706,10 @@ extern "C" int p3m_hip_time_fft_pass(p3m_ctx *c, int32_t which, int32_t reps, fl
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   const int64_t bcs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
-  P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2, bcs));  // warm-up
+  auto one = [&]() { return which == 7 ? fine_time_fused_kick(c) : fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2, bcs); };
+  P3M_TRY(one());  // warm-up
   HIP_TRY(hipEventRecord(e0, c->stream));
-  for (int i = 0; i < reps; i++) P3M_TRY(fft_single_pass(c, c->plan_f, which, c->rho, c->work, c->kern_f, nt, c->fbox, g.fb, g.nb - 2, bcs));
+  for (int i = 0; i < reps; i++) P3M_TRY(one());
   HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));

@@ -49,6 +49,42 @@ __device__ __forceinline__ int rec_index(const float4 &p) { return __float_as_in
 __device__ __forceinline__ float4 with_index(float x, float y, float z, int i) { return make_float4(x, y, z, __int_as_float(i)); }
 #endif
 
+// ------------------------------------------------------------------ per-phase GPU times of a step (timers.f90:68-77, -DMPI_TIME)
+// Off by default (p3m_hip_phase_timing / p3m_hip_group_phase_timing): a span is a pair of timing events on the stream the phase is
+// queued on; after the step's last synchronisation the spans are folded into one figure per phase.  The coarse transform runs on the
+// second stream underneath the fine mesh: its span overlaps the others'.
+enum { P3M_PH_DRIFT = 0, P3M_PH_SORT, P3M_PH_GHOST, P3M_PH_FINE_DEPOSIT, P3M_PH_FINE_FFT, P3M_PH_FINE_KICK, P3M_PH_PP_INTRA, P3M_PH_PP_EXT,
+       P3M_PH_COARSE_DEPOSIT, P3M_PH_COARSE_FORCE, P3M_PH_COARSE_KICK, P3M_PH_DELETE, P3M_NPHASE };
+struct PhaseTimer {
+  bool on = false;
+  std::vector<hipEvent_t> pool; size_t used = 0;
+  struct Span { int phase; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  float ms[P3M_NPHASE] = {0};
+  hipEvent_t take() {
+    if (used == pool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+    return pool[used++];
+  }
+  void reset() { used = 0; spans.clear(); }
+  void collect() {   // after a stream synchronisation that covers every span
+    for (float &m : ms) m = 0.f;
+    for (const Span &s : spans) { float t = 0.f; if (s.a && s.b && hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) ms[s.phase] += t; }
+    reset();
+  }
+  ~PhaseTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+struct PhaseScope {   // one span: constructor and destructor record on `stream`
+  PhaseTimer *t; hipStream_t s; int idx = -1;
+  PhaseScope(PhaseTimer *timer, int phase, hipStream_t stream) : t(timer && timer->on ? timer : nullptr), s(stream) {
+    if (!t) return;
+    hipEvent_t a = t->take(), b = t->take();
+    if (!a || !b) { t = nullptr; return; }
+    (void)hipEventRecord(a, s);
+    idx = (int)t->spans.size(); t->spans.push_back({phase, a, b});
+  }
+  ~PhaseScope() { if (t) (void)hipEventRecord(t->spans[idx].b, s); }
+};
+
 // ------------------------------------------------------------------ FFT plan (fft.hip)
 struct FftPlan {
   int n = 0;               // real transform length per axis
@@ -163,6 +199,7 @@ struct p3m_ctx {
   p3m_step_out last{};
   int np_ghost = 0, np_deleted = 0;
   // ---- transport
+  PhaseTimer *pt = nullptr; bool own_pt = false;   // per-phase times (a group's contexts share the group's timer)
   p3m_transport transport{}; bool have_transport = false;   // unused: exchanges belong to the group (group.hip)
   void *rccl_comm = nullptr;
 };
@@ -211,6 +248,7 @@ int particles_resolve(p3m_ctx *c);   // finish a deferred ghost removal before t
 // ---- fine_mesh.hip
 int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p, bool fuse = false);   // fuse: flag the box rows the fused kick must also store
 int fine_force(p3m_ctx *c, int tile0, int ntile, bool defer_x = false);                // defer_x: stop after the inverse y pass (the x pass runs with the kick)
+int fine_time_fused_kick(p3m_ctx *c);   // timing hook: the fused inverse-x + kick pass, dry
 bool fine_kick_fusable(const p3m_ctx *c);                                               // fine_mesh.hip: this context's whole steps run the fused inverse-x + kick pass
 int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt, bool count_survivors = true);   // false: timing hook (leaves c->flags and cnt_from_kick alone)
 int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float *d_pyz);   // projection.f90: adds this rank's tiles to the device maps

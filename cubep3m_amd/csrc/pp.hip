@@ -339,9 +339,8 @@ __device__ __forceinline__ void pp_ext_eval2(const float4 &p, const float4 &A, c
 // the half width are multiples of 1/2: exact), one fused multiply-add with the clamp modifier and one add per partner; the two
 // cuts on r^2 are factors of the same kind (pp_force_constants).  All operands sit in vector registers; no compare, no select,
 // no scalar-register operand (4.3 cycles of a SIMD's issue each against 2.6 for plain vector arithmetic: tools/valubench.hip):
-// 26 vector instructions per partner.  OWN: some lane's own cell lies in this stretch (a masked partner may be the home record
-// itself: r = 0, so the reciprocal square root is taken of max(r^2, tiny) and every factor stays finite)
-struct PPSweepK { float c1, K, K34, K74, big_s, nrp_big, nbig_t, r2t_big; };
+// 26-27 vector instructions per partner.  OWN: some lane's own cell lies in this stretch (its partners are masked: :515-516)
+struct PPSweepK { float c1, K, K34, K74, big_s, nrp_big, nbig_t, r2t_big, tiny; };
 template <bool OWN, bool TAPER_ALL>
 __device__ __forceinline__ void pp_sweep_row(const float4 *pr, int ua, int ub, float hx, float hy, float hz, float d, float k4, float dO, float k4o,
                                              const PPSweepK &S, float &ax, float &ay, float &az) {
@@ -357,7 +356,12 @@ __device__ __forceinline__ void pp_sweep_row(const float4 *pr, int ua, int ub, f
     }
     const float sx = hx - o.x, sy = hy - o.y, sz = hz - o.z;               // :551
     const float r2 = sx * sx + sy * sy + sz * sz;                           // the reference's order, unfused: the cut is decided on it
-    const float r2c = OWN ? __builtin_fmaxf(r2, 1.0e-20f) : r2;
+    // r = 0 (the home record itself, or two records on one point): the reciprocal square root is taken of max(r^2, 1e-12) -- far
+    // below r_soft^2 -- so that ir^3 stays near 1e18 and the cut factors below multiply a FINITE value by zero.  In BOTH templates: a
+    // heavy rim record's own row can be swept for another lane of its group without that lane's window test ever holding the own
+    // cell (the non-OWN template then met r = 0: inf * 0 = NaN in the partial sum, dropped silently from the tile maximum)
+    float r2c;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r2c) : "v"(r2), "v"(S.tiny));
     const float ir = __builtin_amdgcn_rsqf(r2c), qq = (r2c * ir) * S.c1;
     const float q2 = qq * qq;
     float q3 = q2 * qq;
@@ -874,10 +878,10 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
       hj[k] = (unsigned char)j;
     }
     const int ngrp = (Hn + 63) >> 6;                  // uniform, <= NW
-    PPSweepK SK{F.c1, F.K, F.K34, F.K74, F.big_s, F.nrp_big, F.nbig_t, F.r2t_big};
+    PPSweepK SK{F.c1, F.K, F.K34, F.K74, F.big_s, F.nrp_big, F.nbig_t, F.r2t_big, 1.0e-12f};
     // the constants of the swept evaluation in VECTOR registers: an instruction with a scalar-register operand costs 4.3 cycles of
     // a SIMD's issue against 2.6 (tools/valubench.hip, profiles/r04_valubench.txt)
-    asm volatile("" : "+v"(SK.c1), "+v"(SK.K), "+v"(SK.K34), "+v"(SK.K74), "+v"(SK.big_s), "+v"(SK.nrp_big), "+v"(SK.nbig_t), "+v"(SK.r2t_big));
+    asm volatile("" : "+v"(SK.c1), "+v"(SK.K), "+v"(SK.K34), "+v"(SK.K74), "+v"(SK.big_s), "+v"(SK.nrp_big), "+v"(SK.nbig_t), "+v"(SK.r2t_big), "+v"(SK.tiny));
     float acc[NW][3];
 #pragma unroll
     for (int gi = 0; gi < NW; gi++) { acc[gi][0] = 0.f; acc[gi][1] = 0.f; acc[gi][2] = 0.f; }

@@ -69,6 +69,16 @@ subroutine particle_mesh
       real(c_float), intent(in) :: offset(3), move_back(3)
       type(p3m_step_out), intent(out) :: sout
     end function
+    integer(c_int) function p3m_hip_phase_timing(ctx, on) bind(C, name="p3m_hip_phase_timing")
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int32_t), value :: on
+    end function
+    integer(c_int) function p3m_hip_last_phase_ms(ctx, ms12) bind(C, name="p3m_hip_last_phase_ms")
+      import :: c_int, c_float, c_ptr
+      type(c_ptr), value :: ctx
+      real(c_float), intent(out) :: ms12(12)
+    end function
     function p3m_hip_last_error() bind(C, name="p3m_hip_last_error") result(msg)
       import :: c_ptr
       type(c_ptr) :: msg
@@ -86,6 +96,12 @@ subroutine particle_mesh
   real(c_float) :: offset(3), fine_tab(3, 16, 16, 16), coarse_tab(3, 4, 4, 4), rt(3)
   integer(c_int32_t) :: np_c
   integer :: ierr_c, i, j, k, temp(3), fstat
+#ifdef MPI_TIME
+  real(c_float) :: phase_ms(12)
+  ! the reference's tags (timers.f90:68-77) where a phase has one, in the order of p3m_hip_last_phase_ms
+  character(len=8), parameter :: phase_tag(12) = (/ 'pos updt', 'linklist', 'par pass', 'fm  mass', 'fm   fft', 'fm  kick', 'pp intra', &
+                                                    'pp   ext', 'cm  mass', 'cm force', 'cm   vel', 'del part' /)
+#endif
 
   if (.not. c_associated(ctx)) then
     if (nodes_dim /= 1) stop 'particle_mesh_hip.f90: single-rank adapter (pass a p3m_transport for nodes_dim > 1)'
@@ -140,6 +156,9 @@ subroutine particle_mesh
     close(11)
     ierr_c = p3m_hip_set_kernel_tables(ctx, fine_tab, coarse_tab)
     if (ierr_c /= 0) stop 'p3m_hip_set_kernel_tables failed'
+#ifdef MPI_TIME
+    ierr_c = p3m_hip_phase_timing(ctx, 1_c_int32_t)       ! per-phase GPU times of every step (printed below)
+#endif
   endif
 
   offset = 0.0
@@ -174,6 +193,14 @@ subroutine particle_mesh
 #endif
 #ifdef MOVE_GRID_BACK
   shake_offset = 0.0
+#endif
+#ifdef MPI_TIME
+  ! what the reference prints phase by phase under -DMPI_TIME, in seconds (timers.f90:68-77; one rank: max = avg = min)
+  if (p3m_hip_last_phase_ms(ctx, phase_ms) == 0) then
+    do i = 1, 12
+      call mpi_time_analyze(phase_tag(i), real(phase_ms(i)) * 1.0e-3, rank, nodes)
+    enddo
+  endif
 #endif
 #ifdef DIAG
   if (rank == 0) write(*,*) 'sum of rho_f=', sout%sum_rho_f

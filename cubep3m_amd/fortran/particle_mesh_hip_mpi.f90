@@ -115,6 +115,16 @@ subroutine particle_mesh
       type(c_ptr), value :: g
       real(c_float), intent(in) :: fine(*), coarse(*)
     end function
+    integer(c_int) function p3m_hip_group_phase_timing(g, on) bind(C, name="p3m_hip_group_phase_timing")
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: g
+      integer(c_int32_t), value :: on
+    end function
+    integer(c_int) function p3m_hip_group_last_phase_ms(g, ms12) bind(C, name="p3m_hip_group_last_phase_ms")
+      import :: c_int, c_float, c_ptr
+      type(c_ptr), value :: g
+      real(c_float), intent(out) :: ms12(12)
+    end function
     integer(c_int) function p3m_hip_group_upload_particles(g, i, xv6, pid, n) bind(C, name="p3m_hip_group_upload_particles")
       import :: c_int, c_ptr, c_float, c_int64_t, c_int32_t
       type(c_ptr), value :: g
@@ -156,6 +166,13 @@ subroutine particle_mesh
   integer(c_int8_t) :: nccl_id(128)
   character(len=8) :: trv
   integer :: trl
+#ifdef MPI_TIME
+  real(c_float) :: phase_ms(12)
+  ! the reference's tags (timers.f90:68-77; link_list.f90:143, particle_pass.f90:767, coarse_mesh.f90, delete_particles.f90) where a phase has
+  ! one, in the order of p3m_hip_group_last_phase_ms
+  character(len=8), parameter :: phase_tag(12) = (/ 'pos updt', 'linklist', 'par pass', 'fm  mass', 'fm   fft', 'fm  kick', 'pp intra', &
+                                                    'pp   ext', 'cm  mass', 'cm force', 'cm   vel', 'del part' /)
+#endif
 
   if (.not. c_associated(grp)) then
     par%nodes_dim = nodes_dim; par%tiles_node_dim = tiles_node_dim; par%nf_tile = nf_tile
@@ -214,12 +231,18 @@ subroutine particle_mesh
       if (rank == 0) then
         if (p3m_hip_rccl_unique_id(nccl_id) /= 0) failed = 1
       endif
+      ! everybody learns whether rank 0 got an id BEFORE anybody enters ncclCommInitRank (an all-zero id would show up as a hang there)
+      call mpi_bcast(failed, 1, mpi_integer, 0, mpi_comm_world, ierr)
+      if (failed /= 0) then
+        if (rank == 0) write(*,*) 'particle_mesh (HIP): no RCCL id (P3M_HIP_TRANSPORT=mpi selects the MPI transport)'
+        call mpi_abort(mpi_comm_world, 1, ierr)
+      endif
       call mpi_bcast(nccl_id, 128, mpi_byte, 0, mpi_comm_world, ierr)
       if (p3m_hip_group_comm_init_rccl(grp, nccl_id, 0_c_int32_t) /= 0) failed = 1
       call mpi_allreduce(failed, any_failed, 1, mpi_integer, mpi_max, mpi_comm_world, ierr)
       if (any_failed /= 0) then
         if (rank == 0) write(*,*) 'particle_mesh (HIP): the RCCL communicator could not be set up (P3M_HIP_TRANSPORT=mpi selects the MPI transport)'
-        call mpi_abort(mpi_comm_world, ierr, ierr)
+        call mpi_abort(mpi_comm_world, 1, ierr)
       endif
       if (rank == 0) write(*,*) 'particle_mesh (HIP): exchanges over RCCL,', nodes, 'ranks,', ndev, 'GPUs per node'
     else
@@ -255,6 +278,9 @@ subroutine particle_mesh
     close(11)
     ierr_c = p3m_hip_group_set_kernel_tables(grp, fine_tab, coarse_tab)      ! collective: builds the distributed coarse kernel
     if (ierr_c /= 0) stop 'p3m_hip_group_set_kernel_tables failed'
+#ifdef MPI_TIME
+    ierr_c = p3m_hip_group_phase_timing(grp, 1_c_int32_t)                    ! per-phase GPU times of every step (printed below)
+#endif
   endif
 
   offset = 0.0
@@ -280,7 +306,7 @@ subroutine particle_mesh
   if (ierr_c == 0 .and. host_reads) ierr_c = p3m_hip_group_download_particles(grp, 0_c_int32_t, xv, PID, np_c)
   if (ierr_c /= 0) then
     write(*,*) 'particle_mesh (HIP) failed with code', ierr_c, ' on rank', rank
-    call mpi_abort(mpi_comm_world, ierr, ierr)
+    call mpi_abort(mpi_comm_world, 1, ierr)
   endif
   device_current = .not. host_reads
   np_local = np_c
@@ -293,6 +319,14 @@ subroutine particle_mesh
 #endif
 #ifdef MOVE_GRID_BACK
   shake_offset = 0.0
+#endif
+#ifdef MPI_TIME
+  ! what the reference prints phase by phase under -DMPI_TIME: "tag : max avg min" over the ranks, in seconds (timers.f90:68-77)
+  if (p3m_hip_group_last_phase_ms(grp, phase_ms) == 0) then
+    do i = 1, 12
+      call mpi_time_analyze(phase_tag(i), real(phase_ms(i)) * 1.0e-3, rank, nodes)
+    enddo
+  endif
 #endif
 #ifdef DIAG
   if (rank == 0) write(*,*) 'sum of rho_f=', sout%sum_rho_f

@@ -208,6 +208,18 @@ class ParticleMeshGroup:
                                                       None if pm is None else pm.ctypes.data_as(C.c_void_p), C.byref(o)))
         return o
 
+    PHASES = ("update_position", "link_list", "particle_pass", "fine_mass", "fine_fft", "fine_kick", "pp_intra", "pp_ext",
+              "coarse_mass", "coarse_force", "coarse_velocity", "delete_particles")
+
+    def phase_timing(self, on=True):
+        """per-phase GPU times of the following steps (timers.f90:68-77, -DMPI_TIME)"""
+        _lib.check(self.L.p3m_hip_group_phase_timing(self.h, 1 if on else 0))
+
+    def last_phase_ms(self):
+        ms = np.zeros(12, np.float32)
+        _lib.check(self.L.p3m_hip_group_last_phase_ms(self.h, ms))
+        return dict(zip(self.PHASES, (float(v) for v in ms)))
+
     def update_position(self, dt, dt_old, offset=None):
         po = None if offset is None else np.ascontiguousarray(offset, np.float32)
         _lib.check(self.L.p3m_hip_group_update_position(self.h, dt, dt_old, None if po is None else po.ctypes.data_as(C.c_void_p)))

@@ -29,7 +29,7 @@ EXPORTS = [
     "p3m_hip_group_create", "p3m_hip_group_destroy", "p3m_hip_group_comm_init_rccl", "p3m_hip_group_set_transport", "p3m_hip_expansion", "p3m_hip_timestep", "p3m_hip_write_checkpoint", "p3m_hip_read_checkpoint", "p3m_hip_write_pid_checkpoint",
     "p3m_hip_read_pid_checkpoint", "p3m_hip_write_ic", "p3m_hip_read_ic", "p3m_hip_group_nlocal", "p3m_hip_group_local_rank",
     "p3m_hip_group_ctx", "p3m_hip_group_set_kernel_tables", "p3m_hip_group_upload_particles", "p3m_hip_group_download_particles",
-    "p3m_hip_group_particle_mesh", "p3m_hip_group_update_position", "p3m_hip_group_probe_coarse",
+    "p3m_hip_group_particle_mesh", "p3m_hip_group_update_position", "p3m_hip_phase_timing", "p3m_hip_last_phase_ms", "p3m_hip_group_phase_timing", "p3m_hip_group_last_phase_ms", "p3m_hip_group_probe_coarse",
     "p3m_hip_group_set_coarse_density", "p3m_hip_group_coarse_transform", "p3m_hip_group_get_coarse_hat", "p3m_hip_group_get_coarse_force",
     "p3m_hip_group_coarse_exchange_bytes", "p3m_hip_group_comm_info", "p3m_hip_group_set_kernels_raw",
     "p3m_hip_projection", "p3m_hip_group_projection", "p3m_hip_coarse_power", "p3m_hip_group_coarse_power", "p3m_hip_coarse_fft_schedule", "p3m_hip_write_power", "p3m_hip_write_projection", "p3m_hip_read_projection",
@@ -124,6 +124,10 @@ def load():
     L.p3m_hip_group_get_coarse_force.argtypes = [vp, i32, vp]
     L.p3m_hip_group_coarse_exchange_bytes.argtypes = [vp]
     L.p3m_hip_group_coarse_exchange_bytes.restype = C.c_int64
+    L.p3m_hip_phase_timing.argtypes = [vp, i32]
+    L.p3m_hip_last_phase_ms.argtypes = [vp, f32p]
+    L.p3m_hip_group_phase_timing.argtypes = [vp, i32]
+    L.p3m_hip_group_last_phase_ms.argtypes = [vp, f32p]
     L.p3m_hip_stream.argtypes = [vp]
     L.p3m_hip_stream.restype = vp
     _lib = L

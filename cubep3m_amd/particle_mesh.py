@@ -108,6 +108,18 @@ class ParticleMesh:
         self.last = o
         return o
 
+    PHASES = ("update_position", "link_list", "particle_pass", "fine_mass", "fine_fft", "fine_kick", "pp_intra", "pp_ext",
+              "coarse_mass", "coarse_force", "coarse_velocity", "delete_particles")
+
+    def phase_timing(self, on=True):
+        """per-phase GPU times of the following steps (timers.f90:68-77, -DMPI_TIME)"""
+        _lib.check(self.L.p3m_hip_phase_timing(self.h, 1 if on else 0))
+
+    def last_phase_ms(self):
+        ms = np.zeros(12, np.float32)
+        _lib.check(self.L.p3m_hip_last_phase_ms(self.h, ms))
+        return dict(zip(self.PHASES, (float(v) for v in ms)))
+
     # -- phases, in the order particle_mesh calls them ---------------------------------------
     def update_position(self, dt, dt_old, offset=None):
         po, _a = _vec3(offset)
@@ -191,7 +203,7 @@ class ParticleMesh:
         _lib.check(self.L.p3m_hip_time_pp(self.h, a_mid, dt, mass_p, reps, C.byref(a), C.byref(b), C.byref(na), C.byref(nb)))
         return a.value, b.value, na.value, nb.value
 
-    FFT_PASSES = ("x_fwd", "y_fwd", "z_fwd", "z_inv_fused", "y_inv", "x_inv_extract", "z_inv_multiply")
+    FFT_PASSES = ("x_fwd", "y_fwd", "z_fwd", "z_inv_fused", "y_inv", "x_inv_extract", "z_inv_multiply")   # 7: "x_inv_kick_fused" (after a whole NGP step)
 
     def time_fft_pass(self, which, reps=20):
         """Average ms per launch of one FFT pass kernel over the tile batch (HIP events on the library stream)."""

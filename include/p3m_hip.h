@@ -213,13 +213,27 @@ int p3m_hip_time_fine_gather(p3m_ctx *ctx, int32_t reps, float *ms_per_pass);
    which: 0 x-forward (r2c rows), 1 y-forward lines, 2 z-forward lines, 3 z-inverse lines fused with
    the i*K multiply, 4 y-inverse lines, 5 x-inverse (c2r rows) + force-box extraction, 6 the multiply +
    inverse z pass on its own (the second launch of the un-fused z pair that tiles longer than 608 cells and
-   P3M_Z_UNFUSED=1 run instead of 3: 2 then 6).  *batch returns the number of tiles one launch processed. */
+   P3M_Z_UNFUSED=1 run instead of 3: 2 then 6), 7 the inverse x pass with the NGP kick inside (kick_fused.hip: what NGP whole steps
+   run instead of 5 and the kick; call after a whole step; the velocities are not stored).  *batch returns the number of tiles one
+   launch processed. */
 int p3m_hip_time_fft_pass(p3m_ctx *ctx, int32_t which, int32_t reps, float *ms_per_launch, int32_t *batch);
 /* Benchmark hook for the two PP kernels (particle_mesh_threaded.f90:324-361 and :378-624) on the sorted records with ghosts
    (call p3m_hip_link_list_and_pass first; velocities are kicked `reps`+1 times): average ms per launch and the number of
    pair evaluations one launch performs (a pair of two kicked records counts twice: each member sums over its partners). */
 int p3m_hip_time_pp(p3m_ctx *ctx, float a_mid, float dt, float mass_p, int32_t reps, float *ms_intra, float *ms_ext, int64_t *evals_intra,
                     int64_t *evals_ext);
+/* Per-phase GPU times of the last whole step -- what a reference host built with -DMPI_TIME prints (timers.f90:68-77; call sites
+   link_list.f90:138-143, particle_pass.f90:762-767, coarse_mesh.f90; test.log:80-94).  Off by default (two timing events per span);
+   `on` != 0 enables it for the following steps.  ms12, in milliseconds of GPU time between the phase's first and last kernel on its stream:
+     0 update_position (+ the copy of the previous step's delete_particles, which rides on it)   1 link_list (the cell sort)
+     2 particle_pass   3 fine mass assignment   4 fine FFT + multiply + inverse (NGP whole steps: up to the inverse y pass)
+     5 fine force maximum + kick (NGP whole steps: with the inverse x pass inside)   6 PP intra-cell   7 PP extended
+     8 coarse_mass   9 coarse_force (+ buffer, max; on the second stream, underneath 3-4)   10 coarse_velocity (0 when it rides on 5)
+     11 delete_particles (count + scan; the copy is deferred into the next step's phase 0)
+   A group reports the spans of ITS ranks (the host reduces max / avg / min over processes as timers.f90 does). */
+#define P3M_NPHASES 12
+int p3m_hip_phase_timing(p3m_ctx *ctx, int32_t on);
+int p3m_hip_last_phase_ms(p3m_ctx *ctx, float *ms12);
 /* HIP stream the kernels are launched on (for hipEvent timing by the host). */
 void *p3m_hip_stream(p3m_ctx *ctx);
 
@@ -308,6 +322,9 @@ int p3m_hip_group_download_particles(p3m_group *g, int32_t i, float *xv6, int64_
 /* `particle_mesh` on all ranks; `out` holds the global dt limits and DIAG sums (identical on every process) */
 /* update_position.f90 on every local rank (the output-step half drift of cubepm.f90:196-198 uses it with dt_old = 0) */
 int p3m_hip_group_update_position(p3m_group *g, float dt, float dt_old, const float *offset);
+/* p3m_hip_phase_timing / p3m_hip_last_phase_ms for the ranks of this process */
+int p3m_hip_group_phase_timing(p3m_group *g, int32_t on);
+int p3m_hip_group_last_phase_ms(p3m_group *g, float *ms12);
 int p3m_hip_group_particle_mesh(p3m_group *g, float a_mid, float dt, float dt_old, float mass_p,
                                 const float *offset, const float *move_back, p3m_step_out *out);
 int p3m_hip_group_probe_coarse(p3m_group *g, float mass_p, int32_t i, float *rho_c, float *force_c);

@@ -59,9 +59,12 @@ PAR
   # an MPI host in the reference's language around the HIP library: the drop-in adapter + the reference's own
   # mpi_initialization.o + COMMON blocks (multi-rank builds only; needs libp3m_hip.so at run time)
   if [ "$nd" -gt 1 ] && [ -f "$HERE/../cubep3m_amd/libp3m_hip.so" ]; then
-    $FC $FFLAGS -DPID_FLAG -J "$D" -c "$HERE/../cubep3m_amd/fortran/particle_mesh_hip_mpi.f90" -o "$D/particle_mesh_hip_mpi.o" 2> "$D/adapter.log" || { cat "$D/adapter.log"; exit 1; }
+    # the adapter with -DMPI_TIME (the reference's per-phase report, timers.f90:68-77: mpi_time_analyze comes from the reference's own
+    # timers.f90, compiled where it lies; the reference's objects themselves stay without the flag)
+    $FC $FFLAGS -DPID_FLAG -DMPI_TIME -J "$D" -c "$HERE/../cubep3m_amd/fortran/particle_mesh_hip_mpi.f90" -o "$D/particle_mesh_hip_mpi.o" 2> "$D/adapter.log" || { cat "$D/adapter.log"; exit 1; }
+    $FC $FFLAGS -c "$REF/timers.f90" -o "$D/timers.o" 2> "$D/timers.log" || { cat "$D/timers.log"; exit 1; }
     $FC $FFLAGS -c "$HERE/hip_mpi_driver.f90" -o "$D/hip_mpi_driver.o"
-    $FC -fopenmp -o "$D/hip_mpi_driver" "$D/hip_mpi_driver.o" "$D/particle_mesh_hip_mpi.o" "$D/mpi_initialization.o" \
+    $FC -fopenmp -o "$D/hip_mpi_driver" "$D/hip_mpi_driver.o" "$D/particle_mesh_hip_mpi.o" "$D/mpi_initialization.o" "$D/timers.o" \
         -L"$HERE/../cubep3m_amd" -lp3m_hip -Wl,-rpath,'$ORIGIN/../../../cubep3m_amd' -L$MPI_LIB -Wl,-rpath,$MPI_LIB -lmpifort -lmpi
     echo "built $D/hip_mpi_driver"
   fi

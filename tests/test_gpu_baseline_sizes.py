@@ -193,4 +193,25 @@ def test_config4_full_eight_rank_step_properties():
     assert o1.dt_c_acc == pytest.approx(ref[4], rel=1e-5), (o1.dt_c_acc, ref[4])
     assert o2.dt_f_acc == pytest.approx(ref[0], rel=1e-5), (o2.dt_f_acc, ref[0])      # (step 2 starts from step 1's kicks)
     assert o2.dt_c_acc == pytest.approx(ref[1], rel=1e-5), (o2.dt_c_acc, ref[1])
+    # per-phase GPU times through the C ABI (timers.f90:68-77 prints such a table under -DMPI_TIME): a third step with the timers on
+    import time
+
+    import torch
+
+    g.phase_timing(True)
+    g.particle_mesh(0.5, 0.05, 0.05, mass_p)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.particle_mesh(0.5, 0.05, 0.05, mass_p)
+    torch.cuda.synchronize()
+    wall = 1e3 * (time.perf_counter() - t0)
+    ms = g.last_phase_ms()
+    assert len(ms) == 12 and all(v >= 0.0 for v in ms.values()), ms
+    ran = ("update_position", "link_list", "particle_pass", "fine_mass", "fine_fft", "fine_kick", "coarse_mass", "coarse_force", "delete_particles")
+    assert all(ms[k] > 0.0 for k in ran), ms
+    assert ms["pp_intra"] == 0.0 and ms["pp_ext"] == 0.0 and ms["coarse_velocity"] == 0.0, ms     # PM-only; the coarse kick rides on the fine one
+    # the spans cover the step (the coarse transform runs underneath the fine mesh on the second stream: it is not added)
+    tot = sum(v for k, v in ms.items() if k != "coarse_force")
+    assert 0.9 * wall <= tot <= 1.1 * wall, (tot, wall, ms)
+    g.phase_timing(False)
     g.close()

@@ -414,6 +414,27 @@ def test_extended_pp_dense_blob_overflows_the_lds_staging(PM):
     assert rel_rms(xg[:, 3:], xo[:, 3:]) <= KICK_TOL
 
 
+def test_extended_pp_blobs_on_the_rim_planes_of_a_tile(PM):
+    """Blobs (heavy records: the wavefront sweep of the second extended-PP launch) centred on the planes just above a tile's
+    pt + pp_range, where a home record sweeps downwards only (particle_mesh_threaded.f90:496) and its own row is swept for other
+    lanes of its group without being its own window: the sweep then meets r = 0 outside the own-cell template (inf * 0 =
+    NaN in a rim record's partial sum, dropped silently from maxval(pp_ext_force_accum), :617).  (pt + pp_range) % 8 != 0 here
+    (32 + 2).  The per-tile maximum -- dt_pp_ext_acc -- and the kicks against the oracle."""
+    p = cfg1(ngp=True, ppint=True, pp_ext=True, density_buffer=3.0)
+    rng = np.random.default_rng(321)
+    xv = uniform_particles(10000, 64.0, seed=11)
+    n0 = 0
+    for (cx, cy, cz) in [(20.3, 20.2, 33.5), (44.1, 20.7, 34.5), (20.6, 44.4, 35.5), (44.8, 44.2, 36.5), (30.2, 31.9, 2.5), (12.5, 50.5, 1.5)]:
+        blob = np.array([cx, cy, cz], np.float32) + rng.normal(0, 0.8, (1200, 3)).astype(np.float32)
+        xv[n0:n0 + 1200, :3] = np.mod(blob, np.float32(64.0)).astype(np.float32)
+        n0 += 1200
+    xv[:, :3] = np.clip(xv[:, :3], 0.0, np.float32(63.999))
+    xg, pg, xo, po, outs = run_step(PM, p, xv, (0.005, 0.2, 0.0, 8.0))
+    check_step(xv, xg, pg, xo, po, outs, "pp ext")
+    assert np.isfinite(xg).all()
+    assert rel_rms(xg[:, 3:], xo[:, 3:]) <= KICK_TOL
+
+
 @pytest.mark.parametrize("move_back", [False, True])
 def test_disp_mesh_offsets_and_move_grid_back(PM, move_back):
     """-DDISP_MESH: update_position adds a random mesh offset (update_position.f90:56-76, the host keeps the RNG and the
@@ -644,7 +665,7 @@ FALLBACKS = {
     "P3M_PP_EXT_REF": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",   # k_pp_ext: the reference's own sqrt / division arithmetic
     "P3M_PP_FAT_LIMIT": "(config1_kick_parity and p3m_ext) or dense_blob",   # = 1: every task with a row of two records takes the global-memory path
     "P3M_CAND_SEG": "half_an_ulp or fine_deposit_vs or heavy_blob or (config1_kick_parity and pm_ngp_uniform)",   # = 1: every candidate list overflows
-    "P3M_KICK_UNFUSED": "(config1_kick_parity and (pm_ngp or p3m)) or two_steps_with_drift or half_an_ulp or (other_tilings and not kw2)",   # the force box + k_fine_kick_rows pair instead of the fused inverse-x + kick pass
+    "P3M_KICK_UNFUSED": "(config1_kick_parity and (pm_ngp or p3m_ext)) or two_steps_with_drift or half_an_ulp or (other_tilings and kw0)",   # the force box + k_fine_kick_rows pair instead of the fused inverse-x + kick pass
 }
 
 
@@ -793,18 +814,21 @@ def test_config2_pm_only_full_size_properties(PM):
 def test_config5_one_gpu_share_properties(PM):
     """BASELINE config 5 (2048^3 mesh / 1024^3 particles, PM + PP + extended PP on 8 GPUs): ONE GPU's share -- 1024^3
     fine cells, 512^3 particles, 2^3 tiles of 560, PPINT + PP_EXT -- through size-independent properties: every particle
-    back exactly once, mass on both meshes, momentum, finite limits."""
+    back exactly once, mass on both meshes, momentum, finite limits; no velocity NaN."""
     p = Params(tiles_node_dim=2, nf_tile=560, ngp=True, ppint=True, pp_ext=True, density_buffer=1.3)
     n = 512 ** 3
-    rng = np.random.default_rng(5)
-    xv = np.zeros((n, 6), np.float32)
-    xv[:, :3] = rng.random((n, 3), dtype=np.float32) * np.float32(1024.0)
-    np.minimum(xv[:, :3], np.float32(1023.999), out=xv[:, :3])
+    # the CLUSTERED particle set of SURVEY Appendix C at its density (30 % of the particles in Gaussian blobs of ~205, sigma 0.6 cells):
+    # the heavy-task pass of the extended PP (wavefront sweeps) runs on the 2^3 tiles of 560 beside the lists and walks of the background
+    import bench
+
+    xv = bench.clustered(512, 1024.0, 2024, 0.3, 48 * 16 ** 3, 0.6)
     g = PM(p, FINE_TABLE, COARSE_TABLE)
     g.upload_particles(xv)
     out = g.particle_mesh(0.005, 0.2, 0.0, 8.0)
     assert out.np_total == n and out.np_deleted == 0
-    assert out.sum_rho_f == 8.0 * n
+    # (a record half an ulp below a tile's upper face is rounded by xv + offset_tile into the buffer zone and counted nowhere, in the
+    # reference as here: particle_mesh_threaded.f90:134,139)
+    assert abs(out.sum_rho_f - 8.0 * n) <= 8.0 * 100
     assert out.sum_rho_c == pytest.approx(8.0 * n, rel=1e-6)
     for name in ("dt_f_acc", "dt_pp_acc", "dt_pp_ext_acc", "dt_c_acc"):
         v = getattr(out, name)
@@ -817,6 +841,7 @@ def test_config5_one_gpu_share_properties(PM):
     assert seen[1:].all()
     o = np.argsort(pid)
     assert np.array_equal(xo[o, :3], xv[:, :3])
+    assert np.isfinite(xo[:, 3:]).all()
     sv = xo[:, 3:].sum(0, dtype=np.float64)
     sq = np.sqrt((xo[:, 3:].astype(np.float64) ** 2).mean())
     assert np.abs(sv / n).max() < 2e-3 * sq

@@ -126,6 +126,20 @@ def test_coarse_force_of_point_masses_is_the_real_space_kernel(tiles):
     run(7, (5, 7, 11), 1.0)
     f0c = g.coarse_force(0)                                     # rank 0's share of the field of the mass on rank 7
     assert np.abs(f0b - (2.5 * f0 + f0c)).max() < 6e-6 * fmax
+    # repetition (the persistent x passes reuse their row tables across trips): the same transform of a random density
+    # three times, every rank's force array bit-identical each time
+    rng = np.random.default_rng(5)
+    cubes = [rng.poisson(8.0, (n, n, n)).astype(np.float32) * 8.0 for _ in range(2)]
+    ref = None
+    for rep in range(3):
+        for i in range(8):
+            g.set_coarse_density(i, cubes[i & 1])
+        g.coarse_transform("force")
+        got = [g.coarse_force(i) for i in (0, 3, 7)]
+        if ref is None:
+            ref = got
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref)), rep
     g.close()
 
 
