@@ -17,14 +17,13 @@
 //
 // Pipeline of one workgroup (persistent, grid-stride over the batches).  Trip i:
 //   A  gathered LY elements of batch i (registers, requested in trip i-1) -> B
-//   B  requests: LY elements of batch i+1, records of batch i+1, velocities of batch i (their records
-//      arrived during trip i-1) -- the chain range -> record -> velocity costs no exposed round trip; stage 1 (dft<R1>) B -> X
-//   C  requests: the 24 coarse-force values around every record of batch i (they depend on the position only; they arrive underneath
-//      stage 2); stage 2 (dft<R2>) X -> F (= B's memory): real box rows, 1/n^3 applied
+//      ; requests: the records of batch i (the chain range -> record -> velocity costs no exposed round trip: ranges two trips ahead)
+//   B  requests: LY elements of batch i+1; stage 1 (dft<R1>) B -> X
+//   C  requests: the velocities of batch i's records; stage 2 (dft<R2>) X -> F (= B's memory): real box rows, 1/n^3 applied
 //   D  max |F|^2 from F; the records of batch i take their force from F; both kicks; velocities stored; the last wavefront
 //      writes the tables of batch i+2 (row ranges requested in trip i-1) and requests the row ranges of batch i+3
-// with a barrier after each step (the rows in LDS are read across wavefronts).  LDS: the x pass's own 58 KB at n = 560 + 2 KB
-// (two workgroups per CU, as before).  Measured with shader-clock stamps per step (-DKF_TRACE): with the coarse gathers inside
+// with a barrier after each step where the workgroup is four wavefronts (the rows in LDS are then read across wavefronts), a
+// wavefront-wide fence where it is one (KCfg).  LDS: 18.5 KB per wavefront at n = 560, eight wavefronts per CU.  Measured with shader-clock stamps per step (-DKF_TRACE): with the coarse gathers inside
 // step D that step was two exposed round trips long (the second slot of records belongs to the first wavefront alone).
 #include "p3m_internal.h"
 #include "fft_core.h"
@@ -101,12 +100,34 @@ __device__ long long kf_trace_buf[8 * 64 * 8];
 #define KF_STAMP(k) do { } while (0)
 #endif
 
+// Workgroup shape.  A wavefront of the x pass holds RPW = 64 / max(R1, R2) whole rows.  Where that is a multiple of three (n = 560: exactly
+// three) a wavefront owns the three components of its box rows from the gather to the kick, nothing is shared between wavefronts, and the
+// workgroup IS one wavefront: no s_barrier anywhere (the four steps of a trip are separated by wavefront-wide fences), and the eight
+// wavefronts of a CU drift apart -- one gathers coarse forces while another runs its butterflies.  (As one workgroup of four wavefronts
+// with four barriers per trip the pass was 55 % VALU-busy and scaled 1.6x from one workgroup per CU to two: latency, not throughput.)
+// Other shapes keep 256 threads: the slots 3*row + comp then straddle wavefronts.
+template <int TB> __device__ __forceinline__ void kf_sync() {
+  if constexpr (TB == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // LDS operations of a wavefront complete in order
+  else __syncthreads();
+}
+template <int R1, int R2> struct KCfg {
+  using X = X2Cfg<R1, R2>;
+  static constexpr int h = X::h, Q = X::Q, RPW = X::RPW, R2P = X::R2P, P = X::P, NCH = X::NCH;
+  static constexpr int TB = (RPW % 3 == 0) ? 64 : 256, RB = RPW * (TB / 64), NLD = (RB * NCH * 8 + TB - 1) / TB;
+  // One wavefront per workgroup: the gather buffer B, the exchange buffer X and the real rows F are ONE buffer (each is dead when the next is
+  // written: a wavefront-wide fence between the last read and the first write suffices) -- 11.8 KB per wavefront at n = 560 instead of
+  // 18.5, i.e. room for three wavefronts per SIMD.  Four wavefronts: B | X apart (F over B), the steps separated by barriers.
+  static constexpr bool WAVE = TB == 64;
+  static constexpr size_t ube = WAVE ? ((size_t)RB * P > (size_t)RB * R1 * R2P ? (size_t)RB * P : (size_t)RB * R1 * R2P) : (size_t)RB * P + (size_t)RB * R1 * R2P;
+  static constexpr size_t lds = sizeof(float2) * (ube + h + (size_t)R2 * (R1 | 1));   // B (| X) | tw | twl
+};
 template <int R1, int R2, bool COARSE>
-__global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
-  using C = X2Cfg<R1, R2>;
-  constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P, NLD = C::NLD, NR = RB / 3, NS = 2, R1P = R1 | 1;
+__global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuseArgs a) {
+  using C = KCfg<R1, R2>;
+  constexpr int TB = C::TB;
+  constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P, NLD = C::NLD, NR = RB / 3, R1P = R1 | 1;
   extern __shared__ float2 lds[];
-  c32 *B = reinterpret_cast<c32 *>(lds), *X = B + RB * P, *tw = X + RB * R1 * R2P, *twl = tw + h;
+  c32 *B = reinterpret_cast<c32 *>(lds), *X = C::WAVE ? B : B + RB * P, *tw = B + C::ube, *twl = tw + h;
   float *F = reinterpret_cast<float *>(lds);          // [3*NR][FP] real box rows of the batch, over B
   // three sets of the per-batch tables: trip i reads the sets of batch i (steps C, D) and of batch i+1 (the requests of step B), and its
   // LAST wavefront writes the set of batch i+2 in step D -- where it would otherwise wait for the first one, which alone holds the
@@ -194,17 +215,15 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
     idx = f + d;
     return f < cum[NR];
   };
-  float4 pf[NS], pfn[NS], vf[NS]; int ps[NS], psn[NS], pr[NS], prn[NS];   // record, its sorted index (-1: none), its row of the batch
+  // The batch's records, flattened over the threads (one per thread; a batch of NR rows holds ~TB of them at the reference's density: the
+  // rest, and the whole of a crowded batch, take the unprefetched loop in step D).  Requested in step A, their velocities -- reached
+  // through the arrival index in the record -- in step C, both used in step D: the chain costs no exposed round trip.
+  float4 pf = make_float4(-1.f, -1.f, -1.f, 0.f), vf = make_float4(0.f, 0.f, 0.f, 0.f); int ps = -1, pr = 0;   // record, velocity, sorted index (-1: none), row of the batch
   auto records = [&](int set) {
     ranges(set);
-#pragma unroll
-    for (int u = 0; u < NS; u++) {
-      pfn[u] = make_float4(-1.f, -1.f, -1.f, 0.f); psn[u] = -1; prn[u] = 0;
-      if (256 * u + (tid & ~63) < cum[NR]) {   // this wavefront holds records of the slot (uniform)
-        int row, idx;
-        if (locate(tid + 256 * u, row, idx)) { pfn[u] = a.spos[idx]; psn[u] = idx; prn[u] = row; }
-      }
-    }
+    pf = make_float4(-1.f, -1.f, -1.f, 0.f); ps = -1; pr = 0;
+    int row, idx;
+    if (locate(tid, row, idx)) { pf = a.spos[idx]; ps = idx; pr = row; }
   };
   auto physical = [&](const float4 &p) { return p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn; };   // chains of hoc(1..ncn) only (:234-236)
   float fmax2 = 0.f;
@@ -256,10 +275,8 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
     rangeload(w + G); if (w + G < nbatch) tables(w + G, 1);
     rangeload(w + 2 * G);
   }
-  __syncthreads();
-  if (w < nbatch) { fetch(w, 0); records(0); }
-#pragma unroll
-  for (int u = 0; u < NS; u++) { pf[u] = pfn[u]; ps[u] = psn[u]; pr[u] = prn[u]; }
+  kf_sync<TB>();
+  if (w < nbatch) fetch(w, 0);
   int trip = 0; (void)trip;
   for (; w < nbatch; w += G, set = set == 2 ? 0 : set + 1, trip++) {
     KF_STAMP(0);
@@ -274,17 +291,12 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
         if (k <= h) pb[0] = (c32){g4[u].x, g4[u].y};
         if (k + 1 <= h) pb[1] = (c32){g4[u].z, g4[u].w};
       }
+    records(set);
     KF_STAMP(1);
-    __syncthreads();
+    kf_sync<TB>();
     KF_STAMP(2);
     // ---- B
-    if (wn < nbatch) { fetch(wn, nxt); records(nxt); }
-    else {
-#pragma unroll
-      for (int u = 0; u < NS; u++) { pfn[u] = make_float4(-1.f, -1.f, -1.f, 0.f); psn[u] = -1; prn[u] = 0; }
-    }
-#pragma unroll
-    for (int u = 0; u < NS; u++) { vf[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (ps[u] >= 0) vf[u] = a.vel[rec_index(pf[u])]; }
+    if (wn < nbatch) fetch(wn, nxt);
     if (s1 && rowok) {
       const c32 *pk = B + r * P + q, *pm = B + r * P + (h - R2 * (R1 - 1)) - q, *pt = tw + q;
       c32 v[R1];
@@ -296,30 +308,24 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
         v[i] = (c32){e2.x - o.y, -(e2.y + o.x)};                        // conj(e + i o): the forward machinery then yields conj(IFFT)
       }
       dft<R1>(v);
+      if (C::WAVE) kf_sync<TB>();   // X is B's memory: every lane has read its elements of B
       c32 *pxw = X + (r * R1) * R2P + q;
 #pragma unroll
       for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twl[q * R1P + k1]) : v[0];
-    }
+    } else if (C::WAVE) kf_sync<TB>();
     KF_STAMP(3);
-    __syncthreads();
+    kf_sync<TB>();
     KF_STAMP(4);
     // ---- C
-    CoarseCell cc[NS]; float cf[NS][24];
-#pragma unroll
-    for (int u = 0; u < NS; u++) {
-      cc[u] = CoarseCell{0u, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 24; e++) cf[u][e] = 0.f;
-#if !defined(KF_AB_NOKICK) && !defined(KF_AB_NOCOARSE)
-      if (COARSE && ps[u] >= 0 && physical(pf[u])) { cc[u] = kf_coarse_cell(pf[u], a); kf_coarse_gather(cf[u], cc[u].o0, a); }
-#endif
-    }
+    vf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ps >= 0) vf = a.vel[rec_index(pf)];
     if (s2 && rowok) {
       c32 u[R2];
       const c32 *pxr = X + (r * R1 + q) * R2P;
 #pragma unroll
       for (int b = 0; b < R2; b++) u[b] = pxr[b];
       dft<R2>(u);
+      if (C::WAVE) kf_sync<TB>();   // F is X's memory: every lane has read its elements of X
       const int x0 = 2 * q - lo;   // box column of real element 2j for k2 = 0; lo is even
       float *pd = F + r * FP + x0;
       const bool tobox = rflag[set][rbr] != 0;
@@ -335,9 +341,9 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
           if (tobox) *reinterpret_cast<float2 *>(pg + 2 * R1 * k2) = o2;
         }
       }
-    }
+    } else if (C::WAVE) kf_sync<TB>();
     KF_STAMP(5);
-    __syncthreads();
+    kf_sync<TB>();
     KF_STAMP(6);
     // ---- D
     if (w + 2 * G < nbatch) tables(w + 2 * G, nn);   // (the last wavefront: see the tables)
@@ -351,22 +357,19 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
       ranges(set);
       const int total = cum[NR];
 #ifndef KF_AB_NOKICK
-#pragma unroll
-      for (int u = 0; u < NS; u++)
-        if (256 * u < total) kick_one(ps[u] >= 0, pf[u], vf[u], true, cc[u], cf[u], true, ps[u], pr[u], set, row0, nbr);
-      for (int f0 = 256 * NS; f0 < total; f0 += 256) {   // a crowded batch (a blob): the records past the prefetched ones
+      CoarseCell cc{0u, 0.f, 0.f, 0.f}; float cf[24];
+      kick_one(ps >= 0, pf, vf, true, cc, cf, false, ps, pr, set, row0, nbr);
+      for (int f0 = TB; f0 < total; f0 += TB) {   // a crowded batch (a blob): the records past the prefetched ones
         int row, idx;
         const bool have = locate(f0 + tid, row, idx);
         float4 p = make_float4(-1.f, -1.f, -1.f, 0.f);
         if (have) p = a.spos[idx];
-        kick_one(have, p, p, false, cc[0], cf[0], false, idx, row, set, row0, nbr);
+        kick_one(have, p, p, false, cc, cf, false, idx, row, set, row0, nbr);
       }
 #endif
     }
-#pragma unroll
-    for (int u = 0; u < NS; u++) { pf[u] = pfn[u]; ps[u] = psn[u]; pr[u] = prn[u]; }
     KF_STAMP(7);
-    __syncthreads();
+    kf_sync<TB>();
   }
   for (int o = 32; o > 0; o >>= 1) fmax2 = fmaxf(fmax2, __shfl_down(fmax2, o, 64));
   if (lane == 0 && fmax2 > 0.f) p3m_atomic_max_nonneg(a.fmax_out + p3m_slot() * 16, fmax2);
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2_kick(KickFuseArgs a) {
 // pitch of the rows in LDS: = 8 (mod 32) floats where that fits -- the (up to) RPW row groups of a wavefront's 8-byte stores then start
 // 8 banks apart; 0: the box rows of a batch do not fit the staging buffer they are laid over
 template <int R1, int R2> static int fused_row_pitch(int fbp) {
-  using C = X2Cfg<R1, R2>;
+  using C = KCfg<R1, R2>;
   constexpr int NR = C::RB / 3;
   if (NR < 1) return 0;
   const int limit = (int)(((size_t)C::RB * C::P * 2) / (3 * NR)) & ~3;
@@ -385,17 +388,17 @@ template <int R1, int R2> static int fused_row_pitch(int fbp) {
   return fp <= limit ? fp : 0;
 }
 template <int R1, int R2, bool COARSE> static int kick_fused_impl(p3m_ctx *c, KickFuseArgs &a) {
-  using C = X2Cfg<R1, R2>;
+  using C = KCfg<R1, R2>;
   constexpr int NR = C::RB / 3;
   a.FP = fused_row_pitch<R1, R2>(a.fbp);
   if (a.FP == 0) { p3m_set_error("fused kick: the box rows do not fit the staging buffer"); return P3M_EINVAL; }
   if ((int64_t)a.rows_total * a.fb >= 0xffffffffLL) { p3m_set_error("fused kick: too many box rows"); return P3M_EINVAL; }
   a.m_fb = fdiv_magic(a.fb);
   auto kern = k_fft_x_inv2_kick<R1, R2, COARSE>;
-#ifdef KF_OCC1   // diagnostic build: one workgroup per CU (how much of the pass is hidden by the second one?)
-  constexpr size_t lds = C::lds + sizeof(float2) * (size_t)R2 * (R1 | 1) + 40 * 1024;
+#ifdef KF_OCC1   // diagnostic build: half the workgroups per CU (how much of the pass is hidden by the others?)
+  constexpr size_t lds = 2 * C::lds;
 #else
-  constexpr size_t lds = C::lds + sizeof(float2) * (size_t)R2 * (R1 | 1);   // + the stage-1 twiddles
+  constexpr size_t lds = C::lds;
 #endif
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   static int occ = 0;
@@ -426,7 +429,7 @@ template <int R1, int R2, bool COARSE> static int kick_fused_impl(p3m_ctx *c, Ki
 // box rows per batch of the fused pass for this line length and box row pitch (0: no fused pass): what k_ngp_fixup, k_fft_x_inv2_kick and
 // k_kick_fix must agree on
 int kick_fused_rows(int n, int fbp) {
-#define X(H, A, B) if (n == 2 * H) return fused_row_pitch<A, B>(fbp) ? X2Cfg<A, B>::RB / 3 : 0;
+#define X(H, A, B) if (n == 2 * H) return fused_row_pitch<A, B>(fbp) ? KCfg<A, B>::RB / 3 : 0;
   P3M_X2_SIZES(X)
 #undef X
   return 0;
