@@ -184,7 +184,7 @@ int coarse_deposit(p3m_ctx *c, float mass_p) {
   CGeo G{g.nb, g.E, g.Nn, g.ms, g.ncn, g.nc, (c->p.flags & P3M_FLAG_COARSE_NGP) ? 1 : 0};
   if (g.ms / 2 > g.nb) { p3m_set_error("coarse_deposit: mesh_scale/2 > nf_buf"); return P3M_EINVAL; }
   const int64_t m1 = g.ncn + 1, tot = m1 * m1 * m1, n3 = (int64_t)g.ncn * g.ncn * g.ncn;
-  HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));
+  if (!c->step_zeroed) HIP_TRY(hipMemsetAsync(c->rho_c, 0, sizeof(float) * n3, c->stream));   // (whole steps: step_prezero)
   const int *crow = c->cells_compact ? (const int *)c->crow : (const int *)nullptr;
   hipLaunchKernelGGL(k_coarse_moments, dim3((unsigned)cdiv(tot, 256)), dim3(256), sizeof(int) * CM_CAP * 256, c->stream, (const float4 *)c->spos, (const int *)c->cell_end, c->cmom, G,
                      mass_p, c->rho_c, crow, c->crow_w, (int)std::max<int64_t>(CM_HEAVY, 3 * (int64_t)c->np_all / tot));

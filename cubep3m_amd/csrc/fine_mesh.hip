@@ -192,8 +192,7 @@ __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, 
   }
 }
 // candidates: sorted indices of records within 2^-10 below a cell face in some coordinate, in P3M_CAND_SLOTS lists (k_row_sort;
-// blockIdx.y = list).  ALL: a list overflowed (cand_cnt[16 * slots] != 0): every sorted record is looked at instead (blockIdx.y = 0
-// only; the list kernel then leaves everything to this one)
+// blockIdx.y = list).  A list overflowed (cand_cnt[16 * slots] != 0): every sorted record is looked at instead, by the same launch
 // The fused inverse-x + kick pass (kick_fused.hip) kicks a record from the box rows of ITS batch of `fuse_nr` rows: a physical record of
 // this tile whose reference cell lies in a row of another batch than the row it is sorted into gets that row flagged here -- the pass
 // then stores the row to the force box as well and k_kick_fix kicks the record from there.
@@ -232,15 +231,13 @@ __device__ __forceinline__ void ngp_fixup_record(const float4 &p, float *__restr
     if (ig != ir) atomicAdd(sum_interior, ir ? (double)mass_p : -(double)mass_p);
   }
 }
-template <bool ALL>
 __global__ __launch_bounds__(256) void k_ngp_fixup(const float4 *__restrict__ spos, int nrec, const int *__restrict__ cand, const int *__restrict__ cand_cnt, int cand_seg,
                                                    float *__restrict__ rho, int tile0, int ntile, TileGeo G, float mass_p, double *__restrict__ sum_interior, FuseFlag ff) {
   // the candidate counts stay on the device (written by k_row_sort of this step): no host round trip between sort and deposit
-  const bool overflow = cand_cnt[16 * P3M_CAND_SLOTS] != 0;
-  if (ALL != overflow) return;
-  if (ALL) {
+  if (cand_cnt[16 * P3M_CAND_SLOTS] != 0) {   // a list overflowed: every sorted record is looked at instead, by the same grid (one launch either way)
     const float thr = 1.0f - 0.0009765625f;
-    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < (int64_t)nrec * ntile; id += (int64_t)gridDim.x * 256) {
+    const int64_t nthr = (int64_t)gridDim.x * gridDim.y * 256;
+    for (int64_t id = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; id < (int64_t)nrec * ntile; id += nthr) {
       const int tl = (int)(id / nrec); const int s = (int)(id - (int64_t)tl * nrec);
       const float4 p = spos[s];
       if ((p.x - floorf(p.x) >= thr) || (p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) ngp_fixup_record(p, rho, tile0, tl, G, mass_p, sum_interior, ff);
@@ -269,9 +266,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p, bool fuse) {   
       // records within 2^-10 below a cell face: ~0.3 % of the records; the grids are sized for that share, the loops cover any count
       const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256 / P3M_CAND_SLOTS) * ntile;
       const FuseFlag ff{fuse ? c->rowflag : (unsigned char *)nullptr, c->fuse_nr, g.Nn, g.ms};
-      hipLaunchKernelGGL(k_ngp_fixup<false>, dim3((unsigned)std::min<int64_t>(256, cdiv(guess, 256)), P3M_CAND_SLOTS), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,
-                         (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums, ff);
-      hipLaunchKernelGGL(k_ngp_fixup<true>, dim3(2048), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,   // leaves at once unless a list overflowed
+      hipLaunchKernelGGL(k_ngp_fixup, dim3((unsigned)std::min<int64_t>(256, cdiv(guess, 256)), P3M_CAND_SLOTS), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,
                          (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums, ff);
       HIP_TRY(hipGetLastError());
     }
@@ -606,7 +601,7 @@ __global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const floa
 // ------------------------------------------------------------------ the fused inverse-x + NGP kick pass (kick_fused.hip) and its fix-up
 // k_kick_fix: the records the fused pass left out -- reference cell floor(xv + offset_tile) in a box row of another batch than the row
 // they are sorted into (flagged by k_ngp_fixup, stored to the box by the pass) -- get their kick (:244-270), their coarse kick
-// and their survivor count here, from the box.  Candidates as in k_ngp_fixup (lists of k_row_sort; ALL: a list overflowed).
+// and their survivor count here, from the box.  Candidates as in k_ngp_fixup (lists of k_row_sort; every record when a list overflowed).
 template <bool COARSE>
 __device__ __forceinline__ void kick_fix_record(const float4 &p, int s, const TileGeo &G, int Nn, int ms, int nr, unsigned char *__restrict__ rowflag, const float *__restrict__ fbox,
                                                 int64_t comp_stride, float a_mid, float dt, float4 *__restrict__ vel, const float *__restrict__ fc, int ncn, int *__restrict__ cnt256) {
@@ -649,15 +644,14 @@ __device__ __forceinline__ void kick_fix_record(const float4 &p, int s, const Ti
   if (cnt256) atomicAdd(&cnt256[s >> 8], 1);
   rowflag[br] = 0;   // every record that needed the row clears it: the flags are all zero again when the step ends
 }
-template <bool ALL, bool COARSE>
+template <bool COARSE>
 __global__ __launch_bounds__(256) void k_kick_fix(const float4 *__restrict__ spos, int nrec, const int *__restrict__ cand, const int *__restrict__ cand_cnt, int cand_seg, TileGeo G,
                                                   int Nn, int ms, int nr, unsigned char *__restrict__ rowflag, const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt,
                                                   float4 *__restrict__ vel, const float *__restrict__ fc, int ncn, int *__restrict__ cnt256) {
-  const bool overflow = cand_cnt[16 * P3M_CAND_SLOTS] != 0;
-  if (ALL != overflow) return;
-  if (ALL) {
+  if (cand_cnt[16 * P3M_CAND_SLOTS] != 0) {   // a candidate list overflowed: the same grid looks at every record
     const float thr = 1.0f - 0.0009765625f;
-    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < nrec; s += (int64_t)gridDim.x * 256) {
+    const int64_t nthr = (int64_t)gridDim.x * gridDim.y * 256;
+    for (int64_t s = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; s < nrec; s += nthr) {
       const float4 p = spos[s];
       if ((p.y - floorf(p.y) >= thr) || (p.z - floorf(p.z) >= thr)) kick_fix_record<COARSE>(p, (int)s, G, Nn, ms, nr, rowflag, fbox, comp_stride, a_mid, dt, vel, fc, ncn, cnt256);
     }
@@ -697,10 +691,9 @@ static int fine_xinv_kick_fused(p3m_ctx *c, float a_mid, float dt, int *cnt256, 
     TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
     const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256 / P3M_CAND_SLOTS);
     const dim3 gl((unsigned)std::min<int64_t>(64, cdiv(guess, 256)), P3M_CAND_SLOTS);
-#define P3M_FIX(ALLv, COv, GRID) hipLaunchKernelGGL((k_kick_fix<ALLv, COv>), GRID, dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all, (const int *)c->cand, (const int *)c->cand_cnt, \
+#define P3M_FIX(COv) hipLaunchKernelGGL((k_kick_fix<COv>), gl, dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all, (const int *)c->cand, (const int *)c->cand_cnt, \
       c->cand_seg, G, g.Nn, g.ms, c->fuse_nr, c->rowflag, (const float *)c->fbox, cs, a_mid, dt, c->vel, (const float *)a.fc, g.ncn, cnt256)
-    if (c->coarse_first) { P3M_FIX(false, true, gl); P3M_FIX(true, true, dim3(2048)); }   // the second leaves at once unless a candidate list overflowed
-    else { P3M_FIX(false, false, gl); P3M_FIX(true, false, dim3(2048)); }
+    if (c->coarse_first) P3M_FIX(true); else P3M_FIX(false);
 #undef P3M_FIX
     HIP_TRY(hipGetLastError());
   }
@@ -750,7 +743,7 @@ int fine_max_and_kick(p3m_ctx *c, float a_mid, float dt, bool count_survivors) {
   if (count_survivors) c->cnt_from_kick = 0;
   if (count_survivors && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK) && c->np_all > 0) {
     cnt256 = c->flags;
-    HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));
+    if (!c->step_zeroed) HIP_TRY(hipMemsetAsync(cnt256, 0, sizeof(int) * (size_t)(cdiv(c->np_all, 256) + 1), c->stream));   // (whole steps: step_prezero)
     c->cnt_from_kick = c->np_all;
   }
   if (c->xinv_deferred) { c->xinv_deferred = false; return fine_xinv_kick_fused(c, a_mid, dt, cnt256); }   // the force phase stopped after the inverse y pass

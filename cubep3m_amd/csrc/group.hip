@@ -1210,7 +1210,7 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   G->pt.reset();
   { PhaseScope ps(&G->pt, P3M_PH_DRIFT, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset)); }                      // :56
   { PhaseScope ps(&G->pt, P3M_PH_GHOST, G->stream); P3M_TRY(ghost_pass(G)); }                                                                          // :61-63
-  { PhaseScope ps(&G->pt, P3M_PH_SORT, G->stream); for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_clear(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); } }   // every rank's sort queued ...
+  { PhaseScope ps(&G->pt, P3M_PH_SORT, G->stream); for (p3m_ctx *c : G->ctx) { P3M_TRY(step_prezero(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); } }   // every rank's sort queued ...
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort_finish(c, false));                                      // ... and nobody waits: the counters come in with the step's results
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
   // fine-mesh force sweeps (many small kernels and the all-to-all exchanges against bandwidth-bound FFT passes).  Its kick
@@ -1248,6 +1248,7 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   { PhaseScope ps(&G->pt, P3M_PH_DELETE, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_enqueue(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr)); }  // :716-720
   // ONE host wait for everything the host reads back: survivor counts, the sort's counters, maxima and sums
   for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_download(c)); HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, c->g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream)); }
+  for (p3m_ctx *c : G->ctx) c->step_zeroed = false;
   HIP_TRY(hipStreamSynchronize(G->stream));
   if (G->pt.on) { if (G->stream2) HIP_TRY(hipStreamSynchronize(G->stream2)); G->pt.collect(); }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_finish(c, false));

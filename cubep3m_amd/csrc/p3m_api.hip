@@ -352,8 +352,25 @@ static int fine_sweep(p3m_ctx *c, float mass_p, bool kick_follows) {
 }
 
 int reductions_clear(p3m_ctx *c) {
+  if (c->step_zeroed) return P3M_OK;   // whole steps: step_prezero
   HIP_TRY(hipMemsetAsync(c->d_red, 0, 8 * P3M_RED_SPAN * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_sums, 0, 4 * P3M_SUM_SPAN * sizeof(double), c->stream));
+  return P3M_OK;
+}
+// Whole steps: everything the step accumulates into, cleared in ONE launch right after the drift (the drift's compaction still reads the
+// previous step's block offsets in c->flags; nothing queued later in the step needs an old value of any of these): the reduction slots,
+// the candidate lists' lengths, the per-tile PP maxima, the coarse density and the kick's survivor counts.  The phase-level entry
+// points clear what they need themselves (step_zeroed == false).
+int step_prezero(p3m_ctx *c) {
+  const Geometry &g = c->g;
+  P3M_TRY(zero_add(c, c->d_red, 8 * P3M_RED_SPAN * sizeof(float)));
+  P3M_TRY(zero_add(c, c->d_sums, 4 * P3M_SUM_SPAN * sizeof(double)));
+  P3M_TRY(zero_add(c, c->cand_cnt, sizeof(int) * (16 * P3M_CAND_SLOTS + 16)));
+  P3M_TRY(zero_add(c, c->d_tile_ext, g.ntiles * sizeof(float)));
+  P3M_TRY(zero_add(c, c->rho_c, sizeof(float) * (size_t)g.ncn * g.ncn * g.ncn));
+  if ((c->p.flags & P3M_FLAG_NGP) && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK)) P3M_TRY(zero_add(c, c->flags, sizeof(int) * (size_t)(cdiv(c->cap, 256) + 1)));   // fine_max_and_kick's cnt256
+  P3M_TRY(zero_flush(c));
+  c->step_zeroed = true;
   return P3M_OK;
 }
 int reductions_download(p3m_ctx *c) {
@@ -381,7 +398,7 @@ int fine_mesh_force_phase(p3m_ctx *c, float mass_p, bool may_clear) {
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(need_kernels(c));
   if (may_clear && !c->rho_from_sort) P3M_TRY(reductions_clear(c));   // else cleared before the sort, which already added the NGP mass sum
-  HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
+  if (!c->step_zeroed) HIP_TRY(hipMemsetAsync(c->d_tile_ext, 0, c->g.ntiles * sizeof(float), c->stream));
   return fine_sweep(c, mass_p, true);
 }
 int fine_mesh_kick_phase(p3m_ctx *c, float a_mid, float dt, float mass_p) {
@@ -502,7 +519,7 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
 // after an error in the middle of a step: nothing that was queued for "later" may be trusted by the next call -- the next sort
 // counts its rows itself (k_row_hist), no survivor counts, no deferred counters, no half-finished ghost removal
 void particles_reset_after_error(p3m_ctx *c) {
-  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false; c->xinv_deferred = false;
+  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false; c->xinv_deferred = false; c->step_zeroed = false; c->zl.cnt = 0;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 }
@@ -522,7 +539,7 @@ static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, f
   if (c->pt) c->pt->reset();
   { PhaseScope ps(c->pt, P3M_PH_DRIFT, c->stream); P3M_TRY(p3m_hip_update_position(c, dt, dt_old, offset)); }   // :56
   HIP_TRY(hipSetDevice(c->device));
-  P3M_TRY(reductions_clear(c));
+  P3M_TRY(step_prezero(c));
   { PhaseScope ps(c->pt, P3M_PH_GHOST, c->stream); P3M_TRY(particles_pass_self(c)); }                           // :61-63
   { PhaseScope ps(c->pt, P3M_PH_SORT, c->stream); P3M_TRY(particles_sort_enqueue(c, mass_p)); }
   P3M_TRY(particles_sort_finish(c, false));                  // no host wait: the sort's counters come in with the step's results
@@ -559,6 +576,7 @@ static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, f
   }
   // :716-720; the survivor count, the sort's counters and the step's maxima and sums reach the host behind ONE wait
   { PhaseScope ps(c->pt, P3M_PH_DELETE, c->stream); P3M_TRY(particles_finalize_enqueue(c, (c->p.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr)); }
+  c->step_zeroed = false;
   p3m_step_out o;
   P3M_TRY(p3m_hip_get_step_out(c, a_mid, &o));               // :643-706 (synchronises the stream)
   if (c->pt && c->pt->on) { if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2)); c->pt->collect(); }

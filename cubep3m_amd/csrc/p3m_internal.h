@@ -85,6 +85,12 @@ struct PhaseScope {   // one span: constructor and destructor record on `stream`
   ~PhaseScope() { if (t) (void)hipEventRecord(t->spans[idx].b, s); }
 };
 
+// ------------------------------------------------------------------ one launch for the small buffers a step accumulates into
+// A step zeroes a dozen counters, histograms and reduction slots per rank; as hipMemsetAsync calls each is a launch of its own (5 us of
+// kernel + the gap around it, ~90 per step on 8 ranks).  zero_add collects (pointer, bytes) pairs, zero_flush clears them in ONE launch.
+#define P3M_ZERO_MAX 12
+struct ZeroList { void *p[P3M_ZERO_MAX]; unsigned long long n[P3M_ZERO_MAX]; int cnt; };   // bytes: multiples of 4, pointers 4-byte aligned
+
 // ------------------------------------------------------------------ FFT plan (fft.hip)
 struct FftPlan {
   int n = 0;               // real transform length per axis
@@ -199,6 +205,7 @@ struct p3m_ctx {
   p3m_step_out last{};
   int np_ghost = 0, np_deleted = 0;
   // ---- transport
+  ZeroList zl{}; bool step_zeroed = false;   // whole steps: everything the step accumulates into was cleared in one launch (step_prezero, p3m_api.hip)
   PhaseTimer *pt = nullptr; bool own_pt = false;   // per-phase times (a group's contexts share the group's timer)
   p3m_transport transport{}; bool have_transport = false;   // unused: exchanges belong to the group (group.hip)
   void *rccl_comm = nullptr;
@@ -274,3 +281,6 @@ int reductions_clear(p3m_ctx *c);      // zero d_red / d_sums
 int reductions_download(p3m_ctx *c);   // enqueue the copies to the pinned mirrors
 void reductions_fold(p3m_ctx *c);      // after the stream sync: slots -> c->h_red[], c->h_sums[]
 int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n);  // in place; data[n] (one past) receives the total
+int zero_add(p3m_ctx *c, void *p, size_t bytes);   // scan.hip: queue a buffer for zero_flush (flushes first when the list is full)
+int zero_flush(p3m_ctx *c);                        // one launch on c->stream
+int step_prezero(p3m_ctx *c);                      // p3m_api.hip: whole steps, after the drift

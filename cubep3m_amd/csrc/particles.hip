@@ -275,7 +275,7 @@ struct RowCompact { int *crow; int w, ncn, ms, T, pt, lo, fb; };   // crow == nu
 __device__ __forceinline__ void row_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_row_sort(const float4 *__restrict__ tpos, const int *__restrict__ rs, int E, int nrows, float nb, int *__restrict__ cs,
                                                  float4 *__restrict__ spos,
-                                                 int *__restrict__ cand, int *__restrict__ cand_cnt, int cand_seg, RowDep dep, RowCompact cc) {
+                                                 int *__restrict__ cand, int *__restrict__ cand_cnt, int cand_seg, RowDep dep, RowCompact cc, int n_cur) {
   extern __shared__ int bins_all[];
   const int row = blockIdx.x * P3M_SORT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= nrows) return;
@@ -380,6 +380,9 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
 #pragma unroll
   for (int u = 0; u < RR; u++) if (rin[u]) place(rp[u]);
   for (int i = r0 + RR * 64 + lane; i < r1; i += 64) place(tpos[i]);
+  // records that left the chaining mesh were dropped (link_list.f90:26-53): the slots behind the last row's records get a position no
+  // range test accepts, so everything downstream may run over n_cur records without the host knowing the deleted count
+  if (row == nrows - 1) for (int i = r1 + lane; i < n_cur; i += 64) spos[i] = make_float4(-1.0e30f, -1.0e30f, -1.0e30f, 0.f);
 }
 
 // cell_end from the sorted records (after a sort that wrote only the compact table): one wavefront per row, as k_row_sort
@@ -440,9 +443,6 @@ int particles_pass_self(p3m_ctx *c) {
   return P3M_OK;
 }
 
-__global__ __launch_bounds__(PT) void k_pad_tail(float4 *__restrict__ spos, const int *__restrict__ nsorted, int n) {
-  for (int i = *nsorted + blockIdx.x * PT + threadIdx.x; i < n; i += gridDim.x * PT) spos[i] = make_float4(-1.0e30f, -1.0e30f, -1.0e30f, 0.f);
-}
 // sort of the c->np_all unsorted records (physical + ghosts) by extended fine cell; deposit_mass >= 0 (whole-step
 // entry points, where mass_p is known here) also writes the NGP density of every tile (c->rho_from_sort)
 int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
@@ -482,18 +482,12 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   RowCompact cc{nullptr, c->crow_w, g.ncn, g.ms, g.T, g.pt, g.nb - 2, g.fb};
   c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT));
   if (c->cells_compact) cc.crow = c->crow;
-  HIP_TRY(hipMemsetAsync(c->cand_cnt, 0, sizeof(int) * (16 * P3M_CAND_SLOTS + 16), c->stream));   // empty candidate lists
+  if (!c->step_zeroed) HIP_TRY(hipMemsetAsync(c->cand_cnt, 0, sizeof(int) * (16 * P3M_CAND_SLOTS + 16), c->stream));   // empty candidate lists (whole steps: step_prezero)
   hipLaunchKernelGGL(k_row_sort, dim3(cdiv(nrows, P3M_SORT_WPB)), dim3(64 * P3M_SORT_WPB), (size_t)g.E * sizeof(int) * P3M_SORT_WPB, c->stream, (const float4 *)c->tpos,
                      (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->cand, c->cand_cnt,
-                     c->cand_seg, dep, cc);
+                     c->cand_seg, dep, cc, n_cur);
   HIP_TRY(hipGetLastError());
-  // records that left the chaining mesh were dropped (link_list.f90:26-53): the sorted arrays hold n_cur - deleted records.
-  // The slots behind them get a position no range test accepts, so everything downstream may run over n_cur records
-  // without the host knowing the deleted count (whole steps read it with the step's other results, particles_sort_finish)
-  if (n_cur > 0) {
-    hipLaunchKernelGGL(k_pad_tail, dim3(32), dim3(PT), 0, c->stream, c->spos, (const int *)(c->row_end + 1 + nrows), n_cur);
-    HIP_TRY(hipGetLastError());
-  }
+  // (the tail behind the sorted records is padded by k_row_sort's last row: whole steps read the deleted count with the step's other results)
   HIP_TRY(hipMemcpyAsync(c->h_counters, cnt, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   c->sort_ncur = n_cur;
   return P3M_OK;
@@ -928,11 +922,11 @@ int particles_preload() {
 static int particles_hist_begin(p3m_ctx *c) {
   const Geometry &g = c->g;
   const int nrows = g.E * g.E;
-  HIP_TRY(hipMemsetAsync(c->d_counters + 4, 0, 2 * sizeof(int), c->stream));
-  HIP_TRY(hipMemsetAsync(c->gl_cnt, 0, 16 * P3M_GL_SLOTS * sizeof(int), c->stream));
-  HIP_TRY(hipMemsetAsync(c->row_end - 3, 0, (size_t)(nrows + 8) * sizeof(int), c->stream));
-  if (c->p.flags & P3M_FLAG_PPINT) { const int64_t ec = g.E / g.ms; HIP_TRY(hipMemsetAsync(c->cflag, 0, (size_t)(ec * ec * ec), c->stream)); }
-  return P3M_OK;
+  P3M_TRY(zero_add(c, c->d_counters + 4, 2 * sizeof(int)));
+  P3M_TRY(zero_add(c, c->gl_cnt, 16 * P3M_GL_SLOTS * sizeof(int)));
+  P3M_TRY(zero_add(c, c->row_end - 3, (size_t)(nrows + 8) * sizeof(int)));
+  if (c->p.flags & P3M_FLAG_PPINT) { const int64_t ec = g.E / g.ms; P3M_TRY(zero_add(c, c->cflag, (size_t)(ec * ec * ec))); }   // (allocated with 16 bytes of slack)
+  return zero_flush(c);   // one launch (p3m_internal.h, ZeroList)
 }
 int particles_compact(p3m_ctx *c, bool drift, float dt, float dt_old, const float *offset) {
   if (!c->pending_compact) return P3M_OK;

@@ -3,6 +3,7 @@
 // Three-kernel scheme (block sums -> recursive scan of the sums -> apply); HBM-bound:
 // 2 reads + 1 write of the array.
 #include "p3m_internal.h"
+#include <algorithm>
 
 #define SCAN_T 256
 #define SCAN_I 16
@@ -113,4 +114,34 @@ int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n) {
     c->scan_tmp_n = need;
   }
   return scan_rec(c, data, n, c->scan_tmp, data + n);
+}
+
+// ------------------------------------------------------------------ zero_add / zero_flush (p3m_internal.h)
+__global__ __launch_bounds__(256) void k_zero_many(ZeroList z) {
+  const int b = blockIdx.y;
+  unsigned *p = reinterpret_cast<unsigned *>(z.p[b]);
+  const unsigned long long nw = z.n[b] >> 2;   // 4-byte words
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    const unsigned long long n4 = nw >> 2;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < (nw & 3)) p[4 * n4 + threadIdx.x] = 0u;
+  } else
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nw; i += (unsigned long long)gridDim.x * 256) p[i] = 0u;
+}
+int zero_flush(p3m_ctx *c) {
+  if (c->zl.cnt == 0) return P3M_OK;
+  unsigned long long big = 0;
+  for (int i = 0; i < c->zl.cnt; i++) big = std::max(big, c->zl.n[i]);
+  const unsigned gx = (unsigned)std::min<unsigned long long>(128, (big / 16 + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_zero_many, dim3(gx, c->zl.cnt), dim3(256), 0, c->stream, c->zl);
+  c->zl.cnt = 0;
+  HIP_TRY(hipGetLastError());
+  return P3M_OK;
+}
+int zero_add(p3m_ctx *c, void *p, size_t bytes) {
+  if (bytes == 0) return P3M_OK;
+  if (c->zl.cnt == P3M_ZERO_MAX) P3M_TRY(zero_flush(c));
+  c->zl.p[c->zl.cnt] = p; c->zl.n[c->zl.cnt] = (bytes + 3) & ~(size_t)3; c->zl.cnt++;
+  return P3M_OK;
 }
