@@ -1124,8 +1124,7 @@ static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out, bool do
   float v[4] = {0, 0, 0, 0}; double sums[3] = {0, 0, 0}; int ng = 0, ndel = 0;
   if (!downloaded) {
     for (p3m_ctx *c : G->ctx) {
-      P3M_TRY(reductions_download(c));
-      HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream));
+      P3M_TRY(reductions_download(c));   // (with the per-tile PP maxima: one block)
     }
     HIP_TRY(hipStreamSynchronize(G->stream));
   }
@@ -1247,7 +1246,7 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   }
   { PhaseScope ps(&G->pt, P3M_PH_DELETE, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_enqueue(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr)); }  // :716-720
   // ONE host wait for everything the host reads back: survivor counts, the sort's counters, maxima and sums
-  for (p3m_ctx *c : G->ctx) { P3M_TRY(reductions_download(c)); HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, c->g.ntiles * sizeof(float), hipMemcpyDeviceToHost, G->stream)); }
+  for (p3m_ctx *c : G->ctx) P3M_TRY(reductions_download(c));   // (with the per-tile PP maxima: one block)
   for (p3m_ctx *c : G->ctx) c->step_zeroed = false;
   HIP_TRY(hipStreamSynchronize(G->stream));
   if (G->pt.on) { if (G->stream2) HIP_TRY(hipStreamSynchronize(G->stream2)); G->pt.collect(); }

@@ -133,10 +133,17 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
         hipMemset(c->kern_c, 0, (size_t)3 * g.nc * g.nc * g.pxc * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
     A(fft_plan_create(&c->plan_c, g.nc));
   }
-  A(dalloc(&c->d_red, 8 * P3M_RED_SPAN)); A(dalloc(&c->d_tile_ext, g.ntiles)); A(dalloc(&c->d_sums, 4 * P3M_SUM_SPAN));
-  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_red_raw), 8 * P3M_RED_SPAN * sizeof(float)) != hipSuccess) return fail(P3M_ENOMEM);
-  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_tile_ext), g.ntiles * sizeof(float)) != hipSuccess) return fail(P3M_ENOMEM);
-  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sums_raw), 4 * P3M_SUM_SPAN * sizeof(double)) != hipSuccess) return fail(P3M_ENOMEM);
+  // the step's reduced scalars in ONE block (sums | maxima | per-tile PP maxima) with one pinned mirror: one download per rank and step
+  {
+    const size_t nb_sums = 4 * P3M_SUM_SPAN * sizeof(double), nb_red = 8 * P3M_RED_SPAN * sizeof(float), nb_ext = ((size_t)g.ntiles * sizeof(float) + 15) & ~(size_t)15;
+    c->red_bytes = nb_sums + nb_red + nb_ext;
+    char *blk = nullptr; A(dalloc(&blk, c->red_bytes)); c->d_redblk = blk;
+    c->d_sums = reinterpret_cast<double *>(blk); c->d_red = reinterpret_cast<float *>(blk + nb_sums); c->d_tile_ext = reinterpret_cast<float *>(blk + nb_sums + nb_red);
+    char *hb = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&hb), c->red_bytes) != hipSuccess) return fail(P3M_ENOMEM);
+    c->h_redblk = hb;
+    c->h_sums_raw = reinterpret_cast<double *>(hb); c->h_red_raw = reinterpret_cast<float *>(hb + nb_sums); c->h_tile_ext = reinterpret_cast<float *>(hb + nb_sums + nb_red);
+  }
 #undef A
   // variable_initialization.f90:22-29
   c->last.dt_f_acc = c->last.dt_pp_acc = c->last.dt_pp_ext_acc = c->last.dt_c_acc = 1000.f;
@@ -149,17 +156,15 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->vel_alt); dfree(c->pid_home); dfree(c->spos);
-  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter); dfree(c->pp_htask);
+  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->scan_state); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter); dfree(c->pp_htask);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);
   dfree(c->rho); dfree(c->work); dfree(c->fbox); dfree(c->rowflag); dfree(c->kern_f);
   dfree(c->rho_c); dfree(c->cmom); dfree(c->force_c); dfree(c->slab); dfree(c->slab_w); dfree(c->slab_o); dfree(c->kern_c);
-  dfree(c->d_red); dfree(c->d_tile_ext); dfree(c->d_sums);
+  dfree(c->d_redblk); c->d_red = nullptr; c->d_tile_ext = nullptr; c->d_sums = nullptr;
   if (c->h_counters) (void)hipHostFree(c->h_counters);
-  if (c->h_red_raw) (void)hipHostFree(c->h_red_raw);
-  if (c->h_tile_ext) (void)hipHostFree(c->h_tile_ext);
-  if (c->h_sums_raw) (void)hipHostFree(c->h_sums_raw);
+  if (c->h_redblk) (void)hipHostFree(c->h_redblk);
   fft_plan_destroy(&c->plan_f); fft_plan_destroy(&c->plan_c);
   if (c->own_pt) { delete c->pt; } c->pt = nullptr;
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -363,10 +368,8 @@ int reductions_clear(p3m_ctx *c) {
 // points clear what they need themselves (step_zeroed == false).
 int step_prezero(p3m_ctx *c) {
   const Geometry &g = c->g;
-  P3M_TRY(zero_add(c, c->d_red, 8 * P3M_RED_SPAN * sizeof(float)));
-  P3M_TRY(zero_add(c, c->d_sums, 4 * P3M_SUM_SPAN * sizeof(double)));
+  P3M_TRY(zero_add(c, c->d_redblk, c->red_bytes));   // sums | maxima | per-tile PP maxima
   P3M_TRY(zero_add(c, c->cand_cnt, sizeof(int) * (16 * P3M_CAND_SLOTS + 16)));
-  P3M_TRY(zero_add(c, c->d_tile_ext, g.ntiles * sizeof(float)));
   P3M_TRY(zero_add(c, c->rho_c, sizeof(float) * (size_t)g.ncn * g.ncn * g.ncn));
   if ((c->p.flags & P3M_FLAG_NGP) && !(c->p.flags & P3M_FLAG_MOVE_GRID_BACK)) P3M_TRY(zero_add(c, c->flags, sizeof(int) * (size_t)(cdiv(c->cap, 256) + 1)));   // fine_max_and_kick's cnt256
   P3M_TRY(zero_flush(c));
@@ -374,8 +377,7 @@ int step_prezero(p3m_ctx *c) {
   return P3M_OK;
 }
 int reductions_download(p3m_ctx *c) {
-  HIP_TRY(hipMemcpyAsync(c->h_red_raw, c->d_red, 8 * P3M_RED_SPAN * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_sums_raw, c->d_sums, 4 * P3M_SUM_SPAN * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_redblk, c->d_redblk, c->red_bytes, hipMemcpyDeviceToHost, c->stream));   // sums, maxima and the per-tile PP maxima: one block
   return P3M_OK;
 }
 void reductions_fold(p3m_ctx *c) {
@@ -479,7 +481,6 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
   HIP_TRY(hipSetDevice(c->device));
   const Geometry &g = c->g;
   P3M_TRY(reductions_download(c));
-  HIP_TRY(hipMemcpyAsync(c->h_tile_ext, c->d_tile_ext, g.ntiles * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->finalize_queued) P3M_TRY(particles_finalize_finish(c, false));   // a ghost removal queued by the whole-step call
   particles_collect_counters(c);

@@ -150,6 +150,7 @@ struct p3m_ctx {
   int *crow = nullptr; int crow_w = 0; bool cells_compact = false;
   float4 *tpos = nullptr;      // row-bucketed intermediate of the sort: position and arrival index
   int *scan_tmp = nullptr; size_t scan_tmp_n = 0;
+  unsigned long long *scan_state = nullptr; size_t scan_state_n = 0; unsigned scan_epoch = 0;   // the one-launch scan's look-back words (scan.hip)
   int *flags = nullptr;        // [cap] compaction flags / offsets
   unsigned char *cflag = nullptr; // [(E/ms)^3] coarse cells holding a record whose tile-local cell differs from floor(x)
   // sorted indices of the records within 2^-10 below a cell face (the only ones xv + offset_tile can round into the next cell):
@@ -201,6 +202,7 @@ struct p3m_ctx {
   float *d_tile_ext = nullptr; // [ntiles] per-tile pp_ext max
   double *d_sums = nullptr;    // [4][P3M_SUM_SPAN]: [0] sum rho_f (interior) [1] sum rho_c
   float *h_red_raw = nullptr; double *h_sums_raw = nullptr; float *h_tile_ext = nullptr;  // pinned mirrors
+  char *d_redblk = nullptr, *h_redblk = nullptr; size_t red_bytes = 0;   // d_sums | d_red | d_tile_ext are ONE allocation (one download, one clear)
   float h_red[8] = {0}; double h_sums[4] = {0};   // folded values
   p3m_step_out last{};
   int np_ghost = 0, np_deleted = 0;

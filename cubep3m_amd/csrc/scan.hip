@@ -73,6 +73,68 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(int *__restrict__ d, int6
   }
 }
 
+// ------------------------------------------------------------------ one-launch scan (decoupled look-back)
+// The three-kernel scheme costs three launches per scan and a step runs two scans per rank (x-row counts, survivor counts): 48 launches of
+// ~5 us per step on 8 ranks.  Here every block takes a ticket (its chunk: tickets are handed out in the order blocks START, so a block
+// only ever waits for blocks that are already running), publishes its aggregate, walks back over its predecessors' words until it meets an
+// inclusive prefix, and publishes its own.  A word = value | flag << 32 | epoch << 34; the epoch (one per launch, a kernel argument)
+// makes every earlier launch's words read as "nothing yet", so nothing is cleared between scans; the holder of the last ticket resets
+// the ticket counter (every ticket of this launch has been taken by then).
+#define SCAN_AGG 1ull
+#define SCAN_PRE 2ull
+__global__ __launch_bounds__(SCAN_T) void k_scan_lookback(int *__restrict__ d, int64_t n, unsigned long long *__restrict__ state, int *__restrict__ ticket,
+                                                          unsigned epoch, int *__restrict__ total_out) {
+  __shared__ int bid_s, prefix_s;
+  if (threadIdx.x == 0) { bid_s = atomicAdd(ticket, 1); if (bid_s == (int)gridDim.x - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __syncthreads();
+  const int bid = bid_s;
+  const int64_t base = (int64_t)bid * SCAN_CH + (int64_t)threadIdx.x * SCAN_I;
+  int v[SCAN_I];
+  const bool full = base + SCAN_I <= n;
+  if (full) {
+    const int4 *p = reinterpret_cast<const int4 *>(d + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_I / 4; i++) { int4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++) v[i] = (base + i < n) ? d[base + i] : 0;
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_I; i++) s += v[i];
+  int tot;
+  int run = block_excl_scan(s, &tot);
+  if (threadIdx.x == 0) {
+    const unsigned long long ep = (unsigned long long)epoch << 34;
+    int prefix = 0;
+    if (bid > 0) {
+      __hip_atomic_store(state + bid, ep | (SCAN_AGG << 32) | (unsigned)tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = bid - 1; j >= 0;) {
+        const unsigned long long w = __hip_atomic_load(state + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((w >> 34) != epoch) { __builtin_amdgcn_s_sleep(1); continue; }   // nothing from block j yet
+        prefix += (int)(unsigned)w;
+        if ((w >> 32) & SCAN_PRE) break;
+        j--;
+      }
+    }
+    __hip_atomic_store(state + bid, ep | (SCAN_PRE << 32) | (unsigned)(prefix + tot), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    prefix_s = prefix;
+    if (total_out && bid == (int)gridDim.x - 1) *total_out = prefix + tot;
+  }
+  __syncthreads();
+  run += prefix_s;
+#pragma unroll
+  for (int i = 0; i < SCAN_I; i++) { int t = v[i]; v[i] = run; run += t; }
+  if (full) {
+    int4 *p = reinterpret_cast<int4 *>(d + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_I / 4; i++) p[i] = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++) if (base + i < n) d[base + i] = v[i];
+  }
+}
+
 static int scan_rec(p3m_ctx *c, int *d, int64_t n, int *tmp, int *total_out) {
   const int64_t nb = (n + SCAN_CH - 1) / SCAN_CH;
   if (nb == 1) {
@@ -98,6 +160,13 @@ static size_t scan_tmp_ints(int64_t n) {
 // sized once for the longest scan a context runs (the record flags): a hipFree / hipMalloc pair in the middle of a step
 // is a device-wide synchronisation (28 ms on the default workload, every time the record count set a new maximum)
 int scan_reserve(p3m_ctx *c, int64_t n_max) {
+  const size_t nst = (size_t)((n_max + SCAN_CH - 1) / SCAN_CH) + 2;   // look-back words (k_scan_lookback) and the ticket counter, zero once
+  if (nst > c->scan_state_n) {
+    if (c->scan_state) (void)hipFree(c->scan_state);
+    HIP_TRY(hipMalloc(&c->scan_state, (nst + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->scan_state, 0, (nst + 2) * sizeof(unsigned long long)));
+    c->scan_state_n = nst; c->scan_epoch = 0;
+  }
   const size_t need = scan_tmp_ints(n_max);
   if (need > c->scan_tmp_n) {
     if (c->scan_tmp) (void)hipFree(c->scan_tmp);
@@ -107,6 +176,13 @@ int scan_reserve(p3m_ctx *c, int64_t n_max) {
   return P3M_OK;
 }
 int exclusive_scan_i32(p3m_ctx *c, int *data, int64_t n) {
+  const int64_t nb = (n + SCAN_CH - 1) / SCAN_CH;
+  if (nb > 1 && (size_t)nb + 2 <= c->scan_state_n && c->scan_epoch < 0x3ffffff0u) {   // one launch (k_scan_lookback); the ticket lives behind the words
+    c->scan_epoch++;
+    hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nb), dim3(SCAN_T), 0, c->stream, data, n, c->scan_state, reinterpret_cast<int *>(c->scan_state + c->scan_state_n), c->scan_epoch, data + n);
+    HIP_TRY(hipGetLastError());
+    return P3M_OK;
+  }
   const size_t need = scan_tmp_ints(n);
   if (need > c->scan_tmp_n) {
     if (c->scan_tmp) (void)hipFree(c->scan_tmp);
