@@ -15,12 +15,12 @@ def fft_source_sha16():
     sources it runs hash to the same value (anything else is a stale file and reads as null)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("fft.hip", "fft_core.h"):
+    for f in ("fft.hip", "fft_core.h", "fft_x2.h", "kick_fused.hip"):
         h.update(open(os.path.join(root, "cubep3m_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 PASS_OF = [  # kernel-name prefix (template arguments included where they tell passes apart) -> FFT pass of the fine sweep
-    ("void k_fft_x_fwd", "x_fwd"), ("void k_fft_x_inv", "x_inv_extract"), ("void k_fft_lines3", "z_inv_fused"),
+    ("void k_fft_x_fwd", "x_fwd"), ("void k_fft_x_inv2_kick", "x_inv_kick_fused"), ("void k_fft_x_inv", "x_inv_extract"), ("void k_fft_lines3", "z_inv_fused"),
 ]
 
 
