@@ -346,6 +346,13 @@ def test_fortran_mpi_host_calls_particle_mesh_through_the_adapter(tmp_path, cfg,
     # over the ranks, timers.f90:68-77), from p3m_hip_group_last_phase_ms
     import re
 
+    try:   # keep the report of the PP build for INTEGRATION.md
+        if cfg == "cfg1_8rank_pp":
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "mpi_time_report.txt"), "w") as f:
+                f.write(res.stdout)
+    except OSError:
+        pass
     rows = re.findall(r"^\s*(pos updt|linklist|par pass|fm  mass|fm   fft|fm  kick|pp intra|pp   ext|cm  mass|cm force|cm   vel|del part)\s*:\s+(\S+)\s+(\S+)\s+(\S+)", res.stdout, re.M)
     assert len(rows) == 12 * nsteps, res.stdout[-3000:]
     for tag, mx, av, mn in rows:
