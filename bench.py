@@ -517,6 +517,7 @@ def main():
         traffic = None
         kname = None
         sweep_traffic = None
+        in_step_traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
@@ -532,6 +533,9 @@ def main():
                 step_passes = ("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_extract")
                 if all(k in allp for k in step_passes):   # the five launches of one sweep: PMC bytes and their own launch times
                     sweep_traffic = sum(allp[k]["hbm_bytes_per_launch"] for k in step_passes)
+                in_step = ("x_fwd", "y_fwd", "z_inv_fused", "y_inv", "x_inv_kick_fused")
+                if all(k in allp for k in in_step):       # the step's own five launches (the last one carries the kick's bytes too)
+                    in_step_traffic = sum(allp[k]["hbm_bytes_per_launch"] for k in in_step)
             except Exception:
                 traffic = None
         if not kname:
@@ -549,6 +553,7 @@ def main():
                         "ms": passes["x_fwd"] + passes["y_fwd"] + passes["z_inv_fused"] + passes["y_inv"] + fused_ms,
                         "algorithmic_bytes": 10.5 * S * ntile,
                         "frac": 10.5 * S * ntile / ((passes["x_fwd"] + passes["y_fwd"] + passes["z_inv_fused"] + passes["y_inv"] + fused_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": in_step_traffic,
                         "what": "x_fwd, y_fwd, fused z, y_inv, inverse x with the NGP kick, the coarse kick and the survivor count inside (one rank's tiles)"},
                     "fine_sweep": {"ms": sweep_ms, "algorithmic_bytes": 10.5 * S * ntile,
                                    "achieved_GBs": 10.5 * S * ntile / (sweep_ms * 1e-3) / 1e9,

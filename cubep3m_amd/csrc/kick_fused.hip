@@ -154,10 +154,30 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     const int t2 = fdiv(brow, d_fb); tile = fdiv(t2, d_fb);
     jj = brow - t2 * fb; kk = t2 - tile * fb;
   };
-  // thread 3*br of the first 3*NR of the last wavefront requests the record range and the flag of box row br of a batch ...
+  // Per-batch tables.  One wavefront per workgroup (NR = 1): the batch IS one box row, the same for every lane -- its geometry is
+  // wavefront-uniform arithmetic on the work item (scalar registers), its record range and flag are requested a trip ahead by every
+  // lane from the same address (rgn*), and no table lives in LDS.  Four wavefronts: thread 3*br of the last wavefront requests the
+  // range and the flag of box row br of a batch (rg*) and writes them, with the rows' addresses, into the batch's LDS set a trip later.
   const int tt = tid - (C::TB - 64), tbr = tt / 3, tcomp = tt - 3 * tbr;
-  int rg0 = 0, rg1 = 0, rgf = 0;
+  int rg0 = 0, rg1 = 0, rgf = 0, rgn0 = 0, rgn1 = 0, rgnf = 0;
+  const int64_t comp_src = (int64_t)a.ntile * n * nchunk * n * BXC;        // LY elements between two components of a row
+  auto row_src = [&](int brow) {   // LY offset of component 0 of box row brow
+    int tile, kk, jj; decode(brow, tile, kk, jj);
+    return ((((int64_t)tile * n + (kk + lo)) * nchunk) * n + (jj + lo)) * BXC;
+  };
   auto rangeload = [&](int w) {
+    if constexpr (C::WAVE) {
+      rgn0 = 0; rgn1 = 0; rgnf = 0;
+      if (w < nbatch) {
+        int tile, kk, jj; decode(w, tile, kk, jj);
+        int tx, ty, tz; kf_tile_xyz(tile, a.T, tx, ty, tz);
+        const int64_t erow = (int64_t)(tz * a.pt + kk + lo) * a.E + (ty * a.pt + jj + lo);
+        if (a.crow) { const int *t = a.crow + erow * a.crow_w + a.ncn + 2 + 2 * tx; rgn0 = t[0]; rgn1 = t[1]; }
+        else { const int *t = a.cs + erow * a.E + tx * a.pt + lo; rgn0 = t[0]; rgn1 = t[fb]; }
+        rgnf = a.rowflag[w];
+      }
+      return;
+    }
     rg0 = 0; rg1 = 0; rgf = 0;
     const int brow = w * NR + tbr;
     if (tt >= 0 && tt < 3 * NR && tcomp == 0 && w < nbatch && brow < a.rows_total) {
@@ -169,13 +189,13 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
       rgf = a.rowflag[brow];
     }
   };
-  // ... and writes them into the batch's table set a trip later, with the rows' addresses
   auto tables = [&](int w, int set) {
+    if constexpr (C::WAVE) return;
     if (tt >= 0 && tt < 3 * NR) {
       const int brow = w * NR + tbr;
       if (brow < a.rows_total) {
+        src_row[set][tt] = row_src(brow) + tcomp * comp_src;
         int tile, kk, jj; decode(brow, tile, kk, jj);
-        src_row[set][tt] = (((((int64_t)tcomp * a.ntile + tile) * n + (kk + lo)) * nchunk) * n + (jj + lo)) * BXC;
         if (tcomp == 0) { box_off[set][tbr] = (int64_t)brow * fbp; rp0[set][tbr] = rg0; rp1[set][tbr] = rg1; rtile[set][tbr] = tile; rflag[set][tbr] = rgf; }
       } else if (tcomp == 0) { rp0[set][tbr] = 0; rp1[set][tbr] = 0; rtile[set][tbr] = 0; rflag[set][tbr] = 0; }
     }
@@ -190,11 +210,15 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
   float4 g4[NLD];
   auto fetch = [&](int w, int set) {
     const int nsl = 3 * min(NR, a.rows_total - w * NR);
+    const int64_t wsrc = C::WAVE && w < nbatch ? row_src(w) : 0;
 #pragma unroll
     for (int u = 0; u < NLD; u++) {
       g4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int rr = grc[u] & 255, ch = (grc[u] >> 8) & 255, l4 = grc[u] >> 16;
-      if (grc[u] >= 0 && rr < nsl) g4[u] = reinterpret_cast<const float4 *>(a.src + src_row[set][rr] + ch * cstride)[l4];
+      if (grc[u] >= 0 && rr < nsl) {
+        const int64_t sr = C::WAVE ? wsrc + rr * comp_src : src_row[set][rr];   // (one wavefront: slot rr = component rr of the one row)
+        g4[u] = reinterpret_cast<const float4 *>(a.src + sr + ch * cstride)[l4];
+      }
     }
   };
   // the records of a batch, flattened over the threads: record f of the batch = record f - (records of the rows before) of its row.
@@ -204,8 +228,8 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     cum[0] = 0;
 #pragma unroll
     for (int br = 0; br < NR; br++) {
-      rb0[br] = __builtin_amdgcn_readfirstlane(rp0[set][br]);
-      cum[br + 1] = cum[br] + __builtin_amdgcn_readfirstlane(rp1[set][br]) - rb0[br];
+      rb0[br] = __builtin_amdgcn_readfirstlane(C::WAVE ? rg0 : rp0[set][br]);
+      cum[br + 1] = cum[br] + __builtin_amdgcn_readfirstlane(C::WAVE ? rg1 : rp1[set][br]) - rb0[br];
     }
   };
   auto locate = [&](int f, int &row, int &idx) {   // after ranges(set)
@@ -236,7 +260,8 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     if (a.T > 1) {
       // a record sits in the range of every tile whose box row covers it: only the row of its owner tile kicks it -- the tile of
       // the coarse cell of the chain the particle sits in (link_list.f90:19-21)
-      tile = rtile[set][row]; kf_tile_xyz(tile, a.T, tx, ty, tz);
+      if (C::WAVE) { int kk_, jj_; decode(row0, tile, kk_, jj_); } else tile = rtile[set][row];
+      kf_tile_xyz(tile, a.T, tx, ty, tz);
       go = go && ((int)floorf(p.x / (float)a.ms)) / nct == tx && ((int)floorf(p.y / (float)a.ms)) / nct == ty && ((int)floorf(p.z / (float)a.ms)) / nct == tz;
     }
     float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -270,7 +295,8 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
 
   const int G = (int)gridDim.x;
   int w = blockIdx.x, set = 0;
-  if (w < nbatch) {
+  if (C::WAVE) rangeload(w);   // (consumed at the top of the first trip)
+  else if (w < nbatch) {
     rangeload(w); tables(w, 0);
     rangeload(w + G); if (w + G < nbatch) tables(w + G, 1);
     rangeload(w + 2 * G);
@@ -291,6 +317,7 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
         if (k <= h) pb[0] = (c32){g4[u].x, g4[u].y};
         if (k + 1 <= h) pb[1] = (c32){g4[u].z, g4[u].w};
       }
+    if (C::WAVE) { rg0 = rgn0; rg1 = rgn1; rgf = rgnf; rangeload(wn); }   // this row's range (requested a trip ago); the next row's
     records(set);
     KF_STAMP(1);
     kf_sync<TB>();
@@ -328,8 +355,8 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
       if (C::WAVE) kf_sync<TB>();   // F is X's memory: every lane has read its elements of X
       const int x0 = 2 * q - lo;   // box column of real element 2j for k2 = 0; lo is even
       float *pd = F + r * FP + x0;
-      const bool tobox = rflag[set][rbr] != 0;
-      float *pg = a.box + rcomp * a.bcs + box_off[set][rbr] + x0;
+      const bool tobox = (C::WAVE ? rgf : rflag[set][rbr]) != 0;
+      float *pg = a.box + rcomp * a.bcs + (C::WAVE ? (int64_t)row0 * fbp : box_off[set][rbr]) + x0;
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++) {
         const int x = x0 + 2 * R1 * k2;
@@ -346,8 +373,7 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     kf_sync<TB>();
     KF_STAMP(6);
     // ---- D
-    if (w + 2 * G < nbatch) tables(w + 2 * G, nn);   // (the last wavefront: see the tables)
-    rangeload(w + 3 * G);
+    if (!C::WAVE) { if (w + 2 * G < nbatch) tables(w + 2 * G, nn); rangeload(w + 3 * G); }   // (the last wavefront: see the tables)
     {
 #ifndef KF_AB_NOMAX
       // :217-218 (pad columns are zero): wavefront w takes the rows w, w + 4, ... of the batch
