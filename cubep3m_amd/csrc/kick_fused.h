@@ -20,5 +20,5 @@ struct KickFuseArgs {
 };
 
 struct p3m_ctx;
-int kick_fused_rows(int n, int fbp);                               // box rows per batch of the fused pass for line length n, box pitch fbp (0: none)
+int kick_fused_rows(int n, int fbp, int lo);                       // box rows per batch of the fused pass for line length n, box pitch fbp, box offset lo (0: none)
 int kick_fused_launch(p3m_ctx *c, KickFuseArgs &a, bool coarse);   // coarse: the coarse kick rides along (a.fc)

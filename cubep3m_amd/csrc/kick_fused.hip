@@ -91,6 +91,13 @@ __device__ __forceinline__ float kf_max2(float m, const float *f, int pitch) {
   asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(c), "v"(d));
   return m;
 }
+// one box point (the columns past the last whole group of four)
+__device__ __forceinline__ float kf_max1(float m, const float *f, int pitch) {
+  const float x = f[0], y = f[pitch], z = f[2 * pitch];
+  const float v = x * x + y * y + z * z;
+  asm("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(v));
+  return m;
+}
 #pragma clang fp contract(fast)  // the butterflies may fuse, as in fft.hip
 
 #ifdef KF_TRACE   // diagnostic build (tools/variant.sh ... -DKF_TRACE): shader-clock stamps of the steps of one workgroup's trips
@@ -113,7 +120,7 @@ template <int TB> __device__ __forceinline__ void kf_sync() {
 template <int R1, int R2> struct KCfg {
   using X = X2Cfg<R1, R2>;
   static constexpr int h = X::h, Q = X::Q, RPW = X::RPW, R2P = X::R2P, P = X::P, NCH = X::NCH;
-  static constexpr int TB = (RPW % 3 == 0) ? 64 : 256, RB = RPW * (TB / 64), NLD = (RB * NCH * 8 + TB - 1) / TB;
+  static constexpr int TB = (RPW == 3) ? 64 : 256, RB = RPW * (TB / 64), NLD = (RB * NCH * 8 + TB - 1) / TB;
   // One wavefront per workgroup: the gather buffer B, the exchange buffer X and the real rows F are ONE buffer (each is dead when the next is
   // written: a wavefront-wide fence between the last read and the first write suffices) -- 11.8 KB per wavefront at n = 560 instead of
   // 18.5, i.e. room for three wavefronts per SIMD.  Four wavefronts: B | X apart (F over B), the steps separated by barriers.
@@ -145,6 +152,7 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
   const int64_t cstride = (int64_t)n * BXC;
   const float fNn = (float)a.Nn;
   const int nct = a.pt / a.ms;
+  const int FR = C::WAVE ? (lo + 3) & ~3 : 0;   // front pad of a real row in LDS (one wavefront per workgroup: see step C)
   // W_h^{q*k1} at twl[q*R1P + k1] (k_fft_x_inv2 keeps the R1 factors of its q in registers; here they would push the pass to one
   // wavefront per SIMD: R1P is odd, the R2 lanes of a row read distinct banks, the rows of a wavefront the same words)
   for (int i = tid; i < R1 * R2; i += C::TB) { const int qq = i / R1, k1 = i - qq * R1; twl[qq * R1P + k1] = reinterpret_cast<const c32 *>(a.tw_g)[2 * qq * k1]; }
@@ -207,10 +215,35 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     const int e = tid + u * C::TB, t = e >> 3, ch = t / RB;
     grc[u] = ch < C::NCH ? ((t - ch * RB) | (ch << 8) | ((e & 7) << 16)) : -1;
   }
+  // One wavefront per workgroup: item u of a lane is slot ((tid >> 3) + 8u) % 3 and chunk ((tid >> 3) + 8u) / 3 -- the slot repeats every
+  // three items, eight chunks on: three per-lane offsets (gcl: source, lcl: LDS) serve all items, the rest is a uniform stride, and only
+  // the LAST item holds chunks past the row (its predicates are the only ones: per-item lane masks of a loop-invariant condition are
+  // kept in scalar register pairs, and 40 of them were spilled to vector lanes and read back every trip)
+  int64_t gcl[3] = {0, 0, 0}; int lcl[3] = {0, 0, 0};
+  if constexpr (C::WAVE) {
+#pragma unroll
+    for (int cl = 0; cl < 3; cl++) {
+      const int t0 = (tid >> 3) + 8 * cl, ch0 = t0 / 3, rr0 = t0 - 3 * ch0;
+      gcl[cl] = rr0 * comp_src + ch0 * cstride + 2 * (tid & 7);
+      lcl[cl] = rr0 * P + ch0 * BXC + 2 * (tid & 7);
+    }
+  }
+  auto item_full = [](int u) { return ((7 + 8 * (u % 3)) / 3 + 8 * (u / 3)) * BXC + 15 <= h; };   // every lane's two elements are columns <= h
+  auto item_chunk = [&](int u) { return ((tid >> 3) + 8 * (u % 3)) / 3 + 8 * (u / 3); };
   float4 g4[NLD];
   auto fetch = [&](int w, int set) {
+    if constexpr (C::WAVE) {   // (w < nbatch)
+      const c32 *sb = reinterpret_cast<const c32 *>(a.src) + row_src(w);
+#pragma unroll
+      for (int u = 0; u < NLD; u++) {
+        const float4 *ps = reinterpret_cast<const float4 *>(sb + gcl[u % 3] + (u / 3) * 8 * cstride);
+        if (item_full(u)) g4[u] = *ps;
+        else { g4[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (item_chunk(u) < C::NCH) g4[u] = *ps; }
+      }
+      return;
+    }
     const int nsl = 3 * min(NR, a.rows_total - w * NR);
-    const int64_t wsrc = C::WAVE && w < nbatch ? row_src(w) : 0;
+    const int64_t wsrc = 0;
 #pragma unroll
     for (int u = 0; u < NLD; u++) {
       g4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -271,7 +304,7 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
       const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;         // index into the force box
       const int lr = (tile * fb + k1) * fb + j1 - row0;
       go = (unsigned)lr < (unsigned)nbr && (unsigned)i1 < (unsigned)fb;                                // else: k_kick_fix (fine_mesh.hip)
-      if (go) { const float *f = F + (3 * lr) * FP + i1; fx = f[0]; fy = f[FP]; fz = f[2 * FP]; }
+      if (go) { const float *f = F + (3 * lr) * FP + FR + i1; fx = f[0]; fy = f[FP]; fz = f[2 * FP]; }
     }
     if (a.cnt256) {
       // every physical record passes here exactly once: the survivors of delete_particles, counted per block of 256 sorted records
@@ -309,6 +342,18 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     const int nxt = set == 2 ? 0 : set + 1, nn = nxt == 2 ? 0 : nxt + 1, wn = w + G, row0 = w * NR, nbr = min(NR, a.rows_total - row0);
     const bool rowok = r < 3 * nbr;
     // ---- A
+    if constexpr (C::WAVE) {
+#pragma unroll
+      for (int u = 0; u < NLD; u++) {
+        c32 *pb = B + lcl[u % 3] + (u / 3) * 8 * BXC;
+        if (item_full(u)) { pb[0] = (c32){g4[u].x, g4[u].y}; pb[1] = (c32){g4[u].z, g4[u].w}; }
+        else {
+          const int ch = item_chunk(u), k = ch * BXC + 2 * (tid & 7);
+          if (ch < C::NCH && k <= h) pb[0] = (c32){g4[u].x, g4[u].y};
+          if (ch < C::NCH && k + 1 <= h) pb[1] = (c32){g4[u].z, g4[u].w};
+        }
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < NLD; u++)
       if (grc[u] >= 0) {
@@ -354,9 +399,15 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
       dft<R2>(u);
       if (C::WAVE) kf_sync<TB>();   // F is X's memory: every lane has read its elements of X
       const int x0 = 2 * q - lo;   // box column of real element 2j for k2 = 0; lo is even
-      float *pd = F + r * FP + x0;
-      const bool tobox = (C::WAVE ? rgf : rflag[set][rbr]) != 0;
-      float *pg = a.box + rcomp * a.bcs + (C::WAVE ? (int64_t)row0 * fbp : box_off[set][rbr]) + x0;
+      float *pd = F + r * FP + FR + x0;
+      if constexpr (C::WAVE) {
+        // the WHOLE real row goes to LDS, box column i at F[FR + i] behind a front pad of FR >= lo floats: no lane of no store is masked
+        // (14 x 3 lane masks of loop-invariant column tests otherwise); a flagged row is copied to the box from there in step D
+#pragma unroll
+        for (int k2 = 0; k2 < R2; k2++) *reinterpret_cast<float2 *>(pd + 2 * R1 * k2) = make_float2(u[k2].x * rscale, -u[k2].y * rscale);
+      } else {
+      const bool tobox = rflag[set][rbr] != 0;
+      float *pg = a.box + rcomp * a.bcs + box_off[set][rbr] + x0;
 #pragma unroll
       for (int k2 = 0; k2 < R2; k2++) {
         const int x = x0 + 2 * R1 * k2;
@@ -368,6 +419,7 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
           if (tobox) *reinterpret_cast<float2 *>(pg + 2 * R1 * k2) = o2;
         }
       }
+      }
     } else if (C::WAVE) kf_sync<TB>();
     KF_STAMP(5);
     kf_sync<TB>();
@@ -375,7 +427,17 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     // ---- D
     if (!C::WAVE) { if (w + 2 * G < nbatch) tables(w + 2 * G, nn); rangeload(w + 3 * G); }   // (the last wavefront: see the tables)
     {
+      if constexpr (C::WAVE) {
+        if (rgf) {   // a flagged row (k_ngp_fixup): k_kick_fix takes its forces from the box; pad columns are zero there
+          for (int cmp = 0; cmp < 3; cmp++)
+            for (int x = lane; x < fbp; x += 64) a.box[cmp * a.bcs + (int64_t)row0 * fbp + x] = x < fb ? F[cmp * FP + FR + x] : 0.f;
+        }
+      }
 #ifndef KF_AB_NOMAX
+      if constexpr (C::WAVE) {   // :217-218 over the columns [0, fb) of the one row
+        for (int c4 = lane; c4 < (fb >> 2); c4 += 64) fmax2 = kf_max2(fmax2, F + FR + 4 * c4, FP);
+        if (lane < (fb & 3)) fmax2 = kf_max1(fmax2, F + FR + (fb & ~3) + lane, FP);
+      } else
       // :217-218 (pad columns are zero): wavefront w takes the rows w, w + 4, ... of the batch
       for (int br = tid >> 6; br < nbr; br += C::TB / 64)
         for (int c4 = lane; c4 < (fbp >> 2); c4 += 64) fmax2 = kf_max2(fmax2, F + (3 * br) * FP + 4 * c4, FP);
@@ -404,19 +466,21 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
 // ------------------------------------------------------------------ host side
 // pitch of the rows in LDS: = 8 (mod 32) floats where that fits -- the (up to) RPW row groups of a wavefront's 8-byte stores then start
 // 8 banks apart; 0: the box rows of a batch do not fit the staging buffer they are laid over
-template <int R1, int R2> static int fused_row_pitch(int fbp) {
+template <int R1, int R2> static int fused_row_pitch(int fbp, int lo) {
   using C = KCfg<R1, R2>;
   constexpr int NR = C::RB / 3;
   if (NR < 1) return 0;
-  const int limit = (int)(((size_t)C::RB * C::P * 2) / (3 * NR)) & ~3;
-  int fp = fbp + ((8 - fbp % 32 + 32) % 32);
-  if (fp > limit) fp = fbp;
+  // one wavefront per workgroup: the whole real row behind its front pad (step C), over the larger of B and X
+  const int need = C::WAVE ? (((lo + 3) & ~3) + 2 * C::h - lo + 3) & ~3 : fbp;
+  const int limit = C::WAVE ? (int)(2 * C::ube / 3) & ~3 : (int)(((size_t)C::RB * C::P * 2) / (3 * NR)) & ~3;
+  int fp = need + ((8 - need % 32 + 32) % 32);
+  if (fp > limit) fp = need;
   return fp <= limit ? fp : 0;
 }
 template <int R1, int R2, bool COARSE> static int kick_fused_impl(p3m_ctx *c, KickFuseArgs &a) {
   using C = KCfg<R1, R2>;
   constexpr int NR = C::RB / 3;
-  a.FP = fused_row_pitch<R1, R2>(a.fbp);
+  a.FP = fused_row_pitch<R1, R2>(a.fbp, a.lo);
   if (a.FP == 0) { p3m_set_error("fused kick: the box rows do not fit the staging buffer"); return P3M_EINVAL; }
   if ((int64_t)a.rows_total * a.fb >= 0xffffffffLL) { p3m_set_error("fused kick: too many box rows"); return P3M_EINVAL; }
   a.m_fb = fdiv_magic(a.fb);
@@ -454,8 +518,8 @@ template <int R1, int R2, bool COARSE> static int kick_fused_impl(p3m_ctx *c, Ki
 
 // box rows per batch of the fused pass for this line length and box row pitch (0: no fused pass): what k_ngp_fixup, k_fft_x_inv2_kick and
 // k_kick_fix must agree on
-int kick_fused_rows(int n, int fbp) {
-#define X(H, A, B) if (n == 2 * H) return fused_row_pitch<A, B>(fbp) ? KCfg<A, B>::RB / 3 : 0;
+int kick_fused_rows(int n, int fbp, int lo) {
+#define X(H, A, B) if (n == 2 * H) return fused_row_pitch<A, B>(fbp, lo) ? KCfg<A, B>::RB / 3 : 0;
   P3M_X2_SIZES(X)
 #undef X
   return 0;

@@ -115,7 +115,7 @@ extern "C" int p3m_hip_create(const p3m_params *params, p3m_ctx **out) {
   if (hipMemset(c->rho, 0, S * c->tile_batch * sizeof(float)) != hipSuccess || hipMemset(c->work, 0, 3 * S * c->tile_batch * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
   A(dalloc(&c->fbox, (size_t)3 * g.ntiles * g.fb * g.fb * g.fbp));
   // the fused inverse-x + kick pass of NGP steps (kick_fused.hip): rows per batch (0: this tile size has none) and the per-row flags, all zero between steps
-  c->fuse_nr = kick_fused_rows(g.nf, g.fbp);
+  c->fuse_nr = kick_fused_rows(g.nf, g.fbp, g.nb - 2);
   if (c->fuse_nr > 0) { A(dalloc(&c->rowflag, (size_t)g.ntiles * g.fb * g.fb + 16)); if (hipMemset(c->rowflag, 0, (size_t)g.ntiles * g.fb * g.fb + 16) != hipSuccess) return fail(P3M_EDEVICE); }
   A(dalloc(&c->kern_f, (size_t)3 * g.nf * g.nf * g.px));
   if (hipMemset(c->kern_f, 0, (size_t)3 * g.nf * g.nf * g.px * sizeof(float)) != hipSuccess) return fail(P3M_EDEVICE);
