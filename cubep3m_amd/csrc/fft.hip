@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ sr
       dft<R1>(v);
       c32 *pxw = X + (r * R1) * R2P + q;
 #pragma unroll
-      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twq[k1]) : v[0];
+      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmulr(v[k1], twq[k1]) : v[0];
     }
     __syncthreads();
     fetch(w + gridDim.x);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
       dft<R1>(v);
       c32 *pxw = X + (r * R1) * R2P + q;
 #pragma unroll
-      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twq[k1]) : v[0];
+      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmulr(v[k1], twq[k1]) : v[0];
     }
     __syncthreads();
     if (s2 && rowok) {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2c(const float2 *__restrict__ 
       dft<R1>(v);
       c32 *pxw = X + (r * R1) * R2P + q;
 #pragma unroll
-      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twq[k1]) : v[0];
+      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmulr(v[k1], twq[k1]) : v[0];
     }
     __syncthreads();
     if (s2 && rowok) {
@@ -798,7 +798,7 @@ template <int R, int STRIDE> __device__ __forceinline__ void store_twiddled(c32 
   for (int k1 = 1; k1 < R; k1++) {
     const c32 wk = w[(k1 - 1) % P3M_TWD];
     if (k1 + P3M_TWD < R) w[(k1 - 1) % P3M_TWD] = tw[__mul24(gq, k1 + P3M_TWD)];
-    px[k1 * STRIDE] = vmul(v[k1], wk);
+    px[k1 * STRIDE] = vmulr(v[k1], wk);
   }
 }
 template <int R1, int R2> struct L2Cfg {

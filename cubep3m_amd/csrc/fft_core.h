@@ -52,6 +52,30 @@ __device__ __forceinline__ c32 vmul(c32 a, c32 b) { return a.yx * (c32){-b.y, b.
 // needs them in registers, 4 VGPRs per twiddle, hoisted out of every loop)
 __device__ __forceinline__ c32 vmulk(c32 a, float c, float s) { return (c32){a.x * c + a.y * s, a.y * c - a.x * s}; }
 __device__ __forceinline__ c32 vmi(c32 a) { return (c32){a.y, -a.x}; }   // * -i
+// The same with the swizzles and sign flips spelled out as op_sel / neg modifiers of ONE or TWO packed instructions: from the vector
+// expressions above the compiler builds the swapped / negated operand first (v_xor + v_mov per product or +-i sum).
+//   vmulr: a * b, b in registers (twiddles from LDS or memory; compile-time constants stay with vmul / vmulk)
+__device__ __forceinline__ c32 vmulr(c32 a, c32 b) {
+  c32 t;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));                                           // a * b.xx
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(a), "v"(b));       // + a.yx * (-b.y, b.y)
+  return t;
+}
+//   a - i b and a + i b
+__device__ __forceinline__ c32 vsubi(c32 a, c32 b) { c32 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }   // (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ c32 vaddi(c32 a, c32 b) { c32 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }   // (a.x - b.y, a.y + b.x)
+// The Hermitian unscramble of the real transforms, one packed instruction per line with the swizzles and signs as op_sel / neg modifiers
+// (written on .x / .y the compiler forms sum and difference vectors and then moves their halves about: 12 instructions against 5):
+//   x[m], x[h-m], t = exp(-2 pi i m / n)  ->  conj(e + i o),  e = (x[m] + conj(x[h-m])) , o = (x[m] - conj(x[h-m])) conj(t)
+__device__ __forceinline__ c32 c2r_pre(c32 xk, c32 xm, c32 t) {
+  c32 e, d, o, v;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(e) : "v"(xk), "v"(xm));                                     // (xk.x + xm.x, xk.y - xm.y)
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(xk), "v"(xm));                                     // (xk.x - xm.x, xk.y + xm.y)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(o) : "v"(d), "v"(t));                                    // d * t.xx
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(o) : "v"(d), "v"(t));   // + d.yx * (t.y, -t.y)
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(v) : "v"(e), "v"(o));   // (e.x - o.y, -e.y - o.x)
+  return v;
+}
 
 // forward DFT (sign -1) of R values held in registers
 template <int R> __device__ __forceinline__ void dft(c32 (&v)[R]);
@@ -61,8 +85,7 @@ template <> __device__ __forceinline__ void dft<2>(c32 (&v)[2]) {
 }
 template <> __device__ __forceinline__ void dft<4>(c32 (&v)[4]) {
   const c32 a = v[0] + v[2], b = v[0] - v[2], c = v[1] + v[3], d = v[1] - v[3];
-  const c32 jd = vmi(d);
-  v[0] = a + c; v[1] = b + jd; v[2] = a - c; v[3] = b - jd;
+  v[0] = a + c; v[1] = vsubi(b, d); v[2] = a - c; v[3] = vaddi(b, d);
 }
 template <> __device__ __forceinline__ void dft<8>(c32 (&v)[8]) {
   const float r = 0.70710678118654752440f;
@@ -119,9 +142,8 @@ template <int R> __device__ __forceinline__ void dft_odd(c32 (&v)[R]) {
       const float cc = tab.c[(a * p) % R], ss = tab.s[(a * p) % R];
       A = A + cc * t[p]; B = B + ss * u[p];
     }
-    const c32 jB = vmi(B);
-    v[a] = A + jB;       // A - iB
-    v[R - a] = A - jB;   // A + iB
+    v[a] = vsubi(A, B);       // A - iB
+    v[R - a] = vaddi(A, B);   // A + iB
   }
 }
 template <> __device__ __forceinline__ void dft<3>(c32 (&v)[3]) { dft_odd<3>(v); }
@@ -200,7 +222,7 @@ __device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 
       const c32 *twv = reinterpret_cast<const c32 *>(tw);
       const int ts = __mul24(tstep, k);
 #pragma unroll
-      for (int m = 1; m < R; m++) v[m] = vmul(v[m], twv[__mul24(m, ts)]);   // 24-bit multiply: full rate
+      for (int m = 1; m < R; m++) v[m] = vmulr(v[m], twv[__mul24(m, ts)]);   // 24-bit multiply: full rate
     }
     dft<R>(v);
     const int j0 = __mul24(j - k, R) + k;

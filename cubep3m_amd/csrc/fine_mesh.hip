@@ -667,13 +667,14 @@ __global__ __launch_bounds__(256) void k_kick_fix(const float4 *__restrict__ spo
 
 // Whole NGP steps run the fused pass when the tile size has a two-register-stage x kernel whose staging buffer holds the box rows, all
 // tiles are swept in one batch (the LY rows of every tile must still exist when the kick runs) and the coarse force array can be
-// indexed with 32 bits.  P3M_KICK_UNFUSED=1 keeps the force box + k_fine_kick_rows pair (A/B measurements, tests).
+// indexed with 32-bit byte offsets.  P3M_KICK_UNFUSED=1 keeps the force box + k_fine_kick_rows pair (A/B measurements, tests).
 bool fine_kick_fusable(const p3m_ctx *c) {
-  static const bool off = getenv("P3M_KICK_UNFUSED") && getenv("P3M_KICK_UNFUSED")[0] == '1';
+  const char *env = getenv("P3M_KICK_UNFUSED");   // (read at every step: a test runs both paths in one process)
+  const bool off = env && env[0] == '1';
   const Geometry &g = c->g;
   const int64_t m = g.ncn + 2;
   return !off && (c->p.flags & P3M_FLAG_NGP) && c->tile_batch == g.ntiles && c->fuse_nr > 0 && c->rowflag && fft_x2_box_pass(g.nf, g.nb - 2) &&
-         3 * m * m * m < 0x7fffffffLL && (int64_t)g.ntiles * g.fb * g.fb < 0x7fffffffLL;
+         3 * m * m * m < 0x3fffffffLL && (int64_t)g.ntiles * g.fb * g.fb < 0x7fffffffLL;
 }
 static int fine_xinv_kick_fused(p3m_ctx *c, float a_mid, float dt, int *cnt256, bool dry = false) {
   const Geometry &g = c->g;

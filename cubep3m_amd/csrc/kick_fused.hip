@@ -57,7 +57,12 @@ __device__ __forceinline__ void kf_coarse_gather(float (&cf)[24], unsigned o0, c
       for (int cx = 0; cx < 2; cx++) {
         const unsigned o = o0 + (cz ? m * m : 0u) + (cy ? m : 0u) + (cx ? 1u : 0u);
         const int e = 3 * (4 * cz + 2 * cy + cx);
-        cf[e] = a.fc[o]; cf[e + 1] = a.fc[o + ccs]; cf[e + 2] = a.fc[o + 2u * ccs];
+        if (cx) continue;   // the two x corners are neighbours in memory: one 8-byte load (4-byte aligned: the hardware takes it)
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        const char *fb_ = reinterpret_cast<const char *>(a.fc);
+        const f2u v0 = *reinterpret_cast<const f2u *>(fb_ + (size_t)(o << 2)), v1 = *reinterpret_cast<const f2u *>(fb_ + (size_t)((o + ccs) << 2)),
+                  v2 = *reinterpret_cast<const f2u *>(fb_ + (size_t)((o + 2u * ccs) << 2));
+        cf[e] = v0.x; cf[e + 3] = v0.y; cf[e + 1] = v1.x; cf[e + 4] = v1.y; cf[e + 2] = v2.x; cf[e + 5] = v2.y;
       }
 }
 // :265-266 and coarse_velocity.f90:153-168 -- the arithmetic of k_fine_kick_rows, term by term, in its order
@@ -120,30 +125,39 @@ template <int TB> __device__ __forceinline__ void kf_sync() {
 template <int R1, int R2> struct KCfg {
   using X = X2Cfg<R1, R2>;
   static constexpr int h = X::h, Q = X::Q, RPW = X::RPW, R2P = X::R2P, P = X::P, NCH = X::NCH;
-  static constexpr int TB = (RPW == 3) ? 64 : 256, RB = RPW * (TB / 64), NLD = (RB * NCH * 8 + TB - 1) / TB;
+  static constexpr int TB = (RPW == 3) ? 64 : 256, RB = RPW * (TB / 64), NLD = (RB * NCH * 8 + TB - 1) / TB;   // TB: the threads that share a batch
+  // threads of a workgroup; batches in flight per workgroup.  KF_WG4: the one-wavefront shape as workgroups of four independent wavefronts
+  // sharing the twiddle tables (33 KB for four: 16 wavefronts per CU fit) -- measured 878 us against 857 at three wavefronts per SIMD,
+  // and 920 capped at 128 VGPRs for four (64 bytes of scratch): the pass does not want more wavefronts, it wants fewer instructions
+#ifdef KF_WG4
+  static constexpr int LT = 256, NW = LT / TB;
+#else
+  static constexpr int LT = TB, NW = 1;
+#endif
   // One wavefront per workgroup: the gather buffer B, the exchange buffer X and the real rows F are ONE buffer (each is dead when the next is
   // written: a wavefront-wide fence between the last read and the first write suffices) -- 11.8 KB per wavefront at n = 560 instead of
   // 18.5, i.e. room for three wavefronts per SIMD.  Four wavefronts: B | X apart (F over B), the steps separated by barriers.
   static constexpr bool WAVE = TB == 64;
   static constexpr size_t ube = WAVE ? ((size_t)RB * P > (size_t)RB * R1 * R2P ? (size_t)RB * P : (size_t)RB * R1 * R2P) : (size_t)RB * P + (size_t)RB * R1 * R2P;
-  static constexpr size_t lds = sizeof(float2) * (ube + h + (size_t)R2 * (R1 | 1));   // B (| X) | tw | twl
+  static constexpr size_t lds = sizeof(float2) * (NW * ube + h + (size_t)R2 * (R1 | 1));   // B (| X) of every batch in flight | tw | twl
 };
 template <int R1, int R2, bool COARSE>
-__global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuseArgs a) {
+__global__ __launch_bounds__((KCfg<R1, R2>::LT)) void k_fft_x_inv2_kick(KickFuseArgs a) {
   using C = KCfg<R1, R2>;
   constexpr int TB = C::TB;
   constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P, NLD = C::NLD, NR = RB / 3, R1P = R1 | 1;
   extern __shared__ float2 lds[];
-  c32 *B = reinterpret_cast<c32 *>(lds), *X = C::WAVE ? B : B + RB * P, *tw = B + C::ube, *twl = tw + h;
-  float *F = reinterpret_cast<float *>(lds);          // [3*NR][FP] real box rows of the batch, over B
+  const int wid = C::WAVE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // one wavefront per batch: the workgroup's wavefronts share the twiddle tables, nothing else
+  c32 *B = reinterpret_cast<c32 *>(lds) + wid * C::ube, *X = C::WAVE ? B : B + RB * P, *tw = reinterpret_cast<c32 *>(lds) + C::NW * C::ube, *twl = tw + h;
+  float *F = reinterpret_cast<float *>(B);            // [3*NR][FP] real box rows of the batch, over B
   // three sets of the per-batch tables: trip i reads the sets of batch i (steps C, D) and of batch i+1 (the requests of step B), and its
   // LAST wavefront writes the set of batch i+2 in step D -- where it would otherwise wait for the first one, which alone holds the
   // batch's second slot of records (in step A the tables were on the path every wavefront waits for: 2300 of a trip's 20 000 clocks)
   __shared__ int64_t src_row[3][RB], box_off[3][NR];
   __shared__ int rp0[3][NR], rp1[3][NR], rtile[3][NR], rflag[3][NR];
-  for (int i = threadIdx.x; i < h; i += C::TB) tw[i] = reinterpret_cast<const c32 *>(a.tw_g)[i];
+  for (int i = threadIdx.x; i < h; i += C::LT) tw[i] = reinterpret_cast<const c32 *>(a.tw_g)[i];
   const int n = a.n, fb = a.fb, fbp = a.fbp, lo = a.lo, FP = a.FP, nchunk = a.px / BXC;
-  const int tid = threadIdx.x, lane = tid & 63, rw = lane / Q, q = lane - rw * Q;
+  const int tid = C::WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, rw = lane / Q, q = lane - rw * Q;   // tid: thread of the batch
   const int r = (tid >> 6) * C::RPW + rw;              // slot of the row batch: box row r / 3, component r % 3
   const bool act = rw < C::RPW && r < 3 * NR, s1 = act && q < R2, s2 = act && q < R1;
   const int rbr = r / 3, rcomp = r - 3 * rbr;
@@ -155,7 +169,7 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
   const int FR = C::WAVE ? (lo + 3) & ~3 : 0;   // front pad of a real row in LDS (one wavefront per workgroup: see step C)
   // W_h^{q*k1} at twl[q*R1P + k1] (k_fft_x_inv2 keeps the R1 factors of its q in registers; here they would push the pass to one
   // wavefront per SIMD: R1P is odd, the R2 lanes of a row read distinct banks, the rows of a wavefront the same words)
-  for (int i = tid; i < R1 * R2; i += C::TB) { const int qq = i / R1, k1 = i - qq * R1; twl[qq * R1P + k1] = reinterpret_cast<const c32 *>(a.tw_g)[2 * qq * k1]; }
+  for (int i = threadIdx.x; i < R1 * R2; i += C::LT) { const int qq = i / R1, k1 = i - qq * R1; twl[qq * R1P + k1] = reinterpret_cast<const c32 *>(a.tw_g)[2 * qq * k1]; }
   // box row -> (tile, plane kk, row jj); rows_total * fb < 2^32 (kick_fused_impl): the divisions are one mulhi each
   const fdiv_t d_fb{a.m_fb, fb};
   auto decode = [&](int brow, int &tile, int &kk, int &jj) {
@@ -326,15 +340,15 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
     }
   };
 
-  const int G = (int)gridDim.x;
-  int w = blockIdx.x, set = 0;
+  const int G = (int)gridDim.x * C::NW;
+  int w = (int)blockIdx.x * C::NW + wid, set = 0;
   if (C::WAVE) rangeload(w);   // (consumed at the top of the first trip)
   else if (w < nbatch) {
     rangeload(w); tables(w, 0);
     rangeload(w + G); if (w + G < nbatch) tables(w + G, 1);
     rangeload(w + 2 * G);
   }
-  kf_sync<TB>();
+  __syncthreads();   // the twiddle tables (the only barrier of the one-wavefront shape: its wavefronts part here)
   if (w < nbatch) fetch(w, 0);
   int trip = 0; (void)trip;
   for (; w < nbatch; w += G, set = set == 2 ? 0 : set + 1, trip++) {
@@ -374,16 +388,13 @@ __global__ __launch_bounds__((KCfg<R1, R2>::TB)) void k_fft_x_inv2_kick(KickFuse
       c32 v[R1];
 #pragma unroll
       for (int i = 0; i < R1; i++) {
-        const c32 xk = pk[R2 * i], xm = pm[R2 * (R1 - 1 - i)], t = pt[R2 * i];   // X[m], X[h-m], exp(-2 pi i m / n), m = R2*i + q
-        const c32 e2 = {xk.x + xm.x, xk.y - xm.y}, d = {xk.x - xm.x, xk.y + xm.y};
-        const c32 o = {d.x * t.x + d.y * t.y, d.y * t.x - d.x * t.y};   // d * conj(t)
-        v[i] = (c32){e2.x - o.y, -(e2.y + o.x)};                        // conj(e + i o): the forward machinery then yields conj(IFFT)
+        v[i] = c2r_pre(pk[R2 * i], pm[R2 * (R1 - 1 - i)], pt[R2 * i]);   // X[m], X[h-m], exp(-2 pi i m / n), m = R2*i + q: conj(e + i o), the forward machinery then yields conj(IFFT)
       }
       dft<R1>(v);
       if (C::WAVE) kf_sync<TB>();   // X is B's memory: every lane has read its elements of B
       c32 *pxw = X + (r * R1) * R2P + q;
 #pragma unroll
-      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmul(v[k1], twl[q * R1P + k1]) : v[0];
+      for (int k1 = 0; k1 < R1; k1++) pxw[k1 * R2P] = k1 ? vmulr(v[k1], twl[q * R1P + k1]) : v[0];
     } else if (C::WAVE) kf_sync<TB>();
     KF_STAMP(3);
     kf_sync<TB>();
@@ -493,11 +504,11 @@ template <int R1, int R2, bool COARSE> static int kick_fused_impl(p3m_ctx *c, Ki
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   static int occ = 0;
   if (occ == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), C::TB, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), C::LT, lds));
     if (occ < 1) occ = 1;
   }
-  const int64_t nbatch = cdiv(a.rows_total, NR), g = (int64_t)256 * occ;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), lds, c->stream, a);
+  const int64_t nwg = cdiv(cdiv(a.rows_total, NR), C::NW), g = (int64_t)256 * occ;   // a workgroup works NW batches at a time
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g < nwg ? g : nwg)), dim3(C::LT), lds, c->stream, a);
   HIP_TRY(hipGetLastError());
 #ifdef KF_TRACE
   { static int calls = 0;

@@ -628,6 +628,38 @@ def test_tile_force_at_the_register_fft_sizes(PM, n):
     assert mg == pytest.approx(mo, rel=1e-5)
 
 
+@pytest.mark.parametrize("n", [304, 560, 608])
+def test_fused_kick_in_its_one_wavefront_shape_against_the_force_box_pair(PM, n, monkeypatch):
+    """The tile sizes whose x pass holds exactly three rows per wavefront (19 x 8, 20 x 14, 19 x 16) run the fused inverse-x + kick
+    pass as independent wavefronts (kick_fused.hip): two whole PM steps, clustered records with velocities, against the same
+    library running the force box + k_fine_kick_rows pair (P3M_KICK_UNFUSED=1; its box is held to the oracle at these sizes by
+    test_tile_force_at_the_register_fft_sizes and the 560 tests).  Same records, same order: positions, counts and PIDs exact,
+    velocities to the last bits (the two x passes associate their butterflies differently)."""
+    p = Params(tiles_node_dim=1, nf_tile=n, ngp=True, density_buffer=1.5)
+    box = float(p.nf_physical_node_dim)
+    npart = min(int(box ** 3 / 8), 3000000)
+    xv = clustered_particles(npart, box, seed=n, frac=0.3, nblobs=60, sigma=0.8, vel_sigma=0.5)
+    xv[:2000, 1] = np.nextafter(np.floor(xv[:2000, 1]) + np.float32(1.0), np.float32(0))   # half an ulp below a row face: the flagged rows (k_kick_fix)
+    pid = np.arange(1, npart + 1, dtype=np.int64)
+    res = []
+    for unfused in ("1", "0"):
+        monkeypatch.setenv("P3M_KICK_UNFUSED", unfused)
+        g = PM(p, FINE_TABLE, COARSE_TABLE)
+        g.upload_particles(xv, pid)
+        outs = [g.particle_mesh(0.2, 0.05, 0.04 if s else 0.0, 8.0) for s in range(2)]
+        x, q = by_pid(*g.download_particles())
+        res.append((x, q, outs))
+        g.close()
+    (xa, qa, oa), (xb, qb, ob) = res
+    assert np.array_equal(qa, qb) and np.abs(xa[:, :3] - xb[:, :3]).max() <= POS_TOL   # (the second step drifts with the first one's kick)
+    for a, b in zip(oa, ob):
+        assert (a.np_total, a.np_ghost, a.np_deleted) == (b.np_total, b.np_ghost, b.np_deleted)
+        assert a.dt_f_acc == pytest.approx(b.dt_f_acc, rel=1e-6) and a.dt_c_acc == pytest.approx(b.dt_c_acc, rel=1e-6)
+        assert a.sum_rho_f == pytest.approx(b.sum_rho_f, rel=1e-9)
+    v0 = xv[np.argsort(pid), 3:]
+    assert rel_rms(xa[:, 3:] - v0, xb[:, 3:] - v0) < 1e-6
+
+
 @pytest.mark.parametrize("n", [768, 832, 896, 1024])
 def test_long_lines_forward_transform_vs_numpy(PM, n):
     """Line lengths beyond 608 (register-stage kernels only: 640 ... 1024 = 32 x 32, the literal 1024^3 coarse mesh of BASELINE
