@@ -426,10 +426,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2(const float2 *__restrict__ s
       c32 v[R1];
 #pragma unroll
       for (int a = 0; a < R1; a++) {
-        const c32 xk = pk[R2 * a], xm = pm[R2 * (R1 - 1 - a)], t = pt[R2 * a];   // X[m], X[h-m], exp(-2 pi i m / n), m = R2*a + q
-        const c32 e2 = {xk.x + xm.x, xk.y - xm.y}, d = {xk.x - xm.x, xk.y + xm.y};
-        const c32 o = {d.x * t.x + d.y * t.y, d.y * t.x - d.x * t.y};   // d * conj(t)
-        v[a] = (c32){e2.x - o.y, -(e2.y + o.x)};                        // conj(e + i o): the forward machinery then yields conj(IFFT)
+        v[a] = c2r_pre(pk[R2 * a], pm[R2 * (R1 - 1 - a)], pt[R2 * a]);   // X[m], X[h-m], exp(-2 pi i m / n), m = R2*a + q -> conj(e + i o): the forward machinery then yields conj(IFFT)
       }
       dft<R1>(v);
       c32 *pxw = X + (r * R1) * R2P + q;
@@ -559,10 +556,7 @@ __global__ __launch_bounds__(256) void k_fft_x_inv2c(const float2 *__restrict__ 
       c32 v[R1];
 #pragma unroll
       for (int a = 0; a < R1; a++) {
-        const c32 xk = pk[R2 * a], xm = pm[R2 * (R1 - 1 - a)], t = pt[R2 * a];
-        const c32 e2 = {xk.x + xm.x, xk.y - xm.y}, d = {xk.x - xm.x, xk.y + xm.y};
-        const c32 o = {d.x * t.x + d.y * t.y, d.y * t.x - d.x * t.y};
-        v[a] = (c32){e2.x - o.y, -(e2.y + o.x)};
+        v[a] = c2r_pre(pk[R2 * a], pm[R2 * (R1 - 1 - a)], pt[R2 * a]);
       }
       dft<R1>(v);
       c32 *pxw = X + (r * R1) * R2P + q;
@@ -630,6 +624,10 @@ struct LinesArgs {
   // line element idx of batch entry b belongs to peer idx / direct_s, and is stored straight into THAT peer's receive block
   // (where the all-to-all would have copied it): the normal address plus (peer - b) * direct_delta elements
   int direct_s; unsigned direct_magic; int64_t direct_delta;
+  // kmirror (k_fft_lines3r): K(c, n - z) = +-K(c, z) holds EXACTLY in `kern` (odd for component 2, the line's own axis; even for 0 and 1) --
+  // the upper half of a line is read from its mirror elements, which the thread that owns those reads at the same time: the table's
+  // HBM traffic halves (0.53 of 3.7 GB per pass at n = 560), the values are bit for bit the ones a direct read returns
+  int kmirror;
 };
 // Each workgroup walks a grid-stride list of work items and is software-pipelined: the next
 // item's global loads are issued into registers (LUX 16-byte loads per lane) before the butterflies
@@ -915,7 +913,7 @@ template <int R1, int R2> struct L3Cfg {
   static constexpr int bufe = (R1 * R2P > R2 * R1P ? R1 * R2P : R2 * R1P) * BXC;
   static constexpr size_t lds = sizeof(float2) * ((size_t)2 * bufe + n);
 };
-template <int R1, int R2>
+template <int R1, int R2, bool KM>   // KM: LinesArgs::kmirror (a runtime branch around the loads cost the pass more than the halved table traffic bought)
 __global__ __launch_bounds__((L3Cfg<R1, R2>::TB)) void k_fft_lines3r(LinesArgs a, const float2 *__restrict__ tw_g) {
   using C = L3Cfg<R1, R2>;
   constexpr int n = C::n, R2P = C::R2P, R1P = C::R1P;
@@ -946,6 +944,12 @@ __global__ __launch_bounds__((L3Cfg<R1, R2>::TB)) void k_fft_lines3r(LinesArgs a
     if (!on) return;
     int o, chunk; int64_t b; locate(w, o, chunk, b);
     const float *k = a.kern + comp * a.kern_comp_stride + b * a.kern_batch_stride + bundle_off2(0, a.src_planes, n, a.nchunk, o, chunk) + g * BXC + col;
+    if constexpr (KM) {   // elements z = g + R1*m > n/2 from z' = n - z = (n - R1*m) - g: a second base, compile-time offsets
+      const float *km = k - 2 * g * BXC;   // (the odd component's sign is applied where K is used: a multiply here would wait for the loads)
+#pragma unroll
+      for (int m = 0; m < R2; m++) K[m] = m >= (R2 + 1) / 2 ? km[(n - m * R1) * BXC] : k[m * (R1 * BXC)];
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < R2; m++) K[m] = k[m * (R1 * BXC)];
   };
@@ -979,7 +983,10 @@ __global__ __launch_bounds__((L3Cfg<R1, R2>::TB)) void k_fft_lines3r(LinesArgs a
       if (rB) {
         c32 t[R2];
 #pragma unroll
-        for (int m = 0; m < R2; m++) t[m] = (c32){-rh[m].y * K[m], -(rh[m].x * K[m])};   // conj(i K rho-hat)
+        for (int m = 0; m < R2; m++) {
+          const float km = (KM && m >= (R2 + 1) / 2 && comp == 2) ? -K[m] : K[m];   // K_z is odd along z: the mirrored half carries the other sign
+          t[m] = (c32){-rh[m].y * km, -(rh[m].x * km)};   // conj(i K rho-hat)
+        }
         dft<R2>(t);
         c32 *px = Xw + g * BXC + col;
         int gq = g; asm volatile("" : "+v"(gq));
@@ -1314,16 +1321,17 @@ static bool lines2_has(int n) {
 template <int R1, int R2> static int lines3r_impl(p3m_ctx *c, const FftPlan &pl, LinesArgs a, int batch) {
   using C = L3Cfg<R1, R2>;
   a.n = pl.n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
-  P3M_TRY((set_lds(k_fft_lines3r<R1, R2>, C::lds)));
+  auto kern = a.kmirror ? k_fft_lines3r<R1, R2, true> : k_fft_lines3r<R1, R2, false>;
+  P3M_TRY((set_lds(kern, C::lds)));
   static int occ = 0;
   if (occ == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_lines3r<R1, R2>), C::TB, C::lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), C::TB, C::lds));
     if (occ < 1) occ = 1;
   }
   int grid = 256 * occ;
   if (grid > a.nbundles) grid = a.nbundles;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_fft_lines3r<R1, R2>), dim3((unsigned)grid), dim3(C::TB), C::lds, c->stream, a, pl.d_tw);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::TB), C::lds, c->stream, a, pl.d_tw);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -1432,6 +1440,7 @@ int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch,
 }
 int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, int fb, int lo, bool zfwd) {
   LinesArgs z = full_args(pl, work, rho_hat);
+  z.kmirror = (kern3 == c->kern_f && c->kf_zmirror) ? 1 : 0;
   z.kern = kern3; z.kern_comp_stride = (int64_t)pl.n * pl.n * pl.px;      // one float per complex element, LZ order
   z.dst_comp_stride = (int64_t)batch * pl.n * pl.n * pl.px;
   z.slo = lo; z.scount = fb;                                              // only box planes are stored

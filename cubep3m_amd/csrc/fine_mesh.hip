@@ -22,6 +22,7 @@ int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, floa
 int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, int fb, int lo);
 bool fft_x2_box_pass(int n, int lo);   // fft.hip: the force-box inverse x pass of this size is the two-register-stage kernel
 #include "kick_fused.h"
+#include "fft_x2.h"   // BXC: the bundle width of the LY / LZ layouts
 
 struct TileGeo { int T, nf, nb, pt, E, fb, rp, fbp; };  // rp: real row pitch of a fine array (2*px); fbp: force box row pitch
 
@@ -401,105 +402,146 @@ int fine_force_max(p3m_ctx *c) {
 #define CK_BJ 4
 #define CK_XS 128
 #define CK_XP (CK_XS + 4)
+#define CK_NU (((CK_BK + 1) * (CK_BJ + 1) * (CK_XP / 4) + 255) / 256)   // staging items (three 16-byte loads each) per thread
+// Round 5: PERSISTENT workgroups, software-pipelined.  One block at a time the pass was a chain of four round trips (ranges, box,
+// record, velocity) per block with four blocks per CU to hide it: 2.7 TB/s.  Now a workgroup walks a list of blocks, and the box
+// points and ranges of block i + 1 are requested into registers (12 x 16 bytes per thread) before the records of block i are
+// worked: the staging loads fly under the record -> velocity chain.  x segments are cut evenly (xsl cells: 5 x 104 at fb = 515
+// instead of 4 x 128 + 3).
+struct CicGeom { int k0, j0, x0, nk, nj, nx4, tx, ty, tz; const float *f0; int64_t row; };
 template <bool COARSE>
 __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G, int Nn, int ms,
                                                        const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt, float *__restrict__ fmax_out,
-                                                       const float *__restrict__ fc, int ncn, int nxs, int nbj, int nbk, int nblk) {
+                                                       const float *__restrict__ fc, int ncn, int nxs, int nbj, int nbk, int nblk, int xsl) {
   __shared__ float sb[(CK_BK + 1) * (CK_BJ + 1) * 3 * CK_XP];
   __shared__ int rp0[CK_BK * CK_BJ], rpre[CK_BK * CK_BJ + 1];
-  const int per = (nblk + 7) >> 3, lb = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);   // workgroups go to the XCDs in turn: each gets one contiguous eighth
-  if (lb >= nblk) return;
   const int tid = threadIdx.x, fb = G.fb, fbp = G.fbp, lo = G.nb - 2;
-  const int xs = lb % nxs, bj = (lb / nxs) % nbj, bk = (lb / (nxs * nbj)) % nbk, tile = lb / (nxs * nbj * nbk);
-  int tx, ty, tz; tile_xyz(tile, G.T, tx, ty, tz);
-  const int k0 = bk * CK_BK, j0 = bj * CK_BJ, x0 = xs * CK_XS;
-  const int nk = min(CK_BK + 1, fb - k0), nj = min(CK_BJ + 1, fb - j0), nx4 = min(CK_XP, fbp - x0) >> 2;
-  const float *f0 = fbox + (int64_t)tile * fb * fb * fbp;
-  // the cell rows' record ranges (started first: range -> record -> velocity are three dependent round trips)
-  int rcnt = 0;
-  if (tid < CK_BK * CK_BJ) {
-    const int kk = k0 + tid / CK_BJ, jj = j0 + tid % CK_BJ;
-    int st = 0;
-    if (kk < fb && jj < fb) {
-      const int64_t row = ((int64_t)(tz * G.pt + kk + lo) * G.E + (ty * G.pt + jj + lo)) * G.E + tx * G.pt + lo;   // box column i <-> extended cell tx*pt + lo + i
-      st = cs[row + x0]; rcnt = cs[row + min(x0 + CK_XS, fb)] - st;
+  // workgroups go to the XCDs in turn: XCD x works the contiguous eighth [x*per, (x+1)*per) of the blocks, its workgroups striding it
+  const int per = (nblk + 7) >> 3, xcd = (int)(blockIdx.x & 7u), nsl = (int)(gridDim.x >> 3), lend = min(nblk, (xcd + 1) * per);
+  int lb = xcd * per + (int)(blockIdx.x >> 3);
+  auto geom = [&](int b) {
+    CicGeom g;
+    const int xs = b % nxs, bj = (b / nxs) % nbj, bk = (b / (nxs * nbj)) % nbk, tile = b / (nxs * nbj * nbk);
+    tile_xyz(tile, G.T, g.tx, g.ty, g.tz);
+    g.k0 = bk * CK_BK; g.j0 = bj * CK_BJ; g.x0 = xs * xsl;
+    g.nk = min(CK_BK + 1, fb - g.k0); g.nj = min(CK_BJ + 1, fb - g.j0); g.nx4 = min(xsl + 4, fbp - g.x0) >> 2;
+    g.f0 = fbox + (int64_t)tile * fb * fb * fbp;
+    return g;
+  };
+  float4 ra[CK_NU], rb[CK_NU], rd[CK_NU]; int st = 0, rcnt = 0;
+  auto request = [&](const CicGeom &g) {   // the box points and (threads 0..15) the cell rows' record ranges of a block, into registers
+    st = 0; rcnt = 0;
+    if (tid < CK_BK * CK_BJ) {
+      const int kk = g.k0 + tid / CK_BJ, jj = g.j0 + tid % CK_BJ;
+      if (kk < fb && jj < fb) {
+        const int64_t row = ((int64_t)(g.tz * G.pt + kk + lo) * G.E + (g.ty * G.pt + jj + lo)) * G.E + g.tx * G.pt + lo;   // box column i <-> extended cell tx*pt + lo + i
+        st = cs[row + g.x0]; rcnt = cs[row + min(g.x0 + xsl, fb)] - st;
+      }
     }
-    rp0[tid] = st;
-  }
-  float m = 0.f;
-  for (int e = tid; e < nk * nj * nx4; e += 256) {
-    const int q = e % nx4, t = e / nx4, rj = t % nj, rk = t / nj;
-    const int64_t off = ((int64_t)(k0 + rk) * fb + (j0 + rj)) * fbp + x0 + 4 * q;
-    const float4 a = *reinterpret_cast<const float4 *>(f0 + off), b = *reinterpret_cast<const float4 *>(f0 + off + comp_stride),
-                 d = *reinterpret_cast<const float4 *>(f0 + off + 2 * comp_stride);
-    float *dst = sb + (rk * (CK_BJ + 1) + rj) * 3 * CK_XP + 4 * q;
-    *reinterpret_cast<float4 *>(dst) = a; *reinterpret_cast<float4 *>(dst + CK_XP) = b; *reinterpret_cast<float4 *>(dst + 2 * CK_XP) = d;
-    if (rk < CK_BK && rj < CK_BJ && 4 * q < CK_XS)                                                                   // this block's own points (pad columns are zero)
-      m = fmaxf(m, fmaxf(fmaxf(a.x * a.x + b.x * b.x + d.x * d.x, a.y * a.y + b.y * b.y + d.y * d.y),                // :217-218
-                         fmaxf(a.z * a.z + b.z * b.z + d.z * d.z, a.w * a.w + b.w * b.w + d.w * d.w)));
-  }
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
-  if ((tid & 63) == 0 && m > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, m);
-  if (tid < 64) {   // exclusive prefix of the CK_BK * CK_BJ counts
-    int inc = rcnt;
 #pragma unroll
-    for (int o = 1; o < CK_BK * CK_BJ; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (tid >= o) inc += u; }
-    if (tid < CK_BK * CK_BJ) rpre[tid] = inc - rcnt;
-    if (tid == CK_BK * CK_BJ - 1) rpre[CK_BK * CK_BJ] = inc;
-  }
-  __syncthreads();
-  const int total = rpre[CK_BK * CK_BJ];
+    for (int u = 0; u < CK_NU; u++) {
+      const int e = tid + 256 * u;
+      ra[u] = rb[u] = rd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < g.nk * g.nj * g.nx4) {
+        const int q = e % g.nx4, t = e / g.nx4, rj = t % g.nj, rk = t / g.nj;
+        const float *src = g.f0 + ((int64_t)(g.k0 + rk) * fb + (g.j0 + rj)) * fbp + g.x0 + 4 * q;
+        ra[u] = *reinterpret_cast<const float4 *>(src); rb[u] = *reinterpret_cast<const float4 *>(src + comp_stride); rd[u] = *reinterpret_cast<const float4 *>(src + 2 * comp_stride);
+      }
+    }
+  };
+  float m = 0.f;
   const float fNn = (float)Nn;
   const int nct = G.pt / ms;
-  const float offx = (float)G.nb - (float)(tx * G.pt), offy = (float)G.nb - (float)(ty * G.pt), offz = (float)G.nb - (float)(tz * G.pt);  // :227
-  for (int t = tid; t < total; t += 256) {
-    int r = 0;
+  CicGeom g = geom(lb < lend ? lb : 0);
+  if (lb < lend) request(g);
+  for (; lb < lend; lb += nsl) {
+    // ---- the requested block into LDS; the maximum over its own points (pad columns are zero)
 #pragma unroll
-    for (int k = 1; k < CK_BK * CK_BJ; k++) r += (rpre[k] <= t) ? 1 : 0;
-    const float4 p = spos[rp0[r] + (t - rpre[r])];
-    if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) continue;  // chains of hoc(1..ncn) only (:234-236)
-    // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
-    if (G.T > 1 && (((int)floorf(p.x / (float)ms)) / nct != tx || ((int)floorf(p.y / (float)ms)) / nct != ty || ((int)floorf(p.z / (float)ms)) / nct != tz)) continue;
-    const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
-    float4 v = vel[vi];
-    const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
-    const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
-    const float dx1 = (float)(i1 + lo + 1) - x, dy1 = (float)(j1 + lo + 1) - y, dz1 = (float)(k1 + lo + 1) - z;  // :290
-    const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
-    const int li = i1 - x0, lj = j1 - j0, lk = k1 - k0;
-    const bool staged = li >= 0 && li + 1 < 4 * nx4 && lj >= 0 && lj + 1 < nj && lk >= 0 && lk + 1 < nk;
+    for (int u = 0; u < CK_NU; u++) {
+      const int e = tid + 256 * u;
+      if (e < g.nk * g.nj * g.nx4) {
+        const int q = e % g.nx4, t = e / g.nx4, rj = t % g.nj, rk = t / g.nj;
+        const float4 a = ra[u], b = rb[u], d = rd[u];
+        float *dst = sb + (rk * (CK_BJ + 1) + rj) * 3 * CK_XP + 4 * q;
+        *reinterpret_cast<float4 *>(dst) = a; *reinterpret_cast<float4 *>(dst + CK_XP) = b; *reinterpret_cast<float4 *>(dst + 2 * CK_XP) = d;
+        if (rk < CK_BK && rj < CK_BJ && 4 * q < xsl)                                                                   // this block's own points
+          m = fmaxf(m, fmaxf(fmaxf(a.x * a.x + b.x * b.x + d.x * d.x, a.y * a.y + b.y * b.y + d.y * d.y),              // :217-218
+                             fmaxf(a.z * a.z + b.z * b.z + d.z * d.z, a.w * a.w + b.w * b.w + d.w * d.w)));
+      }
+    }
+    if (tid < CK_BK * CK_BJ) rp0[tid] = st;
+    if (tid < 64) {   // exclusive prefix of the CK_BK * CK_BJ counts
+      int inc = rcnt;
 #pragma unroll
-    for (int cz = 0; cz < 2; cz++)
+      for (int o = 1; o < CK_BK * CK_BJ; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (tid >= o) inc += u; }
+      if (tid < CK_BK * CK_BJ) rpre[tid] = inc - rcnt;
+      if (tid == CK_BK * CK_BJ - 1) rpre[CK_BK * CK_BJ] = inc;
+    }
+    __syncthreads();
+    const CicGeom c = g;
+    if (lb + nsl < lend) { g = geom(lb + nsl); request(g); }   // the next block: in flight under this block's records
+    // ---- the records of the block's cell rows
+    const int total = rpre[CK_BK * CK_BJ];
+    const int nx = 4 * c.nx4;
+    const float offx = (float)G.nb - (float)(c.tx * G.pt), offy = (float)G.nb - (float)(c.ty * G.pt), offz = (float)G.nb - (float)(c.tz * G.pt);  // :227
+#ifdef CKA_NOREC
+    for (int t = tid; t < 0; t += 256) {
+#else
+    for (int t = tid; t < total; t += 256) {
+#endif
+      int r = 0;
 #pragma unroll
-      for (int cy = 0; cy < 2; cy++)
-#pragma unroll
-        for (int cx = 0; cx < 2; cx++) {                                                                // order of :293-316
-          const float dVc = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
-          float fx, fy, fz;
-          if (staged) { const float *q = sb + ((lk + cz) * (CK_BJ + 1) + (lj + cy)) * 3 * CK_XP + (li + cx); fx = q[0]; fy = q[CK_XP]; fz = q[2 * CK_XP]; }
-          else { const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * fbp + (i1 + cx); fx = f0[o]; fy = f0[o + comp_stride]; fz = f0[o + 2 * comp_stride]; }
-          v.x = v.x + fx * dVc; v.y = v.y + fy * dVc; v.z = v.z + fz * dVc;
-        }
-    if (COARSE) {
-      const float inv = 1.0f / (float)ms;
-      const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
-      const int ci = (int)floorf(cx_) + 1, cj = (int)floorf(cy_) + 1, ck = (int)floorf(cz_) + 1;
-      const float ex1 = (float)ci - cx_, ey1 = (float)cj - cy_, ez1 = (float)ck - cz_;
-      const float ex2 = 1.0f - ex1, ey2 = 1.0f - ey1, ez2 = 1.0f - ez1;
-      const int mm = ncn + 2; const int64_t ccs = (int64_t)mm * mm * mm;
+      for (int k = 1; k < CK_BK * CK_BJ; k++) r += (rpre[k] <= t) ? 1 : 0;
+      const float4 p = spos[rp0[r] + (t - rpre[r])];
+      if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) continue;  // chains of hoc(1..ncn) only (:234-236)
+      // owner tile from the coarse cell of the chain the particle sits in: hoc index floor(x/mesh_scale)+1 (link_list.f90:19-21)
+      if (G.T > 1 && (((int)floorf(p.x / (float)ms)) / nct != c.tx || ((int)floorf(p.y / (float)ms)) / nct != c.ty || ((int)floorf(p.z / (float)ms)) / nct != c.tz)) continue;
+      const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
+      float4 v = vel[vi];
+      const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
+      const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
+      const float dx1 = (float)(i1 + lo + 1) - x, dy1 = (float)(j1 + lo + 1) - y, dz1 = (float)(k1 + lo + 1) - z;  // :290
+      const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
+      const int li = i1 - c.x0, lj = j1 - c.j0, lk = k1 - c.k0;
+      const bool staged = li >= 0 && li + 1 < nx && lj >= 0 && lj + 1 < c.nj && lk >= 0 && lk + 1 < c.nk;
 #pragma unroll
       for (int cz = 0; cz < 2; cz++)
 #pragma unroll
         for (int cy = 0; cy < 2; cy++)
 #pragma unroll
-          for (int cx = 0; cx < 2; cx++) {                                                              // :153-168
-            const float dV = a_mid * P3M_G_F * dt * (cx ? ex2 : ex1) * (cy ? ey2 : ey1) * (cz ? ez2 : ez1);
-            const int64_t o = ((int64_t)(ck + cz) * mm + (cj + cy)) * mm + (ci + cx);
-            v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
+          for (int cx = 0; cx < 2; cx++) {                                                                // order of :293-316
+            const float dVc = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
+            float fx, fy, fz;
+            if (staged) { const float *q = sb + ((lk + cz) * (CK_BJ + 1) + (lj + cy)) * 3 * CK_XP + (li + cx); fx = q[0]; fy = q[CK_XP]; fz = q[2 * CK_XP]; }
+            else { const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * fbp + (i1 + cx); fx = c.f0[o]; fy = c.f0[o + comp_stride]; fz = c.f0[o + 2 * comp_stride]; }
+            v.x = v.x + fx * dVc; v.y = v.y + fy * dVc; v.z = v.z + fz * dVc;
           }
+#ifndef CKA_NOCOARSE
+      if (COARSE) {
+        const float inv = 1.0f / (float)ms;
+        const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
+        const int ci = (int)floorf(cx_) + 1, cj = (int)floorf(cy_) + 1, ck = (int)floorf(cz_) + 1;
+        const float ex1 = (float)ci - cx_, ey1 = (float)cj - cy_, ez1 = (float)ck - cz_;
+        const float ex2 = 1.0f - ex1, ey2 = 1.0f - ey1, ez2 = 1.0f - ez1;
+        const int mm = ncn + 2; const int64_t ccs = (int64_t)mm * mm * mm;
+#pragma unroll
+        for (int cz = 0; cz < 2; cz++)
+#pragma unroll
+          for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+            for (int cx = 0; cx < 2; cx++) {                                                              // :153-168
+              const float dV = a_mid * P3M_G_F * dt * (cx ? ex2 : ex1) * (cy ? ey2 : ey1) * (cz ? ez2 : ez1);
+              const int64_t o = ((int64_t)(ck + cz) * mm + (cj + cy)) * mm + (ci + cx);
+              v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
+            }
+      }
+#endif
+      vel[vi] = v;
     }
-    vel[vi] = v;
+    __syncthreads();   // the block's LDS is rewritten at the top
   }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if ((tid & 63) == 0 && m > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, m);
 }
 
 // NGP: max |F|^2 (:208-223) and the kick (:244-270) in ONE pass over the force box.  One wavefront per box row
@@ -719,16 +761,22 @@ static int fine_max_and_kick_cic(p3m_ctx *c, float a_mid, float dt, bool count_s
   const int64_t cs = (int64_t)g.ntiles * g.fb * g.fb * g.fbp;
   P3M_TRY(particles_full_cells(c));
   if (count_survivors_reset) c->cnt_from_kick = 0;   // delete_particles counts its survivors itself
-  const int nxs = cdiv(g.fb, CK_XS), nbj = cdiv(g.fb, CK_BJ), nbk = cdiv(g.fb, CK_BK);
+  const int nxs = cdiv(g.fb, CK_XS), xsl = (cdiv(g.fb, nxs) + 3) & ~3, nbj = cdiv(g.fb, CK_BJ), nbk = cdiv(g.fb, CK_BK);   // x segments of equal length
   const int64_t nblk = (int64_t)g.ntiles * nbk * nbj * nxs;
   if (nblk > 0x0fffffff) { p3m_set_error("CIC kick: too many force-box blocks"); return P3M_EINVAL; }
-  const unsigned grid = 8u * (unsigned)cdiv(nblk, 8);
+  static int occ[2] = {0, 0};
+  const int ci = c->coarse_first ? 1 : 0;
+  if (occ[ci] == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[ci], ci ? reinterpret_cast<const void *>(k_fine_kick_cic<true>) : reinterpret_cast<const void *>(k_fine_kick_cic<false>), 256, 0));
+    if (occ[ci] < 1) occ[ci] = 1;
+  }
+  const unsigned grid = (unsigned)std::min<int64_t>((int64_t)256 * occ[ci], 8 * cdiv(nblk, 8));   // persistent workgroups, a multiple of the eight XCDs
   if (c->coarse_first)
     hipLaunchKernelGGL(k_fine_kick_cic<true>, dim3(grid), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms,
-                       (const float *)c->fbox, cs, a_mid, dt, c->d_red, (const float *)c->force_c, g.ncn, nxs, nbj, nbk, (int)nblk);
+                       (const float *)c->fbox, cs, a_mid, dt, c->d_red, (const float *)c->force_c, g.ncn, nxs, nbj, nbk, (int)nblk, xsl);
   else
     hipLaunchKernelGGL(k_fine_kick_cic<false>, dim3(grid), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, g.Nn, g.ms,
-                       (const float *)c->fbox, cs, a_mid, dt, c->d_red, (const float *)nullptr, g.ncn, nxs, nbj, nbk, (int)nblk);
+                       (const float *)c->fbox, cs, a_mid, dt, c->d_red, (const float *)nullptr, g.ncn, nxs, nbj, nbk, (int)nblk, xsl);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -790,6 +838,19 @@ __global__ __launch_bounds__(256) void k_take_imag(const float *__restrict__ hat
   if (i < ncomplex) kern[i] = hat[2 * i + 1];
 }
 
+// K(c, n - z) := +-K(c, z) for z > n/2 in the bundle layout LZ ([bundle][z][16 columns]): the real-space table is mirrored exactly
+// (k_fine_kernel_real), its transform only to rounding; made exact, the fused z pass may read the upper half of a line from the lower
+// (LinesArgs::kmirror) and every other reader sees the same numbers.  Component 2 is odd along z: its Nyquist plane is zero.
+__global__ __launch_bounds__(256) void k_kf_symmetrise_z(float *__restrict__ kern, int n, int64_t nbundles, int odd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int hz = n / 2;   // planes hz .. n-1 are written (hz itself only for the odd component)
+  if (i >= nbundles * (n - hz) * BXC) return;
+  const int col = (int)(i % BXC); const int64_t t = i / BXC; const int z = hz + (int)(t % (n - hz)); const int64_t b = t / (n - hz);
+  float *line = kern + b * n * BXC + col;
+  if (z == hz) { if (odd && 2 * hz == n) line[(int64_t)z * BXC] = 0.f; return; }
+  const float v = line[(int64_t)(n - z) * BXC];
+  line[(int64_t)z * BXC] = odd ? -v : v;
+}
 int build_fine_kernel(p3m_ctx *c, const float *table16_host) {
   const Geometry &g = c->g;
   float *d_table = nullptr;
@@ -804,9 +865,12 @@ int build_fine_kernel(p3m_ctx *c, const float *table16_host) {
     P3M_TRY(fft3d_forward(c, c->plan_f, c->rho, c->work, 1));   // rho-hat in the bundle layout LZ; so is kern_f
     hipLaunchKernelGGL(k_take_imag, dim3(cdiv(ncx, 256)), dim3(256), 0, c->stream, (const float *)c->rho, c->kern_f + comp * ncx, ncx);
     HIP_TRY(hipGetLastError());
+    const int64_t nbun = (int64_t)g.nf * (g.px / BXC), nsym = nbun * (g.nf - g.nf / 2) * BXC;
+    hipLaunchKernelGGL(k_kf_symmetrise_z, dim3(cdiv(nsym, 256)), dim3(256), 0, c->stream, c->kern_f + comp * ncx, g.nf, nbun, comp == 2 ? 1 : 0);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   (void)hipFree(d_table);
-  c->have_kf = true;
+  c->have_kf = true; c->kf_zmirror = true;
   return P3M_OK;
 }

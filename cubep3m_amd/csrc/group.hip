@@ -1050,7 +1050,7 @@ extern "C" int p3m_hip_group_set_kernel_tables(p3m_group *G, const float *fine_t
     const Geometry &g = G->ctx[0]->g;
     for (size_t i = 1; i < G->ctx.size(); i++) {
       HIP_TRY(hipMemcpyAsync(G->ctx[i]->kern_f, G->ctx[0]->kern_f, sizeof(float) * 3 * g.nf * g.nf * g.px, hipMemcpyDeviceToDevice, G->stream));
-      G->ctx[i]->have_kf = true;
+      G->ctx[i]->have_kf = true; G->ctx[i]->kf_zmirror = G->ctx[0]->kf_zmirror;
     }
   }
   P3M_TRY(build_coarse_kernel_dist(G, coarse_table));
@@ -1077,7 +1077,7 @@ extern "C" int p3m_hip_group_set_kernels_raw(p3m_group *G, const float *kern_f, 
     const Geometry &g0 = G->ctx[0]->g;
     for (size_t i = 1; i < G->ctx.size(); i++) {
       HIP_TRY(hipMemcpyAsync(G->ctx[i]->kern_f, G->ctx[0]->kern_f, sizeof(float) * 3 * g0.nf * g0.nf * g0.px, hipMemcpyDeviceToDevice, G->stream));
-      G->ctx[i]->have_kf = true;
+      G->ctx[i]->have_kf = true; G->ctx[i]->kf_zmirror = G->ctx[0]->kf_zmirror;
     }
   }
   const Geometry &g = G->ctx[0]->g;

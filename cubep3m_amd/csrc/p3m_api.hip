@@ -225,7 +225,7 @@ int kernels_set_fine_raw(p3m_ctx *c, const float *kern_f) {
   std::vector<float> tmp(3 * nf);
   kern_to_device(kern_f, tmp.data(), g.nf, g.hx, g.px);
   HIP_TRY(hipMemcpy(c->kern_f, tmp.data(), sizeof(float) * 3 * nf, hipMemcpyHostToDevice));
-  c->have_kf = true;
+  c->have_kf = true; c->kf_zmirror = false;   // (a table from outside is read as it is)
   return P3M_OK;
 }
 extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const float *kern_c) {
@@ -239,7 +239,7 @@ extern "C" int p3m_hip_set_kernels_raw(p3m_ctx *c, const float *kern_f, const fl
   HIP_TRY(hipMemcpy(c->kern_f, tmp.data(), sizeof(float) * 3 * nf, hipMemcpyHostToDevice));
   kern_to_device(kern_c, tmp.data(), g.nc, g.nc / 2 + 1, g.pxc);
   HIP_TRY(hipMemcpy(c->kern_c, tmp.data(), sizeof(float) * 3 * ncx, hipMemcpyHostToDevice));
-  c->have_kf = c->have_kc = true;
+  c->have_kf = c->have_kc = true; c->kf_zmirror = false;
   return P3M_OK;
 }
 

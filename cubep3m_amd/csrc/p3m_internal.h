@@ -194,6 +194,7 @@ struct p3m_ctx {
   float *kern_c = nullptr;     // [3][nc][nc][pxc]
   FftPlan plan_c;
   bool have_kf = false, have_kc = false;
+  bool kf_zmirror = false;   // kern_f is exactly mirror-symmetric in kz (build_fine_kernel: kf_symmetrise_z): the fused z pass reads the lower half only
   // ---- per-step reductions (device) and results
   // Reduced scalars live in P3M_NSLOT slots of one 64-byte line each: a kernel's workgroups spread their
   // atomics over the slots (tens of thousands of atomics on ONE address serialise at ~12 ns each), the host

@@ -5,7 +5,7 @@ set -u
 : "${GRAFT_REPO_ROOT:?}"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for rnd in 1 2; do
+for rnd in $(seq 1 ${KF_ROUNDS:-2}); do
 for tag in "$@"; do
   lib=$R/cubep3m_amd/libp3m_hip_$tag.so; [ "$tag" == base ] && lib=$R/cubep3m_amd/libp3m_hip.so
   rm -rf /tmp/kfab; cd $R
