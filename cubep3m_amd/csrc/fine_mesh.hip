@@ -407,7 +407,9 @@ int fine_force_max(p3m_ctx *c) {
 // record, velocity) per block with four blocks per CU to hide it: 2.7 TB/s.  Now a workgroup walks a list of blocks, and the box
 // points and ranges of block i + 1 are requested into registers (12 x 16 bytes per thread) before the records of block i are
 // worked: the staging loads fly under the record -> velocity chain.  x segments are cut evenly (xsl cells: 5 x 104 at fb = 515
-// instead of 4 x 128 + 3).
+// instead of 4 x 128 + 3).  897 -> 873 us per 560-tile: less than hoped.  Ablations of this kernel in the step: without the record phase
+// ~510 us (1.64 GB of box at 3.2 TB/s: the k halo plane of a block is re-read 645 blocks later, past the L2), the records add ~360, of
+// which the coarse kick 70.  The next shape: a workgroup that marches along k and keeps the plane it shares with its next block.
 struct CicGeom { int k0, j0, x0, nk, nj, nx4, tx, ty, tz; const float *f0; int64_t row; };
 template <bool COARSE>
 __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G, int Nn, int ms,
@@ -484,11 +486,7 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
     const int total = rpre[CK_BK * CK_BJ];
     const int nx = 4 * c.nx4;
     const float offx = (float)G.nb - (float)(c.tx * G.pt), offy = (float)G.nb - (float)(c.ty * G.pt), offz = (float)G.nb - (float)(c.tz * G.pt);  // :227
-#ifdef CKA_NOREC
-    for (int t = tid; t < 0; t += 256) {
-#else
     for (int t = tid; t < total; t += 256) {
-#endif
       int r = 0;
 #pragma unroll
       for (int k = 1; k < CK_BK * CK_BJ; k++) r += (rpre[k] <= t) ? 1 : 0;
@@ -516,7 +514,6 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
             else { const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * fbp + (i1 + cx); fx = c.f0[o]; fy = c.f0[o + comp_stride]; fz = c.f0[o + 2 * comp_stride]; }
             v.x = v.x + fx * dVc; v.y = v.y + fy * dVc; v.z = v.z + fz * dVc;
           }
-#ifndef CKA_NOCOARSE
       if (COARSE) {
         const float inv = 1.0f / (float)ms;
         const float cx_ = inv * p.x - 0.5f, cy_ = inv * p.y - 0.5f, cz_ = inv * p.z - 0.5f;            // coarse_velocity.f90:143
@@ -535,7 +532,6 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
               v.x = v.x + fc[o] * dV; v.y = v.y + fc[o + ccs] * dV; v.z = v.z + fc[o + 2 * ccs] * dV;
             }
       }
-#endif
       vel[vi] = v;
     }
     __syncthreads();   // the block's LDS is rewritten at the top

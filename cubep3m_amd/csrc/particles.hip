@@ -323,6 +323,7 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
   // LDS; records whose xv + offset_tile rounds into the next cell are moved afterwards by k_ngp_fixup.
   if (dep.rho) {
     const int cz = row / E, cy = row - cz * E, nbi = (int)nb;
+    const float m2 = dep.mass_p + dep.mass_p, m3 = m2 + dep.mass_p;
     float part = 0.f;
     for (int tz = max(0, (cz - dep.nf + dep.pt) / dep.pt); tz < dep.T && tz * dep.pt <= cz; tz++)
       for (int ty = max(0, (cy - dep.nf + dep.pt) / dep.pt); ty < dep.T && ty * dep.pt <= cy; ty++) {
@@ -349,8 +350,9 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
                 const int i = i4 + u;
                 if (i >= 4 && i < dep.nf - 4) {
                   const int cnt = b[u + 1] - b[u];
-                  float r = 0.f;
-                  for (int q = 0; q < cnt; q++) r = r + dep.mass_p;                  // :148, same partial sums
+                  // :148, same partial sums: 0, m, m + m, (m + m) + m by selection (nearly every cell), the loop beyond three
+                  float r = cnt >= 3 ? m3 : (cnt == 2 ? m2 : (cnt == 1 ? dep.mass_p : 0.f));
+                  for (int q = 3; q < cnt; q++) r = r + dep.mass_p;
                   rr[u] = r;
                   if (row_int && i >= nbi && i < dep.nf - nbi) part += r;            // :167-173
                 }
