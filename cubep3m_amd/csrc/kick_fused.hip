@@ -112,8 +112,8 @@ __device__ long long kf_trace_buf[8 * 64 * 8];
 #define KF_STAMP(k) do { } while (0)
 #endif
 
-// Workgroup shape.  A wavefront of the x pass holds RPW = 64 / max(R1, R2) whole rows.  Where that is a multiple of three (n = 560: exactly
-// three) a wavefront owns the three components of its box rows from the gather to the kick, nothing is shared between wavefronts, and the
+// Workgroup shape.  A wavefront of the x pass holds RPW = 64 / max(R1, R2) whole rows.  Where that is exactly three (n = 304, 560, 608)
+// a wavefront owns the three components of its box rows from the gather to the kick, nothing is shared between wavefronts, and the
 // workgroup IS one wavefront: no s_barrier anywhere (the four steps of a trip are separated by wavefront-wide fences), and the eight
 // wavefronts of a CU drift apart -- one gathers coarse forces while another runs its butterflies.  (As one workgroup of four wavefronts
 // with four barriers per trip the pass was 55 % VALU-busy and scaled 1.6x from one workgroup per CU to two: latency, not throughput.)
