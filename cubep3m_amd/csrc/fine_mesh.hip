@@ -409,7 +409,8 @@ int fine_force_max(p3m_ctx *c) {
 // worked: the staging loads fly under the record -> velocity chain.  x segments are cut evenly (xsl cells: 5 x 104 at fb = 515
 // instead of 4 x 128 + 3).  897 -> 873 us per 560-tile: less than hoped.  Ablations of this kernel in the step: without the record phase
 // ~510 us (1.64 GB of box at 3.2 TB/s: the k halo plane of a block is re-read 645 blocks later, past the L2), the records add ~360, of
-// which the coarse kick 70.  The next shape: a workgroup that marches along k and keeps the plane it shares with its next block.
+// which the coarse kick 70.  A workgroup that marches along k and keeps the plane it shares with its next block (four planes fetched per
+// block instead of five, the re-read from beyond the L2 gone) was built next: 900 us.  Neither the bytes nor the round trips, then.
 struct CicGeom { int k0, j0, x0, nk, nj, nx4, tx, ty, tz; const float *f0; int64_t row; };
 template <bool COARSE>
 __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G, int Nn, int ms,
