@@ -23,6 +23,7 @@ int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, in
 bool fft_x2_box_pass(int n, int lo);   // fft.hip: the force-box inverse x pass of this size is the two-register-stage kernel
 #include "kick_fused.h"
 #include "fft_x2.h"   // BXC: the bundle width of the LY / LZ layouts
+#include "fft_core.h" // fdiv: division by a run-time constant as one mulhi
 
 struct TileGeo { int T, nf, nb, pt, E, fb, rp, fbp; };  // rp: real row pitch of a fine array (2*px); fbp: force box row pitch
 
@@ -400,9 +401,12 @@ int fine_force_max(p3m_ctx *c) {
 // ranges as scalar loads 1360 us: 32 misses of the scalar cache are served one after the other.)
 #define CK_BK 4
 #define CK_BJ 4
-#define CK_XS 128
+#define CK_XS 124      // cells of an x segment at most: CK_XS + 4 points = 32 groups of four, one per lane of half a wavefront
 #define CK_XP (CK_XS + 4)
-#define CK_NU (((CK_BK + 1) * (CK_BJ + 1) * (CK_XP / 4) + 255) / 256)   // staging items (three 16-byte loads each) per thread
+#define CK_NU (((CK_BK + 1) * (CK_BJ + 1) + 7) / 8)   // staging items (three 16-byte loads each) per thread: thread (q = tid % 32, r0 = tid / 32) takes the four-point
+                                                   // group q of the box rows r0, r0 + 8, ...  (Flattened as e = tid + 256 u with e % nx4, e / nx4 % nj, e / nx4 / nj -- divisions
+                                                   // by run-time numbers, ~35 vector instructions each -- the index arithmetic was 800 of the kernel's ~1060 vector instructions per
+                                                   // wavefront and block: profiles/r05_cic_sq_counters.txt)
 // Round 5: PERSISTENT workgroups, software-pipelined.  One block at a time the pass was a chain of four round trips (ranges, box,
 // record, velocity) per block with four blocks per CU to hide it: 2.7 TB/s.  Now a workgroup walks a list of blocks, and the box
 // points and ranges of block i + 1 are requested into registers (12 x 16 bytes per thread) before the records of block i are
@@ -411,6 +415,7 @@ int fine_force_max(p3m_ctx *c) {
 // ~510 us (1.64 GB of box at 3.2 TB/s: the k halo plane of a block is re-read 645 blocks later, past the L2), the records add ~360, of
 // which the coarse kick 70.  A workgroup that marches along k and keeps the plane it shares with its next block (four planes fetched per
 // block instead of five, the re-read from beyond the L2 gone) was built next: 900 us.  Neither the bytes nor the round trips, then.
+__device__ __forceinline__ int ck_mj(int nj) { return nj >= 5 ? 52 : nj == 4 ? 64 : nj == 3 ? 86 : nj == 2 ? 128 : 256; }   // ceil(256 / nj)
 struct CicGeom { int k0, j0, x0, nk, nj, nx4, tx, ty, tz; const float *f0; int64_t row; };
 template <bool COARSE>
 __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G, int Nn, int ms,
@@ -422,9 +427,10 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
   // workgroups go to the XCDs in turn: XCD x works the contiguous eighth [x*per, (x+1)*per) of the blocks, its workgroups striding it
   const int per = (nblk + 7) >> 3, xcd = (int)(blockIdx.x & 7u), nsl = (int)(gridDim.x >> 3), lend = min(nblk, (xcd + 1) * per);
   int lb = xcd * per + (int)(blockIdx.x >> 3);
+  const fdiv_t d_xs = mk_fdiv(nxs), d_bj = mk_fdiv(nbj), d_bk = mk_fdiv(nbk);
   auto geom = [&](int b) {
     CicGeom g;
-    const int xs = b % nxs, bj = (b / nxs) % nbj, bk = (b / (nxs * nbj)) % nbk, tile = b / (nxs * nbj * nbk);
+    const int t1 = fdiv(b, d_xs), xs = b - t1 * nxs, t2 = fdiv(t1, d_bj), bj = t1 - t2 * nbj, tile = fdiv(t2, d_bk), bk = t2 - tile * nbk;   // (one mulhi each: nblk * max(nxs, nbj, nbk) < 2^32)
     tile_xyz(tile, G.T, g.tx, g.ty, g.tz);
     g.k0 = bk * CK_BK; g.j0 = bj * CK_BJ; g.x0 = xs * xsl;
     g.nk = min(CK_BK + 1, fb - g.k0); g.nj = min(CK_BJ + 1, fb - g.j0); g.nx4 = min(xsl + 4, fbp - g.x0) >> 2;
@@ -441,12 +447,12 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
         st = cs[row + g.x0]; rcnt = cs[row + min(g.x0 + xsl, fb)] - st;
       }
     }
+    const int q = tid & 31, mj = ck_mj(g.nj);   // row / nj = row * mj >> 8 for row < 32, nj <= 5
 #pragma unroll
     for (int u = 0; u < CK_NU; u++) {
-      const int e = tid + 256 * u;
+      const int row = (tid >> 5) + 8 * u, rk = (row * mj) >> 8, rj = row - rk * g.nj;
       ra[u] = rb[u] = rd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < g.nk * g.nj * g.nx4) {
-        const int q = e % g.nx4, t = e / g.nx4, rj = t % g.nj, rk = t / g.nj;
+      if (q < g.nx4 && row < g.nk * g.nj) {
         const float *src = g.f0 + ((int64_t)(g.k0 + rk) * fb + (g.j0 + rj)) * fbp + g.x0 + 4 * q;
         ra[u] = *reinterpret_cast<const float4 *>(src); rb[u] = *reinterpret_cast<const float4 *>(src + comp_stride); rd[u] = *reinterpret_cast<const float4 *>(src + 2 * comp_stride);
       }
@@ -459,11 +465,11 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
   if (lb < lend) request(g);
   for (; lb < lend; lb += nsl) {
     // ---- the requested block into LDS; the maximum over its own points (pad columns are zero)
+    const int q = tid & 31, mj = ck_mj(g.nj);
 #pragma unroll
     for (int u = 0; u < CK_NU; u++) {
-      const int e = tid + 256 * u;
-      if (e < g.nk * g.nj * g.nx4) {
-        const int q = e % g.nx4, t = e / g.nx4, rj = t % g.nj, rk = t / g.nj;
+      const int row = (tid >> 5) + 8 * u, rk = (row * mj) >> 8, rj = row - rk * g.nj;
+      if (q < g.nx4 && row < g.nk * g.nj) {
         const float4 a = ra[u], b = rb[u], d = rd[u];
         float *dst = sb + (rk * (CK_BJ + 1) + rj) * 3 * CK_XP + 4 * q;
         *reinterpret_cast<float4 *>(dst) = a; *reinterpret_cast<float4 *>(dst + CK_XP) = b; *reinterpret_cast<float4 *>(dst + 2 * CK_XP) = d;
@@ -760,7 +766,7 @@ static int fine_max_and_kick_cic(p3m_ctx *c, float a_mid, float dt, bool count_s
   if (count_survivors_reset) c->cnt_from_kick = 0;   // delete_particles counts its survivors itself
   const int nxs = cdiv(g.fb, CK_XS), xsl = (cdiv(g.fb, nxs) + 3) & ~3, nbj = cdiv(g.fb, CK_BJ), nbk = cdiv(g.fb, CK_BK);   // x segments of equal length
   const int64_t nblk = (int64_t)g.ntiles * nbk * nbj * nxs;
-  if (nblk > 0x0fffffff) { p3m_set_error("CIC kick: too many force-box blocks"); return P3M_EINVAL; }
+  if (nblk * std::max(nxs, std::max(nbj, nbk)) >= 0xffffffffLL) { p3m_set_error("CIC kick: too many force-box blocks"); return P3M_EINVAL; }
   static int occ[2] = {0, 0};
   const int ci = c->coarse_first ? 1 : 0;
   if (occ[ci] == 0) {
