@@ -1323,7 +1323,8 @@ template <int R1, int R2> static int lines3r_impl(p3m_ctx *c, const FftPlan &pl,
   a.n = pl.n; a.nchunk = pl.px / BXC; a.nbundles = batch * a.ocount * a.nchunk;
   auto kern = a.kmirror ? k_fft_lines3r<R1, R2, true> : k_fft_lines3r<R1, R2, false>;
   P3M_TRY((set_lds(kern, C::lds)));
-  static int occ = 0;
+  static int occ2[2] = {0, 0};                        // per variant: the mirrored-table kernel and the plain one differ in registers
+  int &occ = occ2[a.kmirror ? 1 : 0];
   if (occ == 0) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(kern), C::TB, C::lds));
     if (occ < 1) occ = 1;

@@ -156,7 +156,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->vel_alt); dfree(c->pid_home); dfree(c->spos);
-  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->scan_state); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter); dfree(c->pp_htask);
+  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->scan_state); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter); dfree(c->pp_htask); dfree(c->pp_slow);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);
@@ -529,8 +529,12 @@ extern "C" int p3m_hip_particle_mesh(p3m_ctx *c, float a_mid, float dt, float dt
                                      const float *move_back, p3m_step_out *out) {
   if (!c) return P3M_EINVAL;
   P3M_TRY(need_particles(c, "p3m_hip_particle_mesh"));
+  c->step_begun = false;
   const int r = particle_mesh_step(c, a_mid, dt, dt_old, mass_p, offset, move_back, out);
-  if (r != P3M_OK && r != P3M_ESTATE && r != P3M_ECOMM && r != P3M_EINVAL) particles_reset_after_error(c);   // the three leave before the first state change
+  // an error behind the first state change (whatever its code: P3M_EINVAL can come from the coarse deposit, the fused kick or the CIC kick,
+  // after step_prezero and the deferred inverse x pass were set up) leaves nothing queued for "later" to be trusted
+  if (r != P3M_OK && c->step_begun) particles_reset_after_error(c);
+  c->step_begun = false;
   return r;
 }
 static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, float mass_p, const float *offset, const float *move_back, p3m_step_out *out) {
@@ -538,6 +542,7 @@ static int particle_mesh_step(p3m_ctx *c, float a_mid, float dt, float dt_old, f
   // every parameter / state check comes before the first state change (the drift)
   if (c->g.nodes != 1) { p3m_set_error("multi-rank contexts are stepped through a p3m_group (p3m_hip_group_*)"); return P3M_ECOMM; }
   if (c->pt) c->pt->reset();
+  c->step_begun = true;
   { PhaseScope ps(c->pt, P3M_PH_DRIFT, c->stream); P3M_TRY(p3m_hip_update_position(c, dt, dt_old, offset)); }   // :56
   HIP_TRY(hipSetDevice(c->device));
   P3M_TRY(step_prezero(c));

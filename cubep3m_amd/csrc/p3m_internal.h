@@ -60,6 +60,7 @@ struct PhaseTimer {
   std::vector<hipEvent_t> pool; size_t used = 0;
   struct Span { int phase; hipEvent_t a, b; };
   std::vector<Span> spans;
+  static_assert(P3M_NPHASE == P3M_NPHASES, "the phase enum and the public header's P3M_NPHASES");
   float ms[P3M_NPHASE] = {0};
   hipEvent_t take() {
     if (used == pool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
@@ -158,7 +159,8 @@ struct p3m_ctx {
   // of their own in cand_cnt[slot * 16] -- appending to ONE list cost k_row_sort half its run time (66 000 atomics on one
   // address serialise at ~12 ns each); cand_cnt[16 * slots] is set when a list overflowed: the fix-up then scans every record
   int *cand = nullptr; int *cand_cnt = nullptr; int cand_seg = 0;
-  int *pp_plan = nullptr, *pp_task_group = nullptr, *pp_counter = nullptr, *pp_htask = nullptr;   // extended PP (pp.hip): first task of every patch, task -> {patch, sub-task}, task counters, the heavy-task list
+  bool step_begun = false;     // p3m_hip_particle_mesh: the step has changed state (an error from here on resets what was queued)
+  int *pp_plan = nullptr, *pp_task_group = nullptr, *pp_counter = nullptr, *pp_htask = nullptr, *pp_slow = nullptr;   // extended PP (pp.hip): first task of every patch, task -> {patch, sub-task}, task counters, the heavy-task list
   int *d_counters = nullptr;   // small device counter block
   int *h_counters = nullptr;   // pinned mirror
   // ---- fine mesh, all tiles batched

@@ -273,11 +273,15 @@ __global__ __launch_bounds__(64) void k_pp_ext(const float4 *__restrict__ spos, 
 }
 
 
-__global__ __launch_bounds__(256) void k_pp_fill2(const int *__restrict__ plan, int ngroups, int2 *__restrict__ task2, int cap) {
+// task record: {patch, sub-task, gz << 20 | gy << 10 | xb, tz << 20 | ty << 10 | tx}: the patch's and the tile's coordinates are decoded here, once
+// per task by one lane of a small kernel, instead of by four run-time divisions at the head of every task of the pair kernels
+__global__ __launch_bounds__(256) void k_pp_fill2(const int *__restrict__ plan, int ngroups, int4 *__restrict__ task4, int cap, int npz, int npy, int npx, int T) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= ngroups) return;
+  const int xb = g % npx, gy = (g / npx) % npy, gz = (g / (npx * npy)) % npz, tile = g / (npx * npy * npz);
+  const int tz = tile / (T * T), ty = (tile / T) % T, tx = tile % T;
   const int k0 = plan[g], k1 = min(plan[g + 1], cap);
-  for (int k = k0; k < k1; k++) task2[k] = make_int2(g, k - k0);
+  for (int k = k0; k < k1; k++) task4[k] = make_int4(g, k - k0, (gz << 20) | (gy << 10) | xb, (tz << 20) | (ty << 10) | tx);
 }
 // Constants of one pair evaluation.  The force of a partner at separation s, r = |s| (:551-571):
 //   -mass_p s / (r pp_bias)^3 * taper(q),  q = r pp_bias / ncut,  taper = 1 - 7/4 q^3 + 3/4 q^5 while r <= ncut + sqrt(3), else 1
@@ -446,10 +450,11 @@ __global__ __launch_bounds__(256) void k_pp_plan3(const int *__restrict__ cs, PP
 #define PP3_HREC 16      // ints per heavy-task record: patch, sub-task, the heavy lanes' box of partner rows and cells (3 words), 8 words of lane bits
 template <int PPR, bool TAPER_ALL, int PASS>   // PPR > 0: pp_range known at compile time (the reference's default 2); 0: any.  TAPER_ALL: no pair within reach is beyond the taper's range
 __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 0 ? PP3_WPE : PP3_WPE - 1, PASS == 0 ? PP3_WPE : PP3_WPE - 1))) void k_pp_ext3(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, PPGeo G, PPForce F,
-                                                    float a_mid, float dt, float *__restrict__ tile_max, const int *__restrict__ plan,
-                                                    const int2 *__restrict__ task2, int ngroups, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
+                                                    float a_mid, float dt, float *__restrict__ tile_max,
+                                                    const int4 *__restrict__ task4, const int *__restrict__ ntask_ptr, int npy, int npx, int xbw, int ntask_cap, int *__restrict__ counter,
                                                     int Wp, int NRmax, int fat_limit, int *__restrict__ htask, int *__restrict__ hcount) {
-  // fat_limit: 65534 (see "fat" below); task2: {group, sub-task} of every task; Wp: entries per row of the offset table (xbw + 2r + 1 rounded
+  // fat_limit: 65534 (see "fat" below); task4: the task records (k_pp_fill2; pass 0 works the *ntask_ptr first of them: the whole plan, or the list of
+  // tasks the lean light pass k_pp_light left to this kernel); Wp: entries per row of the offset table (xbw + 2r + 1 rounded
   // up to even); NRmax: partner rows; htask / hcount: the heavy-task list (PP3_HREC ints per task, written by pass 0, read by pass 1) and its length
   extern __shared__ int sm[];
   constexpr int NH = PP3_HZ * PP3_HY, NW = PP3_NT / 64;
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned char *mylist = list + (wv * 64 + lane) * PP3_LSTR;                 // this lane's entries
   const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E, npz = (e + PP3_HZ - 1) / PP3_HZ;
-  const int ntask = PASS == 0 ? min(plan[ngroups], ntask_cap) : min(*hcount, ntask_cap);
+  const int ntask = PASS == 0 ? min(*ntask_ptr, ntask_cap) : min(*hcount, ntask_cap);
   if (PASS == 1 && ntask == 0) return;             // no blob anywhere (the rule at the background's density): the launch costs its dispatch only
   const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
   int seg = blockIdx.x % PP3_NSEG;
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
     if (a_live) {
       const int sbeg = min(a_seg * per, ntask), send = min(sbeg + per, ntask), t = sbeg + a_tf;
       if (t < send) {
-        if (PASS == 0) b_val = task2[t];
+        if (PASS == 0) { const int4 t4 = task4[t]; b_val = make_int2(t4.x, t4.y); }
         else { const int4 r4 = *reinterpret_cast<const int4 *>(htask + (size_t)PP3_HREC * t); b_val = make_int2(r4.x, r4.y); b_box0 = r4.z; b_box1 = r4.w; b_box2 = htask[(size_t)PP3_HREC * t + 4]; }
         b_t = t; b_live = true; tried = 0;
       }
@@ -1002,6 +1007,410 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
   }
 }
 
+// ------------------------------------------------------------------ extended PP: the LEAN light pass (round 6)
+// k_pp_ext3's pass 0 spent 2.9 vector wavefront-instructions per pair evaluation at the reference's density (profiles/r05_pp_sq_counters.txt):
+// a quarter of them evaluations, the rest staging (bisections, per-row index arithmetic), 28 instructions for each of a record's 25 windows,
+// and a window walk by every wavefront for the few lanes whose one-byte list entries overflowed.  k_pp_light is that pass for the common
+// task -- pp_range 2, the whole partner region staged in one batch, no row segment of more than 255 records -- with every table laid out
+// for compile-time offsets; any other task is entered in a list that k_pp_ext3<.., 0> works afterwards (none at the background's density).
+//   * geometry: the (8 + 4) x (8 + 4) partner rows of a patch are ALWAYS laid out whole, x boundaries hx0 - 2 ... hx0 + xbw + 2; rows outside the
+//     tile's extended region are empty rows and boundaries outside it are clamped to it, so no window is ever clipped per lane: a window is
+//     5 cells of one row = two bytes of the row's table five apart, at a compile-time offset from the lane's first window;
+//   * offset table T: ONE BYTE per boundary (records of the row before it), 36 bytes per row; the row's first staged position times 16 in
+//     cum16.  A wavefront loads three planes of 12 rows (36 loads in flight), takes each row's first and last value through the scalar unit
+//     and sums the counts there: no cross-lane scan, no bisection;
+//   * staging: a wavefront copies its own 36 rows, (row, slot < 8) items flattened over its lanes (rows of more than 8 records: a second trip);
+//   * lists: 16-bit entries = the partner's byte address in the staged records.  A window is appended by storing its first SIX entries whatever
+//     its count (the next window overwrites what was not a partner) and one add; a window of more than six records (1e-6) sends the
+//     wavefront through a rolled general loop.  No entry can overflow, so no lane walks its windows at the background's density;
+//   * evaluation: four entries per trip, two per packed evaluation; the list's tail is padded with the home record itself (r = 0: below
+//     the soft cut, adds zero), so a trip needs one compare for its four partners;
+//   * the task's coordinates come decoded in its record (k_pp_fill2).
+// Records with more than PPL_LCAP partners are heavy and left to k_pp_ext3<.., 1> exactly as before (same task records, same lane bits).
+#define PPL_NRY 12            // partner rows per plane (PP3_HY + 4) and planes (PP3_HZ + 4)
+#define PPL_NR 144
+#define PPL_TS 36             // bytes per row of T: xbw + 5 boundaries
+#define PPL_XBW_MAX (PPL_TS - 5)
+#define PPL_PCAP 704
+#define PPL_LCAP 32
+#define PPL_LENT 40           // entries per lane (LCAP + the spill of a window's six stores): 80 bytes, so that the four entries of an evaluation trip are one
+                              // ALIGNED 8-byte read (76 bytes: an odd number of words between the lanes' lists, but every other lane's read misaligned)
+typedef __attribute__((address_space(3))) volatile unsigned short lds_vu16;   // an LDS pointer by type: a volatile generic pointer compiles to flat stores
+struct PPLShared {
+  float4 prec[PPL_PCAP + 6];                      // staged partner records (+ what the spill entries of a window's 12-byte store can address)
+  unsigned char T[PPL_NR * PPL_TS + 16];          // T[r][i]: records of row r before boundary i
+  unsigned short cum16[PPL_NR + 8];               // 16 * (staged records before row r)
+  unsigned short lcum[PPL_NR + 8];                // records of the rows of the same wavefront before row r
+  int rowg[PPL_NR + 8];                           // sorted index of the row segment's first record
+  unsigned short lists[PP3_NT * PPL_LENT];
+  alignas(16) int wtot[4];                        // staged records per wavefront
+  int roff[PP3_HZ * PP3_HY + 1];                  // exclusive prefix of the home rows' counts
+  int misc[48];                                   // [0] task state, [1] slow flag, [4] the task has heavy lanes, [5..8] the task record, [8+8..] see below
+};
+struct PPLArgs {
+  const float4 *spos; float4 *vel; const int *cs; PPGeo G; PPForce F; float a_mid, dt; float *tile_max;
+  const int4 *task4; const int *ntask_ptr; int ntask_cap; int *counter; int xbw, fat_limit;
+  int *htask, *hcount; int4 *slow; int *slowcount;
+};
+template <bool TAPER_ALL>
+__device__ __forceinline__ void pp_ext_eval2s(const float4 &p, const float4 &A, const float4 &B, bool ok, const PPForce &F, f32x2 &ax, f32x2 &ay, f32x2 &az) {
+  const f32x2 ox = {A.x, B.x}, oy = {A.y, B.y}, oz = {A.z, B.z};
+  const f32x2 sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
+  const f32x2 r2 = sx * sx + sy * sy + sz * sz;
+  const f32x2 ir = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
+  const f32x2 qq = (r2 * ir) * F.c1;
+  const f32x2 q2 = qq * qq, q3 = q2 * qq;
+  const f32x2 k34 = {F.K34, F.K34}, k74 = {F.K74, F.K74}, kk = {F.K, F.K};
+  f32x2 tp = __builtin_elementwise_fma(q3, __builtin_elementwise_fma(q2, k34, k74), kk);   // :559-564
+  if (!TAPER_ALL) { tp.x = r2.x < F.r2_taper ? tp.x : F.K; tp.y = r2.y < F.r2_taper ? tp.y : F.K; }
+  f32x2 f = tp * ((ir * ir) * ir);
+  f.x = (ok && r2.x >= F.r2_soft) ? f.x : 0.0f; f.y = (ok && r2.y >= F.r2_soft) ? f.y : 0.0f;   // :558 (by selection: r = 0 is met here)
+  ax = __builtin_elementwise_fma(-sx, f, ax); ay = __builtin_elementwise_fma(-sy, f, ay); az = __builtin_elementwise_fma(-sz, f, az);   // :571
+}
+template <bool TAPER_ALL>
+__global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pp_light(const PPLArgs A) {
+  __shared__ PPLShared S;
+  static_assert(PP3_NT == 256 && PP3_HZ == 8 && PP3_HY == 8, "three planes of twelve rows per wavefront");
+  constexpr int NH = PP3_HZ * PP3_HY, NW = PP3_NT / 64, ppr = 2, RW = PPL_NR / NW;   // RW = 36 rows per wavefront = 3 planes
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const PPGeo &G = A.G;
+  const PPForce &F = A.F;
+  const int e = G.pt + 2 * ppr, E = G.E;
+  const int ntask = min(*A.ntask_ptr, A.ntask_cap);
+  const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
+  int seg = blockIdx.x % PP3_NSEG;
+  // thread 0: the two-stage pipeline of task draws (see k_pp_ext3)
+  int a_tf = 0, a_seg = 0, tried = 0;
+  bool a_live = false, b_live = false;
+  int4 b_val = make_int4(0, 0, 0, 0), cur = make_int4(0, 0, 0, 0), prev = make_int4(0, 0, 0, 0);
+  auto advance = [&]() {
+    b_live = false;
+    if (a_live) {
+      const int sbeg = min(a_seg * per, ntask), send = min(sbeg + per, ntask), t = sbeg + a_tf;
+      if (t < send) { b_val = A.task4[t]; b_live = true; tried = 0; }
+      else { tried++; seg = (seg + 1) % PP3_NSEG; }
+    }
+    a_live = tried < PP3_NSEG;
+    if (a_live) { a_seg = seg; a_tf = atomicAdd(A.counter + 32 * seg, 1); }
+  };
+  if (tid == 0) { a_live = true; a_seg = seg; a_tf = atomicAdd(A.counter + 32 * seg, 1); advance(); }
+  // Every list entry that is ever READ must address finite numbers: an entry past a lane's list end (stale, or never written) is
+  // evaluated with a zero factor, and 0 * (p - NaN) is NaN.  The records area and the lists start as zeros; from then on an entry is
+  // zero or a staged address, and a staged slot holds zeros or some task's records
+  for (int i = tid; i < (int)(sizeof(S.prec) / 16); i += PP3_NT) S.prec[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < (int)(sizeof(S.lists) / 4); i += PP3_NT) reinterpret_cast<unsigned *>(S.lists)[i] = 0u;
+  if (tid < 2 * NW) S.misc[16 + tid] = 0;            // [16..23] heavy lanes (bits) per wavefront, [24..47] the wavefronts' boxes
+  if (tid == 0) S.misc[4] = 0;
+  const unsigned mybase = (unsigned)(tid * PPL_LENT * 2), mycap = mybase + 2 * PPL_LCAP;   // byte offsets into S.lists
+  // cell offsets and records through buffer descriptors: a load is then a scalar offset + a 32-bit lane offset (pp_extended takes this pass
+  // only where both arrays are shorter than 4 GB)
+  const __amdgpu_buffer_rsrc_t cs_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(A.cs), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sp_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(A.spos), 0, (int)0xffffffffu, 0x00020000);
+  char *const lbytes = reinterpret_cast<char *>(S.lists);
+  const char *const pbytes = reinterpret_cast<const char *>(S.prec);
+  for (;;) {
+    __syncthreads();                                  // the previous task's readers of the tables are done
+    if (tid == 0) { S.misc[0] = b_live ? 1 : (a_live ? 0 : -1); S.misc[1] = 0; S.misc[5] = b_val.x; S.misc[6] = b_val.y; S.misc[7] = b_val.z; S.misc[8] = b_val.w; cur = b_val; advance(); }
+    __syncthreads();
+    const int state = S.misc[0];
+    if (tid == 0) {
+      if (S.misc[4]) {                                // the task just worked has heavy lanes: its record for k_pp_ext3<.., 1> (same layout)
+        const int slot = atomicAdd(A.hcount, 1);
+        int bz0 = 0x7fff, bz1 = 0, by0 = 0x7fff, by1 = 0, bx0 = 0x7fff, bx1 = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+          if (S.misc[16 + 2 * w] | S.misc[17 + 2 * w]) {
+            const int *bw = S.misc + 24 + 6 * w;
+            bz0 = min(bz0, bw[0]); bz1 = max(bz1, bw[1]); by0 = min(by0, bw[2]); by1 = max(by1, bw[3]); bx0 = min(bx0, bw[4]); bx1 = max(bx1, bw[5]);
+          }
+        if (slot < A.ntask_cap) {
+          int *rec = A.htask + (size_t)PP3_HREC * slot;
+          rec[0] = prev.x; rec[1] = prev.y; rec[2] = bz0 | (bz1 << 16); rec[3] = by0 | (by1 << 16); rec[4] = bx0 | (bx1 << 16);
+#pragma unroll
+          for (int k = 0; k < 2 * NW; k++) rec[5 + k] = S.misc[16 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * NW; k++) S.misc[16 + k] = 0;
+        S.misc[4] = 0;
+      }
+      prev = cur;
+    }
+    if (state < 0) break;
+    if (state == 0) continue;
+    const int sub = __builtin_amdgcn_readfirstlane(S.misc[6]), pk = __builtin_amdgcn_readfirstlane(S.misc[7]), tk = __builtin_amdgcn_readfirstlane(S.misc[8]);
+    const int xb = pk & 1023, gy = (pk >> 10) & 1023, gz = pk >> 20, tx = tk & 1023, ty = (tk >> 10) & 1023, tz = tk >> 20;
+    const int tile = (tz * G.T + ty) * G.T + tx;
+    const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
+    const int hx0 = lox + xb * A.xbw, hx1 = min(hx0 + A.xbw, lox + e);           // home cells [hx0, hx1)
+    const int hz0 = loz + gz * PP3_HZ, hy0 = loy + gy * PP3_HY;
+    const int WV = A.xbw + 5;                          // boundaries hx0 - 2 ... hx0 + xbw + 2 (clamped to the region)
+    // ---- the offset table: this wavefront's three planes of twelve rows
+    {
+      // every lane loads its boundary of every row through a uniform row pointer + a 32-bit lane offset (rows outside the region: the
+      // nearest row inside, so that no load is conditional, and zeros afterwards)
+      const int col4 = 4 * (min(max(hx0 - ppr + lane, lox), lox + e) - lox);
+      const int zb = hz0 - ppr + 3 * wvu, yb = hy0 - ppr;
+      int o[RW];
+#pragma unroll
+      for (int u = 0; u < RW; u++) asm volatile("" : "=v"(o[u]));   // (defined for the compiler; only the lanes below read them)
+      if (lane < PPL_TS) {                            // the 36 boundaries of a row: the other lanes request nothing
+#pragma unroll
+        for (int u = 0; u < RW; u++) {
+          const int zz = min(max(zb + u / PPL_NRY, loz), loz + e - 1), yy = min(max(yb + u % PPL_NRY, loy), loy + e - 1);
+          o[u] = __builtin_amdgcn_raw_buffer_load_b32(cs_rsrc, col4, (unsigned)(((zz * E + yy) * E + lox) * 4), 0);   // scalar row offset + lane offset: no vector address arithmetic
+        }
+      }
+      int pre = 0, orc = 0, vfirst = 0, vpre = 0;
+      unsigned char *trow = S.T + RW * wvu * PPL_TS + lane;
+#pragma unroll
+      for (int u = 0; u < RW; u++) {
+        const int zz = zb + u / PPL_NRY, yy = yb + u % PPL_NRY;
+        if (!(zz >= loz && zz < loz + e && yy >= loy && yy < loy + e)) o[u] = 0;      // (uniform, and rare: patches on the region's faces)
+        const int first = __builtin_amdgcn_readfirstlane(o[u]), last = __builtin_amdgcn_readlane(o[u], WV - 1);
+        if (lane < PPL_TS) trow[u * PPL_TS] = (unsigned char)(o[u] - first);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(vfirst) : "s"(first), "n"(u));      // lane u keeps row u's first record and prefix
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(vpre) : "s"(pre), "n"(u));
+        const int cnt = last - first;
+        pre += cnt; orc |= cnt;                         // (counts are >= 0: their OR exceeds 255 exactly when one of them does)
+      }
+      if (lane < RW) { S.rowg[RW * wvu + lane] = vfirst; S.lcum[RW * wvu + lane] = (unsigned short)vpre; }
+      if (lane == 0) { S.wtot[wvu] = pre; if (orc > 255) S.misc[1] = 1; }
+      // P3M_PP_FAT_LIMIT (a test switch) lowers the longest row segment this pass takes
+      if (A.fat_limit < 255 && lane < RW && (int)S.T[(RW * wvu + lane) * PPL_TS + WV - 1] > A.fat_limit) S.misc[1] = 1;
+    }
+    __syncthreads();
+    const int4 wt = *reinterpret_cast<const int4 *>(S.wtot);
+    const int Ptot = wt.x + wt.y + wt.z + wt.w;
+    if (S.misc[1] != 0 || Ptot > PPL_PCAP) {          // uniform: a crowded region or a long row segment: k_pp_ext3's general pass 0
+      if (tid == 0) { const int s = atomicAdd(A.slowcount, 1); if (s < A.ntask_cap) A.slow[s] = cur; }
+      continue;
+    }
+    {
+      const int wbase = wvu == 0 ? 0 : wvu == 1 ? wt.x : wvu == 2 ? wt.x + wt.y : wt.x + wt.y + wt.z;
+      if (lane < RW) S.cum16[RW * wvu + lane] = (unsigned short)((S.lcum[RW * wvu + lane] + wbase) << 4);
+#if !defined(PPL_ABL) || PPL_ABL < 3
+      // ---- staging: this wavefront's rows, (row, slot) items over the lanes
+      const int rl = lane >> 3, k = lane & 7;
+      constexpr int NIT = (RW + 7) / 8;
+      float4 q[NIT];
+      int cn[NIT], c0[NIT], g0[NIT];
+      bool more = false;
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int r = RW * wvu + it * 8 + rl;
+        const bool rok = it * 8 + 8 <= RW || it * 8 + rl < RW;
+        cn[it] = rok ? (int)S.T[r * PPL_TS + WV - 1] : 0; g0[it] = S.rowg[r]; c0[it] = (int)S.lcum[r] + wbase;
+        if (k < cn[it]) q[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sp_rsrc, (g0[it] + k) * 16, 0, 0));
+        more = more || cn[it] > 8;
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) if (k < cn[it]) S.prec[c0[it] + k] = q[it];
+      if (__any(more)) {
+#pragma unroll 1
+        for (int it = 0; it < NIT; it++)
+          for (int kk = k + 8; kk < cn[it]; kk += 8) S.prec[c0[it] + kk] = A.spos[g0[it] + kk];
+      }
+#endif
+      // ---- the home rows' counts (wavefront 0): exclusive prefix
+      if (wv == 0) {
+        const int rj = ((lane >> 3) + ppr) * PPL_NRY + (lane & 7) + ppr;
+        const int hc = (int)S.T[rj * PPL_TS + ppr + (hx1 - hx0)] - (int)S.T[rj * PPL_TS + ppr];
+        int inc = hc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        S.roff[lane] = inc - hc;
+        if (lane == 63) S.roff[NH] = inc;
+      }
+    }
+    __syncthreads();
+    const int total = S.roff[NH];                     // <= Ptot <= 704: tasks of PP3_NT home records (pp3_task_homes)
+    if (total == 0) continue;
+#if defined(PPL_ABL) && PPL_ABL >= 2   // timing-only ablation builds (tools/variant.sh): 1 no evaluation, 2 nor lists, 3 nor the records' staging
+    continue;
+#endif
+    const int hraw = sub * PP3_NT + tid;
+    const bool valid = hraw < total;
+    const int h = min(hraw, total - 1);               // a lane without a home record repeats the last one's lists (and kicks nothing)
+    // the home row of record h: the last row whose prefix is <= h, found plane first, then row (two LDS round trips of eight independent
+    // values each; a bisection is six dependent ones, and the task is a chain of round trips before it is anything else)
+    int j;
+    {
+      int jzc = 0, jyc = 0;
+#pragma unroll
+      for (int m = 1; m < PP3_HZ; m++) jzc += S.roff[m * PP3_HY] <= h ? 1 : 0;
+#pragma unroll
+      for (int m = 1; m < PP3_HY; m++) jyc += S.roff[jzc * PP3_HY + m] <= h ? 1 : 0;
+      j = jzc * PP3_HY + jyc;
+    }
+    const int jz = j >> 3, jy = j & 7, cz = hz0 + jz, cy = hy0 + jy;
+    const int rh = (jz + ppr) * PPL_NRY + jy + ppr;
+    const unsigned self16 = (unsigned)S.cum16[rh] + (((unsigned)S.T[rh * PPL_TS + ppr] + (unsigned)(h - S.roff[j])) << 4);
+    const float4 p = *reinterpret_cast<const float4 *>(pbytes + self16);
+    const int cx = (int)floorf(p.x) + G.nb;                                     // :412
+    auto is_phys = [&](int ccx, int ccy, int ccz) {                             // :576-582
+      return ccx >= lox + ppr && ccx < lox + ppr + G.pt && ccy - loy >= ppr && ccy - loy < ppr + G.pt && ccz - loz >= ppr && ccz - loz < ppr + G.pt;
+    };
+    const bool phys = valid && is_phys(cx, cy, cz);
+    const int vi = rec_index(p);
+    float4 vrec = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef PPL_NOVEL
+    if (phys) vrec = A.vel[vi];                        // needed after the sums
+#endif
+    // the lane's first window (dz = dy = -2): boundary cx - 2 of row (jz, jy) of the table; window (dz, dy) lies (dz + 2) * 12 + dy + 2 rows on
+    const unsigned char *tb = S.T + (jz * PPL_NRY + jy) * PPL_TS + (cx - hx0);
+    const unsigned short *cb = S.cum16 + jz * PPL_NRY + jy;
+    // the reference's half-shell sweep starts only from the planes k <= pt + pp_range (:496): a record of the planes above sweeps downwards only
+    const bool rim_task = hz0 + PP3_HZ - 1 - loz >= G.pt + ppr;                 // uniform
+    const int dzmax = cz - loz >= G.pt + ppr ? loz + G.pt + ppr - 1 - cz : ppr;
+    unsigned loff = mybase;
+    int cmax = 0;
+    // a window: its first SIX entries in one 12-byte store whatever its count (the next window overwrites what was not a partner); a
+    // window of more than six records (1e-6 at the background's density) sends the wavefront through build_slow
+    auto append = [&](unsigned a16, int cnt) {
+      const unsigned w0 = __umul24(a16, 0x10001u) + 0x100000u;                   // entries a16, a16 + 16
+      const unsigned w1 = w0 + 0x200020u, w2 = w0 + 0x400040u;                  //         ... a16 + 80
+      // six 16-bit stores (ds_write_b16 / _d16_hi: the three registers serve two each).  One 12-byte store at this 2-byte alignment is
+      // legal and was measured: the LDS then stalls on the misalignment for most of the kernel's time (SQ_LDS_UNALIGNED_STALL 589 M of
+      // 963 M busy cycles, profiles/r06_pp_lds_counters.txt)
+      lds_vu16 *const lp = (lds_vu16 *)(lbytes + min(loff, mycap));          // (volatile: the compiler merges plain stores back into one misaligned store)
+      // the first entry by every lane; the other five only by the lanes whose window holds more than one record (13 % at the background's
+      // density): 64 lanes storing to 64 unrelated addresses conflict four or five deep on the banks, and the LDS -- not the vector units --
+      // was what the kernel waited for (SQ_LDS_BANK_CONFLICT 363 M of 657 M busy cycles with six full-width stores per window)
+      lp[0] = (unsigned short)w0;
+      if (cnt > 1) { lp[1] = (unsigned short)(w0 >> 16); lp[2] = (unsigned short)w1; lp[3] = (unsigned short)(w1 >> 16); lp[4] = (unsigned short)w2; lp[5] = (unsigned short)(w2 >> 16); }
+      loff += 2 * cnt;
+      cmax = max(cmax, cnt);
+    };
+    // the general form, rolled: any counts, the half-shell rule of the rim planes (tasks of a tile's last patch along z).  A lane stores
+    // what a list holds and no more (next to a blob a window has a hundred records and the lane is heavy anyway), but counts everything
+    auto build_slow = [&](bool mine) {
+      loff = mybase;
+#pragma unroll 1
+      for (int dz = -ppr; dz <= ppr; dz++)
+#pragma unroll 1
+        for (int dy = -ppr; dy <= ppr; dy++) {
+          const int ro = (dz + ppr) * PPL_NRY + dy + ppr;
+          const int wa = tb[ro * PPL_TS], wb = mine && dz <= dzmax ? (int)tb[ro * PPL_TS + 2 * ppr + 1] : wa;
+          const bool ownrow = dz == 0 && dy == 0;
+          const int o0 = ownrow ? min((int)tb[ro * PPL_TS + ppr], wb) : wb, o1 = ownrow ? min((int)tb[ro * PPL_TS + ppr + 1], wb) : wb;
+          const unsigned c16 = ((lds_vu16 *)cb)[ro];
+#pragma unroll
+          for (int half = 0; half < 2; half++) {       // the own cell [o0, o1) splits the own row's window (:515-516)
+            const int a = half == 0 ? wa : o1, b = half == 0 ? o0 : wb;
+            for (int v = a; v < b && loff + 2 * (unsigned)(v - a) <= mycap + 10; v++) {
+              const unsigned short en = (unsigned short)(c16 + ((unsigned)v << 4));
+              *(lds_vu16 *)(lbytes + loff + 2 * (v - a)) = en;
+            }
+            loff += 2 * max(b - a, 0);
+          }
+        }
+    };
+#ifndef PPL_NOBUILD
+    if (!rim_task) {
+      // two planes of windows at a time: their 30 table reads are requested together, then appended (left to itself the compiler keeps
+      // two windows in flight: thirteen LDS round trips in a row where three do)
+      auto planes = [&](auto DZ0, auto NP) {
+        constexpr int dz0 = decltype(DZ0)::value, np = decltype(NP)::value;
+        int wa[np * 5], wb[np * 5]; unsigned c16[np * 5];
+        int o0 = 0, o1 = 0;
+#pragma unroll
+        for (int q = 0; q < np * 5; q++) {
+          const int ro = (dz0 + q / 5 + ppr) * PPL_NRY + q % 5;
+          wa[q] = tb[ro * PPL_TS]; wb[q] = tb[ro * PPL_TS + 2 * ppr + 1]; c16[q] = ((lds_vu16 *)cb)[ro];   // (volatile: five neighbours would be merged into misaligned wide reads)
+          if (dz0 + q / 5 == 0 && q % 5 == ppr) { o0 = tb[ro * PPL_TS + ppr]; o1 = tb[ro * PPL_TS + ppr + 1]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < np * 5; q++) {
+          if (dz0 + q / 5 == 0 && q % 5 == ppr) {      // the own cell splits the own row's window (:515-516)
+            append(c16[q] + ((unsigned)wa[q] << 4), o0 - wa[q]);
+            append(c16[q] + ((unsigned)o1 << 4), wb[q] - o1);
+          } else append(c16[q] + ((unsigned)wa[q] << 4), wb[q] - wa[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      planes(std::integral_constant<int, -2>{}, std::integral_constant<int, 2>{});
+      planes(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+      planes(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    }
+    {
+      // a list that is USED and has a window of more than six records (or any list of a rim task): the general loop for those lanes
+      const bool redo = rim_task || (cmax > 6 && (int)(loff - mybase) <= 2 * PPL_LCAP);
+      if (__any(redo)) { const unsigned keep = loff; build_slow(redo); if (!redo) loff = keep; }
+    }
+#endif
+    const int n_all = (int)(loff - mybase) >> 1;
+    bool heavy = valid && n_all > PPL_LCAP;
+    bool walker = false;
+    unsigned long long hb = __ballot(heavy);
+    if (hb) {                                         // uniform per wavefront, and rare away from blobs
+      if (__popcll(hb) <= 2 && wave_max_i(heavy ? n_all : 0) <= 2 * PPL_LCAP) { walker = heavy; heavy = false; hb = 0ull; }
+      else {
+        int z0 = max(cz - ppr, loz), z1 = min(min(cz + ppr, loz + e - 1), cz + dzmax);
+        const int y0 = max(cy - ppr, loy), y1 = min(cy + ppr, loy + e - 1), x0 = max(cx - ppr, lox), x1 = min(cx + ppr, lox + e - 1);
+        const int bz0 = wave_min_i(heavy ? z0 : 0x7fff), bz1 = wave_max_i(heavy ? z1 : 0), by0 = wave_min_i(heavy ? y0 : 0x7fff), by1 = wave_max_i(heavy ? y1 : 0);
+        const int bx0 = wave_min_i(heavy ? x0 : 0x7fff), bx1 = wave_max_i(heavy ? x1 : 0);
+        if (lane == 0) {
+          S.misc[16 + 2 * wv] = (int)(unsigned)hb; S.misc[17 + 2 * wv] = (int)(unsigned)(hb >> 32); S.misc[4] = 1;
+          int *bw = S.misc + 24 + 6 * wv;
+          bw[0] = bz0; bw[1] = bz1; bw[2] = by0; bw[3] = by1; bw[4] = bx0; bw[5] = bx1;
+        }
+      }
+    }
+    const int n = (valid && !heavy && !walker) ? n_all : 0;
+    { lds_vu16 *const lp = (lds_vu16 *)(lbytes + mybase + 2 * n);   // the tail of the last trip: the home record itself
+      lp[0] = (unsigned short)self16; lp[1] = (unsigned short)self16; lp[2] = (unsigned short)self16; }
+    f32x2 ax2 = {0.f, 0.f}, ay2 = {0.f, 0.f}, az2 = {0.f, 0.f};
+#if defined(PPL_ABL) && PPL_ABL == 1
+    if (n < -1)
+#endif
+    for (int k = 0;; k += 4) {
+      const bool okm = k < n;
+      if (!__any(okm)) break;
+      const uint2 e4 = *reinterpret_cast<const uint2 *>(lbytes + mybase + 2 * k);
+      const float4 o0 = *reinterpret_cast<const float4 *>(pbytes + (e4.x & 0xffffu)), o1 = *reinterpret_cast<const float4 *>(pbytes + (e4.x >> 16));
+      const float4 o2 = *reinterpret_cast<const float4 *>(pbytes + (e4.y & 0xffffu)), o3 = *reinterpret_cast<const float4 *>(pbytes + (e4.y >> 16));
+      pp_ext_eval2s<TAPER_ALL>(p, o0, o1, okm, F, ax2, ay2, az2);
+      pp_ext_eval2s<TAPER_ALL>(p, o2, o3, okm, F, ax2, ay2, az2);
+    }
+    float ax = ax2.x + ax2.y, ay = ay2.x + ay2.y, az = az2.x + az2.y;
+    if (__any(walker)) {                              // one or two lanes of the wavefront with 33 ... 64 partners: they walk their windows
+      if (walker) {
+        const unsigned own0 = (unsigned)cb[2 * PPL_NRY + 2 + 0] + ((unsigned)tb[(2 * PPL_NRY + 2) * PPL_TS + ppr] << 4);
+        const unsigned own1 = (unsigned)cb[2 * PPL_NRY + 2 + 0] + ((unsigned)tb[(2 * PPL_NRY + 2) * PPL_TS + ppr + 1] << 4);
+        for (int dz = -ppr; dz <= dzmax; dz++)
+          for (int dy = -ppr; dy <= ppr; dy++) {
+            const int ro = (dz + ppr) * PPL_NRY + dy + ppr;
+            const unsigned c16 = cb[ro];
+            unsigned a = c16 + ((unsigned)tb[ro * PPL_TS] << 4);
+            const unsigned b = c16 + ((unsigned)tb[ro * PPL_TS + 2 * ppr + 1] << 4);
+            for (; a < b; a += 16) {
+              if (dz == 0 && dy == 0 && a >= own0 && a < own1) continue;          // own cell is excluded (:515-516)
+              const float4 o = *reinterpret_cast<const float4 *>(pbytes + a);
+              pp_ext_eval(p, o.x, o.y, o.z, F, ax, ay, az);
+            }
+          }
+      }
+    }
+    float mag = 0.f;
+    if (valid && !heavy) {
+      if (phys) {                                                                   // :576-582
+        float4 v = vrec;
+        v.x = v.x + ax * A.a_mid * P3M_G_F * A.dt; v.y = v.y + ay * A.a_mid * P3M_G_F * A.dt; v.z = v.z + az * A.a_mid * P3M_G_F * A.dt;
+#ifdef PPL_NOVEL   // ablation: no velocity read-modify-write
+        if (v.x == 1.2345f)
+#endif
+        A.vel[vi] = v;
+      }
+      mag = sqrtf(ax * ax + ay * ay + az * az);                                     // :617
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
+    if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(A.tile_max + tile, mag);
+  }
+}
+
 // the smallest float r2 with sqrtf(r2) > t (sqrtf is correctly rounded and monotone): "rmag > t" becomes "r2 >= this"
 static float first_r2_with_root_above(float t) {
   float r2 = t * t;
@@ -1030,29 +1439,34 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   // patches of PP3_HZ x PP3_HY rows x xbw cells holding 7/8 of PP3_NT home records at the mean density (one task)
   const double rho_mean = (double)c->np_all / ((double)g.E * g.E * g.E);
   int xbw = (int)std::lround((0.875 * PP3_NT) / std::max(1e-9, rho_mean * PP3_HZ * PP3_HY));
-  xbw = std::max(4, std::min(std::min(xbw, e), 64 - 2 * g.pp_range - 1));      // one load instruction per partner row
+  // the lean light pass (k_pp_light): the reference's reach, record indices that fit a 32-bit byte offset; P3M_PP_LIGHT_OFF=1 (a test
+  // switch) sends every task through the general pass 0 of k_pp_ext3, which otherwise only works the tasks the lean pass leaves to it
+  static const bool light_off = getenv("P3M_PP_LIGHT_OFF") && getenv("P3M_PP_LIGHT_OFF")[0] == '1';
+  const bool light = !light_off && g.pp_range == 2 && (int64_t)c->cap < (1ll << 27) && (int64_t)g.E * g.E * g.E < (1ll << 29);   // (32-bit byte offsets into both arrays)
+  xbw = std::max(4, std::min(std::min(xbw, e), light ? PPL_XBW_MAX : 64 - 2 * g.pp_range - 1));      // one load instruction per partner row
   const int npx = (e + xbw - 1) / xbw, npy = (e + PP3_HY - 1) / PP3_HY, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int64_t ngroups64 = (int64_t)g.ntiles * npz * npy * npx;
   // a record is a home record of every tile whose extended region holds its cell: per axis at most 2 + 2*ppr/pt tiles
   const int64_t mult1 = std::min<int64_t>(g.T, 2 + (2 * g.pp_range) / g.pt), mult = mult1 * mult1 * mult1;
   const int64_t ngroups_max = (int64_t)g.ntiles * npz * npy * ((e + 3) / 4);
   const int64_t ntask_cap64 = mult * (c->cap / PP3_NTD + 1) + ngroups_max + 64;
-  if (ngroups_max > 0x3fffffff || ntask_cap64 > 0x7fffffff) { p3m_set_error("extended PP: too many patches"); return P3M_EINVAL; }
+  if (ngroups_max > 0x3fffffff || ntask_cap64 > 0x7fffffff || npx > 1023 || npy > 1023 || npz > 1023 || g.T > 1023) { p3m_set_error("extended PP: too many patches"); return P3M_EINVAL; }
   const int ngroups = (int)ngroups64, ntask_cap = (int)ntask_cap64;
   // each buffer under its own check: a failed allocation must not leave the others looking ready
   if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
-  if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int2) * (size_t)ntask_cap64));   // {group, sub-task} per task
+  if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int4) * (size_t)ntask_cap64));   // the task records (k_pp_fill2)
+  if (!c->pp_slow) HIP_TRY(hipMalloc(&c->pp_slow, sizeof(int4) * (size_t)ntask_cap64));               // the tasks the lean light pass leaves to the general one
   if (!c->pp_htask) HIP_TRY(hipMalloc(&c->pp_htask, sizeof(int) * PP3_HREC * (size_t)ntask_cap64));    // the heavy-task list (a task enters it once at most)
-  // task counters of the two passes (PP3_NSEG each, on cache lines of their own) and the length of the heavy-task list
-  constexpr int NCNT = 2 * 32 * PP3_NSEG + 32;
+  // task counters of the three launches (PP3_NSEG each, on cache lines of their own), the length of the heavy-task list and of the slow-task list
+  constexpr int NCNT = 3 * 32 * PP3_NSEG + 64;
   if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * NCNT));
   P3M_TRY(scan_reserve(c, ngroups_max + 8));
   HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * NCNT, c->stream));
-  int *hcount = c->pp_counter + 2 * 32 * PP3_NSEG;
+  int *hcount = c->pp_counter + 3 * 32 * PP3_NSEG, *slowcount = hcount + 32;
   hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
   HIP_TRY(hipGetLastError());
   P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
-  hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int2 *>(c->pp_task_group), ntask_cap);
+  hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int4 *>(c->pp_task_group), ntask_cap, npz, npy, npx, g.T);
   HIP_TRY(hipGetLastError());
   const PPForce F = pp_force_constants(mass_p, G.pp_bias, G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f)));
   const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
@@ -1065,14 +1479,24 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   // range (the rule: nf_cutoff = 16) the taper needs no switch
   const float far2 = 3.0f * (float)((g.pp_range + 1) * (g.pp_range + 1));
   const bool taper_all = far2 < F.r2_taper;
+  const int *plan_total = c->pp_plan + ngroups;        // the scan's total: the number of tasks
+  if (light) {
+    PPLArgs A{(const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt, c->d_tile_ext, (const int4 *)c->pp_task_group, plan_total, ntask_cap,
+              c->pp_counter + 2 * 32 * PP3_NSEG, xbw, fat_limit, c->pp_htask, hcount, reinterpret_cast<int4 *>(c->pp_slow), slowcount};
+    const int wpl = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / sizeof(PPLShared)));
+    if (taper_all) hipLaunchKernelGGL(k_pp_light<true>, dim3(256 * wpl), dim3(PP3_NT), 0, c->stream, A);
+    else hipLaunchKernelGGL(k_pp_light<false>, dim3(256 * wpl), dim3(PP3_NT), 0, c->stream, A);
+    HIP_TRY(hipGetLastError());
+  }
   const int wpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));   // resident workgroups per CU by LDS
   for (int pass = 0; pass < 2; pass++) {               // resident workgroups per CU: by LDS, the heavy pass also by its registers
     auto kern = pass == 0 ? (g.pp_range == 2 ? (taper_all ? k_pp_ext3<2, true, 0> : k_pp_ext3<2, false, 0>) : (taper_all ? k_pp_ext3<0, true, 0> : k_pp_ext3<0, false, 0>))
                           : (g.pp_range == 2 ? (taper_all ? k_pp_ext3<2, true, 1> : k_pp_ext3<2, false, 1>) : (taper_all ? k_pp_ext3<0, true, 1> : k_pp_ext3<0, false, 1>));
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // pass 0: the whole plan, or (behind the lean light pass) the tasks it left
     hipLaunchKernelGGL(kern, dim3(256 * (pass == 0 ? wpc : std::min(wpc, PP3_WPE - 1))), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
-                       c->d_tile_ext, (const int *)c->pp_plan, (const int2 *)c->pp_task_group, ngroups, npy, npx, xbw, ntask_cap, c->pp_counter + pass * 32 * PP3_NSEG, Wp, NRmax,
-                       fat_limit, c->pp_htask, hcount);
+                       c->d_tile_ext, light ? (const int4 *)c->pp_slow : (const int4 *)c->pp_task_group, light ? (const int *)slowcount : plan_total, npy, npx, xbw, ntask_cap,
+                       c->pp_counter + pass * 32 * PP3_NSEG, Wp, NRmax, fat_limit, c->pp_htask, hcount);
     HIP_TRY(hipGetLastError());
   }
   return P3M_OK;
@@ -1156,6 +1580,12 @@ extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, 
     HIP_TRY(hipEventRecord(e2, c->stream));
     HIP_TRY(hipEventSynchronize(e2));
     HIP_TRY(hipEventElapsedTime(&a, e0, e1)); HIP_TRY(hipEventElapsedTime(&b, e1, e2));
+    if (getenv("P3M_PP_STATS") && c->pp_counter && c->pp_plan) {   // diagnostic: tasks of the last launch, those left to the general pass, heavy tasks
+      int h[2] = {0, 0};
+      HIP_TRY(hipMemcpy(h, c->pp_counter + 3 * 32 * PP3_NSEG, sizeof(int), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(h + 1, c->pp_counter + 3 * 32 * PP3_NSEG + 32, sizeof(int), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[pp stats] heavy tasks %d, tasks left to the general pass %d\n", h[0], h[1]);
+    }
     return P3M_OK;
   };
   const int rc = body();

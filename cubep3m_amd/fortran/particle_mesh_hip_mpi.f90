@@ -322,11 +322,11 @@ subroutine particle_mesh
 #endif
 #ifdef MPI_TIME
   ! what the reference prints phase by phase under -DMPI_TIME: "tag : max avg min" over the ranks, in seconds (timers.f90:68-77)
-  if (p3m_hip_group_last_phase_ms(grp, phase_ms) == 0) then
-    do i = 1, 12
-      call mpi_time_analyze(phase_tag(i), real(phase_ms(i)) * 1.0e-3, rank, nodes)
-    enddo
-  endif
+  ! (mpi_time_analyze is collective: every rank calls it twelve times whatever its own return code was -- zeros on failure)
+  if (p3m_hip_group_last_phase_ms(grp, phase_ms) /= 0) phase_ms = 0.0
+  do i = 1, 12
+    call mpi_time_analyze(phase_tag(i), real(phase_ms(i)) * 1.0e-3, rank, nodes)
+  enddo
 #endif
 #ifdef DIAG
   if (rank == 0) write(*,*) 'sum of rho_f=', sout%sum_rho_f

@@ -239,7 +239,12 @@ class Oracle:
         self._raw, self._log, self._done, self._nocache = None, [], 0, os.environ.get("P3M_ORACLE_CACHE", "") == "0"
         self._dir = os.environ.get("P3M_ORACLE_CACHE") or "/tmp/p3m_oracle_cache"
         if Oracle._src_hash is None:
-            Oracle._src_hash = hashlib.sha1(open(os.path.join(ROOT, "oracle", "p3m_oracle.c"), "rb").read()).hexdigest()
+            # the key covers what decides the stored bytes: the BUILT oracle library (source, header, flags and compiler all end up in
+            # it) and the layout of the step record the bytes are read back into (the source alone was not enough)
+            hh = hashlib.sha1(open(build(), "rb").read())
+            hh.update(str(C.sizeof(P3MStepOut)).encode())
+            hh.update(open(os.path.join(ROOT, "include", "p3m_hip.h"), "rb").read())
+            Oracle._src_hash = hh.hexdigest()
         self._h = hashlib.sha1((Oracle._src_hash + repr(bytes(params.to_c()))).encode())
 
     # -- plumbing

@@ -1,5 +1,7 @@
 """Measurement tool: the two PP kernels on their own (p3m_hip_time_pp), for rocprofv3.
-    python3 tests/ppbench.py [uniform|clustered|dense] [reps] [cfg3|big]"""
+    python3 tests/ppbench.py [uniform|clustered|dense] [reps] [cfg3|big] [steady]
+"steady": one whole step first, so that the arrival order (the order velocities are stored in) is the previous step's sorted order, as
+in every step of a run but the first; without it the velocities are reached in the upload's random order."""
 import os
 import sys
 
@@ -28,6 +30,9 @@ else:
     xv = bench.clustered(nside, box, 2024, 0.3, 48, 0.6)
 g = ParticleMesh(p, fine, coarse)
 g.upload_particles(xv)
+if len(sys.argv) > 4 and sys.argv[4] == "steady":
+    g.particle_mesh(0.5, 0.0, 0.0, 8.0)
+    g.update_position(0.0, 0.0)
 g.link_list_and_pass()
 ms_i, ms_e, n_i, n_e = g.time_pp(0.5, 0.0, 8.0, reps=reps)
 print("%s %s: intra %.3f ms (%d evaluations, %.3g /s)   extended %.3f ms (%d evaluations, %.3g /s)" %

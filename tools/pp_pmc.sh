@@ -8,4 +8,4 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_LDS 
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   cd $R; rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/$tag -- python3 tests/ppbench.py ${1:-uniform} 3 big > $O/$tag.log 2>&1
 done
-python3 $R/tools/pmc_table.py $O k_pp_ext3 k_pp_intra
+python3 $R/tools/pmc_table.py $O k_pp_light k_pp_ext3 k_pp_intra
