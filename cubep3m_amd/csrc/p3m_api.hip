@@ -156,7 +156,7 @@ extern "C" void p3m_hip_destroy(p3m_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   dfree(c->pos); dfree(c->vel); dfree(c->vel_alt); dfree(c->pid_home); dfree(c->spos);
-  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->scan_state); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter); dfree(c->pp_htask); dfree(c->pp_slow);
+  dfree(c->tpos); dfree(c->flags); dfree(c->cflag); dfree(c->cand); dfree(c->cand_cnt); dfree(c->gl_cnt); dfree(c->scan_tmp); dfree(c->scan_state); dfree(c->d_counters); dfree(c->pp_plan); dfree(c->pp_task_group); dfree(c->pp_counter); dfree(c->pp_htask); dfree(c->pp_slow); dfree(c->pp_intra_done);
   if (c->cell_end) { int *raw = c->cell_end - 3; (void)hipFree(raw); c->cell_end = nullptr; }
   if (c->row_end) { int *raw = c->row_end - 3; (void)hipFree(raw); c->row_end = nullptr; }
   dfree(c->crow);
@@ -406,8 +406,11 @@ int fine_mesh_force_phase(p3m_ctx *c, float mass_p, bool may_clear) {
 int fine_mesh_kick_phase(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   // (NGP whole steps: the inverse x pass of the force runs inside the kick, kick_fused.hip -- it is timed with the kick)
   { PhaseScope ps(c->pt, P3M_PH_FINE_KICK, c->stream); P3M_TRY(fine_max_and_kick(c, a_mid, dt)); }
-  if ((c->p.flags & P3M_FLAG_PPINT) && (c->p.flags & P3M_FLAG_NGP)) { PhaseScope ps(c->pt, P3M_PH_PP_INTRA, c->stream); P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); }
-  if (c->p.flags & P3M_FLAG_PP_EXT) { PhaseScope ps(c->pt, P3M_PH_PP_EXT, c->stream); P3M_TRY(pp_extended(c, a_mid, dt, mass_p)); }
+  // -DPPINT + -DPP_EXT: the extended pass first -- where its lean light pass runs it sums the bucket pairs of the records it stages anyway
+  // (:324-361 inside :378-624's pass) and flags them; pp_intra then works the rest (flagged coarse cells, heavy records, crowded patches)
+  const bool ppint = (c->p.flags & P3M_FLAG_PPINT) && (c->p.flags & P3M_FLAG_NGP), ppext = (c->p.flags & P3M_FLAG_PP_EXT) != 0;
+  if (ppext) { PhaseScope ps(c->pt, P3M_PH_PP_EXT, c->stream); P3M_TRY(pp_extended(c, a_mid, dt, mass_p, ppint)); }
+  if (ppint) { PhaseScope ps(c->pt, P3M_PH_PP_INTRA, c->stream); P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); }
   return P3M_OK;
 }
 extern "C" int p3m_hip_fine_mesh(p3m_ctx *c, float a_mid, float dt, float mass_p) {

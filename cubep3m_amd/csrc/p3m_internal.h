@@ -159,6 +159,7 @@ struct p3m_ctx {
   // of their own in cand_cnt[slot * 16] -- appending to ONE list cost k_row_sort half its run time (66 000 atomics on one
   // address serialise at ~12 ns each); cand_cnt[16 * slots] is set when a list overflowed: the fix-up then scans every record
   int *cand = nullptr; int *cand_cnt = nullptr; int cand_seg = 0;
+  unsigned char *pp_intra_done = nullptr; bool pp_intra_fused = false;   // extended PP with -DPPINT fused (pp.hip): a byte per sorted record whose bucket pairs are summed already
   bool step_begun = false;     // p3m_hip_particle_mesh: the step has changed state (an error from here on resets what was queued)
   int *pp_plan = nullptr, *pp_task_group = nullptr, *pp_counter = nullptr, *pp_htask = nullptr, *pp_slow = nullptr;   // extended PP (pp.hip): first task of every patch, task -> {patch, sub-task}, task counters, the heavy-task list
   int *d_counters = nullptr;   // small device counter block
@@ -273,7 +274,7 @@ int build_fine_kernel(p3m_ctx *c, const float *table16_host);
 
 // ---- pp.hip
 int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p);
-int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p);
+int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra);   // fuse_intra: sum the -DPPINT bucket pairs on the way where the lean light pass runs (pp_intra, called AFTERWARDS, then works the rest)
 
 // ---- coarse_mesh.hip
 int coarse_deposit(p3m_ctx *c, float mass_p);

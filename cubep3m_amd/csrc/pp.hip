@@ -5,6 +5,7 @@
 // llf / hoc_fine / ll_fine: a cell's partners are index ranges.  FP32-ALU bound (about 20 flop per
 // pair incl. the reciprocal square root); reported as pairs/s, not against the HBM roofline.
 #include "p3m_internal.h"
+#include "fft_core.h"
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -58,8 +59,12 @@ __device__ __forceinline__ void ref_bucket(const float4 &p, const PPGeo &G, int 
 #define PP_INTRA_DENSE 12
 __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs,
                                                   const unsigned char *__restrict__ cflag, int n, PPGeo G, float mass_p, float a_mid, float dt,
-                                                  float *__restrict__ fmax_out, float r2_soft) {
+                                                  float *__restrict__ fmax_out, float r2_soft, const unsigned char *__restrict__ done) {
+  // done (or null): a byte per sorted record, set by k_pp_light for the records whose bucket pairs it has summed on its way (pp_extended:
+  // the fused form); a wavefront of such records -- the rule at the background's density -- leaves before it reads anything else
   const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool skip = done != nullptr && s < n && done[s] != 0;
+  if (done != nullptr && __all(skip || s >= n)) return;
   float mag = 0.f;
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
   bool phys = false, slow = false;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   if (s < n) {
     p = spos[s];
     const float fNn = (float)G.Nn;
-    phys = p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;
+    phys = !skip && p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;
     cell = ((int64_t)((int)floorf(p.z) + G.nb) * G.E + ((int)floorf(p.y) + G.nb)) * G.E + ((int)floorf(p.x) + G.nb);
     if (phys) {
       // the hoc coarse cell alone decides the path (ref_bucket's three float and six integer divisions were a third of this
@@ -129,10 +134,17 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
       }
     }
   } else if (fast) {
+    // (the reciprocal square root of the dense path above: the wavefront runs this loop as often as its fullest cell has records, and the
+    // square root and three divisions of pair_force were three quarters of the kernel's instructions)
+    const float ibias = 1.0f / G.pp_bias;
     for (int q = q0; q < q1; q++) {
-      if (q == s) continue;
-      const float3 f = pair_force(p, spos[q], mass_p, G.rsoft, G.pp_bias);
-      ax -= f.x; ay -= f.y; az -= f.z;                            // :346-347
+      const float4 o = spos[q];
+      const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;                 // :336
+      const float r2 = sx * sx + sy * sy + sz * sz;
+      if (q != s && r2 >= r2_soft) {                                              // :340 rmag > rsoft, decided exactly on r^2
+        const float ib = __builtin_amdgcn_rsqf(r2) * ibias, irb3 = ib * ib * ib;
+        ax -= mass_p * (sx * irb3); ay -= mass_p * (sy * irb3); az -= mass_p * (sz * irb3);   // :344-347
+      }
     }
   }
   // Records of flagged coarse cells (some record's reference bucket differs from its sorted cell): partners are the records
@@ -200,10 +212,12 @@ static float first_r2_with_root_above(float t);
 int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   P3M_TRY(particles_full_cells(c));
   const Geometry &g = c->g;
+  const unsigned char *done = c->pp_intra_fused ? c->pp_intra_done : nullptr;   // this step's pp_extended summed the bucket pairs of the records flagged there
+  c->pp_intra_fused = false;
   if (c->np_all == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
   hipLaunchKernelGGL(k_pp_intra, dim3(cdiv(c->np_all, 256)), dim3(256), 0, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end,
-                     (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1 * P3M_RED_SPAN, first_r2_with_root_above(G.rsoft));
+                     (const unsigned char *)c->cflag, c->np_all, G, mass_p, a_mid, dt, c->d_red + 1 * P3M_RED_SPAN, first_r2_with_root_above(G.rsoft), done);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
 }
@@ -480,7 +494,8 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
   unsigned char *mylist = list + (wv * 64 + lane) * PP3_LSTR;                 // this lane's entries
   const int ppr = G.ppr, e = G.pt + 2 * ppr, E = G.E, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int ntask = PASS == 0 ? min(*ntask_ptr, ntask_cap) : min(*hcount, ntask_cap);
-  if (PASS == 1 && ntask == 0) return;             // no blob anywhere (the rule at the background's density): the launch costs its dispatch only
+  if ((int)blockIdx.x >= ntask) return;            // no task (no blob anywhere, nothing left by the lean pass: the rule at the background's density), or fewer tasks than
+                                                   // workgroups: the launch costs its dispatch only (a workgroup without a task probed eight dry counters between barriers)
   const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
   int seg = blockIdx.x % PP3_NSEG;
   // Thread 0 runs a two-stage pipeline of task draws, one stage per task worked: the counter atomic of the task after the next
@@ -1047,13 +1062,35 @@ struct PPLShared {
   int roff[PP3_HZ * PP3_HY + 1];                  // exclusive prefix of the home rows' counts
   int misc[48];                                   // [0] task state, [1] slow flag, [4] the task has heavy lanes, [5..8] the task record, [8+8..] see below
 };
-struct PPLArgs {
-  const float4 *spos; float4 *vel; const int *cs; PPGeo G; PPForce F; float a_mid, dt; float *tile_max;
-  const int4 *task4; const int *ntask_ptr; int ntask_cap; int *counter; int xbw, fat_limit;
-  int *htask, *hcount; int4 *slow; int *slowcount;
+// (the arguments only thread 0, one lane per task or a rare branch reads -- PPLRare -- were tried behind a pointer into device memory, to free the
+// thirty scalar registers they hold: fewer spills, and slower by a fifth -- every scalar load is waited for with the LDS counter at zero)
+struct PPLRare {
+  int *counter; int *htask, *hcount; int *slow; int *slowcount;   // task counters, heavy-task list (k_pp_ext3<.., 1>), patches left to the general pass
+  float *tile_max, *fmax_intra;
+  int ntask_cap, fat_limit;
+  int npx, npxy, per_tile; unsigned m_npx, m_npxy, m_T, m_T2;      // patches per row of patches, per plane, per tile; reciprocals (mulhi) of those and of T, T^2
 };
+struct PPLArgs {
+  const float4 *spos; float4 *vel; const int *cs; PPLRare rare;
+  // -DPPINT fused (or intra_done = null): the pairs inside a home record's own cell -- the reference's buckets wherever the coarse cell is not
+  // flagged (k_pp_intra) -- are summed from the staged records too (:324-361); the records done are flagged for k_pp_intra, which works the rest
+  unsigned char *intra_done; const unsigned char *cflag;
+  int T, nb, pt, E, ms, xbw, ngroups;
+  float c1, K, K34, K74, r2_soft, r2_taper, a_mid, dt;            // pp_force_constants
+};
+__device__ __forceinline__ void pp_ext_eval_l(const float4 &p, float ox, float oy, float oz, const PPLArgs &F, float &ax, float &ay, float &az) {   // pp_ext_eval on the light pass's constants
+  const float sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
+  const float r2 = sx * sx + sy * sy + sz * sz;
+  const float ir = __builtin_amdgcn_rsqf(r2), qq = (r2 * ir) * F.c1;
+  const float q2 = qq * qq, q3 = q2 * qq;
+  float tp = __builtin_fmaf(q3, __builtin_fmaf(q2, F.K34, F.K74), F.K);    // :559-564
+  tp = r2 < F.r2_taper ? tp : F.K;
+  float f = tp * ((ir * ir) * ir);
+  f = r2 >= F.r2_soft ? f : 0.0f;                                        // :558
+  ax = __builtin_fmaf(-sx, f, ax); ay = __builtin_fmaf(-sy, f, ay); az = __builtin_fmaf(-sz, f, az);   // :571
+}
 template <bool TAPER_ALL>
-__device__ __forceinline__ void pp_ext_eval2s(const float4 &p, const float4 &A, const float4 &B, bool ok, const PPForce &F, f32x2 &ax, f32x2 &ay, f32x2 &az) {
+__device__ __forceinline__ void pp_ext_eval2s(const float4 &p, const float4 &A, const float4 &B, bool ok, const PPLArgs &F, f32x2 &ax, f32x2 &ay, f32x2 &az) {
   const f32x2 ox = {A.x, B.x}, oy = {A.y, B.y}, oz = {A.z, B.z};
   const f32x2 sx = p.x - ox, sy = p.y - oy, sz = p.z - oz;               // :551
   const f32x2 r2 = sx * sx + sy * sy + sz * sz;
@@ -1067,19 +1104,29 @@ __device__ __forceinline__ void pp_ext_eval2s(const float4 &p, const float4 &A, 
   f.x = (ok && r2.x >= F.r2_soft) ? f.x : 0.0f; f.y = (ok && r2.y >= F.r2_soft) ? f.y : 0.0f;   // :558 (by selection: r = 0 is met here)
   ax = __builtin_elementwise_fma(-sx, f, ax); ay = __builtin_elementwise_fma(-sy, f, ay); az = __builtin_elementwise_fma(-sz, f, az);   // :571
 }
-template <bool TAPER_ALL>
+template <bool TAPER_ALL, bool FUSE>   // FUSE: -DPPINT's bucket pairs on the way (PPLArgs::intra_done)
 __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pp_light(const PPLArgs A) {
   __shared__ PPLShared S;
   static_assert(PP3_NT == 256 && PP3_HZ == 8 && PP3_HY == 8, "three planes of twelve rows per wavefront");
   constexpr int NH = PP3_HZ * PP3_HY, NW = PP3_NT / 64, ppr = 2, RW = PPL_NR / NW;   // RW = 36 rows per wavefront = 3 planes
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wvu = __builtin_amdgcn_readfirstlane(wv);
-  const PPGeo &G = A.G;
-  const PPForce &F = A.F;
+  const PPLArgs &G = A, &F = A;                      // (geometry and force constants by their old names)
+  const PPLRare *const R = &A.rare;
   const int e = G.pt + 2 * ppr, E = G.E;
-  const int ntask = min(*A.ntask_ptr, A.ntask_cap);
+  // a task is a PATCH (no plan: k_pp_plan3's pass over the cell table, the scan and k_pp_fill2 cost 0.13 ms per tile; a patch of more than
+  // PP3_NT home records -- two per cent of them at the background's density -- is left to the general pass like a crowded one)
+  const int ntask = A.ngroups;
   const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
   int seg = blockIdx.x % PP3_NSEG;
+  // the patch's and the tile's coordinates, decoded by thread 0 a task ahead (multiplications by reciprocals; one real division)
+  auto decode = [&](int g) {
+    const int tile = g / R->per_tile; int rem = g - tile * R->per_tile;
+    const int gz = R->npxy == 1 ? rem : (int)__umulhi((unsigned)rem, R->m_npxy); rem -= gz * R->npxy;      // (the reciprocal of 1 does not fit 32 bits)
+    const int gy = R->npx == 1 ? rem : (int)__umulhi((unsigned)rem, R->m_npx), xb = rem - gy * R->npx;
+    const int tz = (int)__umulhi((unsigned)tile, R->m_T2), t2 = tile - tz * A.T * A.T, ty = (int)__umulhi((unsigned)t2, R->m_T), tx = t2 - ty * A.T;
+    return make_int4(g, 0, (gz << 20) | (gy << 10) | xb, (tz << 20) | (ty << 10) | tx);
+  };
   // thread 0: the two-stage pipeline of task draws (see k_pp_ext3)
   int a_tf = 0, a_seg = 0, tried = 0;
   bool a_live = false, b_live = false;
@@ -1088,13 +1135,13 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     b_live = false;
     if (a_live) {
       const int sbeg = min(a_seg * per, ntask), send = min(sbeg + per, ntask), t = sbeg + a_tf;
-      if (t < send) { b_val = A.task4[t]; b_live = true; tried = 0; }
+      if (t < send) { b_val = decode(t); b_live = true; tried = 0; }
       else { tried++; seg = (seg + 1) % PP3_NSEG; }
     }
     a_live = tried < PP3_NSEG;
-    if (a_live) { a_seg = seg; a_tf = atomicAdd(A.counter + 32 * seg, 1); }
+    if (a_live) { a_seg = seg; a_tf = atomicAdd(R->counter + 32 * seg, 1); }
   };
-  if (tid == 0) { a_live = true; a_seg = seg; a_tf = atomicAdd(A.counter + 32 * seg, 1); advance(); }
+  if (tid == 0) { a_live = true; a_seg = seg; a_tf = atomicAdd(R->counter + 32 * seg, 1); advance(); }
   // Every list entry that is ever READ must address finite numbers: an entry past a lane's list end (stale, or never written) is
   // evaluated with a zero factor, and 0 * (p - NaN) is NaN.  The records area and the lists start as zeros; from then on an entry is
   // zero or a staged address, and a staged slot holds zeros or some task's records
@@ -1103,42 +1150,45 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   if (tid < 2 * NW) S.misc[16 + tid] = 0;            // [16..23] heavy lanes (bits) per wavefront, [24..47] the wavefronts' boxes
   if (tid == 0) S.misc[4] = 0;
   const unsigned mybase = (unsigned)(tid * PPL_LENT * 2), mycap = mybase + 2 * PPL_LCAP;   // byte offsets into S.lists
-  // cell offsets and records through buffer descriptors: a load is then a scalar offset + a 32-bit lane offset (pp_extended takes this pass
-  // only where both arrays are shorter than 4 GB)
+  // cell offsets through a buffer descriptor: a load is then a scalar row offset + a 32-bit lane offset (pp_extended takes this pass
+  // only where the cell table and the records are shorter than 4 GB)
   const __amdgpu_buffer_rsrc_t cs_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(A.cs), 0, (int)0xffffffffu, 0x00020000);
+#ifndef PPL_STAGE_GLOBAL
   const __amdgpu_buffer_rsrc_t sp_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(A.spos), 0, (int)0xffffffffu, 0x00020000);
+#endif
   char *const lbytes = reinterpret_cast<char *>(S.lists);
   const char *const pbytes = reinterpret_cast<const char *>(S.prec);
+  // thread 0, behind a barrier that follows the wavefronts' writes: the task (patch g, sub-task sub) just worked has heavy lanes -- its record
+  // for k_pp_ext3<.., 1> (same layout: a bit per lane, the box of partner rows and cells those lanes reach)
+  auto flush_heavy = [&](int g, int sub) {
+    if (!S.misc[4]) return;
+    const int slot = atomicAdd(R->hcount, 1);
+    int bz0 = 0x7fff, bz1 = 0, by0 = 0x7fff, by1 = 0, bx0 = 0x7fff, bx1 = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++)
+      if (S.misc[16 + 2 * w] | S.misc[17 + 2 * w]) {
+        const int *bw = S.misc + 24 + 6 * w;
+        bz0 = min(bz0, bw[0]); bz1 = max(bz1, bw[1]); by0 = min(by0, bw[2]); by1 = max(by1, bw[3]); bx0 = min(bx0, bw[4]); bx1 = max(bx1, bw[5]);
+      }
+    if (slot < R->ntask_cap) {
+      int *rec = R->htask + (size_t)PP3_HREC * slot;
+      rec[0] = g; rec[1] = sub; rec[2] = bz0 | (bz1 << 16); rec[3] = by0 | (by1 << 16); rec[4] = bx0 | (bx1 << 16);
+#pragma unroll
+      for (int k = 0; k < 2 * NW; k++) rec[5 + k] = S.misc[16 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NW; k++) S.misc[16 + k] = 0;
+    S.misc[4] = 0;
+  };
   for (;;) {
     __syncthreads();                                  // the previous task's readers of the tables are done
     if (tid == 0) { S.misc[0] = b_live ? 1 : (a_live ? 0 : -1); S.misc[1] = 0; S.misc[5] = b_val.x; S.misc[6] = b_val.y; S.misc[7] = b_val.z; S.misc[8] = b_val.w; cur = b_val; advance(); }
     __syncthreads();
     const int state = S.misc[0];
-    if (tid == 0) {
-      if (S.misc[4]) {                                // the task just worked has heavy lanes: its record for k_pp_ext3<.., 1> (same layout)
-        const int slot = atomicAdd(A.hcount, 1);
-        int bz0 = 0x7fff, bz1 = 0, by0 = 0x7fff, by1 = 0, bx0 = 0x7fff, bx1 = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++)
-          if (S.misc[16 + 2 * w] | S.misc[17 + 2 * w]) {
-            const int *bw = S.misc + 24 + 6 * w;
-            bz0 = min(bz0, bw[0]); bz1 = max(bz1, bw[1]); by0 = min(by0, bw[2]); by1 = max(by1, bw[3]); bx0 = min(bx0, bw[4]); bx1 = max(bx1, bw[5]);
-          }
-        if (slot < A.ntask_cap) {
-          int *rec = A.htask + (size_t)PP3_HREC * slot;
-          rec[0] = prev.x; rec[1] = prev.y; rec[2] = bz0 | (bz1 << 16); rec[3] = by0 | (by1 << 16); rec[4] = bx0 | (bx1 << 16);
-#pragma unroll
-          for (int k = 0; k < 2 * NW; k++) rec[5 + k] = S.misc[16 + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 2 * NW; k++) S.misc[16 + k] = 0;
-        S.misc[4] = 0;
-      }
-      prev = cur;
-    }
+    if (tid == 0) { flush_heavy(prev.x, prev.y); prev = cur; }
     if (state < 0) break;
     if (state == 0) continue;
-    const int sub = __builtin_amdgcn_readfirstlane(S.misc[6]), pk = __builtin_amdgcn_readfirstlane(S.misc[7]), tk = __builtin_amdgcn_readfirstlane(S.misc[8]);
+    const int pk = __builtin_amdgcn_readfirstlane(S.misc[7]), tk = __builtin_amdgcn_readfirstlane(S.misc[8]);
     const int xb = pk & 1023, gy = (pk >> 10) & 1023, gz = pk >> 20, tx = tk & 1023, ty = (tk >> 10) & 1023, tz = tk >> 20;
     const int tile = (tz * G.T + ty) * G.T + tx;
     const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
@@ -1177,13 +1227,13 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       if (lane < RW) { S.rowg[RW * wvu + lane] = vfirst; S.lcum[RW * wvu + lane] = (unsigned short)vpre; }
       if (lane == 0) { S.wtot[wvu] = pre; if (orc > 255) S.misc[1] = 1; }
       // P3M_PP_FAT_LIMIT (a test switch) lowers the longest row segment this pass takes
-      if (A.fat_limit < 255 && lane < RW && (int)S.T[(RW * wvu + lane) * PPL_TS + WV - 1] > A.fat_limit) S.misc[1] = 1;
+      if (R->fat_limit < 255 && lane < RW && (int)S.T[(RW * wvu + lane) * PPL_TS + WV - 1] > R->fat_limit) S.misc[1] = 1;
     }
     __syncthreads();
     const int4 wt = *reinterpret_cast<const int4 *>(S.wtot);
     const int Ptot = wt.x + wt.y + wt.z + wt.w;
     if (S.misc[1] != 0 || Ptot > PPL_PCAP) {          // uniform: a crowded region or a long row segment: k_pp_ext3's general pass 0
-      if (tid == 0) { const int s = atomicAdd(A.slowcount, 1); if (s < A.ntask_cap) A.slow[s] = cur; }
+      if (tid == 0) { const int s = atomicAdd(R->slowcount, 1); if (s < A.ngroups) R->slow[s] = cur.x; }
       continue;
     }
     {
@@ -1201,7 +1251,11 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const int r = RW * wvu + it * 8 + rl;
         const bool rok = it * 8 + 8 <= RW || it * 8 + rl < RW;
         cn[it] = rok ? (int)S.T[r * PPL_TS + WV - 1] : 0; g0[it] = S.rowg[r]; c0[it] = (int)S.lcum[r] + wbase;
+#ifndef PPL_STAGE_GLOBAL   // (the scalar-base global load: 1.58 ms per tile against 1.49 with the descriptor, whose four scalars the allocator spills and reloads)
         if (k < cn[it]) q[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sp_rsrc, (g0[it] + k) * 16, 0, 0));
+#else
+        if (k < cn[it]) q[it] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(A.spos) + (size_t)((unsigned)(g0[it] + k) * 16u));   // scalar base + 32-bit lane offset
+#endif
         more = more || cn[it] > 8;
       }
 #pragma unroll
@@ -1229,6 +1283,15 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #if defined(PPL_ABL) && PPL_ABL >= 2   // timing-only ablation builds (tools/variant.sh): 1 no evaluation, 2 nor lists, 3 nor the records' staging
     continue;
 #endif
+    // sub-tasks of PP3_NT home records (total <= 704: pp3_task_homes = PP3_NT, the numbering k_pp_ext3<.., 1> expects); a second one in two
+    // patches of a hundred at the background's density.  Nothing below shares LDS between lanes but the heavy-lane record
+#pragma unroll 1
+    for (int sub = 0; sub * PP3_NT < total; sub++) {
+    if (sub > 0) {
+      __syncthreads();
+      if (tid == 0) { flush_heavy(cur.x, sub - 1); prev.y = sub; }
+      __syncthreads();
+    }
     const int hraw = sub * PP3_NT + tid;
     const bool valid = hraw < total;
     const int h = min(hraw, total - 1);               // a lane without a home record repeats the last one's lists (and kicks nothing)
@@ -1308,31 +1371,22 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     };
 #ifndef PPL_NOBUILD
     if (!rim_task) {
-      // two planes of windows at a time: their 30 table reads are requested together, then appended (left to itself the compiler keeps
-      // two windows in flight: thirteen LDS round trips in a row where three do)
-      auto planes = [&](auto DZ0, auto NP) {
-        constexpr int dz0 = decltype(DZ0)::value, np = decltype(NP)::value;
-        int wa[np * 5], wb[np * 5]; unsigned c16[np * 5];
-        int o0 = 0, o1 = 0;
+      // (the table reads of two planes requested together before the appends -- 30 loads in flight instead of the compiler's four -- were
+      // measured: no faster, 77 more live registers and spills)
 #pragma unroll
-        for (int q = 0; q < np * 5; q++) {
-          const int ro = (dz0 + q / 5 + ppr) * PPL_NRY + q % 5;
-          wa[q] = tb[ro * PPL_TS]; wb[q] = tb[ro * PPL_TS + 2 * ppr + 1]; c16[q] = ((lds_vu16 *)cb)[ro];   // (volatile: five neighbours would be merged into misaligned wide reads)
-          if (dz0 + q / 5 == 0 && q % 5 == ppr) { o0 = tb[ro * PPL_TS + ppr]; o1 = tb[ro * PPL_TS + ppr + 1]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int dz = -ppr; dz <= ppr; dz++) {
 #pragma unroll
-        for (int q = 0; q < np * 5; q++) {
-          if (dz0 + q / 5 == 0 && q % 5 == ppr) {      // the own cell splits the own row's window (:515-516)
-            append(c16[q] + ((unsigned)wa[q] << 4), o0 - wa[q]);
-            append(c16[q] + ((unsigned)o1 << 4), wb[q] - o1);
-          } else append(c16[q] + ((unsigned)wa[q] << 4), wb[q] - wa[q]);
+        for (int dy = -ppr; dy <= ppr; dy++) {
+          const int ro = (dz + ppr) * PPL_NRY + dy + ppr;
+          const int wa = tb[ro * PPL_TS], wb = tb[ro * PPL_TS + 2 * ppr + 1];
+          const unsigned c16 = ((lds_vu16 *)cb)[ro];   // (volatile: five neighbours would be merged into misaligned wide reads)
+          if (dz == 0 && dy == 0) {                    // the own cell splits the own row's window (:515-516)
+            const int o0 = tb[ro * PPL_TS + ppr], o1 = tb[ro * PPL_TS + ppr + 1];
+            append(c16 + ((unsigned)wa << 4), o0 - wa);
+            append(c16 + ((unsigned)o1 << 4), wb - o1);
+          } else append(c16 + ((unsigned)wa << 4), wb - wa);
         }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      planes(std::integral_constant<int, -2>{}, std::integral_constant<int, 2>{});
-      planes(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-      planes(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+      }
     }
     {
       // a list that is USED and has a window of more than six records (or any list of a rim task): the general loop for those lanes
@@ -1375,6 +1429,36 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       pp_ext_eval2s<TAPER_ALL>(p, o2, o3, okm, F, ax2, ay2, az2);
     }
     float ax = ax2.x + ax2.y, ay = ay2.x + ay2.y, az = az2.x + az2.y;
+    // ---- -DPPINT on the way: the pairs inside the own cell (physical records of cells that are the reference's buckets: k_pp_intra)
+    float aix = 0.f, aiy = 0.f, aiz = 0.f;
+    bool idone = false;
+    if (FUSE) {
+      if (phys && !heavy) {                           // (a tile's physical cells lie inside the rank's volume: k_pp_intra's own test)
+        const float fms = (float)A.ms, ims = 1.0f / fms;
+        const bool pow2 = (A.ms & (A.ms - 1)) == 0;   // (x / mesh_scale is x * (1 / mesh_scale) bit for bit when mesh_scale is a power of two: k_pp_intra)
+        const int c0 = (int)floorf(pow2 ? p.x * ims : p.x / fms), c1 = (int)floorf(pow2 ? p.y * ims : p.y / fms), c2 = (int)floorf(pow2 ? p.z * ims : p.z / fms);
+        const int Ec = E / A.ms, cbf = G.nb / A.ms;
+        idone = A.cflag[((c2 + cbf) * Ec + (c1 + cbf)) * Ec + (c0 + cbf)] == 0;
+      }
+      const int ro = ppr * PPL_NRY + ppr;
+      const int ob0 = tb[ro * PPL_TS + ppr], ob1 = tb[ro * PPL_TS + ppr + 1];
+      const unsigned own16 = (unsigned)((lds_vu16 *)cb)[ro] + ((unsigned)ob0 << 4);
+      const int nown = idone ? ob1 - ob0 : 0;         // (the home record itself among them: r = 0, below the soft cut)
+      for (int k = 0; __any(k < nown); k++) {
+        const float4 o = *reinterpret_cast<const float4 *>(pbytes + (k < nown ? own16 + 16 * k : self16));
+        const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;                 // :336
+        const float r2 = sx * sx + sy * sy + sz * sz;
+        const float ir = __builtin_amdgcn_rsqf(r2);
+        float f = F.K * ((ir * ir) * ir);                                           // mass_p / (r pp_bias)^3 (:344)
+        f = (k < nown && r2 >= F.r2_soft) ? f : 0.0f;                               // :340
+        aix = __builtin_fmaf(-sx, f, aix); aiy = __builtin_fmaf(-sy, f, aiy); aiz = __builtin_fmaf(-sz, f, aiz);   // :346-347
+      }
+      if (idone) {
+        // the record's sorted index (k_pp_intra's): its row segment's first record + the records of the row before its cell + its rank
+        const int sidx = S.rowg[rh] + (int)S.T[rh * PPL_TS + ppr] + (h - S.roff[j]);
+        A.intra_done[sidx] = 1;
+      }
+    }
     if (__any(walker)) {                              // one or two lanes of the wavefront with 33 ... 64 partners: they walk their windows
       if (walker) {
         const unsigned own0 = (unsigned)cb[2 * PPL_NRY + 2 + 0] + ((unsigned)tb[(2 * PPL_NRY + 2) * PPL_TS + ppr] << 4);
@@ -1388,7 +1472,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             for (; a < b; a += 16) {
               if (dz == 0 && dy == 0 && a >= own0 && a < own1) continue;          // own cell is excluded (:515-516)
               const float4 o = *reinterpret_cast<const float4 *>(pbytes + a);
-              pp_ext_eval(p, o.x, o.y, o.z, F, ax, ay, az);
+              pp_ext_eval_l(p, o.x, o.y, o.z, F, ax, ay, az);
             }
           }
       }
@@ -1397,6 +1481,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (valid && !heavy) {
       if (phys) {                                                                   // :576-582
         float4 v = vrec;
+        if (idone) { v.x = v.x + aix * A.a_mid * P3M_G_F * A.dt; v.y = v.y + aiy * A.a_mid * P3M_G_F * A.dt; v.z = v.z + aiz * A.a_mid * P3M_G_F * A.dt; }   // :349-350, before the extended kick as there
         v.x = v.x + ax * A.a_mid * P3M_G_F * A.dt; v.y = v.y + ay * A.a_mid * P3M_G_F * A.dt; v.z = v.z + az * A.a_mid * P3M_G_F * A.dt;
 #ifdef PPL_NOVEL   // ablation: no velocity read-modify-write
         if (v.x == 1.2345f)
@@ -1407,7 +1492,41 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
-    if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(A.tile_max + tile, mag);
+    if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(R->tile_max + tile, mag);
+    if (FUSE) {                                       // pp_force_max (:356): one record in nine has a bucket mate at the background's density
+      float magi = sqrtf(aix * aix + aiy * aiy + aiz * aiz);
+      if (__any(magi > 0.f)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) magi = fmaxf(magi, __shfl_xor(magi, o, 64));
+        if (lane == 0) p3m_atomic_max_nonneg(R->fmax_intra + p3m_slot() * 16, magi);
+      }
+    }
+    }
+  }
+}
+
+// the patches k_pp_light left to the general pass: their tasks (k_pp_plan3 + k_pp_fill2 for a list of patches; one wavefront per patch, one
+// lane per home row)
+__global__ __launch_bounds__(256) void k_pp_plan_slow(const int *__restrict__ cs, PPGeo G, int npz, int npy, int npx, int xbw, const int *__restrict__ slow, const int *__restrict__ slowcount,
+                                                      int ngroups, int4 *__restrict__ task4, int *__restrict__ ntask, int cap) {
+  const int nslow = min(*slowcount, ngroups), j = threadIdx.x & 63;
+  const int e = G.pt + 2 * G.ppr;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nslow; i += gridDim.x * 4) {
+    const int g = slow[i];
+    const int xb = g % npx, gy = (g / npx) % npy, gz = (g / (npx * npy)) % npz, tile = g / (npx * npy * npz);
+    const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
+    const int lox = tx * G.pt + G.nb - G.ppr, loy = ty * G.pt + G.nb - G.ppr, loz = tz * G.pt + G.nb - G.ppr;
+    const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);
+    int count = 0;
+    const int rz = gz * PP3_HZ + j / PP3_HY, ry = gy * PP3_HY + j % PP3_HY;
+    if (rz < e && ry < e) { const int64_t rb = ((int64_t)(loz + rz) * G.E + (loy + ry)) * G.E; count = cs[rb + hx1] - cs[rb + hx0]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
+    const int nt = pp3_task_homes(count), n = (count + nt - 1) / nt;
+    int base = 0;
+    if (j == 0 && n > 0) base = atomicAdd(ntask, n);
+    base = __shfl(base, 0, 64);
+    for (int k = j; k < n; k += 64) if (base + k < cap) task4[base + k] = make_int4(g, k, 0, 0);
   }
 }
 
@@ -1419,8 +1538,9 @@ static float first_r2_with_root_above(float t) {
   return r2;
 }
 
-int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
+int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra) {
   P3M_TRY(particles_full_cells(c));
+  c->pp_intra_fused = false;
   const Geometry &g = c->g;
   if (g.pp_range == 0) return P3M_OK;
   PPGeo G{g.T, g.nb, g.pt, g.E, g.Nn, g.ms, g.pp_range, c->p.rsoft, c->p.pp_bias, (float)g.ncut};
@@ -1455,19 +1575,21 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   // each buffer under its own check: a failed allocation must not leave the others looking ready
   if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
   if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int4) * (size_t)ntask_cap64));   // the task records (k_pp_fill2)
-  if (!c->pp_slow) HIP_TRY(hipMalloc(&c->pp_slow, sizeof(int4) * (size_t)ntask_cap64));               // the tasks the lean light pass leaves to the general one
+  if (!c->pp_slow) HIP_TRY(hipMalloc(&c->pp_slow, sizeof(int) * ((size_t)ngroups_max + 8)));         // the patches the lean light pass leaves to the general one
   if (!c->pp_htask) HIP_TRY(hipMalloc(&c->pp_htask, sizeof(int) * PP3_HREC * (size_t)ntask_cap64));    // the heavy-task list (a task enters it once at most)
   // task counters of the three launches (PP3_NSEG each, on cache lines of their own), the length of the heavy-task list and of the slow-task list
-  constexpr int NCNT = 3 * 32 * PP3_NSEG + 64;
+  constexpr int NCNT = 3 * 32 * PP3_NSEG + 96;
   if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * NCNT));
   P3M_TRY(scan_reserve(c, ngroups_max + 8));
   HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * NCNT, c->stream));
-  int *hcount = c->pp_counter + 3 * 32 * PP3_NSEG, *slowcount = hcount + 32;
-  hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
-  HIP_TRY(hipGetLastError());
-  P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
-  hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int4 *>(c->pp_task_group), ntask_cap, npz, npy, npx, g.T);
-  HIP_TRY(hipGetLastError());
+  int *hcount = c->pp_counter + 3 * 32 * PP3_NSEG, *slowcount = hcount + 32, *slow_ntask = hcount + 64;
+  if (!light) {                                        // the plan of every patch: tasks of PP3_NT (PP3_NTD in a blob) home records
+    hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
+    HIP_TRY(hipGetLastError());
+    P3M_TRY(exclusive_scan_i32(c, c->pp_plan, ngroups));
+    hipLaunchKernelGGL(k_pp_fill2, dim3(cdiv(ngroups, 256)), dim3(256), 0, c->stream, (const int *)c->pp_plan, ngroups, reinterpret_cast<int4 *>(c->pp_task_group), ntask_cap, npz, npy, npx, g.T);
+    HIP_TRY(hipGetLastError());
+  }
   const PPForce F = pp_force_constants(mass_p, G.pp_bias, G.ncut, first_r2_with_root_above(G.rsoft), first_r2_with_root_above(G.ncut + sqrtf(3.0f)));
   const int Wp = (xbw + 2 * g.pp_range + 2) & ~1, NRmax = (PP3_HZ + 2 * g.pp_range) * (PP3_HY + 2 * g.pp_range);
   const size_t lds = sizeof(float4) * PP3_PCAP + sizeof(unsigned short) * (size_t)NRmax * Wp + (size_t)(PP3_NT / 64) * 64 * PP3_LSTR +
@@ -1481,11 +1603,28 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   const bool taper_all = far2 < F.r2_taper;
   const int *plan_total = c->pp_plan + ngroups;        // the scan's total: the number of tasks
   if (light) {
-    PPLArgs A{(const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt, c->d_tile_ext, (const int4 *)c->pp_task_group, plan_total, ntask_cap,
-              c->pp_counter + 2 * 32 * PP3_NSEG, xbw, fat_limit, c->pp_htask, hcount, reinterpret_cast<int4 *>(c->pp_slow), slowcount};
+    const PPLRare rare{c->pp_counter + 2 * 32 * PP3_NSEG, c->pp_htask, hcount, c->pp_slow, slowcount, c->d_tile_ext, c->d_red + 1 * P3M_RED_SPAN, ntask_cap, fat_limit,
+                       npx, npx * npy, npx * npy * npz, fdiv_magic(npx), fdiv_magic(npx * npy), fdiv_magic(g.T), fdiv_magic(g.T * g.T)};
+    PPLArgs A{(const float4 *)c->spos, c->vel, (const int *)c->cell_end, rare, nullptr, (const unsigned char *)c->cflag,
+              g.T, g.nb, g.pt, g.E, g.ms, xbw, ngroups, F.c1, F.K, F.K34, F.K74, F.r2_soft, F.r2_taper, a_mid, dt};
+    // -DPPINT in the same pass (NGP builds): built, at parity, and NOT the default -- P3M_PP_INTRA_FUSED=1 turns it on.  Measured on the
+    // headline's geometry with PPINT + PP_EXT: 46.4 ms per step fused against 45.9 with k_pp_intra's own pass over every record.  The
+    // light pass pays 0.13 ms per tile for it (a coarse-cell flag gather, a byte store and three more sums per lane in a kernel that is
+    // out of registers already) and k_pp_intra, which still has to find the records NOT done, only falls from 0.26 to 0.15 ms: a row of
+    // 70 records holds six ghosts that no patch ever visits, so no wavefront of it can leave early
+    static const bool fused = getenv("P3M_PP_INTRA_FUSED") && getenv("P3M_PP_INTRA_FUSED")[0] == '1';
+    if (fuse_intra && fused) {
+      if (!c->pp_intra_done) HIP_TRY(hipMalloc(&c->pp_intra_done, (size_t)c->cap + 16));
+      HIP_TRY(hipMemsetAsync(c->pp_intra_done, 0, (size_t)c->np_all, c->stream));
+      A.intra_done = c->pp_intra_done;
+      c->pp_intra_fused = true;
+    }
     const int wpl = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / sizeof(PPLShared)));
-    if (taper_all) hipLaunchKernelGGL(k_pp_light<true>, dim3(256 * wpl), dim3(PP3_NT), 0, c->stream, A);
-    else hipLaunchKernelGGL(k_pp_light<false>, dim3(256 * wpl), dim3(PP3_NT), 0, c->stream, A);
+    auto kl = A.intra_done ? (taper_all ? k_pp_light<true, true> : k_pp_light<false, true>) : (taper_all ? k_pp_light<true, false> : k_pp_light<false, false>);
+    hipLaunchKernelGGL(kl, dim3(256 * wpl), dim3(PP3_NT), 0, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_pp_plan_slow, dim3(128), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npz, npy, npx, xbw, (const int *)c->pp_slow, (const int *)slowcount, ngroups,
+                       reinterpret_cast<int4 *>(c->pp_task_group), slow_ntask, ntask_cap);
     HIP_TRY(hipGetLastError());
   }
   const int wpc = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));   // resident workgroups per CU by LDS
@@ -1495,7 +1634,7 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p) {
     if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // pass 0: the whole plan, or (behind the lean light pass) the tasks it left
     hipLaunchKernelGGL(kern, dim3(256 * (pass == 0 ? wpc : std::min(wpc, PP3_WPE - 1))), dim3(PP3_NT), lds, c->stream, (const float4 *)c->spos, c->vel, (const int *)c->cell_end, G, F, a_mid, dt,
-                       c->d_tile_ext, light ? (const int4 *)c->pp_slow : (const int4 *)c->pp_task_group, light ? (const int *)slowcount : plan_total, npy, npx, xbw, ntask_cap,
+                       c->d_tile_ext, (const int4 *)c->pp_task_group, light ? (const int *)slow_ntask : plan_total, npy, npx, xbw, ntask_cap,
                        c->pp_counter + pass * 32 * PP3_NSEG, Wp, NRmax, fat_limit, c->pp_htask, hcount);
     HIP_TRY(hipGetLastError());
   }
@@ -1572,11 +1711,11 @@ extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, 
     }
     HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
-    P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); P3M_TRY(pp_extended(c, a_mid, dt, mass_p));   // warm-up
+    P3M_TRY(pp_intra(c, a_mid, dt, mass_p)); P3M_TRY(pp_extended(c, a_mid, dt, mass_p, false));   // warm-up
     HIP_TRY(hipEventRecord(e0, c->stream));
     for (int i = 0; i < reps; i++) P3M_TRY(pp_intra(c, a_mid, dt, mass_p));
     HIP_TRY(hipEventRecord(e1, c->stream));
-    for (int i = 0; i < reps; i++) P3M_TRY(pp_extended(c, a_mid, dt, mass_p));
+    for (int i = 0; i < reps; i++) P3M_TRY(pp_extended(c, a_mid, dt, mass_p, false));
     HIP_TRY(hipEventRecord(e2, c->stream));
     HIP_TRY(hipEventSynchronize(e2));
     HIP_TRY(hipEventElapsedTime(&a, e0, e1)); HIP_TRY(hipEventElapsedTime(&b, e1, e2));
@@ -1585,6 +1724,20 @@ extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, 
       HIP_TRY(hipMemcpy(h, c->pp_counter + 3 * 32 * PP3_NSEG, sizeof(int), hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(h + 1, c->pp_counter + 3 * 32 * PP3_NSEG + 32, sizeof(int), hipMemcpyDeviceToHost));
       fprintf(stderr, "[pp stats] heavy tasks %d, tasks left to the general pass %d\n", h[0], h[1]);
+      if (h[0] > 0 && c->pp_htask) {   // heavy lanes per heavy task
+        std::vector<int> rec((size_t)h[0] * PP3_HREC);
+        HIP_TRY(hipMemcpy(rec.data(), c->pp_htask, rec.size() * sizeof(int), hipMemcpyDeviceToHost));
+        long hist[10] = {0}, lanes = 0; const int edge[10] = {1, 2, 4, 8, 16, 32, 64, 128, 192, 257};
+        for (int t = 0; t < h[0]; t++) {
+          int n = 0;
+          for (int k = 0; k < 8; k++) n += __builtin_popcount((unsigned)rec[(size_t)t * PP3_HREC + 5 + k]);
+          lanes += n;
+          for (int b = 0; b < 10; b++) if (n <= edge[b]) { hist[b]++; break; }
+        }
+        fprintf(stderr, "[pp stats] heavy lanes %ld; tasks by heavy lanes (<=1 2 4 8 16 32 64 128 192 256):", lanes);
+        for (int b = 0; b < 10; b++) fprintf(stderr, " %ld", hist[b]);
+        fprintf(stderr, "\n");
+      }
     }
     return P3M_OK;
   };

@@ -696,6 +696,7 @@ FALLBACKS = {
     "P3M_Z_UNFUSED": "test_tile_force_vs_oracle or (register_fft_sizes and 176) or (config1_kick_parity and pm_ngp_uniform)",
     "P3M_PP_EXT_REF": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",   # k_pp_ext: the reference's own sqrt / division arithmetic
     "P3M_PP_LIGHT_OFF": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or rim_planes or (other_tilings and not kw2)",   # every task through k_pp_ext3's general pass 0 (which otherwise works only what the lean light pass k_pp_light leaves)
+    "P3M_PP_INTRA_FUSED": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or half_an_ulp or (other_tilings and not kw2)",   # the bucket pairs (-DPPINT) summed inside the extended PP's light pass, k_pp_intra for the records it leaves (built and measured: not the default)
     "P3M_PP_FAT_LIMIT": "(config1_kick_parity and p3m_ext) or dense_blob",   # = 1: every task with a row of two records takes the global-memory path
     "P3M_CAND_SEG": "half_an_ulp or fine_deposit_vs or heavy_blob or (config1_kick_parity and pm_ngp_uniform)",   # = 1: every candidate list overflows
     "P3M_KICK_UNFUSED": "(config1_kick_parity and (pm_ngp or p3m_ext)) or two_steps_with_drift or half_an_ulp or (other_tilings and kw0)",   # the force box + k_fine_kick_rows pair instead of the fused inverse-x + kick pass
