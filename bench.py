@@ -542,6 +542,9 @@ def main():
             kname = {"x_fwd": "k_fft_x_fwd*", "y_fwd": "k_fft_lines*", "z_inv_fused": "k_fft_lines3*", "y_inv": "k_fft_lines*", "x_inv_extract": "k_fft_x_inv*"}[dom]
         roofline = {"bound": "hbm", "kernel": "%s (%s pass, %d tile(s)/launch, nf_tile=%d)" % (kname, dom, nb, p.nf_tile), "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    # the byte counts are NOT measured in this run: they are replayed from the PMC passes recorded under profiles/ (guarded by a
+                    # hash of the FFT sources: stale records give null)
+                    "traffic_source": ("replayed profiles/pmc_traffic.json@" + str(recj.get("fft_source_sha16"))) if traffic else None,
                     "ms_per_launch": passes[dom], "pass_ms": passes,
                     # the same launch against the bytes it really moved (PMC): what the memory system sees
                     "traffic_GBs": (traffic / (passes[dom] * 1e-3) / 1e9) if traffic else None,
@@ -549,10 +552,16 @@ def main():
                     # The step's own sweep: the NGP deposit rides on the sort (no deposit kernel) and the last launch is the fused inverse-x +
                     # kick pass, which carries the kick of particle_mesh_threaded.f90:208-270 on top of the transform: four FFT launches + that
                     # one against the same 10.5 S.  "fine_sweep" below is the stand-alone sweep (k_ngp_counts + five launches + a force box).
+                    # Timed AS THE STEP RUNS IT: the spans of one more whole step's own phase timers -- fine_fft (the four FFT
+                    # launches of every rank) + fine_kick (the fused pass with its velocity stores, the survivor count and k_kick_fix), with the
+                    # coarse transform on the second stream underneath -- divided by the ranks on this GPU.  "standalone_dry_ms" is the sum of the
+                    # stand-alone pass timings, whose last launch runs WITHOUT the velocity stores and the fix-up: a lower bound, not the step's figure.
                     "fine_sweep_in_step": None if fused_ms is None else {
-                        "ms": passes["x_fwd"] + passes["y_fwd"] + passes["z_inv_fused"] + passes["y_inv"] + fused_ms,
+                        "ms": (phase_ms["fine_fft"] + phase_ms["fine_kick"]) / len(grp.local_ranks),
+                        "source": "phase_ms of a whole step (GPU event spans), per rank",
                         "algorithmic_bytes": 10.5 * S * ntile,
-                        "frac": 10.5 * S * ntile / ((passes["x_fwd"] + passes["y_fwd"] + passes["z_inv_fused"] + passes["y_inv"] + fused_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac": 10.5 * S * ntile / ((phase_ms["fine_fft"] + phase_ms["fine_kick"]) / len(grp.local_ranks) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "standalone_dry_ms": passes["x_fwd"] + passes["y_fwd"] + passes["z_inv_fused"] + passes["y_inv"] + fused_ms,
                         "traffic": in_step_traffic,
                         "what": "x_fwd, y_fwd, fused z, y_inv, inverse x with the NGP kick, the coarse kick and the survivor count inside (one rank's tiles)"},
                     "fine_sweep": {"ms": sweep_ms, "algorithmic_bytes": 10.5 * S * ntile,
@@ -623,9 +632,16 @@ def main():
                                                       "what": "CIC deposit (fine_cic_mass.f90:13-43) + forward x, y, fused z, inverse y, inverse x of one rank's tiles"},
                                        "cic_gather": {"ms": ga, "algorithmic_bytes": gbytes, "achieved_GBs": gbytes / (ga * 1e-3) / 1e9,
                                                       "frac": gbytes / (ga * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                      "what": "max |F|^2 + CIC interpolation + kick (particle_mesh_threaded.f90:208-223,289-316), one pass over the force box"},
+                                                      # in the step the same pass also carries the coarse kick (coarse_velocity.f90:137-179) and the coarse
+                                                      # transform runs underneath: the step's own span of it, per rank
+                                                      "in_step_ms": leg["phase_ms"]["fine_kick"] / len(g2.local_ranks),
+                                                      "what": "max |F|^2 + CIC interpolation + kick (particle_mesh_threaded.f90:208-223,289-316), one pass over the force box; stand-alone, WITHOUT the coarse kick that rides on it in the step (in_step_ms)"},
                                        "sweep_and_gather": {"ms": sw + ga, "algorithmic_bytes": 10.5 * S2 * nt2 + gbytes,
-                                                            "frac": (10.5 * S2 * nt2 + gbytes) / ((sw + ga) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                                                            "frac": (10.5 * S2 * nt2 + gbytes) / ((sw + ga) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                       # the same bytes against the step's own spans (fine_mass + fine_fft + fine_kick, per rank)
+                                       "sweep_and_gather_in_step": {
+                                           "ms": (leg["phase_ms"]["fine_mass"] + leg["phase_ms"]["fine_fft"] + leg["phase_ms"]["fine_kick"]) / len(g2.local_ranks),
+                                           "frac": (10.5 * S2 * nt2 + gbytes) / ((leg["phase_ms"]["fine_mass"] + leg["phase_ms"]["fine_fft"] + leg["phase_ms"]["fine_kick"]) / len(g2.local_ranks) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
                 g2.close()
                 if p2.ppint:
                     leg.update(dt_pp_acc=o2.dt_pp_acc, dt_pp_ext_acc=o2.dt_pp_ext_acc)

@@ -332,7 +332,11 @@ __global__ __launch_bounds__((KCfg<R1, R2>::LT)) void k_fft_x_inv2_kick(KickFuse
       }
     }
     if (go) {
+#ifdef KF_VEL_BY_S   // timing-only experiment: the velocity at the SORTED index (what a sorted velocity array would cost)
+      const int vi = s;
+#else
       const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
+#endif
       if (!have_v) v = a.vel[vi];
       if (COARSE && !have_c) { cc = kf_coarse_cell(p, a); kf_coarse_gather(cf, cc.o0, a); }
       kf_kick<COARSE>(v, fx, fy, fz, cc, cf, a);
@@ -401,7 +405,11 @@ __global__ __launch_bounds__((KCfg<R1, R2>::LT)) void k_fft_x_inv2_kick(KickFuse
     KF_STAMP(4);
     // ---- C
     vf = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef KF_VEL_BY_S
+    if (ps >= 0) vf = a.vel[ps];
+#else
     if (ps >= 0) vf = a.vel[rec_index(pf)];
+#endif
     if (s2 && rowok) {
       c32 u[R2];
       const c32 *pxr = X + (r * R1 + q) * R2P;

@@ -28,6 +28,27 @@ __device__ __forceinline__ int wave_max_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
   return v;
 }
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside the rows of 16, then the rows' totals by row_bcast:15 / :31
+__device__ __forceinline__ int wave_scan_incl_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// the maximum of a non-negative float over the wavefront, in lane 63 (the same six DPP steps; 0 where a step has no source lane)
+__device__ __forceinline__ float wave_max_nonneg_to_last(float v) {
+  auto step = [&](auto CTRL, auto RM) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(CTRL)::value, decltype(RM)::value, 0xf, false);
+    v = fmaxf(v, __int_as_float(t));
+  };
+  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return v;
+}
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -1211,21 +1232,26 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
           o[u] = __builtin_amdgcn_raw_buffer_load_b32(cs_rsrc, col4, (unsigned)(((zz * E + yy) * E + lox) * 4), 0);   // scalar row offset + lane offset: no vector address arithmetic
         }
       }
-      int pre = 0, orc = 0, vfirst = 0, vpre = 0;
+      int orv = 0;                                    // OR of the offsets a lane has seen: at the last boundary, of the rows' counts
       unsigned char *trow = S.T + RW * wvu * PPL_TS + lane;
 #pragma unroll
       for (int u = 0; u < RW; u++) {
         const int zz = zb + u / PPL_NRY, yy = yb + u % PPL_NRY;
         if (!(zz >= loz && zz < loz + e && yy >= loy && yy < loy + e)) o[u] = 0;      // (uniform, and rare: patches on the region's faces)
-        const int first = __builtin_amdgcn_readfirstlane(o[u]), last = __builtin_amdgcn_readlane(o[u], WV - 1);
-        if (lane < PPL_TS) trow[u * PPL_TS] = (unsigned char)(o[u] - first);
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(vfirst) : "s"(first), "n"(u));      // lane u keeps row u's first record and prefix
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(vpre) : "s"(pre), "n"(u));
-        const int cnt = last - first;
-        pre += cnt; orc |= cnt;                         // (counts are >= 0: their OR exceeds 255 exactly when one of them does)
+        const int d = o[u] - __builtin_amdgcn_readfirstlane(o[u]);
+        if (lane < PPL_TS) trow[u * PPL_TS] = (unsigned char)d;
+        if (lane == 0) S.rowg[RW * wvu + u] = o[u];    // the row segment's first record
+        orv |= d;
       }
-      if (lane < RW) { S.rowg[RW * wvu + lane] = vfirst; S.lcum[RW * wvu + lane] = (unsigned short)vpre; }
-      if (lane == 0) { S.wtot[wvu] = pre; if (orc > 255) S.misc[1] = 1; }
+      if (lane == WV - 1 && orv > 255) S.misc[1] = 1;   // (counts are >= 0: their OR exceeds 255 exactly when one of them does)
+      // the rows' counts back from the table (this wavefront's own stores: in order), one row per lane, and their prefix: three vector
+      // instructions per row above where carrying first / count / prefix through the scalar unit and two v_writelane took five
+      {
+        const int cnt = lane < RW ? (int)S.T[(RW * wvu + lane) * PPL_TS + WV - 1] : 0;
+        const int inc = wave_scan_incl_i(cnt);
+        if (lane < RW) S.lcum[RW * wvu + lane] = (unsigned short)(inc - cnt);
+        if (lane == RW - 1) S.wtot[wvu] = inc;
+      }
       // P3M_PP_FAT_LIMIT (a test switch) lowers the longest row segment this pass takes
       if (R->fat_limit < 255 && lane < RW && (int)S.T[(RW * wvu + lane) * PPL_TS + WV - 1] > R->fat_limit) S.misc[1] = 1;
     }
@@ -1270,9 +1296,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       if (wv == 0) {
         const int rj = ((lane >> 3) + ppr) * PPL_NRY + (lane & 7) + ppr;
         const int hc = (int)S.T[rj * PPL_TS + ppr + (hx1 - hx0)] - (int)S.T[rj * PPL_TS + ppr];
-        int inc = hc;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        const int inc = wave_scan_incl_i(hc);
         S.roff[lane] = inc - hc;
         if (lane == 63) S.roff[NH] = inc;
       }
@@ -1490,9 +1514,8 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       }
       mag = sqrtf(ax * ax + ay * ay + az * az);                                     // :617
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
-    if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(R->tile_max + tile, mag);
+    mag = wave_max_nonneg_to_last(mag);
+    if (lane == 63 && mag > 0.f) p3m_atomic_max_nonneg(R->tile_max + tile, mag);
     if (FUSE) {                                       // pp_force_max (:356): one record in nine has a bucket mate at the background's density
       float magi = sqrtf(aix * aix + aiy * aiy + aiz * aiz);
       if (__any(magi > 0.f)) {
@@ -1563,6 +1586,7 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra
   // switch) sends every task through the general pass 0 of k_pp_ext3, which otherwise only works the tasks the lean pass leaves to it
   static const bool light_off = getenv("P3M_PP_LIGHT_OFF") && getenv("P3M_PP_LIGHT_OFF")[0] == '1';
   const bool light = !light_off && g.pp_range == 2 && (int64_t)c->cap < (1ll << 27) && (int64_t)g.E * g.E * g.E < (1ll << 29);   // (32-bit byte offsets into both arrays)
+  if (getenv("P3M_PP_XBW")) xbw = atoi(getenv("P3M_PP_XBW"));   // (experiments)
   xbw = std::max(4, std::min(std::min(xbw, e), light ? PPL_XBW_MAX : 64 - 2 * g.pp_range - 1));      // one load instruction per partner row
   const int npx = (e + xbw - 1) / xbw, npy = (e + PP3_HY - 1) / PP3_HY, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int64_t ngroups64 = (int64_t)g.ntiles * npz * npy * npx;
