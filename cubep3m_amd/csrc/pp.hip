@@ -580,11 +580,12 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
     }
     if (state < 0) break;                             // every segment has run dry
     if (state == 0) continue;                         // a dry segment: the next draw is on its way
-    const int g = misc[6], sub = misc[7];
+    const int g = misc[6], sub = misc[7] & 0xffffff, half = misc[7] >> 24;   // half (pass 1 only): a task of k_pp_light's second launch -- the lower (1) / upper (2) half of the patch along x
     const int xb = g % npx, gy = (g / npx) % npy, gz = (g / (npx * npy)) % npz, tile = g / (npx * npy * npz);
     const int tz = tile / (G.T * G.T), ty = (tile / G.T) % G.T, tx = tile % G.T;
     const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
-    const int hx0 = lox + xb * xbw, hx1 = min(hx0 + xbw, lox + e);           // home cells [hx0, hx1)
+    const int px0 = lox + xb * xbw, px1 = min(px0 + xbw, lox + e), wl = (xbw + 1) >> 1;
+    const int hx0 = half == 2 ? min(px0 + wl, px1) : px0, hx1 = half == 1 ? min(px0 + wl, px1) : px1;   // home cells [hx0, hx1)
     const int hz0 = loz + gz * PP3_HZ, hy0 = loy + gy * PP3_HY;
     // the partner region: rows [Z0, Z1] x [Y0, Y1], cells [X0, X1]
     // (pass 1: only what the task's heavy lanes reach -- the box pass 0 recorded: a blob's neighbourhood is a third of the patch's)
@@ -1080,6 +1081,7 @@ struct PPLShared {
   int rowg[PPL_NR + 8];                           // sorted index of the row segment's first record
   unsigned short lists[PP3_NT * PPL_LENT];
   alignas(16) int wtot[4];                        // staged records per wavefront
+  int hsum[8];                                    // a crowded patch: the wavefronts' shares of its two halves' staged records
   int roff[PP3_HZ * PP3_HY + 1];                  // exclusive prefix of the home rows' counts
   int misc[48];                                   // [0] task state, [1] slow flag, [4] the task has heavy lanes, [5..8] the task record, [8+8..] see below
 };
@@ -1090,6 +1092,10 @@ struct PPLRare {
   float *tile_max, *fmax_intra;
   int ntask_cap, fat_limit;
   int npx, npxy, per_tile; unsigned m_npx, m_npxy, m_T, m_T2;      // patches per row of patches, per plane, per tile; reciprocals (mulhi) of those and of T, T^2
+  // a crowded patch (more staged records than the LDS holds) whose two HALVES along x both fit is entered here twice, patch * 2 + half, and
+  // worked by a second launch of the same kernel over this list (list != null: the tasks are its entries, half patches); only what is
+  // crowded even then, or holds a row segment of more than 255 records, is left to the general pass
+  int *retry, *retrycount; const int *list, *listcount;
 };
 struct PPLArgs {
   const float4 *spos; float4 *vel; const int *cs; PPLRare rare;
@@ -1125,7 +1131,7 @@ __device__ __forceinline__ void pp_ext_eval2s(const float4 &p, const float4 &A, 
   f.x = (ok && r2.x >= F.r2_soft) ? f.x : 0.0f; f.y = (ok && r2.y >= F.r2_soft) ? f.y : 0.0f;   // :558 (by selection: r = 0 is met here)
   ax = __builtin_elementwise_fma(-sx, f, ax); ay = __builtin_elementwise_fma(-sy, f, ay); az = __builtin_elementwise_fma(-sz, f, az);   // :571
 }
-template <bool TAPER_ALL, bool FUSE>   // FUSE: -DPPINT's bucket pairs on the way (PPLArgs::intra_done)
+template <bool TAPER_ALL, bool FUSE, bool LISTED>   // FUSE: -DPPINT's bucket pairs on the way (PPLArgs::intra_done); LISTED: the second launch (PPLRare::list)
 __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pp_light(const PPLArgs A) {
   __shared__ PPLShared S;
   static_assert(PP3_NT == 256 && PP3_HZ == 8 && PP3_HY == 8, "three planes of twelve rows per wavefront");
@@ -1137,16 +1143,19 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int e = G.pt + 2 * ppr, E = G.E;
   // a task is a PATCH (no plan: k_pp_plan3's pass over the cell table, the scan and k_pp_fill2 cost 0.13 ms per tile; a patch of more than
   // PP3_NT home records -- two per cent of them at the background's density -- is left to the general pass like a crowded one)
-  const int ntask = A.ngroups;
+  constexpr bool listed = LISTED;                     // the second launch: half patches from the first one's retry list
+  const int ntask = listed ? min(*R->listcount, 2 * A.ngroups) : A.ngroups;
+  if ((int)blockIdx.x >= ntask) return;
   const int per = (ntask + PP3_NSEG - 1) / PP3_NSEG;
   int seg = blockIdx.x % PP3_NSEG;
   // the patch's and the tile's coordinates, decoded by thread 0 a task ahead (multiplications by reciprocals; one real division)
-  auto decode = [&](int g) {
+  auto decode = [&](int t) {
+    const int gh = listed ? R->list[t] : 2 * t, g = gh >> 1, half = listed ? (gh & 1) + 1 : 0;   // half: 0 the whole patch, 1 / 2 its lower / upper half along x
     const int tile = g / R->per_tile; int rem = g - tile * R->per_tile;
     const int gz = R->npxy == 1 ? rem : (int)__umulhi((unsigned)rem, R->m_npxy); rem -= gz * R->npxy;      // (the reciprocal of 1 does not fit 32 bits)
     const int gy = R->npx == 1 ? rem : (int)__umulhi((unsigned)rem, R->m_npx), xb = rem - gy * R->npx;
     const int tz = (int)__umulhi((unsigned)tile, R->m_T2), t2 = tile - tz * A.T * A.T, ty = (int)__umulhi((unsigned)t2, R->m_T), tx = t2 - ty * A.T;
-    return make_int4(g, 0, (gz << 20) | (gy << 10) | xb, (tz << 20) | (ty << 10) | tx);
+    return make_int4(g, half << 24, (gz << 20) | (gy << 10) | xb, (tz << 20) | (ty << 10) | tx);
   };
   // thread 0: the two-stage pipeline of task draws (see k_pp_ext3)
   int a_tf = 0, a_seg = 0, tried = 0;
@@ -1213,9 +1222,12 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const int xb = pk & 1023, gy = (pk >> 10) & 1023, gz = pk >> 20, tx = tk & 1023, ty = (tk >> 10) & 1023, tz = tk >> 20;
     const int tile = (tz * G.T + ty) * G.T + tx;
     const int lox = tx * G.pt + G.nb - ppr, loy = ty * G.pt + G.nb - ppr, loz = tz * G.pt + G.nb - ppr;
-    const int hx0 = lox + xb * A.xbw, hx1 = min(hx0 + A.xbw, lox + e);           // home cells [hx0, hx1)
+    const int half = LISTED ? __builtin_amdgcn_readfirstlane(S.misc[6]) >> 24 : 0, wl = (A.xbw + 1) >> 1;   // (a half patch: wl cells, or what is left of the patch)
+    const int px0 = lox + xb * A.xbw, px1 = min(px0 + A.xbw, lox + e);
+    const int hx0 = half == 2 ? min(px0 + wl, px1) : px0, hx1 = half == 1 ? min(px0 + wl, px1) : px1;   // home cells [hx0, hx1)
     const int hz0 = loz + gz * PP3_HZ, hy0 = loy + gy * PP3_HY;
-    const int WV = A.xbw + 5;                          // boundaries hx0 - 2 ... hx0 + xbw + 2 (clamped to the region)
+    const int WV = hx1 - hx0 + 5;                      // boundaries hx0 - 2 ... hx1 + 2 (clamped to the region)
+    if (hx1 <= hx0) continue;                          // (the upper half of a patch cut short by the region's face)
     // ---- the offset table: this wavefront's three planes of twelve rows
     {
       // every lane loads its boundary of every row through a uniform row pointer + a 32-bit lane offset (rows outside the region: the
@@ -1247,10 +1259,20 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       // the rows' counts back from the table (this wavefront's own stores: in order), one row per lane, and their prefix: three vector
       // instructions per row above where carrying first / count / prefix through the scalar unit and two v_writelane took five
       {
-        const int cnt = lane < RW ? (int)S.T[(RW * wvu + lane) * PPL_TS + WV - 1] : 0;
+        const unsigned char *const tr = S.T + (RW * wvu + lane) * PPL_TS;
+        const int cnt = lane < RW ? (int)tr[WV - 1] : 0;
         const int inc = wave_scan_incl_i(cnt);
         if (lane < RW) S.lcum[RW * wvu + lane] = (unsigned short)(inc - cnt);
         if (lane == RW - 1) S.wtot[wvu] = inc;
+        if (!LISTED) {
+          // the staged records of the patch's two halves along x (boundaries 0 ... wl + 4 and wl ... WV - 1), should the whole be crowded: summed
+          // here, on every task, because the rare branch that needs them is no place for two scans and a barrier (they cost the common path
+          // fifty spilled scalars)
+          const int wlh = (A.xbw + 1) >> 1;
+          const int cl = lane < RW ? (int)tr[min(wlh + 2 * ppr, WV - 1)] : 0, cr = lane < RW ? cnt - (int)tr[min(wlh, WV - 1)] : 0;
+          const int sl = wave_scan_incl_i(cl), sr = wave_scan_incl_i(cr);
+          if (lane == RW - 1) { S.hsum[wvu] = sl; S.hsum[4 + wvu] = sr; }
+        }
       }
       // P3M_PP_FAT_LIMIT (a test switch) lowers the longest row segment this pass takes
       if (R->fat_limit < 255 && lane < RW && (int)S.T[(RW * wvu + lane) * PPL_TS + WV - 1] > R->fat_limit) S.misc[1] = 1;
@@ -1258,8 +1280,17 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     __syncthreads();
     const int4 wt = *reinterpret_cast<const int4 *>(S.wtot);
     const int Ptot = wt.x + wt.y + wt.z + wt.w;
-    if (S.misc[1] != 0 || Ptot > PPL_PCAP) {          // uniform: a crowded region or a long row segment: k_pp_ext3's general pass 0
-      if (tid == 0) { const int s = atomicAdd(R->slowcount, 1); if (s < A.ngroups) R->slow[s] = cur.x; }
+    if (S.misc[1] != 0 || Ptot > PPL_PCAP) {          // uniform: a crowded region or a long row segment
+      // the two halves' staged records (hsum; valid with the table: no segment beyond 255)
+      bool halves = false;
+      if (!LISTED && S.misc[1] == 0 && hx1 - hx0 > wl) {
+        const int pl = S.hsum[0] + S.hsum[1] + S.hsum[2] + S.hsum[3], pr = S.hsum[4] + S.hsum[5] + S.hsum[6] + S.hsum[7];
+        halves = pl <= PPL_PCAP && pr <= PPL_PCAP;
+      }
+      if (tid == 0) {
+        if (halves) { const int s = atomicAdd(R->retrycount, 2); R->retry[s] = 2 * cur.x; R->retry[s + 1] = 2 * cur.x + 1; }
+        else { const int s = atomicAdd(R->slowcount, 1); if (s < A.ngroups) R->slow[s] = cur.x; }   // k_pp_ext3's general pass 0 (never a half: see PPLRare)
+      }
       continue;
     }
     {
@@ -1313,7 +1344,7 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     for (int sub = 0; sub * PP3_NT < total; sub++) {
     if (sub > 0) {
       __syncthreads();
-      if (tid == 0) { flush_heavy(cur.x, sub - 1); prev.y = sub; }
+      if (tid == 0) { flush_heavy(cur.x, (cur.y & ~0xffffff) | (sub - 1)); prev.y = (cur.y & ~0xffffff) | sub; }
       __syncthreads();
     }
     const int hraw = sub * PP3_NT + tid;
@@ -1599,14 +1630,14 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra
   // each buffer under its own check: a failed allocation must not leave the others looking ready
   if (!c->pp_plan) HIP_TRY(hipMalloc(&c->pp_plan, sizeof(int) * ((size_t)ngroups_max + 8)));
   if (!c->pp_task_group) HIP_TRY(hipMalloc(&c->pp_task_group, sizeof(int4) * (size_t)ntask_cap64));   // the task records (k_pp_fill2)
-  if (!c->pp_slow) HIP_TRY(hipMalloc(&c->pp_slow, sizeof(int) * ((size_t)ngroups_max + 8)));         // the patches the lean light pass leaves to the general one
+  if (!c->pp_slow) HIP_TRY(hipMalloc(&c->pp_slow, sizeof(int) * (3 * (size_t)ngroups_max + 24)));   // the patches the lean light pass leaves to the general one | its retry list (two halves per patch)
   if (!c->pp_htask) HIP_TRY(hipMalloc(&c->pp_htask, sizeof(int) * PP3_HREC * (size_t)ntask_cap64));    // the heavy-task list (a task enters it once at most)
   // task counters of the three launches (PP3_NSEG each, on cache lines of their own), the length of the heavy-task list and of the slow-task list
-  constexpr int NCNT = 3 * 32 * PP3_NSEG + 96;
+  constexpr int NCNT = 4 * 32 * PP3_NSEG + 128;
   if (!c->pp_counter) HIP_TRY(hipMalloc(&c->pp_counter, sizeof(int) * NCNT));
   P3M_TRY(scan_reserve(c, ngroups_max + 8));
   HIP_TRY(hipMemsetAsync(c->pp_counter, 0, sizeof(int) * NCNT, c->stream));
-  int *hcount = c->pp_counter + 3 * 32 * PP3_NSEG, *slowcount = hcount + 32, *slow_ntask = hcount + 64;
+  int *hcount = c->pp_counter + 4 * 32 * PP3_NSEG, *slowcount = hcount + 32, *slow_ntask = hcount + 64, *retrycount = hcount + 96;
   if (!light) {                                        // the plan of every patch: tasks of PP3_NT (PP3_NTD in a blob) home records
     hipLaunchKernelGGL(k_pp_plan3, dim3(cdiv(ngroups, 4)), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npy, npx, xbw, ngroups, c->pp_plan);
     HIP_TRY(hipGetLastError());
@@ -1627,8 +1658,9 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra
   const bool taper_all = far2 < F.r2_taper;
   const int *plan_total = c->pp_plan + ngroups;        // the scan's total: the number of tasks
   if (light) {
-    const PPLRare rare{c->pp_counter + 2 * 32 * PP3_NSEG, c->pp_htask, hcount, c->pp_slow, slowcount, c->d_tile_ext, c->d_red + 1 * P3M_RED_SPAN, ntask_cap, fat_limit,
-                       npx, npx * npy, npx * npy * npz, fdiv_magic(npx), fdiv_magic(npx * npy), fdiv_magic(g.T), fdiv_magic(g.T * g.T)};
+    int *const retry = c->pp_slow + ngroups_max + 8;
+    PPLRare rare{c->pp_counter + 2 * 32 * PP3_NSEG, c->pp_htask, hcount, c->pp_slow, slowcount, c->d_tile_ext, c->d_red + 1 * P3M_RED_SPAN, ntask_cap, fat_limit,
+                 npx, npx * npy, npx * npy * npz, fdiv_magic(npx), fdiv_magic(npx * npy), fdiv_magic(g.T), fdiv_magic(g.T * g.T), retry, retrycount, nullptr, nullptr};
     PPLArgs A{(const float4 *)c->spos, c->vel, (const int *)c->cell_end, rare, nullptr, (const unsigned char *)c->cflag,
               g.T, g.nb, g.pt, g.E, g.ms, xbw, ngroups, F.c1, F.K, F.K34, F.K74, F.r2_soft, F.r2_taper, a_mid, dt};
     // -DPPINT in the same pass (NGP builds): built, at parity, and NOT the default -- P3M_PP_INTRA_FUSED=1 turns it on.  Measured on the
@@ -1644,8 +1676,13 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra
       c->pp_intra_fused = true;
     }
     const int wpl = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / sizeof(PPLShared)));
-    auto kl = A.intra_done ? (taper_all ? k_pp_light<true, true> : k_pp_light<false, true>) : (taper_all ? k_pp_light<true, false> : k_pp_light<false, false>);
+    auto kl = A.intra_done ? (taper_all ? k_pp_light<true, true, false> : k_pp_light<false, true, false>) : (taper_all ? k_pp_light<true, false, false> : k_pp_light<false, false, false>);
+    auto kl2 = A.intra_done ? (taper_all ? k_pp_light<true, true, true> : k_pp_light<false, true, true>) : (taper_all ? k_pp_light<true, false, true> : k_pp_light<false, false, true>);
     hipLaunchKernelGGL(kl, dim3(256 * wpl), dim3(PP3_NT), 0, c->stream, A);
+    HIP_TRY(hipGetLastError());
+    // the crowded patches whose halves fit, as half patches (none at the background's density: the launch then costs its dispatch)
+    A.rare.counter = c->pp_counter + 3 * 32 * PP3_NSEG; A.rare.list = retry; A.rare.listcount = retrycount;
+    hipLaunchKernelGGL(kl2, dim3(256 * wpl), dim3(PP3_NT), 0, c->stream, A);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_pp_plan_slow, dim3(128), dim3(256), 0, c->stream, (const int *)c->cell_end, G, npz, npy, npx, xbw, (const int *)c->pp_slow, (const int *)slowcount, ngroups,
                        reinterpret_cast<int4 *>(c->pp_task_group), slow_ntask, ntask_cap);
@@ -1744,10 +1781,11 @@ extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, 
     HIP_TRY(hipEventSynchronize(e2));
     HIP_TRY(hipEventElapsedTime(&a, e0, e1)); HIP_TRY(hipEventElapsedTime(&b, e1, e2));
     if (getenv("P3M_PP_STATS") && c->pp_counter && c->pp_plan) {   // diagnostic: tasks of the last launch, those left to the general pass, heavy tasks
-      int h[2] = {0, 0};
-      HIP_TRY(hipMemcpy(h, c->pp_counter + 3 * 32 * PP3_NSEG, sizeof(int), hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(h + 1, c->pp_counter + 3 * 32 * PP3_NSEG + 32, sizeof(int), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[pp stats] heavy tasks %d, tasks left to the general pass %d\n", h[0], h[1]);
+      int h[3] = {0, 0, 0};
+      HIP_TRY(hipMemcpy(h, c->pp_counter + 4 * 32 * PP3_NSEG, sizeof(int), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(h + 1, c->pp_counter + 4 * 32 * PP3_NSEG + 32, sizeof(int), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(h + 2, c->pp_counter + 4 * 32 * PP3_NSEG + 96, sizeof(int), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[pp stats] heavy tasks %d, patches left to the general pass %d, half patches %d\n", h[0], h[1], h[2]);
       if (h[0] > 0 && c->pp_htask) {   // heavy lanes per heavy task
         std::vector<int> rec((size_t)h[0] * PP3_HREC);
         HIP_TRY(hipMemcpy(rec.data(), c->pp_htask, rec.size() * sizeof(int), hipMemcpyDeviceToHost));
