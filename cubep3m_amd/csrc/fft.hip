@@ -236,10 +236,20 @@ __global__ __launch_bounds__(XTB) void k_fft_x_inv(const float2 *__restrict__ sr
 // CUBES: the rows are not an array of their own -- row (rank r, plane zl, y) of the coarse slab decomposition is read where its cells
 // lie, in plane (r % nd^2)*s + zl of the ncn^3 cubes of the ranks layer(r) + (y/ncn)*nd + i, i < nd (pack_slab, fftw3ds.f90:24-52, with
 // every logical rank in this process: p3m_group::direct), so the redistribution costs no pass over memory of its own
-template <int R1, int R2, bool CUBES = false>
+// U8 (round 6, the NGP density of whole steps: RowDep::rho8): a row is 2*px BYTES, the cells' counts; a count becomes the density the
+// reference's deposit leaves -- mass_p added count times (particle_mesh_threaded.f90:148) -- through a table of the first 256 such sums
+// (built once per workgroup; beyond 255 the additions are made in place).  A quarter of the bytes of the float rows, and the rows' writer
+// (k_row_sort) is rid of the partial sums
+template <int R1, int R2, bool CUBES = false, bool U8 = false>
 __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ src, float2 *__restrict__ dst_, int n, int px, int rows_total,
-                                                    const float2 *__restrict__ tw_g, int rpp, RowGeom cq) {   // rpp: rows per plane of the LY output (n; fewer for a y-split pencil)
+                                                    const float2 *__restrict__ tw_g, int rpp, RowGeom cq, float mass_p = 0.f) {   // rpp: rows per plane of the LY output (n; fewer for a y-split pencil)
   using C = X2Cfg<R1, R2>;
+  __shared__ float ctab[U8 ? 256 : 1];
+  if constexpr (U8) {
+    float r = 0.f;
+    for (int i = 0; i < (int)threadIdx.x && i < 255; i++) r = r + mass_p;
+    if (threadIdx.x < 256) ctab[threadIdx.x] = r;
+  }
   constexpr int h = C::h, Q = C::Q, RB = C::RB, R2P = C::R2P, P = C::P;
   extern __shared__ float2 lds[];
   c32 *Y = reinterpret_cast<c32 *>(lds), *X = Y + RB * P, *tw = X + RB * R1 * R2P;
@@ -256,8 +266,20 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ sr
 #pragma unroll
   for (int k1 = 0; k1 < R1; k1++) twq[k1] = reinterpret_cast<const c32 *>(tw_g)[s1 ? 2 * q * k1 : 0];
   c32 v[R1];
+  unsigned short cr[U8 ? R1 : 1];   // U8: the next batch's counts (two cells per element), turned into v at the top of the trip
+  auto count_mass = [&](unsigned cn) { float m = ctab[min(cn, 255u)]; for (unsigned i = 255u; i < cn; i++) m = m + mass_p; return m; };
   auto fetch = [&](int w) {
     const int64_t row = (int64_t)w * RB + r;
+    if constexpr (U8) {
+#pragma unroll
+      for (int a = 0; a < R1; a++) cr[a] = 0;
+      if (s1 && row < rows_total) {
+        const unsigned short *ps = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(src) + row * (int64_t)(2 * px)) + q;
+#pragma unroll
+        for (int a = 0; a < R1; a++) cr[a] = ps[R2 * a];
+      }
+      return;
+    }
 #pragma unroll
     for (int a = 0; a < R1; a++) v[a] = (c32){0.f, 0.f};
     if (s1 && row < rows_total) {
@@ -292,6 +314,10 @@ __global__ __launch_bounds__(256) void k_fft_x_fwd2(const float *__restrict__ sr
       drow[buf][threadIdx.x] = (((int64_t)bz * nchunk) * rpp + (row - bz * rpp)) * BXC;
     }
     if (s1) {
+      if constexpr (U8) {
+#pragma unroll
+        for (int a = 0; a < R1; a++) v[a] = (c32){count_mass(cr[a] & 255u), count_mass(cr[a] >> 8)};
+      }
       dft<R1>(v);
       c32 *pxw = X + (r * R1) * R2P + q;
 #pragma unroll
@@ -1121,20 +1147,41 @@ template <int RSET> static int x_fwd_rb(p3m_ctx *c, const FftPlan &pl, const flo
     default: return x_fwd_impl<RSET, 64>(c, pl, src, dst, rows, rpp);
   }
 }
-template <int R1, int R2, bool CUBES = false> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp, const RowGeom &cq = RowGeom{}) {
+template <int R1, int R2, bool CUBES = false, bool U8 = false> static int x_fwd2_impl(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, int rpp, const RowGeom &cq = RowGeom{}, float mass_p = 0.f) {
   using C = X2Cfg<R1, R2>;
+  static_assert(!U8 || C::TB == 256, "the count table is built by 256 threads");
   if (rows > 0x7fffffffLL) { p3m_set_error("fft x pass: %lld rows out of range", (long long)rows); return P3M_EINVAL; }
-  P3M_TRY((set_lds(k_fft_x_fwd2<R1, R2, CUBES>, C::lds)));
+  P3M_TRY((set_lds(k_fft_x_fwd2<R1, R2, CUBES, U8>, C::lds)));
   static int occ = 0;
   if (occ == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_fwd2<R1, R2, CUBES>), C::TB, C::lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_fft_x_fwd2<R1, R2, CUBES, U8>), C::TB, C::lds));
     if (occ < 1) occ = 1;
   }
   const int64_t nbatch = cdiv(rows, C::RB), g = (int64_t)256 * occ;
-  hipLaunchKernelGGL((k_fft_x_fwd2<R1, R2, CUBES>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, src, reinterpret_cast<float2 *>(dst), pl.n,
-                     pl.px, (int)rows, pl.d_tw, rpp, cq);
+  hipLaunchKernelGGL((k_fft_x_fwd2<R1, R2, CUBES, U8>), dim3((unsigned)(g < nbatch ? g : nbatch)), dim3(C::TB), C::lds, c->stream, src, reinterpret_cast<float2 *>(dst), pl.n,
+                     pl.px, (int)rows, pl.d_tw, rpp, cq, mass_p);
   HIP_TRY(hipGetLastError());
   return P3M_OK;
+}
+// the tile sizes whose forward x pass also exists reading one byte per cell (the NGP density of whole steps): two register stages, 256 threads
+bool fft_x_forward_reads_u8(const FftPlan &pl) {
+  if (lines2_off(pl.n)) return false;
+#define X(H, A, B) if (pl.n == 2 * H) return X2Cfg<A, B>::TB == 256;
+  P3M_X2_SIZES(X)
+#undef X
+  return false;
+}
+template <int R1, int R2> static int x_fwd2_u8(p3m_ctx *c, const FftPlan &pl, const float *src, float *dst, int64_t rows, float mass_p) {
+  if constexpr (X2Cfg<R1, R2>::TB == 256) return x_fwd2_impl<R1, R2, false, true>(c, pl, src, dst, rows, pl.n, RowGeom{}, mass_p);
+  else { p3m_set_error("fft x pass: no byte-reading kernel for n=%d", pl.n); return P3M_EINVAL; }
+}
+int fft_x_forward_u8(p3m_ctx *c, const FftPlan &pl, const float *src8, float *dst, int batch, float mass_p) {
+  if (!lines2_off(pl.n)) {
+#define X(H, A, B) if (pl.n == 2 * H) return x_fwd2_u8<A, B>(c, pl, src8, dst, (int64_t)batch * pl.n * pl.n, mass_p);
+    P3M_X2_SIZES(X)
+#undef X
+  }
+  p3m_set_error("fft x pass: no byte-reading kernel for n=%d", pl.n); return P3M_EINVAL;
 }
 // the coarse sizes whose x passes read the ranks' cubes / write the ranks' force arrays themselves (instantiated for these only)
 #define P3M_X2_CUBE_SIZES(X) X(32, 8, 4) X(64, 8, 8) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16)
@@ -1435,8 +1482,10 @@ int fft3d_inverse(p3m_ctx *c, const FftPlan &pl, const float *hat, float *tmp, f
 // work holds 3*batch arrays ([comp][tile]); box points at tile0 of component 0, bcs = component stride.
 // data: real ROWS in; out: after the forward x and y passes only (LZ layout, z still in real space) -- input of the
 // fused z pass of fft_inverse3_box_z(..., zfwd = true)
-int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch) {
-  P3M_TRY(fft_x_forward(c, pl, data, scratch, batch));                                        // ROWS -> LY
+// u8: the rows are bytes, the cells' counts, at the head of `data` (fft_x_forward_u8)
+int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch, bool u8, float mass_p) {
+  if (u8) P3M_TRY(fft_x_forward_u8(c, pl, data, scratch, batch, mass_p));
+  else P3M_TRY(fft_x_forward(c, pl, data, scratch, batch));                                   // ROWS -> LY
   return launch_lines<false, true, 0>(c, pl, full_args(pl, data, scratch), batch);            // LY -> LZ
 }
 int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, int fb, int lo, bool zfwd) {

@@ -17,7 +17,7 @@
 
 int fft_inverse3_box(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, float *box, int fb, int lo,
                      int64_t bcs, bool zfwd);
-int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch);
+int fft3d_forward_xy(p3m_ctx *c, const FftPlan &pl, float *data, float *scratch, int batch, bool u8, float mass_p);
 int fft_inverse3_box_z(p3m_ctx *c, const FftPlan &pl, const float *rho_hat, float *work, const float *kern3, int batch, int fb, int lo, bool zfwd);
 int fft_inverse3_box_y(p3m_ctx *c, const FftPlan &pl, float *work, int batch, int fb, int lo);
 bool fft_x2_box_pass(int n, int lo);   // fft.hip: the force-box inverse x pass of this size is the two-register-stage kernel
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_ngp_counts(const int *__restrict__ cs, 
 // The fused inverse-x + kick pass (kick_fused.hip) kicks a record from the box rows of ITS batch of `fuse_nr` rows: a physical record of
 // this tile whose reference cell lies in a row of another batch than the row it is sorted into gets that row flagged here -- the pass
 // then stores the row to the force box as well and k_kick_fix kicks the record from there.
-struct FuseFlag { unsigned char *rowflag; int nr, Nn, ms; };
+struct FuseFlag { unsigned char *rowflag; int nr, Nn, ms; bool u8; float *cmax; };   // u8: the density is one byte per cell (RowDep::rho8); cmax: where a saturated byte is reported
 __device__ __forceinline__ bool owner_is(const float4 &p, const TileGeo &G, int Nn, int ms, int tx, int ty, int tz) {
   const float fNn = (float)Nn;
   if (!(p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn)) return false;   // chains of hoc(1..ncn) only (:234-236)
@@ -224,9 +224,19 @@ __device__ __forceinline__ void ngp_fixup_record(const float4 &p, float *__restr
     const int bs = (tile * G.fb + (gl[2] - lo)) * G.fb + (gl[1] - lo), br = (tile * G.fb + (rr[2] - lo)) * G.fb + (rr[1] - lo);
     if (bs / ff.nr != br / ff.nr) ff.rowflag[br] = 1;
   }
+  if (ff.u8) {
+    // one byte per cell (RowDep::rho8): -1 / +1 on the cell's byte inside its word.  The -1 never borrows (the record itself was counted
+    // there); a +1 onto 255 would carry into the neighbour: it is left out and reported like a saturated count (the step then fails)
+    unsigned *w32 = reinterpret_cast<unsigned *>(rho) + (int64_t)tl * nf * nf * (G.rp / 4);
+    const int64_t ig8 = ((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0], ir8 = ((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0];
+    atomicSub(&w32[ig8 >> 2], 1u << (8 * (ig8 & 3)));
+    const unsigned old = atomicAdd(&w32[ir8 >> 2], 1u << (8 * (ir8 & 3)));
+    if (((old >> (8 * (ir8 & 3))) & 255u) == 255u) { atomicSub(&w32[ir8 >> 2], 1u << (8 * (ir8 & 3))); p3m_atomic_max_nonneg(ff.cmax, 1.0e9f); }
+  } else {
   float *base = rho + (int64_t)tl * nf * nf * G.rp;
   atomicAdd(&base[((int64_t)gl[2] * nf + gl[1]) * G.rp + gl[0]], -mass_p);
   atomicAdd(&base[((int64_t)rr[2] * nf + rr[1]) * G.rp + rr[0]], mass_p);
+  }
   if (sum_interior) {
     const bool ig = gl[0] >= nb && gl[0] < nf - nb && gl[1] >= nb && gl[1] < nf - nb && gl[2] >= nb && gl[2] < nf - nb;
     const bool ir = rr[0] >= nb && rr[0] < nf - nb && rr[1] >= nb && rr[1] < nf - nb && rr[2] >= nb && rr[2] < nf - nb;
@@ -259,7 +269,9 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p, bool fuse) {   
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   if (c->p.flags & P3M_FLAG_NGP) {
     const bool have = c->rho_from_sort && tile0 == 0 && ntile == g.ntiles;   // written by k_row_sort of this step
-    c->rho_from_sort = false;
+    c->rho_u8_force = have && c->rho_u8;               // ... as one byte per cell: the fix-up and fine_force's forward x pass read bytes
+    c->rho_mass = mass_p;
+    c->rho_from_sort = false; c->rho_u8 = false;
     if (!have) P3M_TRY(particles_full_cells(c));
     if (!have) hipLaunchKernelGGL(k_ngp_counts, dim3(cdiv(g.nf, 8), g.nf, ntile), dim3(256), 0, c->stream, (const int *)c->cell_end,
                        c->rho, tile0, ntile, G, mass_p, c->d_sums);
@@ -267,7 +279,7 @@ int fine_deposit(p3m_ctx *c, int tile0, int ntile, float mass_p, bool fuse) {   
     if (c->np_all > 0) {
       // records within 2^-10 below a cell face: ~0.3 % of the records; the grids are sized for that share, the loops cover any count
       const int64_t guess = std::max<int64_t>(1, (int64_t)c->np_all / 256 / P3M_CAND_SLOTS) * ntile;
-      const FuseFlag ff{fuse ? c->rowflag : (unsigned char *)nullptr, c->fuse_nr, g.Nn, g.ms};
+      const FuseFlag ff{fuse ? c->rowflag : (unsigned char *)nullptr, c->fuse_nr, g.Nn, g.ms, c->rho_u8_force, c->d_red + 3 * P3M_RED_SPAN};
       hipLaunchKernelGGL(k_ngp_fixup, dim3((unsigned)std::min<int64_t>(256, cdiv(guess, 256)), P3M_CAND_SLOTS), dim3(256), 0, c->stream, (const float4 *)c->spos, c->np_all,
                          (const int *)c->cand, (const int *)c->cand_cnt, c->cand_seg, c->rho, tile0, ntile, G, mass_p, c->d_sums, ff);
       HIP_TRY(hipGetLastError());
@@ -328,7 +340,7 @@ int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float 
   TileGeo G{g.T, g.nf, g.nb, g.pt, g.E, g.fb, 2 * g.px, g.fbp};
   const int Np = g.Nn * g.nodes_dim;
   const size_t S = (size_t)(2 * g.px) * g.nf * g.nf;
-  c->rho_from_sort = false;
+  c->rho_from_sort = false; c->rho_u8 = false; c->rho_u8_force = false;
   P3M_TRY(particles_full_cells(c));
   for (int t0 = 0; t0 < g.ntiles; t0 += c->tile_batch) {
     const int nt = std::min(c->tile_batch, g.ntiles - t0);
@@ -353,7 +365,8 @@ int fine_projection(p3m_ctx *c, float mass_p, float *d_pxy, float *d_pxz, float 
 int fine_force(p3m_ctx *c, int tile0, int ntile, bool defer_x) {
   const Geometry &g = c->g;
   // forward x and y passes; the forward z pass is the prologue of the inverse z pass (rho-hat never touches HBM)
-  P3M_TRY(fft3d_forward_xy(c, c->plan_f, c->rho, c->work, ntile));
+  P3M_TRY(fft3d_forward_xy(c, c->plan_f, c->rho, c->work, ntile, c->rho_u8_force, c->rho_mass));
+  c->rho_u8_force = false;
   const size_t boxsz = (size_t)g.fb * g.fb * g.fbp;
   if (defer_x) {   // whole NGP steps: the inverse x pass runs with the kick (fine_xinv_kick_fused), no force box
     P3M_TRY(fft_inverse3_box_z(c, c->plan_f, c->rho, c->work, c->kern_f, ntile, g.fb, g.nb - 2, true));

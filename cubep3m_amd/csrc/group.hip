@@ -1130,6 +1130,7 @@ static int reduce_step_out(p3m_group *G, float a_mid, p3m_step_out *out, bool do
   }
   for (p3m_ctx *c : G->ctx) {
     reductions_fold(c);
+    P3M_TRY(rho_u8_check(c));
     v[0] = std::max(v[0], sqrtf(c->h_red[0])); v[1] = std::max(v[1], c->h_red[1]); v[3] = std::max(v[3], c->h_red[2]);
     if (c->p.flags & P3M_FLAG_PP_EXT) {   // per-thread "last tile" overwrite, particle_mesh_threaded.f90:617
       const int cores = std::max(1, c->p.cores), nt = std::min(cores, g.ntiles), base = g.ntiles / nt, rem = g.ntiles % nt;

@@ -284,7 +284,7 @@ extern "C" int p3m_hip_upload_particles(p3m_ctx *c, const float *xv6, const int6
   P3M_TRY(need_particles(c, "p3m_hip_upload_particles"));
   if (np_local > c->cap) { p3m_set_error("np_local %d exceeds max_np %lld", np_local, (long long)c->cap); return P3M_ECAPACITY; }
   HIP_TRY(hipSetDevice(c->device));
-  c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false; c->gl_valid = false; c->cnt_from_kick = 0; c->n_home = 0;
+  c->np_local = np_local; c->np_all = 0; c->pending_compact = false; c->hist_done = false; c->gl_valid = false; c->cnt_from_kick = 0; c->n_home = 0; c->cell_max_known = false;
   if (np_local == 0) return P3M_OK;
   float *tmp = nullptr; P3M_TRY(dalloc(&tmp, (size_t)np_local * 6));
   HIP_TRY(hipMemcpyAsync(tmp, xv6, sizeof(float) * 6 * (size_t)np_local, hipMemcpyHostToDevice, c->stream));
@@ -380,8 +380,18 @@ int reductions_download(p3m_ctx *c) {
   HIP_TRY(hipMemcpyAsync(c->h_redblk, c->d_redblk, c->red_bytes, hipMemcpyDeviceToHost, c->stream));   // sums, maxima and the per-tile PP maxima: one block
   return P3M_OK;
 }
+// a step whose NGP density went through bytes (RowDep::rho8) met a cell of more than 255 records: the density is wrong, the step fails
+int rho_u8_check(p3m_ctx *c) {
+  const bool bad = c->rho_u8_step && c->h_red[3] >= 255.5f;
+  c->rho_u8_step = false;
+  if (bad) { c->cell_max_known = false; p3m_set_error("a fine cell holds more than 255 particles, more than twice what it held a step ago: the byte-per-cell NGP density of this step is saturated (P3M_RHO_F32=1 keeps floats)"); return P3M_ECAPACITY; }
+  return P3M_OK;
+}
 void reductions_fold(p3m_ctx *c) {
   for (int k = 0; k < 8; k++) { float m = 0.f; for (int sl = 0; sl < P3M_NSLOT; sl++) m = std::max(m, c->h_red_raw[k * P3M_RED_SPAN + sl * 16]); c->h_red[k] = m; }
+  // slot 3: the largest count of a fine cell the sort of this step saw (0: below 64) -- what decides whether the NEXT step's NGP density is
+  // written as one byte per cell (particles_sort_enqueue)
+  if (c->cell_max_reported) { c->cell_max = c->h_red[3]; c->cell_max_known = true; c->cell_max_reported = false; }
   for (int k = 0; k < 4; k++) { double t = 0.0; for (int sl = 0; sl < P3M_NSLOT; sl++) t += c->h_sums_raw[k * P3M_SUM_SPAN + sl * 8]; c->h_sums[k] = t; }
 }
 
@@ -488,6 +498,7 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
   if (c->finalize_queued) P3M_TRY(particles_finalize_finish(c, false));   // a ghost removal queued by the whole-step call
   particles_collect_counters(c);
   reductions_fold(c);
+  P3M_TRY(rho_u8_check(c));
   p3m_step_out o; memset(&o, 0, sizeof(o));
   float fmax = sqrtf(c->h_red[0]);                         // :643
   float ppmax = c->h_red[1], cmax = c->h_red[2];
@@ -523,7 +534,7 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
 // after an error in the middle of a step: nothing that was queued for "later" may be trusted by the next call -- the next sort
 // counts its rows itself (k_row_hist), no survivor counts, no deferred counters, no half-finished ghost removal
 void particles_reset_after_error(p3m_ctx *c) {
-  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->coarse_first = false; c->xinv_deferred = false; c->step_zeroed = false; c->zl.cnt = 0;
+  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->rho_u8 = false; c->rho_u8_force = false; c->cell_max_known = false; c->coarse_first = false; c->xinv_deferred = false; c->step_zeroed = false; c->zl.cnt = 0;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 }

@@ -180,6 +180,10 @@ struct p3m_ctx {
   bool lazy_counters = false;  // whole steps: the sort's deleted count has not been read yet, np_all is its upper bound (the tail is padded)
   bool coarse_first = false;   // whole-step PM-only NGP runs: the coarse force is ready before the fine kick, which then adds the coarse kick in the same pass
   bool rho_from_sort = false;  // the sort of this step already wrote the NGP density of every tile (particles.hip)
+  bool rho_u8_force = false; float rho_mass = 0.f;   // fine_deposit -> fine_force: this sweep's density is bytes; its mass_p
+  bool rho_u8 = false;         // ... as one byte per cell (its count) at the head of the rho array (RowDep::rho8; fft3d_forward_xy turns counts into masses)
+  bool cell_max_reported = false, rho_u8_step = false;   // this step's sort reports the count / wrote bytes (rho_u8_check after the fold)
+  bool cell_max_known = false; float cell_max = 0.f;   // the largest fine-cell count the last whole step's sort saw (0: below 64); unknown after an upload
   // NGP steps (round 5): the force phase stops after the inverse y pass (work holds LY rows of the three components) and the inverse x
   // pass runs inside the kick (kick_fused.hip), fuse_nr box rows per batch; rowflag[ntiles*fb*fb]: rows that also go to the force box
   bool xinv_deferred = false; int fuse_nr = 0; unsigned char *rowflag = nullptr;
@@ -273,6 +277,8 @@ int fine_sum_mass(p3m_ctx *c, int tile0, int ntile);
 int build_fine_kernel(p3m_ctx *c, const float *table16_host);
 
 // ---- pp.hip
+int rho_u8_check(p3m_ctx *c);   // p3m_api.hip
+bool fft_x_forward_reads_u8(const FftPlan &pl);   // fft.hip: the tile size has a forward x pass that reads one byte per cell
 int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p);
 int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra);   // fuse_intra: sum the -DPPINT bucket pairs on the way where the lean light pass runs (pp_intra, called AFTERWARDS, then works the rest)
 

@@ -264,7 +264,10 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
 }
 
 // one wavefront per row: bins[] = LDS histogram of the row's x cells -> exclusive prefix (the row of cs) -> cursors
-struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, rp; };   // fused NGP deposit (rho == nullptr: off)
+// fused NGP deposit (rho == nullptr: off).  rho8 (round 6): the density as ONE BYTE per cell, its count -- the forward x pass turns a count into
+// mass_p added count times from a table (k_fft_x_fwd2<.., U8>): a quarter of the bytes written here and read there.  cmax: where the largest
+// count of a cell is reported (a reduction slot; counts beyond 255 saturate, the step then ends with an error: see particles_sort_enqueue)
+struct RowDep { float *rho; double *sum_interior; float mass_p; int T, nf, pt, rp; unsigned char *rho8; float *cmax; };
 // compact cell table (p3m_internal.h, crow): entry ci < ncn+2 = start of cell ms*ci - ms/2 + nb (what k_coarse_moments reads),
 // entries ncn+2 + 2*tx, +1 = start of cells tx*pt + lo and tx*pt + lo + fb (the force-box row of tile column tx)
 struct RowCompact { int *crow; int w, ncn, ms, T, pt, lo, fb; };   // crow == nullptr: write the full cell_end row
@@ -325,6 +328,7 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
     const int cz = row / E, cy = row - cz * E, nbi = (int)nb;
     const float m2 = dep.mass_p + dep.mass_p, m3 = m2 + dep.mass_p;
     float part = 0.f;
+    int icount = 0, cmax8 = 0;
     for (int tz = max(0, (cz - dep.nf + dep.pt) / dep.pt); tz < dep.T && tz * dep.pt <= cz; tz++)
       for (int ty = max(0, (cy - dep.nf + dep.pt) / dep.pt); ty < dep.T && ty * dep.pt <= cy; ty++) {
         const int k = cz - tz * dep.pt, j = cy - ty * dep.pt;
@@ -332,6 +336,33 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
         const bool row_in = (j >= 4 && j < dep.nf - 4 && k >= 4 && k < dep.nf - 4);
         const bool row_int = (j >= nbi && j < dep.nf - nbi && k >= nbi && k < dep.nf - nbi);
         for (int tx = 0; tx < dep.T; tx++) {
+          if (dep.rho8) {
+            // counts: one byte per cell, four cells per lane and trip; the interior mass as count x mass_p in double at the end (what the
+            // selection of partial sums below costs per cell -- half of this kernel's instructions -- is spent once, in the x pass's table)
+            unsigned char *out8 = dep.rho8 + ((((int64_t)(tz * dep.T + ty) * dep.T + tx) * dep.nf + k) * dep.nf + j) * dep.rp;
+            for (int i4 = lane * 4; i4 < dep.rp; i4 += 256) {
+              unsigned pk = 0u;
+              if (row_in) {
+                const int c = tx * dep.pt + i4;
+                int b[5];
+                if (c + 4 <= E) { const int4 q = *reinterpret_cast<const int4 *>(bins + c); b[0] = q.x; b[1] = q.y; b[2] = q.z; b[3] = q.w; b[4] = c + 4 < E ? bins[c + 4] : r1; }
+                else {
+#pragma unroll
+                  for (int u = 0; u < 5; u++) b[u] = c + u < E ? bins[c + u] : r1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  const int i = i4 + u;
+                  const int cnt = (i >= 4 && i < dep.nf - 4) ? b[u + 1] - b[u] : 0;
+                  cmax8 = max(cmax8, cnt);
+                  if (row_int && i >= nbi && i < dep.nf - nbi) icount += cnt;           // :167-173
+                  pk |= (unsigned)min(cnt, 255) << (8 * u);
+                }
+              }
+              *reinterpret_cast<unsigned *>(out8 + i4) = pk;
+            }
+            continue;
+          }
           float *out = dep.rho + ((((int64_t)(tz * dep.T + ty) * dep.T + tx) * dep.nf + k) * dep.nf + j) * dep.rp;
           // four cells per lane and trip (the kernel is bound by its instruction count: 650 vector instructions per row, half of
           // them here when every lane wrote one cell per trip); rp, pt and E are multiples of four
@@ -350,6 +381,7 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
                 const int i = i4 + u;
                 if (i >= 4 && i < dep.nf - 4) {
                   const int cnt = b[u + 1] - b[u];
+                  cmax8 = max(cmax8, cnt);
                   // :148, same partial sums: 0, m, m + m, (m + m) + m by selection (nearly every cell), the loop beyond three
                   float r = cnt >= 3 ? m3 : (cnt == 2 ? m2 : (cnt == 1 ? dep.mass_p : 0.f));
                   for (int q = 3; q < cnt; q++) r = r + dep.mass_p;
@@ -362,9 +394,19 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
           }
         }
       }
-    if (dep.sum_interior) {
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-      if (lane == 0 && part != 0.f) atomicAdd(dep.sum_interior + p3m_slot() * 8, (double)part);
+    if (dep.rho8) {
+      for (int o = 32; o > 0; o >>= 1) { icount += __shfl_down(icount, o, 64); cmax8 = max(cmax8, __shfl_down(cmax8, o, 64)); }
+      if (lane == 0 && icount != 0 && dep.sum_interior) atomicAdd(dep.sum_interior + p3m_slot() * 8, (double)icount * (double)dep.mass_p);
+      if (lane == 0 && cmax8 >= 64) p3m_atomic_max_nonneg(dep.cmax + p3m_slot() * 16, (float)cmax8);   // (small counts are not worth an atomic: the host only asks "below 100?")
+    } else {
+      if (dep.sum_interior) {
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+        if (lane == 0 && part != 0.f) atomicAdd(dep.sum_interior + p3m_slot() * 8, (double)part);
+      }
+      if (dep.cmax && __any(cmax8 >= 64)) {
+        for (int o = 32; o > 0; o >>= 1) cmax8 = max(cmax8, __shfl_down(cmax8, o, 64));
+        if (lane == 0) p3m_atomic_max_nonneg(dep.cmax + p3m_slot() * 16, (float)cmax8);
+      }
     }
   }
   // records with a coordinate within 2^-10 below a cell face: only these can be moved into the next
@@ -475,10 +517,18 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
                        c->tpos);
     HIP_TRY(hipGetLastError());
   }
-  RowDep dep{nullptr, nullptr, 0.f, g.T, g.nf, g.pt, 2 * g.px};
-  c->rho_from_sort = false;
+  RowDep dep{nullptr, nullptr, 0.f, g.T, g.nf, g.pt, 2 * g.px, nullptr, nullptr};
+  c->rho_from_sort = false; c->rho_u8 = false;
   if (deposit_mass >= 0.f && (c->p.flags & P3M_FLAG_NGP) && c->tile_batch == g.ntiles) {
     dep.rho = c->rho; dep.sum_interior = c->d_sums; dep.mass_p = deposit_mass; c->rho_from_sort = true;
+    dep.cmax = c->d_red + 3 * P3M_RED_SPAN;            // the largest count of a cell, back with the step's maxima (reductions_fold)
+    c->cell_max_reported = true;
+    // One byte per cell where (a) the forward x pass of this tile size reads bytes, (b) the LAST whole step of these particles saw no cell
+    // of 100 records (cell_max_known: nothing is known right after an upload, that step writes floats).  A count beyond 255 in a byte
+    // step -- a cell that more than doubled in one step -- saturates and fails the step loudly (particle_mesh_step); P3M_RHO_F32=1:
+    // floats always (a test switch)
+    static const bool f32 = getenv("P3M_RHO_F32") && getenv("P3M_RHO_F32")[0] == '1';
+    if (!f32 && c->cell_max_known && c->cell_max < 100.0f && fft_x_forward_reads_u8(c->plan_f)) { dep.rho8 = reinterpret_cast<unsigned char *>(c->rho); c->rho_u8 = true; c->rho_u8_step = true; }
   }
   // whole-step PM-only NGP calls: nothing downstream reads per-cell offsets, only the compact table (p3m_internal.h)
   RowCompact cc{nullptr, c->crow_w, g.ncn, g.ms, g.T, g.pt, g.nb - 2, g.fb};

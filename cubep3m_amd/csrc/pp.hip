@@ -1004,6 +1004,15 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
             const bool ownrow = rowok && (zy >> 16) == hcz && (zy & 0xffff) == hcy;
             const float lenf = (float)len, olenf = ownrow ? (float)(hown1 - hown0) : 0.0f;
             const float d0 = (float)(ua - a) - 0.5f * (lenf - 1.0f), k4 = 2.0f * lenf - 1.0f;
+#ifdef PP_SWEEP_STATS   // diagnostic build: swept partners (x 64 lane slots), rows visited, lanes with a home record, into hcount[8..]
+            if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(hcount + 8), (unsigned long long)(ub - ua)); atomicAdd(reinterpret_cast<unsigned long long *>(hcount + 10), 1ull); }
+            { int lo_ = rowok && len > 0 ? max(a, ua) : 0x7fffffff, hi_ = rowok && len > 0 ? min(a + len, ub) : -0x7fffffff;   // the stretch some lane wants
+              lo_ = wave_min_i(lo_); hi_ = wave_max_i(hi_);
+              if (lane == 0 && hi_ > lo_) atomicAdd(reinterpret_cast<unsigned long long *>(hcount + 14), (unsigned long long)(hi_ - lo_)); }
+            { const int acc_ = rowok ? max(min(a + len, ub) - max(a, ua), 0) : 0; unsigned long long t_ = (unsigned long long)acc_;
+              for (int o_ = 32; o_ > 0; o_ >>= 1) t_ += __shfl_xor(t_, o_, 64);
+              if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(hcount + 12), t_); }
+#endif
             if (__any(ownrow)) {
               const float dO = (float)(ua - hown0) - 0.5f * (olenf - 1.0f), k4o = 1.0f - 2.0f * olenf;
               pp_sweep_row<true, TAPER_ALL>(pr, ua, ub, hx, hy, hz, d0, k4, dO, k4o, SK, sx_, sy_, sz_);
@@ -1786,6 +1795,10 @@ extern "C" int p3m_hip_time_pp(p3m_ctx *c, float a_mid, float dt, float mass_p, 
       HIP_TRY(hipMemcpy(h + 1, c->pp_counter + 4 * 32 * PP3_NSEG + 32, sizeof(int), hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(h + 2, c->pp_counter + 4 * 32 * PP3_NSEG + 96, sizeof(int), hipMemcpyDeviceToHost));
       fprintf(stderr, "[pp stats] heavy tasks %d, patches left to the general pass %d, half patches %d\n", h[0], h[1], h[2]);
+#ifdef PP_SWEEP_STATS
+      { unsigned long long q[4]; HIP_TRY(hipMemcpy(q, c->pp_counter + 4 * 32 * PP3_NSEG + 8, sizeof(q), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pp stats] sweep: %llu partners swept per wavefront-row visit x 64 lanes = %.3g lane slots, %llu row visits, %llu accepted (incl. own cell); tight stretches %llu\n", q[0], 64.0 * (double)q[0], q[1], q[2], q[3]); }
+#endif
       if (h[0] > 0 && c->pp_htask) {   // heavy lanes per heavy task
         std::vector<int> rec((size_t)h[0] * PP3_HREC);
         HIP_TRY(hipMemcpy(rec.data(), c->pp_htask, rec.size() * sizeof(int), hipMemcpyDeviceToHost));
