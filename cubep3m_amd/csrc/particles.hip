@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
     if (dep.rho8) {
       for (int o = 32; o > 0; o >>= 1) { icount += __shfl_down(icount, o, 64); cmax8 = max(cmax8, __shfl_down(cmax8, o, 64)); }
       if (lane == 0 && icount != 0 && dep.sum_interior) atomicAdd(dep.sum_interior + p3m_slot() * 8, (double)icount * (double)dep.mass_p);
-      if (lane == 0 && cmax8 >= 64) p3m_atomic_max_nonneg(dep.cmax + p3m_slot() * 16, (float)cmax8);   // (small counts are not worth an atomic: the host only asks "below 100?")
+      if (lane == 0 && cmax8 >= 64) p3m_atomic_max_nonneg(dep.cmax + p3m_slot() * 16, (float)cmax8);   // (small counts are not worth an atomic: the host only asks "below 128?")
     } else {
       if (dep.sum_interior) {
         for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
@@ -524,11 +524,12 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
     dep.cmax = c->d_red + 3 * P3M_RED_SPAN;            // the largest count of a cell, back with the step's maxima (reductions_fold)
     c->cell_max_reported = true;
     // One byte per cell where (a) the forward x pass of this tile size reads bytes, (b) the LAST whole step of these particles saw no cell
-    // of 100 records (cell_max_known: nothing is known right after an upload, that step writes floats).  A count beyond 255 in a byte
+    // of 128 records (cell_max_known: nothing is known right after an upload, that step writes floats).  A count beyond 255 in a byte
     // step -- a cell that more than doubled in one step -- saturates and fails the step loudly (particle_mesh_step); P3M_RHO_F32=1:
     // floats always (a test switch)
     static const bool f32 = getenv("P3M_RHO_F32") && getenv("P3M_RHO_F32")[0] == '1';
-    if (!f32 && c->cell_max_known && c->cell_max < 100.0f && fft_x_forward_reads_u8(c->plan_f)) { dep.rho8 = reinterpret_cast<unsigned char *>(c->rho); c->rho_u8 = true; c->rho_u8_step = true; }
+    if (getenv("P3M_RHO_TRACE")) fprintf(stderr, "[rho] known %d cell_max %g\n", (int)c->cell_max_known, c->cell_max);
+    if (!f32 && c->cell_max_known && c->cell_max < 128.0f && fft_x_forward_reads_u8(c->plan_f)) { dep.rho8 = reinterpret_cast<unsigned char *>(c->rho); c->rho_u8 = true; c->rho_u8_step = true; }
   }
   // whole-step PM-only NGP calls: nothing downstream reads per-cell offsets, only the compact table (p3m_internal.h)
   RowCompact cc{nullptr, c->crow_w, g.ncn, g.ms, g.T, g.pt, g.nb - 2, g.fb};
