@@ -1184,7 +1184,11 @@ int fft_x_forward_u8(p3m_ctx *c, const FftPlan &pl, const float *src8, float *ds
   p3m_set_error("fft x pass: no byte-reading kernel for n=%d", pl.n); return P3M_EINVAL;
 }
 // the coarse sizes whose x passes read the ranks' cubes / write the ranks' force arrays themselves (instantiated for these only)
-#define P3M_X2_CUBE_SIZES(X) X(32, 8, 4) X(64, 8, 8) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16)
+#define P3M_X2_CUBE_SIZES(X) X(32, 8, 4) X(64, 8, 8) X(128, 16, 8) X(256, 16, 16) X(512, 16, 32)
+// (round 6: h = 512 as 16 x 32 -- the first stage, which also holds the next batch's loads, on the small radix: the forward pass of the literal
+// 1024^3 slab transform 2.4 -> 1.86 ms per launch at 289 registers (361).  The force-writing inverse pass is the other way round -- its
+// SECOND stage carries the three components' squares for max |F| -- and stays 32 x 16: 7.4 ms against 7.96)
+#define P3M_X2_CUBE_INV_SIZES(X) X(32, 8, 4) X(64, 8, 8) X(128, 16, 8) X(256, 16, 16) X(512, 32, 16)
 bool fft_x_has_cubes(const FftPlan &pl, const RowGeom &q) {
   if (lines2_off(pl.n) || q.ncn % 2 || (int64_t)q.nd * q.ncn * q.ncn * q.ncn >= 0x7fffffffLL) return false;
 #define X(H, A, B) if (pl.n == 2 * H) return q.ncn % X2Cfg<A, B>::RB == 0;
@@ -1280,7 +1284,7 @@ template <int R1, int R2> static int x_inv2c_impl(p3m_ctx *c, const FftPlan &pl,
 }
 int fft_x_inverse_cubes(p3m_ctx *c, const FftPlan &pl, const float *src, float *fc, const RowGeom &q, const RankPtrs &red) {
 #define X(H, A, B) if (pl.n == 2 * H) return x_inv2c_impl<A, B>(c, pl, src, fc, q, red);
-  P3M_X2_CUBE_SIZES(X)
+  P3M_X2_CUBE_INV_SIZES(X)
 #undef X
   p3m_set_error("fft_x_inverse_cubes: n=%d has no force-writing x pass", pl.n); return P3M_EINVAL;
 }
