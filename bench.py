@@ -117,6 +117,12 @@ def pp_leg():
     out = {"geometry": CONFIGS["cfg3"]["workload"], "peak_fp32_valu_TFLOPs": FP32_VALU_PEAK_TFLOPS,
            "flop_per_evaluation": {"intra": PP_FLOP_INTRA, "extended": PP_FLOP_EXT},
            "note": "an evaluation is one partner summed into one kicked record (a pair of two kicked records is evaluated twice)"}
+    def rates(ms_i, ms_e, n_i, n_e):
+        return {"intra": {"evaluations": n_i, "ms": ms_i, "evaluations_per_s": n_i / (ms_i * 1e-3) if ms_i > 0 else None,
+                          "valu_frac": n_i * PP_FLOP_INTRA / (ms_i * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12) if ms_i > 0 else None},
+                "extended": {"evaluations": n_e, "ms": ms_e, "evaluations_per_s": n_e / (ms_e * 1e-3) if ms_e > 0 else None,
+                             "valu_frac": n_e * PP_FLOP_EXT / (ms_e * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12) if ms_e > 0 else None}}
+
     ics = {"uniform": lambda: make_particles(128, 256.0),
            "clustered_205_per_blob": lambda: clustered(128, 256.0, 2024, 0.3, 3072, 0.6),     # Appendix C's blobs at Appendix C's density
            "clustered_13k_per_blob": lambda: clustered(128, 256.0, 2024, 0.3, 48, 0.6)}      # the same 48 blobs holding 64x the particles
@@ -127,11 +133,22 @@ def pp_leg():
         ms_i, ms_e, n_i, n_e = g.time_pp(0.5, 0.0, 8.0, reps=5)       # dt = 0: the repeated kicks leave the velocities alone
         g.delete_particles()
         g.close()
-        out[name] = {
-            "intra": {"evaluations": n_i, "ms": ms_i, "evaluations_per_s": n_i / (ms_i * 1e-3) if ms_i > 0 else None,
-                      "valu_frac": n_i * PP_FLOP_INTRA / (ms_i * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12) if ms_i > 0 else None},
-            "extended": {"evaluations": n_e, "ms": ms_e, "evaluations_per_s": n_e / (ms_e * 1e-3) if ms_e > 0 else None,
-                         "valu_frac": n_e * PP_FLOP_EXT / (ms_e * 1e-3) / (FP32_VALU_PEAK_TFLOPS * 1e12) if ms_e > 0 else None}}
+        out[name] = rates(ms_i, ms_e, n_i, n_e)
+    # The same kernels on the HEADLINE's tile (one rank of the default workload: a 560 tile, 256^3 particles), in the order every step but the
+    # first after an upload finds them in: one whole step first, so that the velocities are reached in the last step's sorted order
+    # (tests/ppbench.py ... big steady).  These are the figures the pm_pp and clustered.pm_pp legs are made of.
+    p5 = Params(tiles_node_dim=1, nf_tile=560, ngp=True, ppint=True, pp_ext=True, density_buffer=1.3)
+    out["tile560_steady"] = {"geometry": "one 560 tile (512^3 cells / 256^3 particles: one rank of the headline), velocities in steady-state order"}
+    for name, gen in {"uniform": lambda: make_particles(256, 512.0), "clustered_205_per_blob": lambda: clustered(256, 512.0, 2024, 0.3, 3072 * 8, 0.6)}.items():
+        g = ParticleMesh(p5, fine, coarse)
+        g.upload_particles(gen())
+        g.particle_mesh(0.5, 0.0, 0.0, 8.0)
+        g.update_position(0.0, 0.0)
+        g.link_list_and_pass()
+        ms_i, ms_e, n_i, n_e = g.time_pp(0.5, 0.0, 8.0, reps=5)
+        g.delete_particles()
+        g.close()
+        out["tile560_steady"][name] = rates(ms_i, ms_e, n_i, n_e)
     return out
 
 

@@ -683,6 +683,32 @@ def test_fused_kick_whole_step_against_the_oracle_at_one_tile_per_rank(PM, n):
     assert err <= KICK_TOL, (n, err)
 
 
+def test_byte_density_saturation_fails_the_step_loudly(PM):
+    """From the second whole step after an upload on, the NGP density travels as one byte per cell (its count; k_row_sort ->
+    k_fft_x_fwd2<.., U8>) if the step before saw no cell of 128 records.  A cell that jumps beyond 255 in ONE step cannot be held:
+    the step must fail with an error, not return a saturated density -- and the step after it (floats again: nothing is known
+    after an error) must work.  300 particles on a shell fall into one cell during the second step's drift."""
+    from cubep3m_amd.lib import P3MError
+
+    p = cfg1(ngp=True)
+    xv = uniform_particles(32768, 64.0)
+    rng = np.random.default_rng(5)
+    u = rng.normal(size=(300, 3)); u /= np.linalg.norm(u, axis=1)[:, None]
+    r = (3.0 + 5.0 * rng.random(300))[:, None] * u
+    dt = 0.05
+    xv[:300, :3] = (np.array([20.5, 20.5, 20.5]) + r).astype(np.float32)
+    xv[:300, 3:] = (-r / (0.5 * (dt + dt))).astype(np.float32)
+    g = PM(p, FINE_TABLE, COARSE_TABLE)
+    g.upload_particles(xv)
+    assert g.particle_mesh(1e-6, 0.0, 0.0, 8.0).np_total == 32768   # a step that moves nobody: floats, and the largest cell count becomes known (small)
+    with pytest.raises(P3MError):
+        g.particle_mesh(1e-6, dt, dt, 8.0)            # bytes; the drift piles 300 records into one cell
+    xv2 = uniform_particles(32768, 64.0)
+    g.upload_particles(xv2)
+    assert g.particle_mesh(1e-6, dt, 0.0, 8.0).np_total == 32768    # and the context is usable again
+    g.close()
+
+
 @pytest.mark.parametrize("n", [768, 832, 896, 1024])
 def test_long_lines_forward_transform_vs_numpy(PM, n):
     """Line lengths beyond 608 (register-stage kernels only: 640 ... 1024 = 32 x 32, the literal 1024^3 coarse mesh of BASELINE
@@ -720,6 +746,7 @@ FALLBACKS = {
     "P3M_PP_EXT_REF": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or (other_tilings and not kw2)",   # k_pp_ext: the reference's own sqrt / division arithmetic
     "P3M_PP_LIGHT_OFF": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or dense_blob or rim_planes or (other_tilings and not kw2)",   # every task through k_pp_ext3's general pass 0 (which otherwise works only what the lean light pass k_pp_light leaves)
     "P3M_PP_INTRA_FUSED": "(config1_kick_parity and p3m_ext) or two_steps_with_drift or half_an_ulp or (other_tilings and not kw2)",   # the bucket pairs (-DPPINT) summed inside the extended PP's light pass, k_pp_intra for the records it leaves (built and measured: not the default)
+    "P3M_RHO_F32": "two_steps_with_drift or fused_kick_in_its_one_wavefront or multi_step",   # the NGP density of whole steps as floats in every step (default: one byte per cell, its count, from the second step after an upload on)
     "P3M_PP_FAT_LIMIT": "(config1_kick_parity and p3m_ext) or dense_blob",   # = 1: every task with a row of two records takes the global-memory path
     "P3M_CAND_SEG": "half_an_ulp or fine_deposit_vs or heavy_blob or (config1_kick_parity and pm_ngp_uniform)",   # = 1: every candidate list overflows
     "P3M_KICK_UNFUSED": "(config1_kick_parity and (pm_ngp or p3m_ext)) or two_steps_with_drift or half_an_ulp or (other_tilings and kw0)",   # the force box + k_fine_kick_rows pair instead of the fused inverse-x + kick pass
