@@ -528,7 +528,6 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
     // step -- a cell that more than doubled in one step -- saturates and fails the step loudly (particle_mesh_step); P3M_RHO_F32=1:
     // floats always (a test switch)
     static const bool f32 = getenv("P3M_RHO_F32") && getenv("P3M_RHO_F32")[0] == '1';
-    if (getenv("P3M_RHO_TRACE")) fprintf(stderr, "[rho] known %d cell_max %g\n", (int)c->cell_max_known, c->cell_max);
     if (!f32 && c->cell_max_known && c->cell_max < 128.0f && fft_x_forward_reads_u8(c->plan_f)) { dep.rho8 = reinterpret_cast<unsigned char *>(c->rho); c->rho_u8 = true; c->rho_u8_step = true; }
   }
   // whole-step PM-only NGP calls: nothing downstream reads per-cell offsets, only the compact table (p3m_internal.h)

@@ -1626,7 +1626,6 @@ int pp_extended(p3m_ctx *c, float a_mid, float dt, float mass_p, bool fuse_intra
   // switch) sends every task through the general pass 0 of k_pp_ext3, which otherwise only works the tasks the lean pass leaves to it
   static const bool light_off = getenv("P3M_PP_LIGHT_OFF") && getenv("P3M_PP_LIGHT_OFF")[0] == '1';
   const bool light = !light_off && g.pp_range == 2 && (int64_t)c->cap < (1ll << 27) && (int64_t)g.E * g.E * g.E < (1ll << 29);   // (32-bit byte offsets into both arrays)
-  if (getenv("P3M_PP_XBW")) xbw = atoi(getenv("P3M_PP_XBW"));   // (experiments)
   xbw = std::max(4, std::min(std::min(xbw, e), light ? PPL_XBW_MAX : 64 - 2 * g.pp_range - 1));      // one load instruction per partner row
   const int npx = (e + xbw - 1) / xbw, npy = (e + PP3_HY - 1) / PP3_HY, npz = (e + PP3_HZ - 1) / PP3_HZ;
   const int64_t ngroups64 = (int64_t)g.ntiles * npz * npy * npx;
