@@ -534,7 +534,7 @@ extern "C" int p3m_hip_get_step_out(p3m_ctx *c, float a_mid, p3m_step_out *out) 
 // after an error in the middle of a step: nothing that was queued for "later" may be trusted by the next call -- the next sort
 // counts its rows itself (k_row_hist), no survivor counts, no deferred counters, no half-finished ghost removal
 void particles_reset_after_error(p3m_ctx *c) {
-  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->rho_u8 = false; c->rho_u8_force = false; c->cell_max_known = false; c->coarse_first = false; c->xinv_deferred = false; c->step_zeroed = false; c->zl.cnt = 0;
+  c->hist_done = false; c->gl_valid = false; c->lazy_counters = false; c->finalize_queued = false; c->cnt_from_kick = 0; c->rho_from_sort = false; c->rho_u8 = false; c->rho_u8_force = false; c->cell_max_known = false; c->cell_max_reported = false; c->rho_u8_step = false; c->coarse_first = false; c->xinv_deferred = false; c->step_zeroed = false; c->zl.cnt = 0;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
 }
