@@ -1058,20 +1058,24 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
 // a quarter of them evaluations, the rest staging (bisections, per-row index arithmetic), 28 instructions for each of a record's 25 windows,
 // and a window walk by every wavefront for the few lanes whose one-byte list entries overflowed.  k_pp_light is that pass for the common
 // task -- pp_range 2, the whole partner region staged in one batch, no row segment of more than 255 records -- with every table laid out
-// for compile-time offsets; any other task is entered in a list that k_pp_ext3<.., 0> works afterwards (none at the background's density).
-//   * geometry: the (8 + 4) x (8 + 4) partner rows of a patch are ALWAYS laid out whole, x boundaries hx0 - 2 ... hx0 + xbw + 2; rows outside the
+// for compile-time offsets.  A crowded patch whose two halves along x fit is worked as two half patches by a second launch (LISTED); what is
+// left then is entered in a list that k_pp_plan_slow + k_pp_ext3<.., 0> work afterwards (nothing at the background's density).
+//   * no plan: a task is a patch, drawn from eight counters; its and its tile's coordinates are decoded by thread 0 a task ahead
+//     (multiplications by reciprocals); a patch of more than 256 home records runs a second sub-task inside;
+//   * geometry: the (8 + 4) x (8 + 4) partner rows of a patch are ALWAYS laid out whole, x boundaries hx0 - 2 ... hx1 + 2; rows outside the
 //     tile's extended region are empty rows and boundaries outside it are clamped to it, so no window is ever clipped per lane: a window is
 //     5 cells of one row = two bytes of the row's table five apart, at a compile-time offset from the lane's first window;
 //   * offset table T: ONE BYTE per boundary (records of the row before it), 36 bytes per row; the row's first staged position times 16 in
-//     cum16.  A wavefront loads three planes of 12 rows (36 loads in flight), takes each row's first and last value through the scalar unit
-//     and sums the counts there: no cross-lane scan, no bisection;
+//     cum16.  A wavefront loads three planes of 12 rows (36 buffer loads in flight: scalar row offset + lane offset), stores each row
+//     minus its first value, and takes the rows' counts back from the table for one DPP scan: three vector instructions per row, no bisection;
 //   * staging: a wavefront copies its own 36 rows, (row, slot < 8) items flattened over its lanes (rows of more than 8 records: a second trip);
-//   * lists: 16-bit entries = the partner's byte address in the staged records.  A window is appended by storing its first SIX entries whatever
-//     its count (the next window overwrites what was not a partner) and one add; a window of more than six records (1e-6) sends the
-//     wavefront through a rolled general loop.  No entry can overflow, so no lane walks its windows at the background's density;
+//   * lists: 16-bit entries = the partner's byte address in the staged records.  A window is appended by storing its first entry -- and
+//     five more only in the lanes whose window holds more than one record -- and one add (the next window overwrites what was not a
+//     partner); a window of more than six records (1e-6 at the background's density) sends the lanes that use their lists through a rolled
+//     general loop.  16-bit stores only: a wider store at this alignment is legal and stalls the LDS.  No entry
+//     can overflow, so no lane walks its windows at the background's density;
 //   * evaluation: four entries per trip, two per packed evaluation; the list's tail is padded with the home record itself (r = 0: below
-//     the soft cut, adds zero), so a trip needs one compare for its four partners;
-//   * the task's coordinates come decoded in its record (k_pp_fill2).
+//     the soft cut, adds zero), so a trip needs one compare for its four partners.
 // Records with more than PPL_LCAP partners are heavy and left to k_pp_ext3<.., 1> exactly as before (same task records, same lane bits).
 #define PPL_NRY 12            // partner rows per plane (PP3_HY + 4) and planes (PP3_HZ + 4)
 #define PPL_NR 144
