@@ -93,19 +93,19 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   // The records of a fine cell are neighbours in the sorted order: a record's cell mates are found by comparing cell indices along
   // the wavefront (plus the record before and the one after it) instead of two look-ups in cell_end per record, which at the mean
   // density cost four times the bytes of the records themselves.  Only a run that crosses the wavefront's ends reads cell_end
-  int64_t cell = -1, ncell = -1;
+  int cell = -1, ncell = -1;                          // (E^3 < 2^31: pp_intra checks)
   {
     const int t = lane == 0 ? s - 1 : s + 1;           // the neighbours beyond the wavefront's ends
     if ((lane == 0 || lane == 63) && t >= 0 && t < n) {
       const float4 o = spos[t];
-      ncell = ((int64_t)((int)floorf(o.z) + G.nb) * G.E + ((int)floorf(o.y) + G.nb)) * G.E + ((int)floorf(o.x) + G.nb);
+      ncell = (((int)floorf(o.z) + G.nb) * G.E + ((int)floorf(o.y) + G.nb)) * G.E + ((int)floorf(o.x) + G.nb);
     }
   }
   if (s < n) {
     p = spos[s];
     const float fNn = (float)G.Nn;
     phys = !skip && p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;
-    cell = ((int64_t)((int)floorf(p.z) + G.nb) * G.E + ((int)floorf(p.y) + G.nb)) * G.E + ((int)floorf(p.x) + G.nb);
+    cell = (((int)floorf(p.z) + G.nb) * G.E + ((int)floorf(p.y) + G.nb)) * G.E + ((int)floorf(p.x) + G.nb);
     if (phys) {
       // the hoc coarse cell alone decides the path (ref_bucket's three float and six integer divisions were a third of this
       // kernel's instructions; x / mesh_scale is x * (1 / mesh_scale) bit for bit when mesh_scale is a power of two)
@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     }
   }
   {
-    const int64_t before = __shfl_up(cell, 1, 64);
+    const int before = __builtin_amdgcn_update_dpp(-2, cell, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0 keeps -2: it heads a run anyway)
     const unsigned long long heads = __ballot(lane == 0 || cell != before);            // bit l: a run of equal cells starts at lane l
-    const bool open_l = __shfl(cell == ncell ? 1 : 0, 0, 64) != 0, open_r = __shfl(cell == ncell ? 1 : 0, 63, 64) != 0;
+    const int same = cell == ncell ? 1 : 0;
+    const bool open_l = __builtin_amdgcn_readlane(same, 0) != 0, open_r = __builtin_amdgcn_readlane(same, 63) != 0;
     const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
     const unsigned long long after = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
     const int end = after ? __ffsll((long long)after) - 1 : 64;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   }
   float ax = 0.f, ay = 0.f, az = 0.f;
   const bool fast = phys && !slow;
-  const int maxc = wave_max_i(fast ? q1 - q0 : 0);
+  const int maxc = (int)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_nonneg_to_last((float)(fast ? q1 - q0 : 0))), 63));   // (a count: exact as a float)
   if (maxc > PP_INTRA_DENSE) {
     const int Q0 = wave_min_i(fast ? q0 : 0x7fffffff), Q1 = wave_max_i(fast ? q1 : 0);
     const float ibias = 1.0f / G.pp_bias;
@@ -225,14 +226,15 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     vel[vi] = v;
     mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356
   }
-  for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_down(mag, o, 64));
-  if ((threadIdx.x & 63) == 0 && mag > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, mag);
+  mag = wave_max_nonneg_to_last(mag);
+  if ((threadIdx.x & 63) == 63 && mag > 0.f) p3m_atomic_max_nonneg(fmax_out + p3m_slot() * 16, mag);
 }
 
 static float first_r2_with_root_above(float t);
 int pp_intra(p3m_ctx *c, float a_mid, float dt, float mass_p) {
   P3M_TRY(particles_full_cells(c));
   const Geometry &g = c->g;
+  if ((int64_t)g.E * g.E * g.E >= (1ll << 31)) { p3m_set_error("pp_intra: the extended mesh does not fit a 32-bit cell index"); return P3M_EINVAL; }
   const unsigned char *done = c->pp_intra_fused ? c->pp_intra_done : nullptr;   // this step's pp_extended summed the bucket pairs of the records flagged there
   c->pp_intra_fused = false;
   if (c->np_all == 0) return P3M_OK;
