@@ -90,9 +90,7 @@ __global__ __launch_bounds__(256) void k_coarse_moments(const float4 *__restrict
       const int lx0 = G.ms * lci - h + G.nb, ly0 = G.ms * lcj - h + G.nb, lz0 = G.ms * lck - h + G.nb;
       int ra0 = 0, ra1 = 0;                              // lane r < nrow: the range of row r of the lead's cube
       if (lane < nrow) row_range(lci, ly0, lz0, lx0, lane, ra0, ra1);
-      int inc = ra1 - ra0;                               // inclusive prefix of the lengths over the lanes
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+      const int inc = wave_scan_incl_i(ra1 - ra0);       // inclusive prefix of the lengths over the lanes
       const int ltot = __builtin_amdgcn_readlane(inc, 63);
       float pa[8];
 #pragma unroll

@@ -1,6 +1,7 @@
 // p3m_internal.h -- context, geometry and launch helpers shared by the HIP translation units.
 // gfx950 only (wave64, 256 CUs / 8 XCDs, 160 KiB LDS per CU).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -45,6 +46,44 @@ __device__ __forceinline__ int p3m_slot() { return (int)((blockIdx.x + 13u * blo
 #endif
 
 #ifdef __HIPCC__
+// Cross-lane scans and reductions by DPP (data-parallel primitives: an operand modifier of the vector instruction) instead of __shfl_*, which
+// compile to ds_bpermute -- an LDS round trip per step, six dependent ones per scan: in the latency-bound particle kernels (one wavefront per
+// row, a chain of round trips) that chain is time, not instructions.  Four row_shr steps inside the rows of 16 lanes, then the rows' totals
+// by row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3); a lane without a source keeps `old` (the neutral element).
+__device__ __forceinline__ int wave_scan_incl_i(int v) {   // inclusive prefix sum over the 64 lanes
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ float wave_scan_incl_f(float v) {   // the same on floats (lane 63: the wavefront's sum, added in lane order by halves)
+  auto step = [&](auto CTRL, auto RM) { v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(CTRL)::value, decltype(RM)::value, 0xf, false)); };
+  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return v;
+}
+// the maximum of a non-negative float over the wavefront, in lane 63 (0 where a step has no source lane)
+__device__ __forceinline__ float wave_max_nonneg_to_last(float v) {
+  auto step = [&](auto CTRL, auto RM) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(CTRL)::value, decltype(RM)::value, 0xf, false);
+    v = fmaxf(v, __int_as_float(t));
+  };
+  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return v;
+}
+__device__ __forceinline__ int wave_max_nonneg_to_last_i(int v) {
+  auto step = [&](auto CTRL, auto RM) { v = max(v, __builtin_amdgcn_update_dpp(0, v, decltype(CTRL)::value, decltype(RM)::value, 0xf, false)); };
+  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return v;
+}
 __device__ __forceinline__ int rec_index(const float4 &p) { return __float_as_int(p.w); }
 __device__ __forceinline__ float4 with_index(float x, float y, float z, int i) { return make_float4(x, y, z, __int_as_float(i)); }
 #endif

@@ -151,9 +151,7 @@ __global__ __launch_bounds__(PT) void k_make_images(float4 *__restrict__ pos, fl
   }
   // block exclusive scan of cnt
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  const int inc = wave_scan_incl_i(cnt);
   if (lane == 63) wsum[w] = inc;
   __syncthreads();
   int off = 0, tot = 0;
@@ -300,9 +298,7 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
   const int chunk = (E + 63) / 64, j0 = min(lane * chunk, E), j1 = min(j0 + chunk, E);
   int sum = 0;
   for (int j = j0; j < j1; j++) sum += bins[j];
-  int inc = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  const int inc = wave_scan_incl_i(sum);            // (DPP: six dependent LDS round trips as __shfl_up)
   int run = r0 + inc - sum;
   for (int j = j0; j < j1; j++) { const int t = bins[j]; bins[j] = run; run += t; }
   row_sync();
@@ -395,9 +391,9 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
         }
       }
     if (dep.rho8) {
-      for (int o = 32; o > 0; o >>= 1) { icount += __shfl_down(icount, o, 64); cmax8 = max(cmax8, __shfl_down(cmax8, o, 64)); }
-      if (lane == 0 && icount != 0 && dep.sum_interior) atomicAdd(dep.sum_interior + p3m_slot() * 8, (double)icount * (double)dep.mass_p);
-      if (lane == 0 && cmax8 >= 64) p3m_atomic_max_nonneg(dep.cmax + p3m_slot() * 16, (float)cmax8);   // (small counts are not worth an atomic: the host only asks "below 128?")
+      icount = wave_scan_incl_i(icount); cmax8 = wave_max_nonneg_to_last_i(cmax8);   // lane 63: the row's sum / maximum
+      if (lane == 63 && icount != 0 && dep.sum_interior) atomicAdd(dep.sum_interior + p3m_slot() * 8, (double)icount * (double)dep.mass_p);
+      if (lane == 63 && cmax8 >= 64) p3m_atomic_max_nonneg(dep.cmax + p3m_slot() * 16, (float)cmax8);   // (small counts are not worth an atomic: the host only asks "below 128?")
     } else {
       if (dep.sum_interior) {
         for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
@@ -441,9 +437,7 @@ __global__ __launch_bounds__(64) void k_cells_from_sorted(const float4 *__restri
   const int chunk = (E + 63) / 64, j0 = min(lane * chunk, E), j1 = min(j0 + chunk, E);
   int sum = 0;
   for (int j = j0; j < j1; j++) sum += bins[j];
-  int inc = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  const int inc = wave_scan_incl_i(sum);            // (DPP: six dependent LDS round trips as __shfl_up)
   int run = r0 + inc - sum;
   int *csr = cs + (int64_t)row * E;
   for (int j = j0; j < j1; j++) { const int t = bins[j]; csr[j] = run; run += t; }

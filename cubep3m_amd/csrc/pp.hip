@@ -28,27 +28,6 @@ __device__ __forceinline__ int wave_max_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
   return v;
 }
-// inclusive prefix sum over the 64 lanes: four row_shr steps inside the rows of 16, then the rows' totals by row_bcast:15 / :31
-__device__ __forceinline__ int wave_scan_incl_i(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-  return v;
-}
-// the maximum of a non-negative float over the wavefront, in lane 63 (the same six DPP steps; 0 where a step has no source lane)
-__device__ __forceinline__ float wave_max_nonneg_to_last(float v) {
-  auto step = [&](auto CTRL, auto RM) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(CTRL)::value, decltype(RM)::value, 0xf, false);
-    v = fmaxf(v, __int_as_float(t));
-  };
-  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
-  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
-  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
-  return v;
-}
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
