@@ -52,16 +52,22 @@ __device__ __forceinline__ void ref_bucket(const float4 &p, const PPGeo &G, int 
   }
 }
 
-// Dense cells: when a wavefront's records sit in cells of more than PP_INTRA_DENSE records, the wavefront walks the union of
-// its lanes' cell ranges (contiguous in the sorted order) 64 partners at a time -- one coalesced load, then one broadcast
-// (v_readlane) per partner, each lane keeping the partners of its own cell -- instead of every lane streaming its whole
-// cell from global memory.  Same partner order per lane (ascending sorted index) as the per-lane loop.
-#define PP_INTRA_DENSE 12
+// Dense cells: when a wavefront's records sit in cells of more than PP_INTRA_DENSE records, the wavefront stages the union of
+// its lanes' cell ranges (contiguous in the sorted order) in LDS, PP_INTRA_CH partners at a time by coalesced loads, and every
+// lane walks the records of ITS cell there (lanes of one cell read one address: a broadcast) -- instead of every lane streaming
+// its whole cell from global memory.  The wavefront runs as many trips as its fullest cell has records; round 5's form (one
+// v_readlane broadcast per partner of the UNION, each lane keeping those of its own cell) ran as many as the union has, three to
+// five times more for blobs that spread over several cells.  Same partner order per lane (ascending sorted index) as the per-lane loop.
+#ifndef PP_INTRA_DENSE
+#define PP_INTRA_DENSE 6     // (3, 6: 0.323 ms per clustered 560 tile; 12: 0.333; 24: 0.375)
+#endif
+#define PP_INTRA_CH 256
 __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs,
                                                   const unsigned char *__restrict__ cflag, int n, PPGeo G, float mass_p, float a_mid, float dt,
                                                   float *__restrict__ fmax_out, float r2_soft, const unsigned char *__restrict__ done) {
   // done (or null): a byte per sorted record, set by k_pp_light for the records whose bucket pairs it has summed on its way (pp_extended:
   // the fused form); a wavefront of such records -- the rule at the background's density -- leaves before it reads anything else
+  __shared__ float4 ldsp[4][PP_INTRA_CH];   // the dense path's partners, a chunk per wavefront
   const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
   const bool skip = done != nullptr && s < n && done[s] != 0;
   if (done != nullptr && __all(skip || s >= n)) return;
@@ -115,24 +121,40 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   if (maxc > PP_INTRA_DENSE) {
     const int Q0 = wave_min_i(fast ? q0 : 0x7fffffff), Q1 = wave_max_i(fast ? q1 : 0);
     const float ibias = 1.0f / G.pp_bias;
-    for (int base = Q0; base < Q1; base += 64) {
-      const int m = min(64, Q1 - base);
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lane < m) o = spos[base + lane];
-      for (int jj = 0; jj < m; jj++) {
-        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), jj));
-        const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), jj));
-        const float pz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), jj));
-        const int q = base + jj;
-        if (fast && q >= q0 && q < q1 && q != s) {
-          const float sx = p.x - px, sy = p.y - py, sz = p.z - pz;                 // :336
-          const float r2 = sx * sx + sy * sy + sz * sz;
-          if (r2 >= r2_soft) {                                                     // :340 rmag > rsoft, decided exactly on r^2
-            const float ib = __builtin_amdgcn_rsqf(r2) * ibias, irb3 = ib * ib * ib;
-            ax -= mass_p * (sx * irb3); ay -= mass_p * (sy * irb3); az -= mass_p * (sz * irb3);   // :344-347
-          }
+    float4 *const L = ldsp[threadIdx.x >> 6];
+    for (int base = Q0; base < Q1; base += PP_INTRA_CH) {
+      const int m = min(PP_INTRA_CH, Q1 - base);
+      for (int i = lane; i < m; i += 64) L[i] = spos[base + i];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // (LDS operations of a wavefront complete in order)
+      const int lo = fast ? max(q0, base) : 0, hi = fast ? min(q1, base + m) : 0;
+      // four partners per trip: their reads and reciprocal square roots are independent (a blob's wavefront is alone on its SIMD and
+      // paid the LDS round trip and the dependent chain of every partner in full: 235 clocks per partner), the sums stay in order.
+      // A rejected partner adds (x * 0): the sums it leaves are the same up to the sign of a zero
+      int q = lo;
+      for (; q + 4 <= hi; q += 4) {
+        float4 o[4]; float k[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) o[u] = L[q - base + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          o[u].x = p.x - o[u].x; o[u].y = p.y - o[u].y; o[u].z = p.z - o[u].z;      // :336
+          const float r2 = o[u].x * o[u].x + o[u].y * o[u].y + o[u].z * o[u].z;
+          const float ib = __builtin_amdgcn_rsqf(r2) * ibias;
+          k[u] = (q + u != s && r2 >= r2_soft) ? ib * ib * ib : 0.f;                // :340 rmag > rsoft, decided exactly on r^2
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ax -= mass_p * (o[u].x * k[u]); ay -= mass_p * (o[u].y * k[u]); az -= mass_p * (o[u].z * k[u]); }   // :344-347
+      }
+      for (; q < hi; q++) {
+        const float4 o = L[q - base];
+        const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;
+        const float r2 = sx * sx + sy * sy + sz * sz;
+        if (q != s && r2 >= r2_soft) {
+          const float ib = __builtin_amdgcn_rsqf(r2) * ibias, irb3 = ib * ib * ib;
+          ax -= mass_p * (sx * irb3); ay -= mass_p * (sy * irb3); az -= mass_p * (sz * irb3);
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // the chunk is read before the next one overwrites it
     }
   } else if (fast) {
     // (the reciprocal square root of the dense path above: the wavefront runs this loop as often as its fullest cell has records, and the
