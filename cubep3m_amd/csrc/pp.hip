@@ -73,21 +73,27 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   if (done != nullptr && __all(skip || s >= n)) return;
   float mag = 0.f;
   float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  bool phys = false, slow = false;
-  int cc[3] = {0, 0, 0}, sub[3] = {0, 0, 0}, q0 = 0, q1 = 0;
+  bool phys = false, slow = false, closed = true;
+  int cc[3] = {0, 0, 0}, sub[3] = {0, 0, 0}, q0 = 0, q1 = 0, flag = 0;
   // The records of a fine cell are neighbours in the sorted order: a record's cell mates are found by comparing cell indices along
   // the wavefront (plus the record before and the one after it) instead of two look-ups in cell_end per record, which at the mean
   // density cost four times the bytes of the records themselves.  Only a run that crosses the wavefront's ends reads cell_end
+  // The kernel is a chain of round trips (at the reference's density it moves a third of the bytes its time would pay for): the requests
+  // that do not depend on each other go out together -- the compiler, left alone, waits for each load inside the conditional block that
+  // issues it (the empty asm statements name the registers that have to be there, i.e. where the wait may stand)
   int cell = -1, ncell = -1;                          // (E^3 < 2^31: pp_intra checks)
   {
     const int t = lane == 0 ? s - 1 : s + 1;           // the neighbours beyond the wavefront's ends
-    if ((lane == 0 || lane == 63) && t >= 0 && t < n) {
-      const float4 o = spos[t];
-      ncell = (((int)floorf(o.z) + G.nb) * G.E + ((int)floorf(o.y) + G.nb)) * G.E + ((int)floorf(o.x) + G.nb);
-    }
+    const bool nb = (lane == 0 || lane == 63) && t >= 0 && t < n;
+    // both through a buffer descriptor of the wavefront's window [s0 - 1, s0 + 65) of the records: a lane with nothing to read passes an
+    // offset outside it and gets zeros -- no branch around the load, whose merge of the loaded registers is where the compiler waits
+    const int s0 = __builtin_amdgcn_readfirstlane(s - lane), wb = max(s0 - 1, 0), we = min(n, s0 + 65);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(spos + wb), 0, (we - wb) * 16, 0x00020000);
+    const float4 o = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, nb ? (t - wb) * 16 : 0x40000000, 0, 0));
+    p = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (s - wb) * 16, 0, 0));   // (s >= n: outside, zeros)
+    if (nb) ncell = (((int)floorf(o.z) + G.nb) * G.E + ((int)floorf(o.y) + G.nb)) * G.E + ((int)floorf(o.x) + G.nb);
   }
   if (s < n) {
-    p = spos[s];
     const float fNn = (float)G.Nn;
     phys = !skip && p.x >= 0.f && p.x < fNn && p.y >= 0.f && p.y < fNn && p.z >= 0.f && p.z < fNn;
     cell = (((int)floorf(p.z) + G.nb) * G.E + ((int)floorf(p.y) + G.nb)) * G.E + ((int)floorf(p.x) + G.nb);
@@ -98,8 +104,9 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
       const bool pow2 = (G.ms & (G.ms - 1)) == 0;
       cc[0] = (int)floorf(pow2 ? p.x * ims : p.x / fms); cc[1] = (int)floorf(pow2 ? p.y * ims : p.y / fms); cc[2] = (int)floorf(pow2 ? p.z * ims : p.z / fms);
       const int Ec = G.E / G.ms, cb = G.nb / G.ms;
-      slow = cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)] != 0;
-      if (slow) ref_bucket(p, G, cc, sub);             // the sub-cell is only compared on the slow path
+      // requested here, looked at after the bucket pairs of the sorted cell are summed (a flagged coarse cell -- rare -- discards them):
+      // waiting for the byte before the partner loop was a fifth of this kernel's time at the reference's density
+      flag = cflag[((cc[2] + cb) * Ec + (cc[1] + cb)) * Ec + (cc[0] + cb)];
     }
   }
   {
@@ -110,23 +117,31 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
     const int start = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));
     const unsigned long long after = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
     const int end = after ? __ffsll((long long)after) - 1 : 64;
-    if (phys && !slow) {
-      if ((start == 0 && open_l) || (end == 64 && open_r)) { q0 = cs[cell]; q1 = cs[cell + 1]; }
+    if (phys) {
+      if ((start == 0 && open_l) || (end == 64 && open_r)) { q0 = cs[cell]; q1 = cs[cell + 1]; closed = false; }
       else { const int s0 = s - lane; q0 = s0 + start; q1 = s0 + end; }
     }
   }
   float ax = 0.f, ay = 0.f, az = 0.f;
-  const bool fast = phys && !slow;
+  const bool fast = phys;
+  // the velocity of a record with a cell mate (6 % at the reference's density) is requested here, with the flag and the cell ranges,
+  // not after the sums: one round trip less in the chain.  (vv is only read where vhave is set)
+  float4 vv; const bool vhave = phys && (!closed || q1 - q0 >= 2);
+  if (vhave) vv = vel[__float_as_int(p.w)];
+  float4 *const L = ldsp[threadIdx.x >> 6];
+  L[lane] = p;   // the wavefront's own records: the partners of every run that does not cross its ends
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // (LDS operations of a wavefront complete in order)
   const int maxc = (int)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_max_nonneg_to_last((float)(fast ? q1 - q0 : 0))), 63));   // (a count: exact as a float)
   if (maxc > PP_INTRA_DENSE) {
-    const int Q0 = wave_min_i(fast ? q0 : 0x7fffffff), Q1 = wave_max_i(fast ? q1 : 0);
+    asm volatile("" : "+v"(flag));   // a long walk: the records of flagged coarse cells stay out of it
+    const bool fastd = fast && flag == 0;
+    const int Q0 = wave_min_i(fastd ? q0 : 0x7fffffff), Q1 = wave_max_i(fastd ? q1 : 0);
     const float ibias = 1.0f / G.pp_bias;
-    float4 *const L = ldsp[threadIdx.x >> 6];
     for (int base = Q0; base < Q1; base += PP_INTRA_CH) {
       const int m = min(PP_INTRA_CH, Q1 - base);
       for (int i = lane; i < m; i += 64) L[i] = spos[base + i];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // (LDS operations of a wavefront complete in order)
-      const int lo = fast ? max(q0, base) : 0, hi = fast ? min(q1, base + m) : 0;
+      const int lo = fastd ? max(q0, base) : 0, hi = fastd ? min(q1, base + m) : 0;
       // four partners per trip: their reads and reciprocal square roots are independent (a blob's wavefront is alone on its SIMD and
       // paid the LDS round trip and the dependent chain of every partner in full: 235 clocks per partner), the sums stay in order.
       // A rejected partner adds (x * 0): the sums it leaves are the same up to the sign of a zero
@@ -159,21 +174,29 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   } else if (fast) {
     // (the reciprocal square root of the dense path above: the wavefront runs this loop as often as its fullest cell has records, and the
     // square root and three divisions of pair_force were three quarters of the kernel's instructions)
+    // A run inside the wavefront -- all but the two at its ends -- reads its partners from the records staged above: the loop was a chain
+    // of global round trips, as many as the wavefront's fullest cell has records (0.083 of the kernel's 0.22 ms per 560 tile)
     const float ibias = 1.0f / G.pp_bias;
-    for (int q = q0; q < q1; q++) {
-      const float4 o = spos[q];
+    const int s0 = s - lane;
+    auto pair = [&](int q, const float4 &o) {
       const float sx = p.x - o.x, sy = p.y - o.y, sz = p.z - o.z;                 // :336
       const float r2 = sx * sx + sy * sy + sz * sz;
       if (q != s && r2 >= r2_soft) {                                              // :340 rmag > rsoft, decided exactly on r^2
         const float ib = __builtin_amdgcn_rsqf(r2) * ibias, irb3 = ib * ib * ib;
         ax -= mass_p * (sx * irb3); ay -= mass_p * (sy * irb3); az -= mass_p * (sz * irb3);   // :344-347
       }
-    }
+    };
+    // (two loops: one loop over a pointer selected per lane reads both memories through flat loads)
+    if (closed) for (int q = q0; q < q1; q++) pair(q, L[q - s0]);
+    else for (int q = q0; q < q1; q++) pair(q, spos[q]);
   }
   // Records of flagged coarse cells (some record's reference bucket differs from its sorted cell): partners are the records
   // of the whole coarse cell with the same reference bucket.  Wavefront-cooperative: one flagged coarse cell at a time, its
   // ms*ms x-rows 64 candidates at a time, each candidate's bucket computed once by the lane that loaded it and broadcast
   // with its position (a thousand-particle cell made every lane stream and re-bucket the whole coarse cell on its own).
+  asm volatile("" : "+v"(flag));   // (the look at the flag stands here, not where the byte was requested)
+  slow = phys && flag != 0;
+  if (slow) { ax = 0.f; ay = 0.f; az = 0.f; ref_bucket(p, G, cc, sub); }   // the sub-cell is only compared on the slow path
   {
     const int nct = G.pt / G.ms;
     const int mykey = (sub[2] * G.ms + sub[1]) * G.ms + sub[0];
@@ -222,7 +245,8 @@ __global__ __launch_bounds__(256) void k_pp_intra(const float4 *__restrict__ spo
   // A record alone in its bucket (15 of 16 at the reference's density) has three zero sums: its kick adds zero and its velocity -- a 16-byte
   // gather and a 16-byte scatter through the arrival index, twice the bytes of the record itself -- is left where it is
   if (phys && (ax != 0.f || ay != 0.f || az != 0.f)) {
-    const int vi = __float_as_int(p.w); float4 v = vel[vi];          // the velocity stays in arrival order (p3m_internal.h)
+    const int vi = __float_as_int(p.w); float4 v;                    // the velocity stays in arrival order (p3m_internal.h)
+    if (vhave) v = vv; else v = vel[vi];
     v.x = v.x + ax * a_mid * P3M_G_F * dt; v.y = v.y + ay * a_mid * P3M_G_F * dt; v.z = v.z + az * a_mid * P3M_G_F * dt;  // :349-350
     vel[vi] = v;
     mag = sqrtf(ax * ax + ay * ay + az * az);                       // :356
