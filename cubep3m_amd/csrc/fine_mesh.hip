@@ -430,6 +430,7 @@ int fine_force_max(p3m_ctx *c) {
 // block instead of five, the re-read from beyond the L2 gone) was built next: 900 us.  Neither the bytes nor the round trips, then.
 __device__ __forceinline__ int ck_mj(int nj) { return nj >= 5 ? 52 : nj == 4 ? 64 : nj == 3 ? 86 : nj == 2 ? 128 : 256; }   // ceil(256 / nj)
 struct CicGeom { int k0, j0, x0, nk, nj, nx4, tx, ty, tz; const float *f0; int64_t row; };
+typedef __attribute__((address_space(3))) float lds_cfloat;
 template <bool COARSE>
 __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict__ spos, float4 *__restrict__ vel, const int *__restrict__ cs, TileGeo G, int Nn, int ms,
                                                        const float *__restrict__ fbox, int64_t comp_stride, float a_mid, float dt, float *__restrict__ fmax_out,
@@ -493,9 +494,7 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
     }
     if (tid < CK_BK * CK_BJ) rp0[tid] = st;
     if (tid < 64) {   // exclusive prefix of the CK_BK * CK_BJ counts
-      int inc = rcnt;
-#pragma unroll
-      for (int o = 1; o < CK_BK * CK_BJ; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (tid >= o) inc += u; }
+      const int inc = wave_scan_incl_i(rcnt);   // (DPP; lanes past the sixteen rows hold zero)
       if (tid < CK_BK * CK_BJ) rpre[tid] = inc - rcnt;
       if (tid == CK_BK * CK_BJ - 1) rpre[CK_BK * CK_BJ] = inc;
     }
@@ -522,6 +521,23 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
       const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1, dz2 = 1.0f - dz1;
       const int li = i1 - c.x0, lj = j1 - c.j0, lk = k1 - c.k0;
       const bool staged = li >= 0 && li + 1 < nx && lj >= 0 && lj + 1 < c.nj && lk >= 0 && lk + 1 < c.nk;
+      // the 24 values first, through a pointer that is LDS by its TYPE: with `staged ? LDS : global` inside the corner loop the compiler
+      // selected between two generic pointers per lane and read both memories through 24 flat loads per record
+      float f8[8][3];
+      if (staged) {
+        const lds_cfloat *q0 = (const lds_cfloat *)sb + (lk * (CK_BJ + 1) + lj) * 3 * CK_XP + li;
+#pragma unroll
+        for (int cn = 0; cn < 8; cn++) {
+          const lds_cfloat *q = q0 + ((cn >> 2) * (CK_BJ + 1) + ((cn >> 1) & 1)) * 3 * CK_XP + (cn & 1);
+          f8[cn][0] = q[0]; f8[cn][1] = q[CK_XP]; f8[cn][2] = q[2 * CK_XP];
+        }
+      } else {
+#pragma unroll
+        for (int cn = 0; cn < 8; cn++) {
+          const int64_t o = ((int64_t)(k1 + (cn >> 2)) * fb + (j1 + ((cn >> 1) & 1))) * fbp + (i1 + (cn & 1));
+          f8[cn][0] = c.f0[o]; f8[cn][1] = c.f0[o + comp_stride]; f8[cn][2] = c.f0[o + 2 * comp_stride];
+        }
+      }
 #pragma unroll
       for (int cz = 0; cz < 2; cz++)
 #pragma unroll
@@ -529,10 +545,8 @@ __global__ __launch_bounds__(256) void k_fine_kick_cic(const float4 *__restrict_
 #pragma unroll
           for (int cx = 0; cx < 2; cx++) {                                                                // order of :293-316
             const float dVc = a_mid * P3M_G_F * dt * (cx ? dx2 : dx1) * (cy ? dy2 : dy1) * (cz ? dz2 : dz1);
-            float fx, fy, fz;
-            if (staged) { const float *q = sb + ((lk + cz) * (CK_BJ + 1) + (lj + cy)) * 3 * CK_XP + (li + cx); fx = q[0]; fy = q[CK_XP]; fz = q[2 * CK_XP]; }
-            else { const int64_t o = ((int64_t)(k1 + cz) * fb + (j1 + cy)) * fbp + (i1 + cx); fx = c.f0[o]; fy = c.f0[o + comp_stride]; fz = c.f0[o + 2 * comp_stride]; }
-            v.x = v.x + fx * dVc; v.y = v.y + fy * dVc; v.z = v.z + fz * dVc;
+            const int cn = 4 * cz + 2 * cy + cx;
+            v.x = v.x + f8[cn][0] * dVc; v.y = v.y + f8[cn][1] * dVc; v.z = v.z + f8[cn][2] * dVc;
           }
       if (COARSE) {
         const float inv = 1.0f / (float)ms;
@@ -627,7 +641,7 @@ __global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const floa
     const float x = p.x + offx, y = p.y + offy, z = p.z + offz;                                        // :248
     const int i1 = (int)floorf(x) - lo, j1 = (int)floorf(y) - lo, k1 = (int)floorf(z) - lo;          // index into the force box
     float fx, fy, fz;
-    if (j1 == jj && k1 == kk) { fx = frow[i1]; fy = frow[fbp + i1]; fz = frow[2 * fbp + i1]; }
+    if (j1 == jj && k1 == kk) { const lds_cfloat *fl = (const lds_cfloat *)frow; fx = fl[i1]; fy = fl[fbp + i1]; fz = fl[2 * fbp + i1]; }   // (typed LDS: no flat loads)
     else { const int64_t o = ((int64_t)k1 * fb + j1) * fbp + i1; fx = f0[o]; fy = f0[o + comp_stride]; fz = f0[o + 2 * comp_stride]; }
     const int vi = rec_index(p);   // the velocity stays in arrival order (p3m_internal.h)
     float4 v = first ? vf : vel[vi];

@@ -93,7 +93,7 @@ __device__ __forceinline__ int rowtab_slot(int *key, int row) {
 // per-record table updates, plus a ballot.
 __device__ __forceinline__ bool row_run(int row, int &hl, int &cnt) {
   const int lane = threadIdx.x & 63;
-  const int prev = __shfl_up(row, 1, 64);
+  const int prev = __builtin_amdgcn_update_dpp(row, row, 0x138, 0xf, 0xf, false);   // wave_shr:1 (an operand modifier, not the LDS round trip of __shfl_up; lane 0 heads a run anyway)
   const bool head = lane == 0 || row != prev;
   const unsigned long long hm = __ballot(head);
   const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
