@@ -603,14 +603,15 @@ template <bool LIST>
 __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__ pos, const float4 *__restrict__ vel, const int64_t *__restrict__ pid_home,
                                                    int n, float Nn, float nb, float4 *__restrict__ sbuf, GhostSegs S, int *__restrict__ counts, int all_full,
                                                    const int *__restrict__ glist, const int *__restrict__ gl_cnt, int gl_cap) {
-  __shared__ int lc[GSLOTS], base[GSLOTS];
+  __shared__ int lc[GSLOTS], base[GSLOTS], scap[GSLOTS];
+  __shared__ int64_t soff[GSLOTS];   // the segment table by LDS: indexed per lane, the kernel argument was read through global loads, two per image sent
   int nl = n;
   if (LIST) {
     nl = min(gl_cnt[blockIdx.y * 16], gl_cap);
     if ((int)(blockIdx.x * GP_RPT * GP_NT) >= nl) return;   // the whole workgroup: past the list's end
     glist += (int64_t)blockIdx.y * gl_cap;
   }
-  if (threadIdx.x < GSLOTS) lc[threadIdx.x] = 0;
+  if (threadIdx.x < GSLOTS) { lc[threadIdx.x] = 0; scap[threadIdx.x] = S.cap[threadIdx.x]; soff[threadIdx.x] = S.off[threadIdx.x]; }
   __syncthreads();
   // the images of a record are the non-empty subsets t = 1..7 of its shifted axes (bit 0: x, 1: y, 2: z)
   float4 p[GP_RPT]; int rk[GP_RPT][7]; int sh[GP_RPT];   // sh: sx | sy << 2 | sz << 4, 0: nothing to send
@@ -667,13 +668,13 @@ __global__ __launch_bounds__(GP_NT) void k_ghost_pack(const float4 *__restrict__
       float4 img;
       const int k = slot_of(p[r], t, sx, sy, sz, ix, iy, iz, &img);
       const int s = base[k] + rk[r][t - 1];
-      if (s >= S.cap[k]) return;
+      if (s >= scap[k]) return;
       if (k & 1) {   // migrant: the whole record
         const float4 v = vel[i]; const int64_t id = pid_home[rec_index(v)];
-        float4 *o = sbuf + (int64_t)S.off[k] + 2 * (int64_t)s;
+        float4 *o = sbuf + soff[k] + 2 * (int64_t)s;
         img.w = v.x;
         o[0] = img; o[1] = make_float4(v.y, v.z, __int_as_float((int)(id & 0xffffffffLL)), __int_as_float((int)(id >> 32)));
-      } else sbuf[(int64_t)S.off[k] + s] = img;
+      } else sbuf[soff[k] + s] = img;
     };
     if (sx) send(1);
     if (sy | sz) {
