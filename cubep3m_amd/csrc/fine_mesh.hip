@@ -49,7 +49,7 @@ __device__ __forceinline__ float block_sum_f(float v, float *sh) {
 template <bool NGP>
 __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ spos, const int *__restrict__ cs, float *__restrict__ rho,
                                                      int tile0, TileGeo G, float mass_p, double *__restrict__ sum_interior, int nrows) {
-  extern __shared__ float row[];  // rp floats
+  extern __shared__ __align__(16) float row[];  // rp floats
   const int nf = G.nf, E = G.E, pt = G.pt, nb = G.nb;
   // workgroups go to the eight XCDs in turn: XCD x works the rows x * ceil(nrows / 8) ... of the launch, a slab in z, so that the
   // sorted cell rows a CIC output row gathers from (each feeds four output rows) are fetched into ONE XCD's L2
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
   if (brow >= nrows) return;
   const int j = brow % nf, k = (brow / nf) % nf, tl = brow / (nf * nf);
   int tx, ty, tz; tile_xyz(tile0 + tl, G.T, tx, ty, tz);
-  for (int i = threadIdx.x; i < G.rp; i += 64) row[i] = 0.f;
+  for (int i = 4 * threadIdx.x; i < G.rp; i += 256) *reinterpret_cast<float4 *>(row + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const float offx = (float)(-tx * pt + nb), offy = (float)(-ty * pt + nb), offz = (float)(-tz * pt + nb);  // :134
   const int wlo = NGP ? 4 : 0, whi = NGP ? nf - 4 : nf;                                                  // window [wlo,whi)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
       if (k1 == k) wz = dz1; else if (k1 + 1 == k) wz = dz2; else use = false;
       const float mx1 = mass_p * dx1, mx2 = mass_p * dx2;                                          // :23-24
       const float w1 = mx1 * wy * wz, w2 = mx2 * wy * wz;
-      const int prev = __shfl_up(i1, 1, 64);
+      const int prev = __builtin_amdgcn_update_dpp(i1, i1, 0x138, 0xf, 0xf, false);   // wave_shr:1 (not the LDS round trip of __shfl_up; lane 0 is a first lane anyway)
       const bool first = threadIdx.x == 0 || prev != i1;          // first lane of a run of equal cells
       const bool ascending = __ballot(threadIdx.x != 0 && prev > i1) == 0ull;
       const bool plain = ascending && first;
@@ -146,14 +146,19 @@ __global__ __launch_bounds__(64) void k_fine_deposit(const float4 *__restrict__ 
   float *out = rho + ((int64_t)tl * nf * nf + (int64_t)k * nf + j) * G.rp;
   float part = 0.f;
   const bool interior_row = (j >= nb && j < nf - nb && k >= nb && k < nf - nb);
-  for (int i = threadIdx.x; i < G.rp; i += 64) {
-    const float v = row[i];
-    out[i] = v;
-    if (interior_row && i >= nb && i < nf - nb) part += v;                                               // :167-173
+  for (int i = 4 * threadIdx.x; i < G.rp; i += 256) {   // (rp is a multiple of four: 16-byte stores)
+    const float4 v = *reinterpret_cast<const float4 *>(row + i);
+    *reinterpret_cast<float4 *>(out + i) = v;
+    if (interior_row) {                                                                                  // :167-173
+      if (i >= nb && i < nf - nb) part += v.x;
+      if (i + 1 >= nb && i + 1 < nf - nb) part += v.y;
+      if (i + 2 >= nb && i + 2 < nf - nb) part += v.z;
+      if (i + 3 >= nb && i + 3 < nf - nb) part += v.w;
+    }
   }
   if (sum_interior) {
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-    if (threadIdx.x == 0 && interior_row && part != 0.f) atomicAdd(sum_interior + p3m_slot() * 8, (double)part);
+    part = wave_scan_incl_f(part);   // lane 63: the row's sum (DPP)
+    if (threadIdx.x == 63 && interior_row && part != 0.f) atomicAdd(sum_interior + p3m_slot() * 8, (double)part);
   }
 }
 
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(64 * P3M_KICK_WPB) void k_fine_kick_rows(const floa
       // The lanes hold consecutive sorted indices, i.e. at most two blocks of 256: one atomic per block and wavefront
       const int blk = s >> 8;
       const unsigned long long act = __ballot(1);
-      const int first = __shfl(blk, __ffsll((long long)act) - 1, 64);
+      const int first = __builtin_amdgcn_readlane(blk, __ffsll((long long)act) - 1);
       const unsigned long long m1 = __ballot(blk == first);
       if (lane == __ffsll((long long)m1) - 1) atomicAdd(&cnt256[first], __popcll(m1));
       if (blk != first) { const unsigned long long m2 = __ballot(1); if (lane == __ffsll((long long)m2) - 1) atomicAdd(&cnt256[blk], __popcll(m2)); }

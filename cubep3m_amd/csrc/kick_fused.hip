@@ -325,7 +325,7 @@ __global__ __launch_bounds__((KCfg<R1, R2>::LT)) void k_fft_x_inv2_kick(KickFuse
       const int blk = go ? (s >> 8) : -1;
       unsigned long long rem = __ballot(go);
       while (rem) {
-        const int first = __shfl(blk, __ffsll((long long)rem) - 1, 64);
+        const int first = __builtin_amdgcn_readlane(blk, __ffsll((long long)rem) - 1)   /* (a uniform lane: v_readlane, not the LDS round trip of __shfl) */;
         const unsigned long long m1 = __ballot(blk == first);
         if (lane == __ffsll((long long)m1) - 1) atomicAdd(&a.cnt256[first], __popcll(m1));
         rem &= ~m1;
