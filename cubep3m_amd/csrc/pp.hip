@@ -23,16 +23,22 @@ __device__ __forceinline__ float3 pair_force(const float4 &a, const float4 &b, f
   return make_float3(mass_p * (sx / rb3), mass_p * (sy / rb3), mass_p * (sz / rb3));
 }
 
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;
+// the maximum / minimum of an int over the wavefront's active lanes, in every lane: by DPP (p3m_internal.h) and one v_readlane of lane 63,
+// which has to be active -- as __shfl_xor butterflies (ds_bpermute: an LDS round trip per step) the six-deep chains were 192 LDS operations
+// of the heavy pass's front end.  A lane without a source keeps the neutral element.
+template <bool MAX> __device__ __forceinline__ int wave_red_i(int v) {
+  constexpr int ID = MAX ? (int)0x80000000 : 0x7fffffff;
+  auto step = [&](auto CTRL, auto RM) {
+    const int t = __builtin_amdgcn_update_dpp(ID, v, decltype(CTRL)::value, decltype(RM)::value, 0xf, false);
+    v = MAX ? max(v, t) : min(v, t);
+  };
+  step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{}); step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
-}
+__device__ __forceinline__ int wave_max_i(int v) { return wave_red_i<true>(v); }
+__device__ __forceinline__ int wave_min_i(int v) { return wave_red_i<false>(v); }
 // ------------------------------------------------------------------ intra-cell PP
 // One thread per physical record.  The reference buckets the chain of hoc coarse cell
 // floor(x/mesh_scale) by sub-cell mod(i1-1,mesh_scale), i1 = floor(x + offset_tile) + 1
@@ -657,10 +663,8 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
       }
     }
     if (wv == 0) {
-      int hinc = hcnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(hinc, o, 64); if (lane >= o) hinc += u; }
-      const int total = __shfl(hinc, NH - 1, 64);
+      const int hinc = wave_scan_incl_i(hcnt);
+      const int total = __builtin_amdgcn_readlane(hinc, NH - 1);
       if (lane < NH) { rstart[lane] = hst; roff[lane] = hinc - hcnt; }
       if (lane == 0) roff[NH] = total;
     }
@@ -673,11 +677,9 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
       for (int r0 = 0; r0 < NR; r0 += 64) {
         const int r = r0 + lane;
         const int cnt = r < NR ? (int)offs[r * Wp + W - 1] : 0;
-        int inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        const int inc = wave_scan_incl_i(cnt);
         if (r < NR) cum[r] = carry + inc - cnt;
-        carry += __shfl(inc, 63, 64);
+        carry += __builtin_amdgcn_readlane(inc, 63);
       }
       if (lane == 0) cum[NR] = carry;
     }
@@ -1001,10 +1003,8 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
           {
             // this wavefront's share of the chunk's partners: positions [lo, hi) of the concatenation of the rows' stretches
             const int cnt = max(ub_l - ua_l, 0);
-            int inc = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-            const int tot = __shfl(inc, 63, 64), per_w = (tot + NW - 1) / NW, lo = wv * per_w, hi = min(lo + per_w, tot);
+            const int inc = wave_scan_incl_i(cnt);
+            const int tot = __builtin_amdgcn_readlane(inc, 63), per_w = (tot + NW - 1) / NW, lo = wv * per_w, hi = min(lo + per_w, tot);
             const int before = inc - cnt;                                                  // partners of the rows before this one
             ua_l += max(lo - before, 0); ub_l -= max(inc - hi, 0);
           }
@@ -1074,9 +1074,8 @@ __global__ __launch_bounds__(PP3_NT) __attribute__((amdgpu_waves_per_eu(PASS == 
       }
     }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mag = fmaxf(mag, __shfl_xor(mag, o, 64));
-    if (lane == 0 && mag > 0.f) p3m_atomic_max_nonneg(tile_max + tile, mag);
+    mag = wave_max_nonneg_to_last(mag);
+    if (lane == 63 && mag > 0.f) p3m_atomic_max_nonneg(tile_max + tile, mag);
   }
 }
 
