@@ -105,16 +105,20 @@ __device__ __forceinline__ bool row_run(int row, int &hl, int &cnt) {
 // Row-histogram pieces for the kernels that PRODUCE the arrival arrays (k_compact_drift_hist, k_ghost_unpack, k_make_images):
 // in steady state every record passes through one of them right before the sort, so they count the x-rows on the way and
 // k_row_hist's pass over the positions (16 B per record) is skipped.
+// the LDS counter through a pointer that is LDS by its type: `e >= 0 ? &val[e] : &rs[row + 1]` under one atomicAdd is what the compiler made of
+// the two branches -- a flat atomic on a pointer selected per lane, eight per thread in k_compact_drift_hist
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ void lds_add(int *val, int e, int cnt) { __hip_atomic_fetch_add((lds_int *)val + e, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void hist_row(int *key, int *val, int *rs, int row) {   // every lane of the wavefront calls (row < 0: nothing to count)
   int hl, cnt;
   if (row_run(row, hl, cnt) && row >= 0) {
     const int e = rowtab_slot(key, row);
-    if (e >= 0) atomicAdd(&val[e], cnt); else atomicAdd(&rs[row + 1], cnt);
+    if (e >= 0) lds_add(val, e, cnt); else atomicAdd(&rs[row + 1], cnt);
   }
 }
 __device__ __forceinline__ void hist_row_one(int *key, int *val, int *rs, int row) {   // callers in divergent code
   const int e = rowtab_slot(key, row);
-  if (e >= 0) atomicAdd(&val[e], 1); else atomicAdd(&rs[row + 1], 1);
+  if (e >= 0) lds_add(val, e, 1); else atomicAdd(&rs[row + 1], 1);
 }
 __device__ __forceinline__ void hist_flush(const int *key, const int *val, int *rs) {   // behind a __syncthreads()
   for (int e = threadIdx.x; e < SORT_HB; e += blockDim.x) if (val[e] > 0) atomicAdd(&rs[key[e] + 1], val[e]);
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(PT) void k_row_hist(const float4 *__restrict__ pos,
     int hl, cnt;
     if (row_run(row, hl, cnt) && row >= 0) {
       const int e = rowtab_slot(key, row);
-      if (e >= 0) atomicAdd(&val[e], cnt); else atomicAdd(&rs[row + 1], cnt);
+      if (e >= 0) lds_add(val, e, cnt); else atomicAdd(&rs[row + 1], cnt);
     }
     if (i >= n) continue;
     if (inr) {
@@ -242,12 +246,19 @@ __global__ __launch_bounds__(PT) void k_row_scatter(const float4 *__restrict__ p
     const int i = (blockIdx.x * SORT_RPT + u) * PT + threadIdx.x;
     const bool inr = i < n && in_hoc_range(p[u], -nb, Nn + nb);
     const int row = inr ? ((int)floorf(p[u].z) + (int)nb) * E + (int)floorf(p[u].y) + (int)nb : -1;
-    int hl, cnt, eh = -1, base = 0;
+    // the head's entry and base reach its run in ONE word (one ds_bpermute, an LDS round trip, instead of two): table entry e < 512 and
+    // the base inside the block (< PT * SORT_RPT = 2^11 records) as e << 12 | base; a global slot (< 2^31) with the top bit set; -1: dropped
+    static_assert(PT * SORT_RPT <= 4096 && SORT_HB <= (1 << 19), "the packed (entry, base) word");
+    int hl, cnt; unsigned pk = 0xffffffffu;
     if (row_run(row, hl, cnt) && row >= 0) {
       const int e = rowtab_slot(key, row);
-      if (e >= 0) { eh = e; base = atomicAdd(&val[e], cnt); } else { eh = -2; base = atomicAdd(&rs[row + 1], cnt); }
+      if (e >= 0) pk = ((unsigned)e << 12) | (unsigned)atomicAdd(&val[e], cnt); else pk = 0x80000000u | (unsigned)atomicAdd(&rs[row + 1], cnt);
     }
-    ent[u] = __shfl(eh, hl, 64); rank[u] = __shfl(base, hl, 64) + ((int)(threadIdx.x & 63) - hl);
+    pk = (unsigned)__shfl((int)pk, hl, 64);
+    const int dl = (int)(threadIdx.x & 63) - hl;
+    if (pk == 0xffffffffu) { ent[u] = -1; rank[u] = 0; }
+    else if (pk & 0x80000000u) { ent[u] = -2; rank[u] = (int)(pk & 0x7fffffffu) + dl; }
+    else { ent[u] = (int)(pk >> 12); rank[u] = (int)(pk & 0xfffu) + dl; }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < SORT_HB; e += PT) if (val[e] > 0) val[e] = atomicAdd(&rs[key[e] + 1], val[e]);   // count -> base
@@ -908,7 +919,7 @@ __global__ __launch_bounds__(PT) void k_compact_drift_hist(const float4 *__restr
       if (m) {
         int b = 0;
         if (lane == __ffsll((long long)m) - 1) b = atomicAdd(&gn, __popcll(m));
-        b = __shfl(b, __ffsll((long long)m) - 1, 64);
+        b = __builtin_amdgcn_readlane(b, __ffsll((long long)m) - 1);   // (a uniform lane: not the LDS round trip of __shfl)
         if (cand) gl[b + __popcll(m & ((1ull << lane) - 1ull))] = oc;
       }
     }
