@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64 * P3M_SORT_WPB) __attribute__((amdgpu_waves_per_
                                                  float4 *__restrict__ spos,
                                                  int *__restrict__ cand, int *__restrict__ cand_cnt, int cand_seg, RowDep dep, RowCompact cc, int n_cur) {
   extern __shared__ int bins_all[];
+  // (rows to the XCDs in contiguous eighths -- the lines two neighbouring rows share in one L2 -- was measured: 318 us against 306)
   const int row = blockIdx.x * P3M_SORT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= nrows) return;
   int *bins = bins_all + (threadIdx.x >> 6) * E;
@@ -540,7 +541,8 @@ int particles_sort_enqueue(p3m_ctx *c, float deposit_mass) {
   c->cells_compact = dep.rho != nullptr && !(c->p.flags & (P3M_FLAG_PPINT | P3M_FLAG_PP_EXT));
   if (c->cells_compact) cc.crow = c->crow;
   if (!c->step_zeroed) HIP_TRY(hipMemsetAsync(c->cand_cnt, 0, sizeof(int) * (16 * P3M_CAND_SLOTS + 16), c->stream));   // empty candidate lists (whole steps: step_prezero)
-  hipLaunchKernelGGL(k_row_sort, dim3(cdiv(nrows, P3M_SORT_WPB)), dim3(64 * P3M_SORT_WPB), (size_t)g.E * sizeof(int) * P3M_SORT_WPB, c->stream, (const float4 *)c->tpos,
+  const int sort_grid = cdiv(nrows, P3M_SORT_WPB);
+  hipLaunchKernelGGL(k_row_sort, dim3(sort_grid), dim3(64 * P3M_SORT_WPB), (size_t)g.E * sizeof(int) * P3M_SORT_WPB, c->stream, (const float4 *)c->tpos,
                      (const int *)c->row_end, g.E, nrows, (float)g.nb, c->cell_end, c->spos, c->cand, c->cand_cnt,
                      c->cand_seg, dep, cc, n_cur);
   HIP_TRY(hipGetLastError());
