@@ -608,11 +608,21 @@ def main():
             # short-range kernels on their own
             grp.close()
 
-            def side_leg(cfg_name, gen, data):
-                """full steps of another flag set / another IC on the headline's geometry, timed like the headline"""
+            def side_leg(cfg_name, gen, data, env=None):
+                """full steps of another flag set / another IC on the headline's geometry, timed like the headline (env: library switches,
+                read when the group is created)"""
                 p2 = Params(**CONFIGS[cfg_name]["params"])
                 p2.device = local_dev
-                g2 = ParticleMeshGroup(p2, 0, 1, fine, coarse)
+                saved = {k: os.environ.get(k) for k in (env or {})}
+                os.environ.update(env or {})
+                try:
+                    g2 = ParticleMeshGroup(p2, 0, 1, fine, coarse)
+                finally:
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
                 for i, r in enumerate(g2.local_ranks):
                     xv = gen(r)
                     g2.upload_particles(i, xv, np.arange(1, len(xv) + 1, dtype=np.int64) + r * len(xv))
@@ -683,6 +693,11 @@ def main():
             mdata = "synthetic uniform positions, Gaussian velocities with sigma_v dt = 0.3 cells per step and axis"
             res["moving"] = {"pm": side_leg("cfg4", moving_ic, mdata), "pm_pp": side_leg("cfg4_pp", moving_ic, mdata)}
             res["pm_pp"] = side_leg("cfg4_pp", uniform_ic, "synthetic uniform (the headline's particles)")
+            # the headline's step with a stream per logical rank (P3M_GROUP_STREAMS, opt-in: group.hip): launch gaps, kernel tails and the
+            # latency-bound particle kernels of one rank run underneath another rank's passes.  Not the headline: with kernels of different
+            # ranks sharing the device a kernel's duration is no longer its own, and the roofline above is per kernel
+            res["rank_streams"] = dict(side_leg("cfg4", uniform_ic, "synthetic uniform (the headline's particles)", env={"P3M_GROUP_STREAMS": "8"}),
+                                       what="the headline's workload with P3M_GROUP_STREAMS=8: one stream per logical rank between the ghost pass and the step's host wait")
             # the same two step types on a clustered particle set: dense cells, unequal rows, heavy pair lists
             cdata = "synthetic clustered: 30 % of the particles in Gaussian blobs of ~205 particles, sigma 0.6 cells (SURVEY Appendix C's recipe at its density)"
             res["clustered"] = {"pm": side_leg("cfg4", clustered_ic, cdata), "pm_pp": side_leg("cfg4_pp", clustered_ic, cdata)}

@@ -63,6 +63,15 @@ struct p3m_group {
   // only when they kick
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_dep = nullptr, ev_cf = nullptr;
+  // Several local ranks on one device (the one-GPU bench line: eight): between the ghost pass and the end of the step a rank's kernels depend
+  // on no other rank's -- except for the coarse force, which waits for every rank's coarse density and is waited for by every rank's kick.
+  // Each local rank queues that stretch on a stream of its own (`rstream`), so that one rank's latency-bound particle kernels, launch gaps
+  // and kernel tails run underneath another rank's bandwidth-bound passes; the step forks behind the ghost pass (`ev_fork`) and joins before
+  // its one host wait (`rev_done`).  OPT-IN (P3M_GROUP_STREAMS=n, n streams): the one-GPU headline runs 30.5 -> 29.9 ms with eight, but kernels of
+  // different ranks then share the device and a kernel's rocprofv3 duration is no longer its own (the fused z pass: 735 -> 2090 us average) --
+  // the roofline evidence of bench.py and profiles/ is per-kernel, so the default keeps one stream.  Never on with one local rank (one rank per
+  // GPU: nothing to overlap) or with phase timing on (the spans are taken on ONE stream).
+  std::vector<hipStream_t> rstream; std::vector<hipEvent_t> rev_dep, rev_done; hipEvent_t ev_fork = nullptr; bool multi = false; size_t nrs = 1;   // nrs: streams in use (local rank i queues on rstream[i % nrs]; P3M_GROUP_STREAMS=n)
   std::vector<p3m_ctx *> ctx; std::vector<int> lrank, owner, lidx;
   std::vector<CoarseDist> cd;
   // The coarse arrays of all local ranks are slices of group-wide allocations.  `batched` (slabs whose line length has
@@ -231,6 +240,10 @@ extern "C" void p3m_hip_group_destroy(p3m_group *G) {
   if (G->h_sum3) (void)hipHostFree(G->h_sum3);
   for (int k = 0; k < 2; k++) if (G->h_stage[k]) (void)hipHostFree(G->h_stage[k]);
   fft_plan_destroy(&G->plan_c);
+  for (hipStream_t st : G->rstream) if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t e : G->rev_dep) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : G->rev_done) if (e) (void)hipEventDestroy(e);
+  if (G->ev_fork) (void)hipEventDestroy(G->ev_fork);
   if (G->stream2) (void)hipStreamDestroy(G->stream2);
   if (G->ev_dep) (void)hipEventDestroy(G->ev_dep);
   if (G->ev_cf) (void)hipEventDestroy(G->ev_cf);
@@ -261,12 +274,20 @@ extern "C" int p3m_hip_group_create(const p3m_params *base, int32_t proc, int32_
     int rc = p3m_hip_create(&p, &c);
     p3m_ctx_share_hint = 1;
     if (rc) return fail(rc);
-    (void)hipStreamDestroy(c->stream); c->stream = G->stream;   // one stream for the whole group
+    G->rstream.push_back(c->stream); c->stream = G->stream;   // the group's stream; the context's own one serves the forked stretch of a step (rstream)
     G->lidx[r] = (int)G->ctx.size(); G->ctx.push_back(c); G->lrank.push_back(r);
   }
   if (nodes > 1 && !(getenv("P3M_ONE_STREAM") && getenv("P3M_ONE_STREAM")[0] == '1')) {
     if (hipStreamCreateWithFlags(&G->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&G->ev_dep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&G->ev_cf, hipEventDisableTiming) != hipSuccess) return fail(P3M_EDEVICE);
+  }
+  if (G->stream2 && G->ctx.size() > 1 && getenv("P3M_GROUP_STREAMS") && atoi(getenv("P3M_GROUP_STREAMS")) > 0) {
+    G->rev_dep.assign(G->ctx.size(), nullptr); G->rev_done.assign(G->ctx.size(), nullptr);
+    bool ok = hipEventCreateWithFlags(&G->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (size_t i = 0; ok && i < G->ctx.size(); i++)
+      ok = hipEventCreateWithFlags(&G->rev_dep[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&G->rev_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return fail(P3M_EDEVICE);
+    G->multi = true; G->nrs = std::min<size_t>(G->ctx.size(), (size_t)atoi(getenv("P3M_GROUP_STREAMS")));
   }
   const Geometry &g = G->ctx[0]->g;
   if (nodes > 1 && g.Nn < 2 * g.nb) {   // one ghost shift per axis (k_ghost_pack)
@@ -1210,6 +1231,17 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   G->pt.reset();
   { PhaseScope ps(&G->pt, P3M_PH_DRIFT, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_drift(c, dt, dt_old, offset)); }                      // :56
   { PhaseScope ps(&G->pt, P3M_PH_GHOST, G->stream); P3M_TRY(ghost_pass(G)); }                                                                          // :61-63
+  // ---- fork: from here to the step's one host wait every local rank queues on its own stream (see p3m_group::rstream)
+  const bool multi = G->multi && !G->pt.on;
+  hipStream_t const main_stream = G->stream;
+  struct Rejoin {   // whatever happens below: the contexts are back on the group's stream and nothing of this step is still running on theirs
+    p3m_group *G; hipStream_t main; bool armed;
+    ~Rejoin() { if (!armed) return; for (size_t i = 0; i < G->ctx.size(); i++) { (void)hipStreamSynchronize(G->rstream[i % G->nrs]); G->ctx[i]->stream = main; } G->stream = main; }
+  } rejoin{G, main_stream, multi};
+  if (multi) {
+    HIP_TRY(hipEventRecord(G->ev_fork, main_stream));
+    for (size_t i = 0; i < G->ctx.size(); i++) { HIP_TRY(hipStreamWaitEvent(G->rstream[i % G->nrs], G->ev_fork, 0)); G->ctx[i]->stream = G->rstream[i % G->nrs]; }
+  }
   { PhaseScope ps(&G->pt, P3M_PH_SORT, G->stream); for (p3m_ctx *c : G->ctx) { P3M_TRY(step_prezero(c)); P3M_TRY(particles_sort_enqueue(c, mass_p)); } }   // every rank's sort queued ...
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_sort_finish(c, false));                                      // ... and nobody waits: the counters come in with the step's results
   // The coarse force depends on positions only: it is formed right after the sort, on a second stream underneath the
@@ -1218,22 +1250,29 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
   const bool ride = !G->ctx.empty() && coarse_kick_rides_on_fine(G->ctx[0]);
   { PhaseScope ps(&G->pt, P3M_PH_COARSE_DEPOSIT, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_deposit(c, mass_p)); }                          // coarse_mass
   if (G->stream2) {
-    HIP_TRY(hipEventRecord(G->ev_dep, G->stream));
+    if (multi) { for (size_t i = 0; i < G->ctx.size(); i++) HIP_TRY(hipEventRecord(G->rev_dep[i], G->rstream[i % G->nrs])); }
+    else HIP_TRY(hipEventRecord(G->ev_dep, G->stream));
     for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p, false));                     // :72-204 of every tile, queued first
-    HIP_TRY(hipStreamWaitEvent(G->stream2, G->ev_dep, 0));
-    hipStream_t main = G->stream;
+    if (multi) { for (size_t i = 0; i < G->ctx.size(); i++) HIP_TRY(hipStreamWaitEvent(G->stream2, G->rev_dep[i], 0)); }   // the coarse force needs every rank's coarse density
+    else HIP_TRY(hipStreamWaitEvent(G->stream2, G->ev_dep, 0));
     G->stream = G->stream2; for (p3m_ctx *c : G->ctx) c->stream = G->stream2;
     int r;
     { PhaseScope ps(&G->pt, P3M_PH_COARSE_FORCE, G->stream2); r = coarse_force_dist(G); }                                         // coarse_force, _buffer, max
     if (r == P3M_OK && hipEventRecord(G->ev_cf, G->stream2) != hipSuccess) r = P3M_EDEVICE;
-    G->stream = main; for (p3m_ctx *c : G->ctx) c->stream = main;
+    G->stream = main_stream; for (size_t i = 0; i < G->ctx.size(); i++) G->ctx[i]->stream = multi ? G->rstream[i % G->nrs] : main_stream;
     if (r != P3M_OK) { (void)hipStreamSynchronize(G->stream2); return r; }
   } else {
     { PhaseScope ps(&G->pt, P3M_PH_COARSE_FORCE, G->stream); P3M_TRY(coarse_force_dist(G)); }
     for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_force_phase(c, mass_p, false));
   }
+  auto wait_cf = [&]() {   // the kicks need the coarse force
+    if (!G->stream2) return P3M_OK;
+    if (multi) { for (size_t i = 0; i < G->ctx.size(); i++) HIP_TRY(hipStreamWaitEvent(G->rstream[i % G->nrs], G->ev_cf, 0)); }
+    else HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
+    return P3M_OK;
+  };
   if (ride) {
-    if (G->stream2) HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
+    P3M_TRY(wait_cf());
     for (p3m_ctx *c : G->ctx) {
       c->coarse_first = true;
       const int r = fine_mesh_kick_phase(c, a_mid, dt, mass_p);                                     // :208-319 + coarse_velocity
@@ -1242,13 +1281,17 @@ static int group_particle_mesh_step(p3m_group *G, float a_mid, float dt, float d
     }
   } else {
     for (p3m_ctx *c : G->ctx) P3M_TRY(fine_mesh_kick_phase(c, a_mid, dt, mass_p));                  // :208-628
-    if (G->stream2) HIP_TRY(hipStreamWaitEvent(G->stream, G->ev_cf, 0));
+    P3M_TRY(wait_cf());
     { PhaseScope ps(&G->pt, P3M_PH_COARSE_KICK, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(coarse_kick(c, a_mid, dt)); }                          // coarse_velocity
   }
   { PhaseScope ps(&G->pt, P3M_PH_DELETE, G->stream); for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_enqueue(c, (G->base.flags & P3M_FLAG_MOVE_GRID_BACK) ? move_back : nullptr)); }  // :716-720
   // ONE host wait for everything the host reads back: survivor counts, the sort's counters, maxima and sums
   for (p3m_ctx *c : G->ctx) P3M_TRY(reductions_download(c));   // (with the per-tile PP maxima: one block)
   for (p3m_ctx *c : G->ctx) c->step_zeroed = false;
+  if (multi) {   // ---- join: the group's stream waits for every rank's
+    for (size_t i = 0; i < G->ctx.size(); i++) { HIP_TRY(hipEventRecord(G->rev_done[i], G->rstream[i % G->nrs])); HIP_TRY(hipStreamWaitEvent(main_stream, G->rev_done[i], 0)); G->ctx[i]->stream = main_stream; }
+    rejoin.armed = false;
+  }
   HIP_TRY(hipStreamSynchronize(G->stream));
   if (G->pt.on) { if (G->stream2) HIP_TRY(hipStreamSynchronize(G->stream2)); G->pt.collect(); }
   for (p3m_ctx *c : G->ctx) P3M_TRY(particles_finalize_finish(c, false));
