@@ -519,10 +519,9 @@ def test_pid_slots_are_repacked_while_migrants_keep_arriving():
     assert moved == len(xv)
 
 
-@pytest.mark.parametrize("switch", ["P3M_COARSE_PER_RANK", "P3M_COARSE_COPY", "P3M_ONE_STREAM", "P3M_GROUP_STREAMS"])
+@pytest.mark.parametrize("switch", ["P3M_COARSE_PER_RANK", "P3M_COARSE_COPY", "P3M_ONE_STREAM"])
 def test_per_rank_coarse_path_stays_at_parity(switch):
-    """P3M_ONE_STREAM=1 keeps the coarse force on the main stream (no second stream, no events).  P3M_GROUP_STREAMS=8 gives every local
-    rank a stream of its own between the ghost pass and the step's host wait (by default they queue on the group's one stream).  P3M_COARSE_PER_RANK=1 runs the distributed coarse transform rank by rank (the path of pencil decompositions and of mesh
+    """P3M_ONE_STREAM=1 keeps the coarse force on the main stream (no second stream, no events).  P3M_COARSE_PER_RANK=1 runs the distributed coarse transform rank by rank (the path of pencil decompositions and of mesh
     sizes without register-stage FFT kernels) where the default batches every stage over the local ranks; P3M_COARSE_COPY=1
     keeps the batched stages but moves the three redistributions as messages (what several processes run) where a single
     process gathers / stores them in place: both held to the same tests, in a child process (the switches are read when the
@@ -534,14 +533,23 @@ def test_per_rank_coarse_path_stays_at_parity(switch):
     here = os.path.dirname(os.path.abspath(__file__))
     # (the whole-step comparisons reuse the oracle results the parent's tests left in the oracle cache, tests/oracle_lib.py)
     sel = {"P3M_ONE_STREAM": "(eight_logical_ranks_match_oracle and (uniform-kw0 or clustered-kw1)) or distributed_coarse_mesh_vs_oracle",
-           "P3M_GROUP_STREAMS": "eight_logical_ranks_match_oracle and (uniform-kw0 or clustered-kw1)",
            "P3M_COARSE_PER_RANK": "distributed_coarse_mesh_vs_oracle or (eight_logical_ranks_match_oracle and uniform) or nc256",
            "P3M_COARSE_COPY": "distributed_coarse_mesh_vs_oracle or (eight_logical_ranks_match_oracle and uniform) or nc256 or (distributed_coarse_mesh_at_the_bench_size and False)"}[switch]
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_group.py"), os.path.join(here, "test_gpu_baseline_sizes.py"),
                         os.path.join(here, "test_gpu_slab1024.py"), "-q", "-x", "-m", "gpu", "-k", sel],
-                       env=dict(os.environ, **{switch: "8" if switch == "P3M_GROUP_STREAMS" else "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
+                       env=dict(os.environ, **{switch: "1"}), cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("kind,kw", [("uniform", dict(ngp=True)), ("clustered", dict(ngp=True, ppint=True, pp_ext=True))])
+def test_a_stream_per_local_rank_stays_at_parity(kind, kw, monkeypatch):
+    """P3M_GROUP_STREAMS=8 (read when the group is created): between the ghost pass and the step's host wait every local rank queues on a
+    stream of its own -- the fork behind the ghost pass, the coarse force waiting for every rank's coarse density, every rank's kick
+    waiting for the coarse force, the join before the host wait (group.hip).  Same kernels, same results: held to the oracle by the
+    eight-rank test itself (whose oracle results are in the cache by now)."""
+    monkeypatch.setenv("P3M_GROUP_STREAMS", "8")
+    test_eight_logical_ranks_match_oracle(kind, kw, False)
 
 
 def test_group_takes_the_kernels_a_host_already_holds():
