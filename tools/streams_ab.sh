@@ -1,3 +1,8 @@
+#!/bin/bash
+# P3M_GROUP_STREAMS=8 (a stream per logical rank) against the default: the step, and what rocprofv3 then reads as the kernels' durations
+# (kernels of different ranks share the device: a kernel's duration is no longer its own).  Run through gpurun: bash tools/streams_ab.sh
+set -u
+: "${GRAFT_REPO_ROOT:?}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in 8 0; do
